@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the IMPORTED REFERENCE (CPU, this container only) and check
+the oracle restatement against it, stage by stage.
+
+    python -m oracle.gen_golden            # regenerate + verify (needs /root/reference)
+
+Only OUTPUTS of the reference are stored (KBs); inputs are regenerated from seeds by
+tests/golden_inputs.py and nopesac_amd/synth.py.  No reference source travels.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from nopesac_amd.synth import state_dict_spec, synth_pair, synth_state_dict  # noqa: E402
+from oracle import nopesac_oracle as O  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+from tests import golden_inputs as GI  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+LOOSE_OV = {"TEST.OVERLAP_THRESHOLD": 0.0, "TEST.PLANE_SCORE_THRESHOLD": 0.5,
+            "TEST.MATCHING_SCORE_THRESHOLD": 0.0, "TEST.MASK_PROB_THRESHOLD": 0.3}
+
+
+def loose_cfg(nq=50):
+    return O.OracleConfig(num_queries=nq, overlap_threshold=0.0, plane_score_threshold=0.5,
+                          matching_score_threshold=0.0, mask_prob_threshold=0.3)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+class Report:
+    def __init__(self):
+        self.rows = []
+
+    def check(self, name, got, want, tol=1e-5, exact=False):
+        got, want = torch.as_tensor(got), torch.as_tensor(want)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        if exact:
+            ok = bool((got == want).all())
+            err = 0.0 if ok else 1.0
+        else:
+            err = rel_err(got, want)
+            ok = err <= tol
+        self.rows.append((name, err, ok))
+        print(f"  {'OK ' if ok else 'BAD'} {name:58s} rel-err {err:.2e}")
+        assert ok, name
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"),
+                        **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 8)
+    rep = Report()
+    sd = synth_state_dict(50)
+    with quiet():
+        model = ref_shim.build_reference_model(sd)
+    # ---- state-dict contract -----------------------------------------------------------
+    ref_sd = {k: v for k, v in model.state_dict().items() if not k.startswith("criterion.")}
+    spec = state_dict_spec(50)
+    assert list(ref_sd) and set(ref_sd) == set(spec), "key set mismatch"
+    assert all(tuple(ref_sd[k].shape) == tuple(spec[k]) for k in spec), "shape mismatch"
+    print(f"state-dict contract: {len(spec)} keys match the reference")
+    save("state_dict_keys", keys=np.array(list(spec)), checksum=np.array(
+        [float(sd[k].double().sum()) for k in spec]))
+    cfg = O.OracleConfig()
+    head = model.camera_head_list[0]
+    import NopeSAC_Net.modeling.camera_net.camera_modules as cm
+
+    with torch.no_grad():
+        # ---- A backbone + preprocess on a small image -------------------------------------
+        print("[A] backbone")
+        img = synth_pair(11, 64, 96)["0"]["image"]
+        x_ref = model.preprocess_image([{"image": img}]).tensor
+        rep.check("preprocess", O.preprocess([img], cfg), x_ref, 1e-6)
+        f_ref = model.backbone(x_ref)
+        f_or = O.backbone(sd, x_ref)
+        probes = {}
+        for k in f_ref:
+            rep.check(f"backbone.{k}", f_or[k], f_ref[k], 2e-5)
+            probes[k + "_sum"] = f_ref[k].double().sum()
+            probes[k + "_probe"] = f_ref[k].flatten()[:: max(f_ref[k].numel() // 64, 1)][:64]
+        save("A_backbone_64x96", **probes)
+
+        # ---- B plane head on small designed features --------------------------------------
+        print("[B] plane head")
+        feats = GI.feature_maps(21, 6, 8)
+        o_ref, q_ref = model.sem_seg_head(feats)
+        o_or, q_or = O.plane_head(sd, feats, cfg)
+        rep.check("plane_head.query_feat", q_or, q_ref, 2e-4)
+        for k in ("pred_logits", "pred_mask_logits", "pred_params", "pred_centers", "pixel_centers"):
+            rep.check("plane_head." + k, o_or[k], o_ref[k], 2e-4)
+        save("B_plane_head_6x8", query_feat=q_ref, pred_logits=o_ref["pred_logits"], pred_params=o_ref["pred_params"],
+             pred_centers=o_ref["pred_centers"], mask_logits_sub=o_ref["pred_mask_logits"][0, :, ::4, ::4],
+             pixel_centers_sub=o_ref["pixel_centers"][0, :, ::4, ::4])
+
+        # ---- C post-selection on designed logits --------------------------------------------
+        print("[C] post-selection")
+        for kind, seed in (("multi", 31), ("none_pass", 32), ("all_overlap_rejected", 33), ("full", 34)):
+            logits, params, mask, feat = GI.postselect_case(kind, seed)
+            binp = [{"image_id": "x", "file_name": "x", "height": 480, "width": 640}]
+            pd = {"pred_logits": logits[None], "pred_params": params[None], "pred_mask_logits": mask[None]}
+            r = model._postprocess_planeHeadMask(pd, [None], binp, [(480, 640)], feat[None])[0]
+            s = O.post_select(logits, params, mask, feat, cfg)
+            ref_idx = torch.tensor([int(i) for i in r["pred_plane_oriIdxs"]])
+            rep.check(f"postselect.{kind}.idx", s["pred_plane_oriIdxs"], ref_idx, exact=True)
+            rep.check(f"postselect.{kind}.planes", s["pred_plane"], r["pred_plane"], 1e-6)
+            rep.check(f"postselect.{kind}.feats", s["pred_plane_feats"], r["pred_plane_feats"], 1e-6)
+            rep.check(f"postselect.{kind}.masks", s["pred_plane_masks"], r["pred_plane_masks"], exact=True)
+            rep.check(f"postselect.{kind}.centers", s["pred_plane_ins_center"], r["pred_plane_ins_center"], 1e-5)
+            save(f"C_postselect_{kind}", idx=ref_idx, planes=r["pred_plane"], centers=r["pred_plane_ins_center"],
+                 areas=r["pred_plane_masks"].flatten(1).sum(1), scores=np.array([i["score"] for i in r["instances"]]),
+                 mask_rowsum=r["pred_plane_masks"].sum(2).to(torch.int32))
+
+        # ---- D pixel pose net + AIM on designed features ------------------------------------
+        print("[D] pixel pose net")
+        fa, fb = GI.feature_maps(41), GI.feature_maps(42)
+        _, cam, pf = head._PlaneCameraHead__forward_PixelCameraHead(fa, fb)
+        t_or, r_or, tf_or, rf_or, aff_or = O.pixel_pose_net(sd, fa, fb)
+        rep.check("posenet.trans", t_or, cam["pred_trans"], 2e-5)
+        rep.check("posenet.rot", r_or, cam["pred_rot"], 2e-5)
+        rep.check("posenet.trans_feat", tf_or, pf["trans_feat"], 2e-5)
+        rep.check("posenet.rots_feat", rf_or, pf["rots_feat"], 2e-5)
+        rot_in = cam["pred_rot"] if cam["pred_rot"][0, 0] >= 0 else -cam["pred_rot"]
+        _, rr, rfeat = head._PlaneCameraHead__forward_RotRecHead(rot_in)
+        _, rt, tfeat = head._PlaneCameraHead__forward_TransRecHead(cam["pred_trans"])
+        a_t, a_r, a_tf, a_rf = O.aim_reembed(sd, cam["pred_trans"], rot_in)
+        rep.check("aim.rot", a_r, rr, 2e-5); rep.check("aim.trans", a_t, rt, 2e-5)
+        rep.check("aim.rot_feat", a_rf, rfeat, 2e-5); rep.check("aim.trans_feat", a_tf, tfeat, 2e-5)
+        save("D_posenet", trans=cam["pred_trans"], rot=cam["pred_rot"], trans_feat=pf["trans_feat"],
+             rots_feat=pf["rots_feat"], aim_rot=rr, aim_trans=rt, aim_rot_feat=rfeat, aim_trans_feat=tfeat)
+
+        # ---- E matcher ----------------------------------------------------------------------
+        print("[E] matcher")
+        for n1, n2, seed in ((1, 1, 50), (5, 3, 51), (17, 40, 52), (32, 32, 53), (50, 50, 54)):
+            app1, app2, cam7, p1, p2 = GI.matcher_case(n1, n2, seed)
+            _, ls_ref = model.matching_head(app1[None], app2[None], cam7[None], p1[None], p2[None])
+            ls_or = O.matcher(sd, app1, app2, cam7, p1, p2, cfg)
+            rep.check(f"matcher.{n1}x{n2}.log_scores", ls_or, ls_ref[0], 2e-5)
+            A_ref = cm.get_assignment_matrix(ls_ref, 0.2)[0]
+            rep.check(f"matcher.{n1}x{n2}.assignment", O.assignment_matrix(ls_or, 0.2), A_ref, exact=True)
+            print(f"       matches: {int(A_ref.sum())}")
+            save(f"E_matcher_{n1}x{n2}", log_scores=ls_ref[0], assignment=A_ref)
+
+        # ---- F refine (neural one-plane RANSAC) ---------------------------------------------
+        print("[F] RANSAC refine")
+
+        def run_refine(mdl, sdict, nq, m, seed, cam_type):
+            hd = mdl.camera_head_list[0]
+            c = GI.refine_case(nq, m, seed)
+            ocfg = O.OracleConfig(num_queries=nq, out_cam_type=cam_type)
+            dev = torch.device("cpu")
+            kw = dict(planes1=c["planes1"][None], planes2=c["planes2"][None], pred_assignment_matrix=c["A"][None], device=dev)
+            gl, _, _ = hd.get_pred_geo_sequence(pred_cams=None, **kw)
+            gg, sc, mn = hd.get_pred_geo_sequence(pred_cams={"tran": c["init_trans"][None], "rot": c["init_rot"][None]}, **kw)
+            ga, _, _ = hd.get_pred_geo_sequence(pred_cams={"tran": torch.zeros(1, 3), "rot": c["init_rot"][None]}, **kw)
+            sig = (((gg[:, :, 0:1] * ga[:, :, 0:1]) >= 0).float() - 0.5) * 2.0
+            with quiet():
+                _, pr = hd._PlaneCameraHead__inference_PlaneCamRefHead(
+                    c["trans_feat"][None], c["rot_feat"][None], gg, sc, gt_pose=None, geo_sequence_local=gl,
+                    matched_nums=mn, out_cam_type=cam_type, sig_seq=sig, initial_rot=c["init_rot"][None],
+                    initial_trans=c["init_trans"][None])
+            o_gl, o_m = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq)
+            o_gg, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], c["init_trans"])
+            o_ga, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], torch.zeros(3))
+            o_sig = (((o_gg[:, 0:1] * o_ga[:, 0:1]) >= 0).float() - 0.5) * 2.0
+            tag = f"refine.nq{nq}.m{m}.{cam_type}"
+            assert o_m == mn[0] == m, (o_m, mn, m)
+            rep.check(tag + ".geo_local", o_gl, gl[0], 1e-6); rep.check(tag + ".geo_global", o_gg, gg[0], 1e-5)
+            rep.check(tag + ".sig", o_sig, sig[0], exact=True)
+            o = O.ransac_refine(sdict, c["trans_feat"], c["rot_feat"], o_gg, o_gl, o_sig, o_m, c["init_trans"], c["init_rot"], ocfg)
+            out = {"geo_global": gg[0], "sig": sig[0]}
+            for k, v in pr.items():
+                if k == "sig_seq":
+                    continue
+                assert k in o, k
+                rep.check(f"{tag}.{k}", o[k], v[0], 3e-5)
+                out[k] = v[0]
+            save(f"F_refine_nq{nq}_m{m}_{cam_type}", **out)
+
+        for m in (0, 1, 2, 7, 32, 50):
+            run_refine(model, sd, 50, m, 60 + m, "soft")
+        for ct in ("avg-all", "min-cost", "max-score"):
+            run_refine(model, sd, 50, 7, 67, ct)
+        sd64 = synth_state_dict(64)
+        with quiet():
+            model64 = ref_shim.build_reference_model(sd64, num_queries=64)
+        run_refine(model64, sd64, 64, 64, 164, "soft")
+        run_refine(model64, sd64, 64, 33, 133, "soft")
+
+        # ---- camera head D->E->F on designed planes + designed features ----------------------
+        print("[DEF] camera head")
+        for n1, n2, seed in ((12, 9, 70), (32, 32, 71), (1, 1, 72)):
+            app1, app2, _, p1, p2 = GI.matcher_case(n1, n2, seed)
+            fa, fb = GI.feature_maps(seed + 100), GI.feature_maps(seed + 200)
+            with quiet():
+                cams, _, _, ls, ass, _ = head(fa, fb, p1[None], p2[None], planeApp1=app1[None], planeApp2=app2[None],
+                                              matching_net=model.matching_head)
+            ocams, oass, aux = O.camera_head(sd, fa, fb, p1, p2, app1, app2, cfg)
+            out = {}
+            for k, v in cams.items():
+                rep.check(f"camhead.{n1}x{n2}.{k}.tran", ocams[k][0], v["tran"][0], 5e-5)
+                rep.check(f"camhead.{n1}x{n2}.{k}.rot", ocams[k][1], v["rot"][0], 5e-5)
+                out[k + "_tran"], out[k + "_rot"] = v["tran"][0], v["rot"][0]
+            for k, v in ass.items():
+                rep.check(f"camhead.{n1}x{n2}.{k}", oass[k], v[0], exact=True)
+                out[k] = v[0]
+            print(f"       m = {aux['matched_num']}")
+            save(f"DEF_camhead_{n1}x{n2}", log_scores=ls[0][0], **out)
+
+        # ---- end to end --------------------------------------------------------------------
+        print("[e2e]")
+        with quiet():
+            model_loose = ref_shim.build_reference_model(sd, LOOSE_OV)
+        for tag, mdl, ocfg, structured, idx in (("default_noise", model, cfg, False, 0),
+                                                ("loose_structured", model_loose, loose_cfg(), True, 0),
+                                                ("loose_structured", model_loose, loose_cfg(), True, 2)):
+            inp = [synth_pair(idx, structured=structured)]
+            with quiet():
+                r = mdl(inp)[0]
+            o = O.inference(sd, inp, ocfg)[0]
+            out = {}
+            for v in "01":
+                ref_idx = torch.tensor([int(i) for i in r[v]["pred_plane_oriIdxs"]])
+                rep.check(f"e2e.{tag}{idx}.v{v}.idx", o[v]["pred_plane_oriIdxs"], ref_idx, exact=True)
+                rep.check(f"e2e.{tag}{idx}.v{v}.planes", o[v]["pred_plane"], r[v]["pred_plane"], 5e-5)
+                mism = int((o[v]["pred_plane_masks"] != r[v]["pred_plane_masks"]).sum())
+                print(f"       view {v}: n={len(ref_idx)} mask mismatches {mism}")
+                assert mism <= 64
+                out[f"v{v}_idx"], out[f"v{v}_planes"] = ref_idx, r[v]["pred_plane"]
+                out[f"v{v}_areas"] = r[v]["pred_plane_masks"].flatten(1).sum(1)
+                out[f"v{v}_centers"] = r[v]["pred_plane_ins_center"]
+            for k in r:
+                if "camera" in k:
+                    rep.check(f"e2e.{tag}{idx}.{k}.tran", o[k]["tran"], r[k]["tran"], 5e-5)
+                    rep.check(f"e2e.{tag}{idx}.{k}.rot", o[k]["rot"], r[k]["rot"], 5e-5)
+                    out[k + "_tran"], out[k + "_rot"] = r[k]["tran"], r[k]["rot"]
+                if "assignment" in k:
+                    rep.check(f"e2e.{tag}{idx}.{k}", o[k], r[k], exact=True)
+                    out[k] = r[k]
+            save(f"e2e_{tag}_{idx}", **out)
+    worst = max(e for _, e, _ in rep.rows)
+    print(f"\n{len(rep.rows)} checks passed; worst relative error {worst:.2e}")
+
+
+if __name__ == "__main__":
+    if not ref_shim.reference_available():
+        sys.exit("reference tree not available: fixtures can only be regenerated in the build container")
+    main()

@@ -1,0 +1,151 @@
+"""Seeded generators of *designed* stage inputs, shared by oracle/gen_golden.py (which feeds them
+to the imported reference and stores only the OUTPUTS under tests/golden/) and by the tests
+(which regenerate the same inputs from the seed).  Pure data — no reference code involved.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.nn import functional as F
+
+
+def _g(seed: int) -> torch.Generator:
+    return torch.Generator().manual_seed(seed)
+
+
+def rand_unit_quat(g, w_nonneg=True) -> torch.Tensor:
+    q = F.normalize(torch.randn(4, generator=g), dim=0)
+    return -q if (w_nonneg and q[0] < 0) else q
+
+
+def rand_planes(n: int, g) -> torch.Tensor:
+    """n*d plane vectors [n,3], offsets in [0.5, 4]."""
+    nrm = F.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    d = 0.5 + 3.5 * torch.rand(n, 1, generator=g)
+    return nrm * d
+
+
+def quat_to_rotmat(q):
+    w, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+                         [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                         [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def consistent_planes(n1: int, n2: int, n_common: int, g, noise=0.02):
+    """Two plane sets related by a ground-truth pose on the first `n_common` (permuted) planes:
+    warp(view-1 plane) ~= flip(view-2 plane), so geometric matching terms are informative.
+    Returns planes1 [n1,3], planes2 [n2,3], perm (view-2 index of view-1 plane i, -1 if none), (t,q)."""
+    q = rand_unit_quat(g)
+    t = 0.4 * torch.randn(3, generator=g)
+    R = quat_to_rotmat(q)
+    flip = torch.tensor([1.0, -1.0, -1.0])
+    planes1 = rand_planes(n1, g)
+    planes2 = rand_planes(n2, g)
+    perm2 = torch.randperm(n2, generator=g)[:n_common]
+    idx1 = torch.randperm(n1, generator=g)[:n_common]
+    perm = torch.full((n1,), -1, dtype=torch.long)
+    for i1, i2 in zip(idx1.tolist(), perm2.tolist()):
+        p = planes1[i1] * flip
+        nrm = R @ (p / p.norm())
+        d = p.norm() + (t * nrm).sum()
+        glob = nrm * d + noise * torch.randn(3, generator=g)
+        planes2[i2] = glob * flip
+        perm[i1] = i2
+    return planes1, planes2, perm, (t, q)
+
+
+def matcher_case(n1: int, n2: int, seed: int):
+    """(app1 [n1,256], app2 [n2,256], cam7 [7]=(t,q), planes1, planes2): matched planes share
+    appearance (+1% noise) and geometry; the rest are distractors."""
+    g = _g(seed)
+    nc = max(min(n1, n2) - (min(n1, n2) // 4), 1) if min(n1, n2) > 1 else 1
+    planes1, planes2, perm, (t, q) = consistent_planes(n1, n2, nc, g)
+    app1 = torch.randn(n1, 256, generator=g)
+    app2 = torch.randn(n2, 256, generator=g)
+    for i1 in range(n1):
+        if perm[i1] >= 0:
+            app2[perm[i1]] = app1[i1] + 0.01 * torch.randn(256, generator=g)
+    # the matcher gets a perturbed pose, as it would from the pixel pose net
+    qn = F.normalize(q + 0.03 * torch.randn(4, generator=g), dim=0)
+    cam7 = torch.cat([t + 0.05 * torch.randn(3, generator=g), qn])
+    return app1, app2, cam7, planes1, planes2
+
+
+def refine_case(nq: int, m: int, seed: int, n1: int | None = None, n2: int | None = None):
+    """Inputs of the one-plane RANSAC stage: planes, a binary assignment with exactly m ones
+    (at most one per row/col), the re-embedded initial pose and its two 256-d features."""
+    g = _g(seed)
+    n1 = n1 if n1 is not None else max(m, 1) + (3 if m + 3 <= nq else 0)
+    n2 = n2 if n2 is not None else max(m, 1) + (1 if m + 1 <= nq else 0)
+    planes1, planes2, perm, (t, q) = consistent_planes(n1, n2, m, g, noise=0.05) if m > 0 else (
+        rand_planes(n1, g), rand_planes(n2, g), torch.full((n1,), -1, dtype=torch.long),
+        (0.4 * torch.randn(3, generator=g), rand_unit_quat(g)))
+    A = torch.zeros(n1, n2)
+    for i1 in range(n1):
+        if perm[i1] >= 0:
+            A[i1, perm[i1]] = 1.0
+    init_rot = F.normalize(q + 0.05 * torch.randn(4, generator=g), dim=0)
+    if init_rot[0] < 0:
+        init_rot = -init_rot
+    init_trans = t + 0.1 * torch.randn(3, generator=g)
+    trans_feat = F.relu(torch.randn(256, generator=g))
+    rot_feat = F.relu(torch.randn(256, generator=g))
+    return {"planes1": planes1, "planes2": planes2, "A": A, "init_trans": init_trans, "init_rot": init_rot,
+            "trans_feat": trans_feat, "rot_feat": rot_feat}
+
+
+def _blob_field(h, w, g, cells=6):
+    """Smooth random field in [-1,1] (bilinear up-sampling of a coarse random grid)."""
+    coarse = torch.rand(1, 1, cells, cells + 2, generator=g) * 2 - 1
+    return F.interpolate(coarse, size=(h, w), mode="bilinear", align_corners=True)[0, 0]
+
+
+def postselect_case(kind: str, seed: int, nq: int = 50, h: int = 120, w: int = 160):
+    """(pred_logits [nq,2], pred_params [nq,3], mask_logits [nq,h,w], query_feat [nq,256]).
+    kinds: 'multi' (several disjoint planes), 'none_pass' (no query beats the score threshold ->
+    arg-max fallback), 'all_overlap_rejected' (every candidate loses its area -> max-overlap
+    fallback), 'full' (every query is a plane)."""
+    g = _g(seed)
+    logits = torch.zeros(nq, 2)
+    logits[:, 1] = 2.0 + torch.rand(nq, generator=g)           # non-plane by default
+    params = rand_planes(nq, g)
+    feat = torch.randn(nq, 256, generator=g)
+    mask = -6.0 + 0.5 * torch.randn(nq, h, w, generator=g)
+    n_on = {"multi": min(9, nq), "none_pass": 4, "all_overlap_rejected": 5, "full": nq}[kind]
+    on = torch.randperm(nq, generator=g)[:n_on].sort().values
+    # label map: vertical/horizontal stripes of unequal width with wavy borders
+    lab = torch.zeros(h, w, dtype=torch.long)
+    cols = max(int(math.ceil(math.sqrt(n_on * w / h))), 1)
+    rows = int(math.ceil(n_on / cols))
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    wob = (_blob_field(h, w, g) * 4).round().long()
+    lab = (((yy + wob).clamp(0, h - 1) * rows) // h) * cols + ((xx + wob).clamp(0, w - 1) * cols) // w
+    lab = lab.clamp(max=n_on - 1)
+    for k, q in enumerate(on.tolist()):
+        inside = (lab == k).float()
+        mask[q] = (12.0 * inside - 6.0) + 0.8 * _blob_field(h, w, g) + 0.2 * torch.randn(h, w, generator=g)
+        if kind != "none_pass":
+            logits[q, 0] = 3.0 + 2.0 * torch.rand(1, generator=g).item()
+            logits[q, 1] = 0.0
+    if kind == "none_pass":
+        logits[:, 0] = 1.0 + 0.5 * torch.rand(nq, generator=g)  # p0 < 0.5 everywhere
+    if kind == "all_overlap_rejected":
+        # every "on" query is positive over the whole image -> original area = H*W while its
+        # owned area is ~1/n_on of that -> overlap << 0.6 for all
+        for k, q in enumerate(on.tolist()):
+            mask[q] = 3.0 + 2.0 * (lab == k).float() + 0.3 * _blob_field(h, w, g)
+    return logits, params, mask, feat
+
+
+def feature_maps(seed: int, h5: int = 15, w5: int = 20, batch: int = 1):
+    """Random non-negative res2..res5 maps (post-ReLU statistics) at strides 4..32."""
+    g = _g(seed)
+    out = {}
+    for name, c, s in (("res2", 256, 8), ("res3", 512, 4), ("res4", 1024, 2), ("res5", 2048, 1)):
+        x = torch.randn(batch, c, h5 * s, w5 * s, generator=g)
+        lowf = F.interpolate(torch.randn(batch, c, 4, 5, generator=g), size=(h5 * s, w5 * s), mode="bilinear",
+                             align_corners=False)
+        out[name] = F.relu(0.6 * x + 1.2 * lowf + 0.3)
+    return out
