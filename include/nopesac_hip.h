@@ -1,0 +1,213 @@
+/*
+ * nopesac_hip.h — C ABI of libnopesac_hip.so: the MI355X (gfx950) kernels behind NopeSAC's inference
+ * hot path.
+ *
+ * The reference (IceTTTb/NopeSAC) is pure Python on torch/cuDNN and has NO native interface
+ * (SURVEY.md fact 1); this ABI is therefore build-defined (SURVEY.md §8b last row).  Each entry point
+ * names the reference computation it replaces (path:line under NopeSAC_Net/modeling/).  The host side
+ * that binds it is nopesac_amd/_lib.py (ctypes); INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current device (tensor.data_ptr()); the caller owns all
+ *    buffers and allocates outputs; nothing is retained after return;
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *    enqueued on it, no call synchronises, so every call is capturable into a hipGraph;
+ *  - return value 0 = enqueued, <0 = argument error (NPS_E_*), >0 = hipError_t from the launch;
+ *  - activations are NHWC ("pixels x channels", channels contiguous); conv weights are
+ *    [Cout][KH][KW][Cin] (K-contiguous rows); token matrices are [rows][features] row-major;
+ *  - dtype codes: 0 = f32, 1 = bf16.  Accumulation is always f32.
+ *  - ragged per-pair sizes (n1, n2, m) live in int32 device arrays; padded rows are ignored/zeroed.
+ */
+#ifndef NOPESAC_HIP_H
+#define NOPESAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPS_DT_F32 0
+#define NPS_DT_BF16 1
+
+#define NPS_ACT_NONE 0
+#define NPS_ACT_RELU 1
+#define NPS_ACT_LEAKY 2   /* LeakyReLU(0.01), camera_modules.py:47 */
+#define NPS_ACT_SIGMOID 3
+
+#define NPS_E_ARG (-1)
+#define NPS_E_UNSUPPORTED (-2)
+
+/* library / ABI version (major*10000 + minor*100 + patch) */
+int nopesac_version(void);
+/* last error string of this thread's most recent failing call ("" if none) */
+const char* nopesac_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer with fused epilogue (MFMA).
+ *   y[b,oh,ow,n] = act( (sum_{kh,kw,c} x[b, oh*s-p+kh, ow*s-p+kw, c] * w[n,kh,kw,c]) * scale[n] + bias[n]
+ *                       + residual[b,oh,ow,n] )
+ * Replaces every torch conv2d/linear(+BN/bias/residual/activation) on the path: d2 ResNet-50
+ * (meta_arch/siamese_planeTR.py:456), planeTR_net/planeTR_head.py:126,148-162,209-215,
+ * camera_net/camera_modules.py:36-48,271-321, camera_net/camera_head.py:957-962,983-990,
+ * transformer linears, matching_net/matching_head.py:101-113.
+ *   in_dt/out_dt : NPS_DT_*; weights have dtype in_dt.
+ *   x_cstride / y_cstride / r_cstride : elements between consecutive pixels (>= channels) so that
+ *       inputs/outputs can live inside wider (concatenated) buffers.
+ *   w_bstride : elements between per-image weight sets (0 = shared weights).  With w_bstride != 0
+ *       the call is a batched GEMM  y[b] = x[b] * w[b]^T  (mask einsum planeTR_head.py:150, attention-
+ *       free correlations camera_head.py:1128, descriptor scores matching_head.py:113).
+ *   scale/bias : f32[Cout] or NULL; residual: out_dt NHWC or NULL.
+ */
+int nopesac_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
+                        const void* residual, void* y,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                        int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int64_t w_bstride,
+                        int act, int in_dt, int out_dt, void* stream);
+
+/* (x - mean[c]) / std[c], NCHW f32 -> NHWC (C padded with zeros to Cpad), out_dt f32/bf16.
+ * siamese_planeTR.py:85-89,534-542. */
+int nopesac_preprocess_nchw_to_nhwc(const float* x, void* y, const float* mean, const float* std,
+                                    int B, int C, int H, int W, int Cpad, int out_dt, void* stream);
+
+/* max-pool K x K / stride / pad on NHWC (d2 BasicStem 3/2/1; camera_head.py:81-87 2/2/0). */
+int nopesac_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int K, int stride, int pad,
+                         int dt, void* stream);
+
+/* y = act(bilinear_x2(x) [align_corners=False]) (+ addend) ; planeTR_head.py:225,246-250. */
+int nopesac_upsample2x_bilinear_nhwc(const void* x, const void* addend, void* y, int B, int H, int W, int C,
+                                     int act, int dt, void* stream);
+/* y = lateral + nearest_x2(x) ; camera_modules.py:346. */
+int nopesac_upsample2x_nearest_add_nhwc(const void* x, const void* lateral, void* y, int B, int H, int W,
+                                        int C, int dt, void* stream);
+
+/* GroupNorm(G groups, eps) [+ReLU] on NHWC, per image; camera_modules.py:271-303 (d2 get_norm "GN"). */
+int nopesac_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y,
+                           int B, int HW, int C, int G, float eps, int act, int dt, void* stream);
+
+/* y = LayerNorm(x [+ res]) * gamma + beta over the last dim D (<= 1024, multiple of 64);
+ * optional second output y2 = y + addend (addend row index = row % addend_rows), used for the
+ * "with_pos_embed" sums of transformer/transformer.py:180-199,304-321.  f32 only. */
+int nopesac_layernorm(const float* x, const float* res, const float* gamma, const float* beta,
+                      float* y, const float* addend, int addend_rows, float* y2,
+                      int rows, int D, float eps, void* stream);
+
+/* out = a + b (b row index = row % b_rows); f32. */
+int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream);
+
+/* row softmax over the last dim (<= 1024); camera_head.py:1131 (after the NHWC re-layout the 300
+ * view-2 positions are the channel dim). f32. */
+int nopesac_softmax_rows(const float* x, float* y, int rows, int D, void* stream);
+
+/* Multi-head softmax attention for short sequences (<= 512 keys), head dim 32.
+ *   o[b,i,h,:] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] ) v[b,j,h,:]
+ * q/k/v/o are row-major token matrices with arbitrary row strides (elements); batch b's rows start at
+ * b*Lq (resp. b*Lk).  qlen/klen: optional int32[B] of valid rows per batch (NULL = all);
+ * rows >= qlen[b] are written as zeros.  nn.MultiheadAttention (transformer/transformer.py:166,242-243)
+ * and FullAttention (transformer/gnn.py:19-44). f32. */
+int nopesac_attention_small(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                            const float* v, int64_t v_stride, float* o, int64_t o_stride,
+                            int B, int Lq, int Lk, int heads, float scale,
+                            const int32_t* qlen, const int32_t* klen, void* stream);
+
+/* gather rows of a [B, H*W, C] map into (w,h) order: y[b, w*H + h, :] = x[b, h*W + w, :]
+ * (camera_head.py:1120-1124). f32. */
+int nopesac_transpose_hw_rows(const float* x, float* y, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plane post-selection, fused (meta_arch/siamese_planeTR.py:625-803), per image.
+ *   cls_logits f32[B,nq,2]; mask_prob f32[B,h,w,nq] = sigmoid(mask logits) at 1/4 resolution;
+ *   params f32[B,nq,3]; query_feat f32[B,nq,D].
+ * Outputs (caller-allocated, per image b):
+ *   n_kept int32[B]; kept_idx int32[B,nq] (ascending query index, -1 padded);
+ *   planes f32[B,nq,3]; feats f32[B,nq,D]; scores f32[B,nq]; areas int32[B,nq]; centers f32[B,nq,2];
+ *   winner uint8[B,H,W]: low 7 bits = arg-max query id, bit 7 = weighted prob > mask_thr
+ *       (plane masks are decoded from it: mask_q = (id==q) & bit7, or id==q in the fallback case);
+ *   flags int32[B]: bit0 = zero_flag (no query passed the score test), bit1 = overlap fallback used.
+ *   work int32[B, 9*nq+8]: scratch, zeroed by the call.
+ */
+int nopesac_postselect_planes(const float* cls_logits, const float* mask_prob, const float* params,
+                              const float* query_feat,
+                              int B, int nq, int D, int h, int w, int H, int W,
+                              float score_thr, float mask_thr, float overlap_thr,
+                              int32_t* n_kept, int32_t* kept_idx, float* planes, float* feats, float* scores,
+                              int32_t* areas, float* centers, uint8_t* winner, int32_t* flags, int32_t* work,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Matching head tail: geometric priors + log-space Sinkhorn with dustbin + mutual-NN assignment,
+ * one persistent workgroup per pair (matching_net/matching_head.py:75-96,113-128,228-306;
+ * camera_net/camera_modules.py:15-34).
+ *   desc_dot f32[B,nq,nq] = D1.D2^T / sqrt(256) (from nopesac_conv2d_nhwc batched);
+ *   planes1/2 f32[B,nq,3]; cam7 f32[B,7] = (t, q); n1,n2 int32[B].
+ *   log_scores f32[B,nq+1,nq+1]: rows/cols [0,n) are planes, index nq is the dustbin, the rest -inf-like
+ *       padding (-1e30); assignment f32[B,nq,nq] in {0,1}.
+ */
+int nopesac_matcher_sinkhorn(const float* desc_dot, const float* planes1, const float* planes2,
+                             const float* cam7, const int32_t* n1, const int32_t* n2,
+                             const float* bin_score, float offset_mult, float normal_mult,
+                             int iters, float match_thr, int B, int nq,
+                             float* log_scores, float* assignment, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Neural one-plane RANSAC, wavefront-level parts (camera_net/camera_head.py:512-569,925-1115).
+ *
+ * geo_sequence: matched pairs in row-major order of `assignment` -> geo_local f32[B,nq,6],
+ *   geo_global f32[B,nq,6] (under init pose), sig f32[B,nq], geo_enc f32[B,nq,8] (the MLP input,
+ *   :937-957), m int32[B].  (:1352-1425, :568-569)
+ */
+int nopesac_geo_sequence(const float* assignment, const float* planes1, const float* planes2,
+                         const int32_t* n1, const int32_t* n2, const float* init_trans, const float* init_rot,
+                         int B, int nq, int warp_in_ref,
+                         float* geo_local, float* geo_global, float* sig, float* geo_enc, int32_t* m,
+                         void* stream);
+
+/* hypothesis scoring maps (:990-1006,1018-1035): for pair b, hypothesis h in [0,nq] (0 = initial pose,
+ * h>=1 from rot_raw/trans_raw row h-1) and matched pair j in [0,nq):
+ *   normal_score[b,h,j] = exp(-|n(R_h p0_j) - n(flip p1_j)|) * mask, param_score[b,h,j] =
+ *   exp(-|warp(p0_j; R_h,t_h) - flip p1_j|) * mask, mask = (h<=m)&(j<m).
+ * Also writes rots_all f32[B,nq+1,4] (normalised) and trans_all f32[B,nq+1,3], and the diagnostic maps
+ * l2_dist / normal_angle / offset_dist f32[B,nq+1,nq] if non-NULL, and the row sums used by
+ * 'min-cost' (dn_sum, dl2_sum f32[B,nq+1]). */
+int nopesac_ransac_score_maps(const float* geo_local, const float* rot_raw, const float* trans_raw,
+                              const float* init_rot, const float* init_trans, const int32_t* m,
+                              int B, int nq,
+                              float* rots_all, float* trans_all, float* normal_score, float* param_score,
+                              float* l2_dist, float* normal_angle, float* offset_dist,
+                              float* dn_sum, float* dl2_sum, void* stream);
+
+/* masked softmax over the m+1 hypotheses + soft / average aggregation of the 256-d pose features +
+ * final pose regression (:1009-1014,1038-1087) and the m==0 / m<=1 special cases (:964-969,1068-1075).
+ *   score_feat_{rot,trans} f32[B,nq+1,64] (outputs of the score MLPs), reg_{rot,trans}_{w f32[64], b f32[1]};
+ *   init_{rot,trans}_feat f32[B,256]; fused_{rot,trans}_feat f32[B,nq,256] (already ReLU'd);
+ *   rots_{w f32[4,256], b f32[4]}, trans_{w f32[3,256], b f32[3]}.
+ *   mode: 0 soft, 1 avg-all, 2 min-cost, 3 max-score.
+ * Outputs: pred_rot f32[B,4], pred_trans f32[B,3], avg_rot f32[B,4], avg_trans f32[B,3],
+ *   score_rot/score_trans f32[B,nq+1]. */
+int nopesac_ransac_soft_vote(const float* score_feat_rot, const float* score_feat_trans,
+                             const float* reg_rot_w, const float* reg_rot_b,
+                             const float* reg_trans_w, const float* reg_trans_b,
+                             const float* init_rot_feat, const float* init_trans_feat,
+                             const float* fused_rot_feat, const float* fused_trans_feat,
+                             const float* rots_w, const float* rots_b, const float* trans_w, const float* trans_b,
+                             const float* rots_all, const float* trans_all, const float* dn_sum, const float* dl2_sum,
+                             const float* init_rot, const float* init_trans, const int32_t* m,
+                             int B, int nq, int mode,
+                             float* pred_rot, float* pred_trans, float* avg_rot, float* avg_trans,
+                             float* score_rot, float* score_trans, void* stream);
+
+/* assignment re-filter under the refined pose (:605-629): keep matches with normal angle < 45 deg and
+ * offset distance < 1; `rot` is sign-canonicalised inside (w >= 0). In/out f32[B,nq,nq]. */
+int nopesac_refilter_assignment(const float* assignment_in, const float* planes1, const float* planes2,
+                                const int32_t* n1, const int32_t* n2, const float* rot, const float* trans,
+                                int B, int nq, float* assignment_out, void* stream);
+
+/* small pose utilities on [B,*]: L2-normalise rows of a [rows,D] matrix (F.normalize, eps 1e-12),
+ * optionally flip the sign so that component 0 >= 0 (camera_head.py:436-437,695-696). */
+int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOPESAC_HIP_H */

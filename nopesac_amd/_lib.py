@@ -1,0 +1,79 @@
+"""ctypes binding of libnopesac_hip.so (the C ABI declared in include/nopesac_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved, importing
+the ops raises.  Build it with `python -m nopesac_amd.build` (or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnopesac_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "nopesac_hip.h")
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes (return type is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "nopesac_version": [],
+    "nopesac_last_error": [],
+    "nopesac_conv2d_nhwc": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, P],
+    "nopesac_preprocess_nchw_to_nhwc": [P, P, P, P, I, I, I, I, I, I, P],
+    "nopesac_maxpool_nhwc": [P, P, I, I, I, I, I, I, I, I, P],
+    "nopesac_upsample2x_bilinear_nhwc": [P, P, P, I, I, I, I, I, I, P],
+    "nopesac_upsample2x_nearest_add_nhwc": [P, P, P, I, I, I, I, I, P],
+    "nopesac_groupnorm_nhwc": [P, P, P, P, I, I, I, I, F, I, I, P],
+    "nopesac_layernorm": [P, P, P, P, P, P, I, P, I, I, F, P],
+    "nopesac_add_rows": [P, P, P, I, I, I, P],
+    "nopesac_softmax_rows": [P, P, I, I, P],
+    "nopesac_attention_small": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
+    "nopesac_transpose_hw_rows": [P, P, I, I, I, I, P],
+    "nopesac_postselect_planes": [P, P, P, P, I, I, I, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P, P, P, P],
+    "nopesac_matcher_sinkhorn": [P, P, P, P, P, P, P, F, F, I, F, I, I, P, P, P],
+    "nopesac_geo_sequence": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
+    "nopesac_ransac_score_maps": [P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P],
+    "nopesac_ransac_soft_vote": [P] * 21 + [I, I, I] + [P] * 6 + [P],
+    "nopesac_refilter_assignment": [P, P, P, P, P, P, P, I, I, P, P],
+    "nopesac_normalize_rows": [P, P, I, I, I, P],
+}
+_RESTYPE = {"nopesac_last_error": c_char_p}
+
+_lib = None
+
+
+def declared_symbols() -> list:
+    """Every entry point include/nopesac_hip.h declares."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nopesac_\w+)\s*\(", text)))
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -m nopesac_amd.build` "
+            "(needs hipcc for gfx950).  nopesac_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def check(rc: int, name: str):
+    if rc != 0:
+        msg = load().nopesac_last_error()
+        raise HipKernelError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

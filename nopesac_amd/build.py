@@ -1,0 +1,66 @@
+"""Build libnopesac_hip.so (gfx950) in-tree with hipcc.  `python -m nopesac_amd.build [--force]`."""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnopesac_hip.so")
+OBJ = os.path.join(CSRC, "_obj")
+SOURCES = ["capi.hip", "conv_igemm.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
+           "ransac.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in sorted(os.listdir(CSRC)) + ["../../include/nopesac_hip.h"]:
+        p = os.path.join(CSRC, name)
+        if os.path.isfile(p) and (name.endswith((".hip", ".h"))):
+            h.update(name.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    stamp = os.path.join(OBJ, "digest.txt")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    cc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,103 @@
+// Shared helpers for the gfx950 kernels of libnopesac_hip.so (not a public header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nopesac_hip.h"
+
+namespace nps {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case NPS_ACT_RELU: return v > 0.f ? v : 0.f;
+        case NPS_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        case NPS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// quaternion (w,x,y,z) -> row-major 3x3 (camera_head.py:1148-1173)
+__device__ __forceinline__ void quat_to_rot(const float q[4], float R[9]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+    R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
+    R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
+}
+
+// warp a view-1 plane vector p (= n*d, camera frame) into the common frame under (R,t)
+// (camera_head.py:1446-1454): end = R*flip(p) + t; b = end - t; out = ((end.b)/(|b|+1e-5)^2) b
+__device__ __forceinline__ void warp_plane(const float p[3], const float R[9], const float t[3], float out[3]) {
+    const float f0 = p[0], f1 = -p[1], f2 = -p[2];
+    float e[3], b[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // keep torch's bmm order: ((R[i0]*f0 + R[i1]*f1) + R[i2]*f2), then + t
+        float s = __fmul_rn(R[3 * i], f0);
+        s = __fmaf_rn(R[3 * i + 1], f1, s);
+        s = __fmaf_rn(R[3 * i + 2], f2, s);
+        e[i] = __fadd_rn(s, t[i]);
+        b[i] = __fsub_rn(e[i], t[i]);
+    }
+    const float dot = e[0] * b[0] + e[1] * b[1] + e[2] * b[2];
+    const float nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]) + 1e-5f;
+    const float c = dot / (nb * nb);
+    out[0] = c * b[0]; out[1] = c * b[1]; out[2] = c * b[2];
+}
+
+__device__ __forceinline__ float norm3(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+// F.normalize(p=2, eps=1e-12)
+__device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
+    const float n = fmaxf(norm3(v), 1e-12f);
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+
+void set_error(const char* fmt, ...);
+
+}  // namespace nps
+
+#define NPS_CHECK_ARG(cond, ...)               \
+    do {                                       \
+        if (!(cond)) {                         \
+            nps::set_error(__VA_ARGS__);       \
+            return NPS_E_ARG;                  \
+        }                                      \
+    } while (0)
+
+#define NPS_LAUNCH_RET()                                                   \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            nps::set_error("launch failed: %s", hipGetErrorString(e__));   \
+            return (int)e__;                                               \
+        }                                                                  \
+        return 0;                                                          \
+    } while (0)

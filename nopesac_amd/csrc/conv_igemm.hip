@@ -1,0 +1,293 @@
+// Implicit-GEMM NHWC convolution / linear layer on the CDNA4 matrix cores, fused epilogue.
+//
+//   GEMM view: M = B*OH*OW output pixels, N = Cout, K = KH*KW*Cin, A = im2col(x) gathered on the fly,
+//   B^T = w [N][K] (K contiguous), C -> y NHWC.
+//
+// Structure (one 256-thread workgroup = 4 waves in a 2x2 grid, each wave owns a (BM/2)x(BN/2) tile):
+//   global --(16-byte vectors, im2col address math per vector)--> registers --> LDS (double buffered,
+//   rows padded to 80 bytes so ds_read_b128 fragment reads are bank-conflict free) --> MFMA
+//   32x32x16 bf16 / 32x32x2 f32 with f32 accumulators --> scale/bias/residual/activation --> store.
+// The next K-tile's global loads are issued before the current tile's MFMAs (one barrier per K-tile).
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous run of tiles that share
+// A rows.
+#include "common.h"
+
+namespace nps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+    const void* x; const void* w; const float* scale; const float* bias; const void* res; void* y;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
+    long long x_cs, y_cs, r_cs, w_bs;
+    int M, N, K;       // M = rows per grid.y slice
+    int rows_per_b;    // OH*OW
+    int batched;       // 1: grid.y = batch index, per-batch weights
+    int act, out_dt;
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> { static constexpr int BK = 32; static constexpr int VECW = 8; };
+template <> struct Cfg<float> { static constexpr int BK = 16; static constexpr int VECW = 4; };
+
+template <typename T, int V> struct VecT;
+template <> struct VecT<bf16_t, 8> { typedef us8 type; };
+template <> struct VecT<bf16_t, 4> { typedef us4 type; };
+template <> struct VecT<bf16_t, 1> { typedef unsigned short type; };
+template <> struct VecT<float, 4> { typedef f32x4 type; };
+template <> struct VecT<float, 1> { typedef float type; };
+
+template <typename T, int BM, int BN, int VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int BK = Cfg<T>::BK;
+    constexpr int LDS_STRIDE = BK + Cfg<T>::VECW;          // elements; 80 bytes per row for both dtypes
+    constexpr int VPR = BK / VEC;                           // vectors per tile row
+    constexpr int A_VECS = BM * VPR / 256;                  // vectors per thread (A)
+    constexpr int B_VECS = BN * VPR / 256;
+    static_assert(BM * VPR % 256 == 0 && BN * VPR % 256 == 0, "tile/vec mismatch");
+    constexpr int WM = BM / 2, WN = BN / 2;                 // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;               // 32x32 MFMA tiles per wave
+    typedef typename VecT<T, VEC>::type vec_t;
+
+    __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * LDS_STRIDE];
+    constexpr int BUF_ELEMS = (BM + BN) * LDS_STRIDE;    // A tile then B tile, per buffer
+
+    // ---- XCD-aware tile mapping: block id -> contiguous chunk per XCD (bijective form)
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int bz = p.batched ? blockIdx.y : 0;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ Wt = (const T*)p.w + (long long)bz * p.w_bs;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- per-thread A row bookkeeping (rows are fixed across K-tiles)
+    long long a_base[A_VECS];   // element offset of pixel (b, ih0, iw0) channel 0; may point outside (checked per tap)
+    int a_ih0[A_VECS], a_iw0[A_VECS];
+    bool a_ok[A_VECS];
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) {
+        const int v = tid + i * 256;
+        const int row = v / VPR;
+        int m = m0 + row;
+        a_ok[i] = m < p.M;
+        if (!a_ok[i]) m = 0;
+        const int mg = m + bz * p.rows_per_b;          // global pixel index
+        const int b = mg / p.rows_per_b, rem = mg % p.rows_per_b;
+        const int oh = rem / p.OW, ow = rem % p.OW;
+        a_ih0[i] = oh * p.stride - p.pad;
+        a_iw0[i] = ow * p.stride - p.pad;
+        a_base[i] = (long long)b * p.H * p.W;
+    }
+    const bool is1x1 = (p.KH == 1 && p.KW == 1);
+
+    vec_t a_reg[A_VECS], b_reg[B_VECS];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) {
+            const int v = tid + i * 256;
+            const int kv = v % VPR;
+            const int k = kt * BK + kv * VEC;
+            vec_t val = vec_t{};
+            if (a_ok[i] && k < p.K) {
+                int c = k, ih = a_ih0[i], iw = a_iw0[i];
+                if (!is1x1) {
+                    const int tap = k / p.Cin;
+                    c = k - tap * p.Cin;
+                    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                    ih += kh; iw += kw;
+                }
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+                    const T* src = X + (a_base[i] + (long long)ih * p.W + iw) * p.x_cs + c;
+                    val = *(const vec_t*)src;
+                }
+            }
+            a_reg[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < B_VECS; ++i) {
+            const int v = tid + i * 256;
+            const int row = v / VPR, kv = v % VPR;
+            const int n = n0 + row, k = kt * BK + kv * VEC;
+            vec_t val = vec_t{};
+            if (n < p.N && k < p.K) val = *(const vec_t*)(Wt + (long long)n * p.K + k);
+            b_reg[i] = val;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) {
+            const int v = tid + i * 256;
+            *(vec_t*)(lds + buf * BUF_ELEMS + (v / VPR) * LDS_STRIDE + (v % VPR) * VEC) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_VECS; ++i) {
+            const int v = tid + i * 256;
+            *(vec_t*)(lds + buf * BUF_ELEMS + (BM + v / VPR) * LDS_STRIDE + (v % VPR) * VEC) = b_reg[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const T* Ab = lds + buf * BUF_ELEMS + (wm * WM + (lane & 31)) * LDS_STRIDE;
+        const T* Bb = lds + buf * BUF_ELEMS + (BM + wn * WN + (lane & 31)) * LDS_STRIDE;
+        if constexpr (sizeof(T) == 2) {
+            // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) .. +8], same for B^T
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[TM], bfr[TN];
+                const int ko = kk * 16 + (lane >> 5) * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(Ab + i * 32 * LDS_STRIDE + ko);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(Bb + j * 32 * LDS_STRIDE + ko);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // v_mfma_f32_32x32x2_f32 (exact f32): lane l supplies A[row l&31][k = l>>5]; we feed it the
+            // k-slots {4h+s, h=l>>5} for s=0..3 from one 16-byte fragment read (any consistent A/B k
+            // pairing is a valid contraction order).
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 af[TM], bfr[TN];
+                const int ko = kk * 8 + (lane >> 5) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * LDS_STRIDE + ko);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *(const f32x4*)(Bb + j * 32 * LDS_STRIDE + ko);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31, row_q = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + col_l;
+        if (n >= p.N) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + row_q;
+                if (m >= p.M) continue;
+                const long long pix = (long long)m + (long long)bz * p.rows_per_b;
+                float v = acc[i][j][r] * sc + bi;
+                if (p.res) {
+                    v += (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n]
+                                                  : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n]);
+                }
+                v = apply_act(v, p.act);
+                if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n] = v;
+                else ((bf16_t*)p.y)[pix * p.y_cs + n] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
+    ConvParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    dim3 grid(p.tiles_m * p.tiles_n, p.batched ? p.B : 1, 1);
+    constexpr int VW = Cfg<T>::VECW;
+    if (vec == VW) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, VW>), grid, dim3(256), 0, stream, p);
+    else if (sizeof(T) == 2 && vec == 4) {
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, 4>), grid, dim3(256), 0, stream, p);
+    } else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, 1>), grid, dim3(256), 0, stream, p);
+    return 0;
+}
+
+template <typename T>
+static int launch_dtype(const ConvParams& p, hipStream_t stream) {
+    // widest vector such that every vector stays inside one (kh,kw) tap and is 16/8-byte aligned
+    int vec = 1;
+    constexpr int VW = Cfg<T>::VECW;
+    auto ok = [&](int v) {
+        return p.Cin % v == 0 && p.K % v == 0 && p.x_cs % v == 0 && p.w_bs % v == 0 &&
+               ((uintptr_t)p.x % (v * sizeof(T)) == 0) && ((uintptr_t)p.w % (v * sizeof(T)) == 0);
+    };
+    if (ok(VW)) vec = VW;
+    else if (sizeof(T) == 2 && ok(4)) vec = 4;
+    const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batched ? p.B : 1);
+    if (p.N > 64 && tiles128 >= 192) return launch_cfg<T, 128, 128>(p, stream, vec);
+    return launch_cfg<T, 64, 64>(p, stream, vec);
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
+                                   const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride,
+                                   int64_t r_cstride, int64_t w_bstride, int act, int in_dt, int out_dt,
+                                   void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && w && y, "conv2d: null pointer");
+    NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+                  "conv2d: bad dims B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d", B, H, W, Cin, Cout, KH, KW, stride, pad);
+    NPS_CHECK_ARG(in_dt == NPS_DT_F32 || in_dt == NPS_DT_BF16, "conv2d: bad in_dt %d", in_dt);
+    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d: bad out_dt %d", out_dt);
+    NPS_CHECK_ARG(x_cstride >= Cin && y_cstride >= Cout, "conv2d: channel stride smaller than channel count");
+    NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d: residual stride");
+    NPS_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad act %d", act);
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    NPS_CHECK_ARG(p.OH > 0 && p.OW > 0, "conv2d: empty output");
+    p.x_cs = x_cstride; p.y_cs = y_cstride; p.r_cs = r_cstride; p.w_bs = w_bstride;
+    p.rows_per_b = p.OH * p.OW;
+    p.batched = w_bstride != 0;
+    p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
+    p.N = Cout; p.K = KH * KW * Cin;
+    p.act = act; p.out_dt = out_dt;
+    if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t>(p, (hipStream_t)stream);
+    else launch_dtype<float>(p, (hipStream_t)stream);
+    NPS_LAUNCH_RET();
+}

@@ -1,0 +1,348 @@
+// HBM-bound NHWC / row kernels around the GEMMs: preprocessing, pooling, up-sampling, GroupNorm,
+// LayerNorm, row softmax, small re-layouts.  All are streaming kernels: channels are the fastest
+// dimension, so a wave touches contiguous bytes; reductions use wave shuffles (+LDS across waves).
+#include "common.h"
+
+namespace nps {
+
+// ---------------------------------------------------------------------------------------------
+// (x - mean)/std, NCHW f32 -> NHWC(Cpad)
+template <typename T>
+__global__ void preprocess_kernel(const float* __restrict__ x, T* __restrict__ y, const float* __restrict__ mean,
+                                  const float* __restrict__ stdv, int B, int C, int H, int W, int Cpad) {
+    const long long npix = (long long)B * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)H * W), hw = i % ((long long)H * W);
+        for (int c = 0; c < Cpad; ++c) {
+            float v = 0.f;
+            if (c < C) v = (x[(b * C + c) * H * W + hw] - mean[c]) / stdv[c];
+            y[i * Cpad + c] = from_f32<T>(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int K,
+                               int stride, int pad, int OH, int OW) {
+    const long long total = (long long)B * OH * OW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long long pix = i / C;
+        const int ow = pix % OW; pix /= OW;
+        const int oh = pix % OH;
+        const int b = pix / OH;
+        float m = -INFINITY;
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = oh * stride - pad + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = ow * stride - pad + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                m = fmaxf(m, to_f32<T>(x[(((long long)b * H + ih) * W + iw) * C + c]));
+            }
+        }
+        y[i] = from_f32<T>(m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear x2, align_corners=False: src = 0.5*(dst+0.5)-0.5, clamped at 0 (PyTorch
+// area_pixel_compute_source_index), i1 = min(i0+1, size-1)
+template <typename T>
+__global__ void upsample_bilinear2x_kernel(const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
+                                           int B, int H, int W, int C, int act) {
+    const int OH = 2 * H, OW = 2 * W;
+    const long long total = (long long)B * OH * OW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long long pix = i / C;
+        const int ow = pix % OW; pix /= OW;
+        const int oh = pix % OH;
+        const int b = pix / OH;
+        float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const long long base = (long long)b * H * W;
+        const float v00 = to_f32<T>(x[((base + (long long)y0 * W + x0)) * C + c]);
+        const float v01 = to_f32<T>(x[((base + (long long)y0 * W + x1)) * C + c]);
+        const float v10 = to_f32<T>(x[((base + (long long)y1 * W + x0)) * C + c]);
+        const float v11 = to_f32<T>(x[((base + (long long)y1 * W + x1)) * C + c]);
+        float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        v = apply_act(v, act);
+        if (addend) v += to_f32<T>(addend[i]);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void upsample_nearest2x_add_kernel(const T* __restrict__ x, const T* __restrict__ lat, T* __restrict__ y,
+                                              int B, int H, int W, int C) {
+    const int OH = 2 * H, OW = 2 * W;
+    const long long total = (long long)B * OH * OW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long long pix = i / C;
+        const int ow = pix % OW; pix /= OW;
+        const int oh = pix % OH;
+        const int b = pix / OH;
+        const float v = to_f32<T>(lat[i]) + to_f32<T>(x[(((long long)b * H + (oh >> 1)) * W + (ow >> 1)) * C + c]);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm on NHWC: one workgroup per (image, group-chunk); two passes (mean, then centred variance)
+// over an L2-resident map, then the normalise pass.  blockDim = 256, each thread owns channel
+// (tid % CPB) of the chunk and strides over pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int HW,
+                                                        int C, int G, float eps, int act, int groups_per_block) {
+    const int cpg = C / G;                       // channels per group
+    const int CPB = cpg * groups_per_block;      // channels per block (<= 256, divides 256)
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c_local = threadIdx.x % CPB, prow = threadIdx.x / CPB, nprow = 256 / CPB;
+    const int c = chunk * CPB + c_local;
+    const int g_local = c_local / cpg;
+    const T* xb = x + (long long)b * HW * C;
+    T* yb = y + (long long)b * HW * C;
+    __shared__ float red[256];
+    __shared__ float stat[64];
+    const float cnt = (float)HW * cpg;
+    // pass 1: mean
+    float s = 0.f;
+    for (int p = prow; p < HW; p += nprow) s += to_f32<T>(xb[(long long)p * C + c]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < groups_per_block) {
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i)
+            if ((i % CPB) / cpg == (int)threadIdx.x) t += red[i];
+        stat[threadIdx.x] = t / cnt;
+    }
+    __syncthreads();
+    const float mean = stat[g_local];
+    // pass 2: variance
+    float s2 = 0.f;
+    for (int p = prow; p < HW; p += nprow) {
+        const float d = to_f32<T>(xb[(long long)p * C + c]) - mean;
+        s2 += d * d;
+    }
+    __syncthreads();
+    red[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < groups_per_block) {
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i)
+            if ((i % CPB) / cpg == (int)threadIdx.x) t += red[i];
+        stat[32 + threadIdx.x] = rsqrtf(t / cnt + eps);
+    }
+    __syncthreads();
+    const float rstd = stat[32 + g_local];
+    const float ga = gamma[c] * rstd, be = beta[c] - mean * gamma[c] * rstd;
+    for (int p = prow; p < HW; p += nprow) {
+        const float v = to_f32<T>(xb[(long long)p * C + c]) * ga + be;
+        yb[(long long)p * C + c] = from_f32<T>(apply_act(v, act));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over D (one wave per row), optional residual, optional second output y + addend
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, const float* __restrict__ addend,
+                                                        int addend_rows, float* __restrict__ y2, int rows, int D,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int per = D / 64;  // <= 16
+    float v[16];
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        const int d = lane + i * 64;
+        float t = x[(long long)row * D + d];
+        if (res) t += res[(long long)row * D + d];
+        v[i] = t;
+        s += t;
+    }
+    const float mean = wave_sum(s) / D;
+    float s2 = 0.f;
+    for (int i = 0; i < per; ++i) {
+        const float d = v[i] - mean;
+        s2 += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / D + eps);
+    for (int i = 0; i < per; ++i) {
+        const int d = lane + i * 64;
+        const float o = (v[i] - mean) * rstd * gamma[d] + beta[d];
+        y[(long long)row * D + d] = o;
+        if (y2) y2[(long long)row * D + d] = o + addend[(long long)(row % addend_rows) * D + d];
+    }
+}
+
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                long long total, int D, int b_rows) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / D;
+        out[i] = a[i] + b[(row % b_rows) * D + (i % D)];
+    }
+}
+
+// row softmax, one wave per row, D <= 1024
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[16];
+    float m = -INFINITY;
+    const int per = (D + 63) / 64;
+    for (int i = 0; i < per; ++i) {
+        const int d = lane + i * 64;
+        v[i] = d < D ? x[(long long)row * D + d] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = expf(v[i] - m);
+        s += v[i];
+    }
+    s = wave_sum(s);
+    for (int i = 0; i < per; ++i) {
+        const int d = lane + i * 64;
+        if (d < D) y[(long long)row * D + d] = v[i] / s;
+    }
+}
+
+__global__ void transpose_hw_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
+                                         int C) {
+    const long long total = (long long)B * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        long long r = i / C;
+        const int hw = r % (H * W);
+        const int b = r / (H * W);
+        const int wi = hw / H, hi = hw % H;  // output row index = w*H + h
+        y[i] = x[(((long long)b * H + hi) * W + wi) * C + c];
+    }
+}
+
+__global__ void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int D, int canon) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += x[row * D + d] * x[row * D + d];
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+    float sign = 1.f;
+    if (canon && x[row * D] / n < 0.f) sign = -1.f;
+    for (int d = 0; d < D; ++d) y[row * D + d] = sign * (x[row * D + d] / n);
+}
+
+static inline int grid_for(long long total, int block = 256) {
+    long long g = (total + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace nps
+
+using namespace nps;
+
+extern "C" int nopesac_preprocess_nchw_to_nhwc(const float* x, void* y, const float* mean, const float* stdv, int B,
+                                               int C, int H, int W, int Cpad, int out_dt, void* stream) {
+    NPS_CHECK_ARG(x && y && mean && stdv && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "preprocess: bad args");
+    const int g = grid_for((long long)B * H * W);
+    if (out_dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, mean, stdv, B, C, H, W, Cpad);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (float*)y, mean, stdv, B, C, H, W, Cpad);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_maxpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int K, int stride, int pad,
+                                    int dt, void* stream) {
+    NPS_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && stride > 0, "maxpool: bad args");
+    const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+    const int g = grid_for((long long)B * OH * OW * C);
+    if (dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, K, stride, pad, OH, OW);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C, K, stride, pad, OH, OW);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_upsample2x_bilinear_nhwc(const void* x, const void* addend, void* y, int B, int H, int W,
+                                                int C, int act, int dt, void* stream) {
+    NPS_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "upsample_bilinear: bad args");
+    const int g = grid_for((long long)B * 4 * H * W * C);
+    if (dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(upsample_bilinear2x_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)y, B, H, W, C, act);
+    else
+        hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)addend, (float*)y, B, H, W, C, act);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_upsample2x_nearest_add_nhwc(const void* x, const void* lateral, void* y, int B, int H, int W,
+                                                   int C, int dt, void* stream) {
+    NPS_CHECK_ARG(x && lateral && y && B > 0 && H > 0 && W > 0 && C > 0, "upsample_nearest: bad args");
+    const int g = grid_for((long long)B * 4 * H * W * C);
+    if (dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(upsample_nearest2x_add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)lateral, (bf16_t*)y, B, H, W, C);
+    else
+        hipLaunchKernelGGL(upsample_nearest2x_add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)lateral, (float*)y, B, H, W, C);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y, int B, int HW,
+                                      int C, int G, float eps, int act, int dt, void* stream) {
+    NPS_CHECK_ARG(x && gamma && beta && y && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm: bad args");
+    const int cpg = C / G;
+    NPS_CHECK_ARG(cpg <= 256 && 256 % cpg == 0, "groupnorm: channels/group %d must divide 256", cpg);
+    int gpb = 256 / cpg / 16;  // 16 pixel rows per block
+    if (gpb < 1) gpb = 1;
+    while (G % gpb) --gpb;
+    while (256 % (cpg * gpb)) --gpb;
+    NPS_CHECK_ARG(gpb >= 1 && gpb <= 32, "groupnorm: cannot tile groups");
+    dim3 grid(G / gpb, B);
+    if (dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(groupnorm_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, HW, C, G, eps, act, gpb);
+    else
+        hipLaunchKernelGGL(groupnorm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta, (float*)y, HW, C, G, eps, act, gpb);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                 const float* addend, int addend_rows, float* y2, int rows, int D, float eps,
+                                 void* stream) {
+    NPS_CHECK_ARG(x && gamma && beta && y && rows > 0 && D > 0 && D % 64 == 0 && D <= 1024, "layernorm: bad args (D=%d)", D);
+    NPS_CHECK_ARG(!y2 || (addend && addend_rows > 0), "layernorm: y2 needs addend");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, addend, addend_rows, y2, rows, D, eps);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream) {
+    NPS_CHECK_ARG(a && b && out && rows > 0 && D > 0 && b_rows > 0, "add_rows: bad args");
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for((long long)rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)rows * D, D, b_rows);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_softmax_rows(const float* x, float* y, int rows, int D, void* stream) {
+    NPS_CHECK_ARG(x && y && rows > 0 && D > 0 && D <= 1024, "softmax_rows: bad args");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, rows, D);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_transpose_hw_rows(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    NPS_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "transpose_hw_rows: bad args");
+    hipLaunchKernelGGL(transpose_hw_rows_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream) {
+    NPS_CHECK_ARG(x && y && rows > 0 && D > 0, "normalize_rows: bad args");
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, y, rows, D, canonical_sign);
+    NPS_LAUNCH_RET();
+}

@@ -1,0 +1,238 @@
+// Matching-head tail, one persistent workgroup per image pair:
+//   geometric priors (matching_head.py:75-96)  ->  scores = D1.D2^T/16 - offset/4 - angle/8 (:113-119)
+//   -> log-space Sinkhorn with a dustbin row/column, 200 iterations (:228-234, 259-306)
+//   -> mutual-nearest-neighbour assignment with exp(score) > thr (camera_modules.py:15-34).
+// The reference issues ~400 dependent tiny kernels for the Sinkhorn loop; here the whole (n1+1)x(n2+1)
+// coupling matrix lives in LDS for the entire loop (<= 129x131 fp32 = 66 KB) and each iteration is two
+// barrier-separated passes of group-of-lanes log-sum-exp reductions (wave shuffles, no atomics).
+#include "common.h"
+
+namespace nps {
+
+constexpr float NEG_PAD = -1e30f;
+
+__device__ __forceinline__ float group_max(float v, int tg) {
+    for (int o = tg >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group_sum(float v, int tg) {
+    for (int o = tg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
+    const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
+    const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
+    const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
+    float* __restrict__ log_scores, float* __restrict__ assignment) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = nq + 1;
+    const int LD = (R & 1) ? R : R + 1;            // odd leading dimension: column walks hit distinct banks
+    float* Z = smem;                               // R*LD
+    float* u = Z + R * LD;                         // R
+    float* v = u + R;                              // R
+    float* lmu = v + R;                            // R
+    float* lnu = lmu + R;                          // R
+    float* g1r = lnu + R;                          // nq*3 normals of view-1 planes warped by (R,0)
+    float* g1rt = g1r + 3 * nq;                    // nq*3 normals warped by (R,t)
+    float* o1 = g1rt + 3 * nq;                     // nq offsets (R,t)
+    float* g2 = o1 + nq;                           // nq*3 flipped view-2 normals
+    float* o2 = g2 + 3 * nq;                       // nq
+    float* max0 = o2 + nq;                         // R
+    int* idx0 = (int*)(max0 + R);                  // R
+    int* idx1 = idx0 + R;                          // R
+
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    const int R1 = n1 + 1, C1 = n2 + 1;
+    const float* cam = cam7 + 7 * b;
+    // ---- per-plane geometry
+    if (tid < nq) {
+        const int i = tid;
+        if (i < n1) {
+            float Rm[9], q[4] = {cam[3], cam[4], cam[5], cam[6]}, t[3] = {cam[0], cam[1], cam[2]}, z[3] = {0.f, 0.f, 0.f};
+            quat_to_rot(q, Rm);
+            float p[3] = {planes1[((long long)b * nq + i) * 3], planes1[((long long)b * nq + i) * 3 + 1], planes1[((long long)b * nq + i) * 3 + 2]};
+            // reference multiplies the translation by 0 (matching_head.py:82): t*0 keeps the sign of zero only
+            float wr[3], wrt[3], nr[3], nrt[3];
+            warp_plane(p, Rm, z, wr);
+            warp_plane(p, Rm, t, wrt);
+            normalize3(wr, nr);
+            normalize3(wrt, nrt);
+            for (int d = 0; d < 3; ++d) { g1r[3 * i + d] = nr[d]; g1rt[3 * i + d] = nrt[d]; }
+            o1[i] = norm3(wrt);
+        }
+        if (i < n2) {
+            float p[3] = {planes2[((long long)b * nq + i) * 3], -planes2[((long long)b * nq + i) * 3 + 1], -planes2[((long long)b * nq + i) * 3 + 2]};
+            float nn[3];
+            normalize3(p, nn);
+            for (int d = 0; d < 3; ++d) g2[3 * i + d] = nn[d];
+            o2[i] = norm3(p);
+        }
+    }
+    __syncthreads();
+    // ---- couplings
+    const float bin = bin_score[0];
+    const float* dd = desc_dot + (long long)b * nq * nq;
+    for (int e = tid; e < R1 * C1; e += 256) {
+        const int i = e / C1, j = e % C1;
+        float val = bin;
+        if (i < n1 && j < n2) {
+            const float ntn_r = g1r[3 * i] * g2[3 * j] + g1r[3 * i + 1] * g2[3 * j + 1] + g1r[3 * i + 2] * g2[3 * j + 2];
+            const float ang = acosf(fminf(fmaxf(ntn_r, -1.f), 1.f)) / 3.14159265358979323846f * 180.f;
+            const float ntn_rt = g1rt[3 * i] * g2[3 * j] + g1rt[3 * i + 1] * g2[3 * j + 1] + g1rt[3 * i + 2] * g2[3 * j + 2];
+            float off = ntn_rt < 0.f ? fabsf(o1[i] + o2[j]) : fabsf(o1[i] - o2[j]);
+            off = fminf(fmaxf(off, 1e-10f), 5.f);
+            val = dd[i * nq + j] - off / offset_mult - ang / normal_mult;
+        }
+        Z[i * LD + j] = val;
+    }
+    const float norm = -logf((float)(n1 + n2));
+    for (int i = tid; i < R; i += 256) {
+        u[i] = 0.f; v[i] = 0.f;
+        lmu[i] = i < n1 ? norm : logf((float)n2) + norm;
+        lnu[i] = i < n2 ? norm : logf((float)n1) + norm;
+    }
+    __syncthreads();
+    // ---- Sinkhorn: lane groups of tg lanes per row / column
+    const int big = max(R1, C1);
+    int tg = 64;
+    while (tg > 1 && (256 / tg) < big) tg >>= 1;       // largest pow2 group with enough groups; may still need >1 pass
+    const int ngroups = 256 / tg, grp = tid / tg, gl = tid % tg;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = grp; i < ((R1 + ngroups - 1) / ngroups) * ngroups; i += ngroups) {
+            const bool ok = i < R1;
+            float m = -INFINITY;
+            if (ok) for (int j = gl; j < C1; j += tg) m = fmaxf(m, Z[i * LD + j] + v[j]);
+            m = group_max(m, tg);
+            float s = 0.f;
+            if (ok) for (int j = gl; j < C1; j += tg) s += expf(Z[i * LD + j] + v[j] - m);
+            s = group_sum(s, tg);
+            if (ok && gl == 0) u[i] = lmu[i] - (m + logf(s));
+        }
+        __syncthreads();
+        for (int j = grp; j < ((C1 + ngroups - 1) / ngroups) * ngroups; j += ngroups) {
+            const bool ok = j < C1;
+            float m = -INFINITY;
+            if (ok) for (int i = gl; i < R1; i += tg) m = fmaxf(m, Z[i * LD + j] + u[i]);
+            m = group_max(m, tg);
+            float s = 0.f;
+            if (ok) for (int i = gl; i < R1; i += tg) s += expf(Z[i * LD + j] + u[i] - m);
+            s = group_sum(s, tg);
+            if (ok && gl == 0) v[j] = lnu[j] - (m + logf(s));
+        }
+        __syncthreads();
+    }
+    // ---- final scores (kept in LDS for the assignment) + padded output
+    for (int e = tid; e < R1 * C1; e += 256) {
+        const int i = e / C1, j = e % C1;
+        Z[i * LD + j] = Z[i * LD + j] + u[i] + v[j] - norm;
+    }
+    __syncthreads();
+    float* out = log_scores + (long long)b * R * R;
+    for (int e = tid; e < R * R; e += 256) {
+        const int i = e / R, j = e % R;
+        const int si = i < n1 ? i : (i == nq ? n1 : -1), sj = j < n2 ? j : (j == nq ? n2 : -1);
+        out[e] = (si >= 0 && sj >= 0) ? Z[si * LD + sj] : NEG_PAD;
+    }
+    // ---- mutual nearest neighbours over the plane block
+    for (int i = tid; i < n1; i += 256) {
+        float m = -INFINITY; int a = 0;
+        for (int j = 0; j < n2; ++j) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = j; } }
+        max0[i] = m; idx0[i] = a;
+    }
+    for (int j = tid; j < n2; j += 256) {
+        float m = -INFINITY; int a = 0;
+        for (int i = 0; i < n1; ++i) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = i; } }
+        idx1[j] = a;
+    }
+    __syncthreads();
+    float* A = assignment + (long long)b * nq * nq;
+    for (int e = tid; e < nq * nq; e += 256) {
+        const int i = e / nq, j = e % nq;
+        float a = 0.f;
+        if (i < n1 && j < n2 && n2 > 0 && idx0[i] == j && idx1[j] == i && expf(max0[i]) > match_thr) a = 1.f;
+        A[e] = a;
+    }
+}
+
+// assignment re-filter under the refined pose (camera_head.py:605-629)
+__global__ __launch_bounds__(256) void refilter_kernel(const float* __restrict__ Ain, const float* __restrict__ planes1,
+                                                       const float* __restrict__ planes2, const int* __restrict__ n1p,
+                                                       const int* __restrict__ n2p, const float* __restrict__ rot,
+                                                       const float* __restrict__ trans, int nq, float* __restrict__ Aout) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float g1r[128 * 3], g1rt[128 * 3], o1[128], g2[128 * 3], o2[128];
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    if (tid < nq) {
+        const int i = tid;
+        if (i < n1) {
+            float q[4] = {rot[4 * b], rot[4 * b + 1], rot[4 * b + 2], rot[4 * b + 3]};
+            if (q[0] < 0.f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }   // :600-601
+            float Rm[9], t[3] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2]}, z[3] = {0.f, 0.f, 0.f};
+            quat_to_rot(q, Rm);
+            float p[3] = {planes1[((long long)b * nq + i) * 3], planes1[((long long)b * nq + i) * 3 + 1], planes1[((long long)b * nq + i) * 3 + 2]};
+            float wr[3], wrt[3], nr[3], nrt[3];
+            warp_plane(p, Rm, z, wr);
+            warp_plane(p, Rm, t, wrt);
+            normalize3(wr, nr);
+            normalize3(wrt, nrt);
+            for (int d = 0; d < 3; ++d) { g1r[3 * i + d] = nr[d]; g1rt[3 * i + d] = nrt[d]; }
+            o1[i] = norm3(wrt);
+        }
+        if (i < n2) {
+            float p[3] = {planes2[((long long)b * nq + i) * 3], -planes2[((long long)b * nq + i) * 3 + 1], -planes2[((long long)b * nq + i) * 3 + 2]};
+            float nn[3];
+            normalize3(p, nn);
+            for (int d = 0; d < 3; ++d) g2[3 * i + d] = nn[d];
+            o2[i] = norm3(p);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nq * nq; e += 256) {
+        const int i = e / nq, j = e % nq;
+        float a = 0.f;
+        if (i < n1 && j < n2) {
+            const float ntn_r = g1r[3 * i] * g2[3 * j] + g1r[3 * i + 1] * g2[3 * j + 1] + g1r[3 * i + 2] * g2[3 * j + 2];
+            const float ang = acosf(fminf(fmaxf(ntn_r, -1.f), 1.f)) / 3.14159265358979323846f * 180.f;
+            const float ntn_rt = g1rt[3 * i] * g2[3 * j] + g1rt[3 * i + 1] * g2[3 * j + 1] + g1rt[3 * i + 2] * g2[3 * j + 2];
+            float off = ntn_rt < 0.f ? fabsf(o1[i] + o2[j]) : fabsf(o1[i] - o2[j]);
+            off = fminf(fmaxf(off, 1e-4f), 10.f);
+            a = Ain[(long long)b * nq * nq + e] * ((ang < 45.f && off < 1.f) ? 1.f : 0.f);
+        }
+        Aout[(long long)b * nq * nq + e] = a;
+    }
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_matcher_sinkhorn(const float* desc_dot, const float* planes1, const float* planes2,
+                                        const float* cam7, const int32_t* n1, const int32_t* n2,
+                                        const float* bin_score, float offset_mult, float normal_mult, int iters,
+                                        float match_thr, int B, int nq, float* log_scores, float* assignment,
+                                        void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(desc_dot && planes1 && planes2 && cam7 && n1 && n2 && bin_score && log_scores && assignment, "sinkhorn: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && iters >= 0, "sinkhorn: bad dims (nq<=128)");
+    const int R = nq + 1, LD = (R & 1) ? R : R + 1;
+    const size_t lds = sizeof(float) * ((size_t)R * LD + 4 * R + 11 * nq + R + 2 * R);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)matcher_sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(matcher_sinkhorn_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
+                       cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_refilter_assignment(const float* assignment_in, const float* planes1, const float* planes2,
+                                           const int32_t* n1, const int32_t* n2, const float* rot, const float* trans,
+                                           int B, int nq, float* assignment_out, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(assignment_in && planes1 && planes2 && n1 && n2 && rot && trans && assignment_out, "refilter: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "refilter: bad dims");
+    hipLaunchKernelGGL(refilter_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, assignment_in, planes1, planes2, n1, n2,
+                       rot, trans, nq, assignment_out);
+    NPS_LAUNCH_RET();
+}

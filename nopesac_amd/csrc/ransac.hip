@@ -1,0 +1,318 @@
+// Neural one-plane RANSAC, the wavefront-level (non-GEMM) parts (camera_net/camera_head.py):
+//   geo_sequence      : matched pairs -> padded geometry sequences + the 8-d MLP input     (:512-569, 937-957, 1352-1425)
+//   ransac_score_maps : (K+1) hypotheses x K matched planes: plane warps under each hypothesis,
+//                       normal / plane-parameter distances -> exp(-d) score rows           (:990-1006, 1018-1035)
+//   ransac_soft_vote  : score regression, masked softmax over the m+1 live hypotheses,
+//                       soft / uniform aggregation of 256-d pose features, pose regression  (:1009-1014, 1038-1099)
+// One workgroup per image pair; hypotheses x planes are spread over lanes, reductions over hypotheses /
+// feature dims use wave shuffles + a 4-entry LDS exchange.  The MLP stacks between these kernels are
+// MFMA GEMMs (conv_igemm.hip).
+#include "common.h"
+
+namespace nps {
+
+__global__ __launch_bounds__(128) void geo_sequence_kernel(
+    const float* __restrict__ A, const float* __restrict__ planes1, const float* __restrict__ planes2,
+    const int* __restrict__ n1p, const int* __restrict__ n2p, const float* __restrict__ init_trans,
+    const float* __restrict__ init_rot, int nq, int warp_in_ref, float* __restrict__ geo_local,
+    float* __restrict__ geo_global, float* __restrict__ sig, float* __restrict__ geo_enc, int* __restrict__ m_out) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    __shared__ int cnt[129];
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    const float* Ab = A + (long long)b * nq * nq;
+    int c = 0;
+    if (i < n1)
+        for (int j = 0; j < n2; ++j) c += Ab[i * nq + j] != 0.f;
+    cnt[i] = c;
+    __syncthreads();
+    if (i == 0) {   // exclusive prefix over <=128 rows
+        int run = 0;
+        for (int r = 0; r < 128; ++r) { const int t = cnt[r]; cnt[r] = run; run += t; }
+        cnt[128] = run;
+    }
+    __syncthreads();
+    const int m = min(cnt[128], nq);
+    if (i == 0) m_out[b] = m;
+    float Rm[9], q[4] = {init_rot[4 * b], init_rot[4 * b + 1], init_rot[4 * b + 2], init_rot[4 * b + 3]};
+    float t[3] = {init_trans[3 * b], init_trans[3 * b + 1], init_trans[3 * b + 2]}, z[3] = {0.f, 0.f, 0.f};
+    quat_to_rot(q, Rm);
+    if (i < n1) {
+        int k = cnt[i];
+        for (int j = 0; j < n2 && k < nq; ++j) {
+            if (Ab[i * nq + j] == 0.f) continue;
+            const long long o = (long long)b * nq + k;
+            float p1[3], p2[3], g1[3], ga[3];
+            for (int d = 0; d < 3; ++d) { p1[d] = planes1[((long long)b * nq + i) * 3 + d]; p2[d] = planes2[((long long)b * nq + j) * 3 + d]; }
+            warp_plane(p1, Rm, t, g1);
+            warp_plane(p1, Rm, z, ga);
+            const float f2[3] = {p2[0], -p2[1], -p2[2]};
+            const float sg = (g1[0] * ga[0] >= 0.f) ? 1.f : -1.f;
+            for (int d = 0; d < 3; ++d) {
+                geo_local[o * 6 + d] = p1[d]; geo_local[o * 6 + 3 + d] = p2[d];
+                geo_global[o * 6 + d] = g1[d]; geo_global[o * 6 + 3 + d] = f2[d];
+            }
+            sig[o] = sg;
+            const float* s0 = warp_in_ref ? g1 : p1;
+            const float* s1 = warp_in_ref ? f2 : p2;
+            float o0 = norm3(s0), o1 = norm3(s1);
+            float e[8];
+            for (int d = 0; d < 3; ++d) { e[d] = s0[d] / (o0 + 1e-10f); e[4 + d] = s1[d] / (o1 + 1e-10f); }
+            e[3] = o0; e[7] = o1;
+            if (warp_in_ref) { for (int d = 0; d < 4; ++d) e[d] *= sg; }
+            for (int d = 0; d < 8; ++d) geo_enc[o * 8 + d] = e[d];
+            ++k;
+        }
+    }
+    // zero the padding rows [m, nq)
+    for (int k = m + i; k < nq; k += 128) {
+        const long long o = (long long)b * nq + k;
+        for (int d = 0; d < 6; ++d) { geo_local[o * 6 + d] = 0.f; geo_global[o * 6 + d] = 0.f; }
+        for (int d = 0; d < 8; ++d) geo_enc[o * 8 + d] = 0.f;
+        sig[o] = 1.f;
+    }
+}
+
+struct PairDist { float ang, dn, doff, dl2; };
+
+__device__ __forceinline__ PairDist hyp_plane_dist(const float* gl, const float* Rm, const float* t) {
+    const float p0[3] = {gl[0], gl[1], gl[2]};
+    const float p1[3] = {gl[3], -gl[4], -gl[5]};
+    const float z[3] = {0.f, 0.f, 0.f};
+    float w_r[3], w_rt[3], n0[3], n1v[3], n0t[3];
+    warp_plane(p0, Rm, z, w_r);
+    warp_plane(p0, Rm, t, w_rt);
+    normalize3(w_r, n0);
+    normalize3(p1, n1v);
+    normalize3(w_rt, n0t);
+    PairDist r;
+    const float c = n0[0] * n1v[0] + n0[1] * n1v[1] + n0[2] * n1v[2];
+    r.ang = acosf(fminf(fmaxf(c, -1.f), 1.f)) / 3.14159265358979323846f * 180.f;
+    const float d0 = n0[0] - n1v[0], d1 = n0[1] - n1v[1], d2 = n0[2] - n1v[2];
+    r.dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float off0 = norm3(w_rt), off1 = norm3(p1);
+    const float ntn = n0t[0] * n1v[0] + n0t[1] * n1v[1] + n0t[2] * n1v[2];
+    r.doff = ntn < 0.f ? fabsf(off0 + off1) : fabsf(off0 - off1);
+    const float e0 = w_rt[0] - p1[0], e1 = w_rt[1] - p1[1], e2 = w_rt[2] - p1[2];
+    r.dl2 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ransac_score_maps_kernel(
+    const float* __restrict__ geo_local, const float* __restrict__ rot_raw, const float* __restrict__ trans_raw,
+    const float* __restrict__ init_rot, const float* __restrict__ init_trans, const int* __restrict__ mp, int nq,
+    float* __restrict__ rots_all, float* __restrict__ trans_all, float* __restrict__ normal_score,
+    float* __restrict__ param_score, float* __restrict__ l2_dist, float* __restrict__ normal_angle,
+    float* __restrict__ offset_dist, float* __restrict__ dn_sum, float* __restrict__ dl2_sum) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NH = nq + 1;
+    __shared__ float sR[129 * 9], sT[129 * 3], sG[128 * 6];
+    const int m = min(max(mp[b], 0), nq);
+    for (int h = tid; h < NH; h += 256) {
+        float q[4], t[3];
+        if (h == 0) {
+            for (int d = 0; d < 4; ++d) q[d] = init_rot[4 * b + d];
+            for (int d = 0; d < 3; ++d) t[d] = init_trans[3 * b + d];
+        } else {
+            const float* rr = rot_raw + ((long long)b * nq + h - 1) * 4;
+            const float nn = fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3]), 1e-12f);
+            for (int d = 0; d < 4; ++d) q[d] = rr[d] / nn;
+            for (int d = 0; d < 3; ++d) t[d] = trans_raw[((long long)b * nq + h - 1) * 3 + d];
+        }
+        quat_to_rot(q, sR + 9 * h);
+        for (int d = 0; d < 3; ++d) sT[3 * h + d] = t[d];
+        for (int d = 0; d < 4; ++d) rots_all[((long long)b * NH + h) * 4 + d] = q[d];
+        for (int d = 0; d < 3; ++d) trans_all[((long long)b * NH + h) * 3 + d] = t[d];
+    }
+    for (int e = tid; e < nq * 6; e += 256) sG[e] = geo_local[(long long)b * nq * 6 + e];
+    __syncthreads();
+    for (int e = tid; e < NH * nq; e += 256) {
+        const int h = e / nq, j = e % nq;
+        const PairDist d = hyp_plane_dist(sG + 6 * j, sR + 9 * h, sT + 3 * h);
+        const float mask = (h <= m && j < m) ? 1.f : 0.f;
+        const long long o = (long long)b * NH * nq + e;
+        normal_score[o] = expf(-(d.dn * mask)) * mask;
+        param_score[o] = expf(-(d.dl2 * mask)) * mask;
+        if (l2_dist) l2_dist[o] = d.dl2;
+        if (normal_angle) normal_angle[o] = d.ang;
+        if (offset_dist) offset_dist[o] = d.doff;
+    }
+    // masked row sums in j order (deterministic); used by the 'min-cost' selection (:1005,1032,1090-1093)
+    for (int h = tid; h < NH; h += 256) {
+        float a = 0.f, c = 0.f;
+        if (h <= m)
+            for (int j = 0; j < m; ++j) {
+                const PairDist d = hyp_plane_dist(sG + 6 * j, sR + 9 * h, sT + 3 * h);
+                a += d.dn; c += d.dl2;
+            }
+        if (dn_sum) dn_sum[(long long)b * NH + h] = a;
+        if (dl2_sum) dl2_sum[(long long)b * NH + h] = c;
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+__global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
+    const float* __restrict__ sf_rot, const float* __restrict__ sf_trans, const float* __restrict__ reg_rot_w,
+    const float* __restrict__ reg_rot_b, const float* __restrict__ reg_trans_w, const float* __restrict__ reg_trans_b,
+    const float* __restrict__ init_rot_feat, const float* __restrict__ init_trans_feat,
+    const float* __restrict__ fused_rot, const float* __restrict__ fused_trans, const float* __restrict__ rots_w,
+    const float* __restrict__ rots_b, const float* __restrict__ trans_w, const float* __restrict__ trans_b,
+    const float* __restrict__ rots_all, const float* __restrict__ trans_all, const float* __restrict__ dn_sum,
+    const float* __restrict__ dl2_sum, const float* __restrict__ init_rot, const float* __restrict__ init_trans,
+    const int* __restrict__ mp, int nq, int mode, float* __restrict__ pred_rot, float* __restrict__ pred_trans,
+    float* __restrict__ avg_rot, float* __restrict__ avg_trans, float* __restrict__ score_rot,
+    float* __restrict__ score_trans) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NH = nq + 1;
+    __shared__ float s_r[129], s_t[129], sh4[4], outv[16];
+    const int m = min(max(mp[b], 0), nq);
+    for (int h = tid; h < NH; h += 256) { score_rot[(long long)b * NH + h] = 0.f; score_trans[(long long)b * NH + h] = 0.f; }
+    if (m == 0) {   // :964-969
+        if (tid < 4) { pred_rot[4 * b + tid] = init_rot[4 * b + tid]; avg_rot[4 * b + tid] = init_rot[4 * b + tid]; }
+        if (tid < 3) { pred_trans[3 * b + tid] = init_trans[3 * b + tid]; avg_trans[3 * b + tid] = init_trans[3 * b + tid]; }
+        return;
+    }
+    // ---- score regression (Linear 64->1) for the live hypotheses
+    for (int h = tid; h <= m; h += 256) {
+        const float* fr = sf_rot + ((long long)b * NH + h) * 64;
+        const float* ft = sf_trans + ((long long)b * NH + h) * 64;
+        float a = 0.f, c = 0.f;
+        for (int d = 0; d < 64; ++d) { a = fmaf(fr[d], reg_rot_w[d], a); c = fmaf(ft[d], reg_trans_w[d], c); }
+        s_r[h] = a + reg_rot_b[0];
+        s_t[h] = c + reg_trans_b[0];
+    }
+    __syncthreads();
+    if (tid < 2) {   // masked softmax over h in [0, m] (serial, <=129 terms, deterministic)
+        float* s = tid == 0 ? s_r : s_t;
+        float mx = -INFINITY;
+        for (int h = 0; h <= m; ++h) mx = fmaxf(mx, s[h]);
+        float sum = 0.f;
+        for (int h = 0; h <= m; ++h) { s[h] = expf(s[h] - mx); sum += s[h]; }
+        for (int h = 0; h <= m; ++h) s[h] = s[h] / sum;
+    }
+    __syncthreads();
+    for (int h = tid; h <= m; h += 256) { score_rot[(long long)b * NH + h] = s_r[h]; score_trans[(long long)b * NH + h] = s_t[h]; }
+    // ---- aggregate features: thread = feature dim
+    const int d = tid;
+    const float avg_w = 1.f / ((float)(m + 1) + 1e-10f);
+    float fr_avg, ft_avg, fr_soft = 0.f, ft_soft = 0.f;
+    const float* FR = fused_rot + (long long)b * nq * 256;
+    const float* FT = fused_trans + (long long)b * nq * 256;
+    if (m > 1) {
+        float ar = init_rot_feat[256 * b + d] * avg_w, at = init_trans_feat[256 * b + d] * avg_w;
+        fr_soft = init_rot_feat[256 * b + d] * s_r[0];
+        ft_soft = init_trans_feat[256 * b + d] * s_t[0];
+        for (int h = 1; h <= m; ++h) {
+            const float xr = FR[(h - 1) * 256 + d], xt = FT[(h - 1) * 256 + d];
+            ar += xr * avg_w; at += xt * avg_w;
+            fr_soft += xr * s_r[h]; ft_soft += xt * s_t[h];
+        }
+        fr_avg = ar; ft_avg = at;
+    } else {   // m == 1 (:1059-1063)
+        fr_avg = FR[d] * avg_w / avg_w;
+        ft_avg = FT[d] * avg_w / avg_w;
+    }
+    // ---- pose regression: 4 + 3 outputs for avg, 4 + 3 for soft
+    float r[14];
+    for (int o = 0; o < 4; ++o) r[o] = block_sum_256(fr_avg * rots_w[o * 256 + d], sh4);
+    for (int o = 0; o < 3; ++o) r[4 + o] = block_sum_256(ft_avg * trans_w[o * 256 + d], sh4);
+    for (int o = 0; o < 4; ++o) r[7 + o] = block_sum_256(fr_soft * rots_w[o * 256 + d], sh4);
+    for (int o = 0; o < 3; ++o) r[11 + o] = block_sum_256(ft_soft * trans_w[o * 256 + d], sh4);
+    if (tid == 0) {
+        float ra[4], rs[4], na = 0.f, ns = 0.f;
+        for (int o = 0; o < 4; ++o) { ra[o] = r[o] + rots_b[o]; rs[o] = r[7 + o] + rots_b[o]; na += ra[o] * ra[o]; ns += rs[o] * rs[o]; }
+        na = fmaxf(sqrtf(na), 1e-12f); ns = fmaxf(sqrtf(ns), 1e-12f);
+        float ta[3], ts[3];
+        for (int o = 0; o < 3; ++o) { ta[o] = r[4 + o] + trans_b[o]; ts[o] = r[11 + o] + trans_b[o]; }
+        for (int o = 0; o < 4; ++o) { ra[o] /= na; rs[o] /= ns; avg_rot[4 * b + o] = ra[o]; }
+        for (int o = 0; o < 3; ++o) avg_trans[3 * b + o] = ta[o];
+        float pr[4], pt[3];
+        for (int o = 0; o < 4; ++o) pr[o] = ra[o];
+        for (int o = 0; o < 3; ++o) pt[o] = ta[o];
+        if (m > 1) {
+            if (mode == 0) {
+                for (int o = 0; o < 4; ++o) pr[o] = rs[o];
+                for (int o = 0; o < 3; ++o) pt[o] = ts[o];
+            } else if (mode == 2 || mode == 3) {
+                int hr = 0, ht = 0;
+                if (mode == 2) {   // min geometric cost (:1088-1093)
+                    float br = INFINITY, bt = INFINITY;
+                    for (int h = 0; h <= m; ++h) {
+                        if (dn_sum[(long long)b * NH + h] < br) { br = dn_sum[(long long)b * NH + h]; hr = h; }
+                        if (dl2_sum[(long long)b * NH + h] < bt) { bt = dl2_sum[(long long)b * NH + h]; ht = h; }
+                    }
+                } else {           // max score (:1094-1099)
+                    float br = -INFINITY, bt = -INFINITY;
+                    for (int h = 0; h <= m; ++h) {
+                        if (s_r[h] > br) { br = s_r[h]; hr = h; }
+                        if (s_t[h] > bt) { bt = s_t[h]; ht = h; }
+                    }
+                }
+                for (int o = 0; o < 4; ++o) pr[o] = rots_all[((long long)b * NH + hr) * 4 + o];
+                for (int o = 0; o < 3; ++o) pt[o] = trans_all[((long long)b * NH + ht) * 3 + o];
+            }
+        }
+        for (int o = 0; o < 4; ++o) pred_rot[4 * b + o] = pr[o];
+        for (int o = 0; o < 3; ++o) pred_trans[3 * b + o] = pt[o];
+    }
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_geo_sequence(const float* assignment, const float* planes1, const float* planes2,
+                                    const int32_t* n1, const int32_t* n2, const float* init_trans,
+                                    const float* init_rot, int B, int nq, int warp_in_ref, float* geo_local,
+                                    float* geo_global, float* sig, float* geo_enc, int32_t* m, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(assignment && planes1 && planes2 && n1 && n2 && init_trans && init_rot && geo_local && geo_global && sig && geo_enc && m,
+                  "geo_sequence: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "geo_sequence: bad dims (nq<=128)");
+    hipLaunchKernelGGL(geo_sequence_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, assignment, planes1, planes2, n1, n2,
+                       init_trans, init_rot, nq, warp_in_ref, geo_local, geo_global, sig, geo_enc, m);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_ransac_score_maps(const float* geo_local, const float* rot_raw, const float* trans_raw,
+                                         const float* init_rot, const float* init_trans, const int32_t* m, int B,
+                                         int nq, float* rots_all, float* trans_all, float* normal_score,
+                                         float* param_score, float* l2_dist, float* normal_angle, float* offset_dist,
+                                         float* dn_sum, float* dl2_sum, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(geo_local && rot_raw && trans_raw && init_rot && init_trans && m && rots_all && trans_all && normal_score && param_score,
+                  "ransac_score_maps: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "ransac_score_maps: bad dims (nq<=128)");
+    hipLaunchKernelGGL(ransac_score_maps_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, geo_local, rot_raw, trans_raw,
+                       init_rot, init_trans, m, nq, rots_all, trans_all, normal_score, param_score, l2_dist, normal_angle,
+                       offset_dist, dn_sum, dl2_sum);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_ransac_soft_vote(const float* score_feat_rot, const float* score_feat_trans,
+                                        const float* reg_rot_w, const float* reg_rot_b, const float* reg_trans_w,
+                                        const float* reg_trans_b, const float* init_rot_feat,
+                                        const float* init_trans_feat, const float* fused_rot_feat,
+                                        const float* fused_trans_feat, const float* rots_w, const float* rots_b,
+                                        const float* trans_w, const float* trans_b, const float* rots_all,
+                                        const float* trans_all, const float* dn_sum, const float* dl2_sum,
+                                        const float* init_rot, const float* init_trans, const int32_t* m, int B, int nq,
+                                        int mode, float* pred_rot, float* pred_trans, float* avg_rot, float* avg_trans,
+                                        float* score_rot, float* score_trans, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(score_feat_rot && score_feat_trans && reg_rot_w && reg_rot_b && reg_trans_w && reg_trans_b && init_rot_feat &&
+                      init_trans_feat && fused_rot_feat && fused_trans_feat && rots_w && rots_b && trans_w && trans_b && rots_all &&
+                      trans_all && init_rot && init_trans && m && pred_rot && pred_trans && avg_rot && avg_trans && score_rot && score_trans,
+                  "ransac_soft_vote: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && mode >= 0 && mode <= 3, "ransac_soft_vote: bad dims/mode");
+    NPS_CHECK_ARG(mode != 2 || (dn_sum && dl2_sum), "ransac_soft_vote: min-cost needs dn_sum/dl2_sum");
+    hipLaunchKernelGGL(ransac_soft_vote_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, score_feat_rot, score_feat_trans,
+                       reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot_feat,
+                       fused_trans_feat, rots_w, rots_b, trans_w, trans_b, rots_all, trans_all, dn_sum, dl2_sum, init_rot,
+                       init_trans, m, nq, mode, pred_rot, pred_trans, avg_rot, avg_trans, score_rot, score_trans);
+    NPS_LAUNCH_RET();
+}

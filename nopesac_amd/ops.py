@@ -1,0 +1,316 @@
+"""Thin typed wrappers: torch tensors (device memory + the current HIP stream) -> C-ABI calls.
+
+torch is plumbing here (allocation, streams); every computation below runs in libnopesac_hip.so.
+All wrappers enqueue on torch's current stream and never synchronise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)"
+    return t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=None, contiguous=True):
+    assert t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+    if contiguous:
+        assert t.is_contiguous()
+    return t
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=None, *, stride=1, pad=0, act=ACT_NONE,
+           out: Optional[torch.Tensor] = None, out_dtype=None, x_channels: Optional[int] = None,
+           batched_weights: bool = False) -> torch.Tensor:
+    """NHWC conv / linear.  x: [B,H,W,Cx] (a channel slice view of a wider buffer is allowed: only the
+    last-dim stride may exceed the channel count); w: [Cout,KH,KW,Cin] or [B,Cout,KH,KW,Cin] when
+    `batched_weights`.  `out` may be a channel-slice view of a wider NHWC buffer."""
+    assert x.dim() == 4 and x.stride(3) == 1
+    B, H, W, Cx = x.shape
+    x_cs = x.stride(2)
+    assert x.stride(1) == W * x_cs and x.stride(0) == H * W * x_cs, "x must be pixel-dense NHWC"
+    if batched_weights:
+        assert w.dim() == 5 and w.shape[0] == B and w.is_contiguous()
+        Cout, KH, KW, Cin = w.shape[1:]
+        w_bs = Cout * KH * KW * Cin
+    else:
+        assert w.dim() == 4 and w.is_contiguous()
+        Cout, KH, KW, Cin = w.shape
+        w_bs = 0
+    assert Cin == (x_channels or Cx), (Cin, Cx)
+    assert w.dtype == x.dtype
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    out_dtype = out_dtype or (out.dtype if out is not None else x.dtype)
+    if out is None:
+        out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=out_dtype)
+    assert out.shape == (B, OH, OW, Cout) and out.stride(3) == 1 and out.dtype == out_dtype
+    y_cs = out.stride(2)
+    assert out.stride(1) == OW * y_cs and out.stride(0) == OH * OW * y_cs
+    r_cs = 0
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == out_dtype and residual.stride(3) == 1
+        r_cs = residual.stride(2)
+    for v in (scale, bias):
+        if v is not None:
+            _chk(v, torch.float32)
+            assert v.numel() == Cout
+    rc = _L().nopesac_conv2d_nhwc(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,
+                                  stride, pad, x_cs, y_cs, r_cs, w_bs, act, _DT[x.dtype], _DT[out_dtype], _stream())
+    _lib.check(rc, "nopesac_conv2d_nhwc")
+    return out
+
+
+def _rows4d(t: torch.Tensor, width: int) -> torch.Tensor:
+    """View `t` ([..., width]: contiguous, or a column slice of a contiguous wider buffer) as a
+    [1,1,rows,width] NHWC tensor whose pixel stride is the buffer's row stride."""
+    assert t.stride(-1) == 1 and t.shape[-1] == width
+    rows = t.numel() // width
+    rs = width if t.is_contiguous() else t.stride(-2)
+    if t.dim() > 2 and not t.is_contiguous():
+        for d in range(t.dim() - 2):     # leading dims must be dense multiples of the row stride
+            assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "unsupported row layout"
+    return torch.as_strided(t, (1, 1, rows, width), (rows * rs, rows * rs, rs, 1), t.storage_offset())
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias=None, *, act=ACT_NONE, residual=None, out=None, scale=None,
+           out_dtype=None) -> torch.Tensor:
+    """y = act((x @ w.T) * scale + bias + residual).  x [..., K] / out [..., N] / residual [..., N] may be
+    column slices of wider row-major buffers (free concatenation); w [N, K] contiguous."""
+    K = x.shape[-1]
+    N = w.shape[0]
+    y = conv2d(_rows4d(x, K), w.view(N, 1, 1, K), scale, bias, None if residual is None else _rows4d(residual, N), act=act,
+               out=None if out is None else _rows4d(out, N), out_dtype=out_dtype)
+    return out if out is not None else y.view(*x.shape[:-1], N)
+
+
+def preprocess(images_nchw: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, cpad: int, out_dtype) -> torch.Tensor:
+    x = _chk(images_nchw, torch.float32)
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, cpad), device=x.device, dtype=out_dtype)
+    rc = _L().nopesac_preprocess_nchw_to_nhwc(_p(x), _p(y), _p(_chk(mean, torch.float32)), _p(_chk(std, torch.float32)), B, C, H, W,
+                                              cpad, _DT[out_dtype], _stream())
+    _lib.check(rc, "nopesac_preprocess_nchw_to_nhwc")
+    return y
+
+
+def maxpool(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    _chk(x)
+    B, H, W, C = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((B, OH, OW, C), device=x.device, dtype=x.dtype)
+    _lib.check(_L().nopesac_maxpool_nhwc(_p(x), _p(y), B, H, W, C, k, stride, pad, _DT[x.dtype], _stream()), "nopesac_maxpool_nhwc")
+    return y
+
+
+def upsample2x_bilinear(x: torch.Tensor, addend=None, act=ACT_NONE) -> torch.Tensor:
+    _chk(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=x.dtype)
+    if addend is not None:
+        _chk(addend, x.dtype)
+        assert addend.shape == y.shape
+    _lib.check(_L().nopesac_upsample2x_bilinear_nhwc(_p(x), _p(addend), _p(y), B, H, W, C, act, _DT[x.dtype], _stream()),
+               "nopesac_upsample2x_bilinear_nhwc")
+    return y
+
+
+def upsample2x_nearest_add(x: torch.Tensor, lateral: torch.Tensor) -> torch.Tensor:
+    _chk(x); _chk(lateral, x.dtype)
+    B, H, W, C = x.shape
+    assert lateral.shape == (B, 2 * H, 2 * W, C)
+    y = torch.empty_like(lateral)
+    _lib.check(_L().nopesac_upsample2x_nearest_add_nhwc(_p(x), _p(lateral), _p(y), B, H, W, C, _DT[x.dtype], _stream()),
+               "nopesac_upsample2x_nearest_add_nhwc")
+    return y
+
+
+def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act=ACT_NONE) -> torch.Tensor:
+    _chk(x)
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_L().nopesac_groupnorm_nhwc(_p(x), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(y), B, H * W, C,
+                                           groups, eps, act, _DT[x.dtype], _stream()), "nopesac_groupnorm_nhwc")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma, beta, res=None, addend=None, eps=1e-5):
+    """-> y (and y + addend if `addend` [rows_a, D] is given; row index taken modulo rows_a)."""
+    _chk(x, torch.float32)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if addend is not None else None
+    if res is not None:
+        _chk(res, torch.float32)
+        assert res.shape == x.shape
+    a_rows = 0 if addend is None else _chk(addend, torch.float32).numel() // D
+    _lib.check(_L().nopesac_layernorm(_p(x), _p(res), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(y),
+                                      _p(addend), a_rows, _p(y2), rows, D, eps, _stream()), "nopesac_layernorm")
+    return (y, y2) if addend is not None else y
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _chk(a, torch.float32); _chk(b, torch.float32)
+    D = a.shape[-1]
+    out = torch.empty_like(a)
+    _lib.check(_L().nopesac_add_rows(_p(a), _p(b), _p(out), a.numel() // D, D, b.numel() // D, _stream()), "nopesac_add_rows")
+    return out
+
+
+def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32)
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_L().nopesac_softmax_rows(_p(x), _p(y), x.numel() // D, D, _stream()), "nopesac_softmax_rows")
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Lq: int, Lk: int, heads: int, scale: float,
+              qlen=None, klen=None) -> torch.Tensor:
+    """q [B*Lq, >=heads*32] etc. as (possibly column-sliced) row-major matrices -> o [B*Lq, heads*32]."""
+    for t in (q, k, v):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    assert q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk
+    o = torch.empty((B * Lq, heads * 32), device=q.device, dtype=torch.float32)
+    rc = _L().nopesac_attention_small(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), B, Lq, Lk,
+                                      heads, scale, _p(qlen), _p(klen), _stream())
+    _lib.check(rc, "nopesac_attention_small")
+    return o
+
+
+def transpose_hw_rows(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _chk(x, torch.float32)
+    B, C = x.shape[0], x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_L().nopesac_transpose_hw_rows(_p(x), _p(y), B, H, W, C, _stream()), "nopesac_transpose_hw_rows")
+    return y
+
+
+def normalize_rows(x: torch.Tensor, canonical_sign: bool = False) -> torch.Tensor:
+    _chk(x, torch.float32)
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_L().nopesac_normalize_rows(_p(x), _p(y), x.numel() // D, D, int(canonical_sign), _stream()), "nopesac_normalize_rows")
+    return y
+
+
+def postselect_planes(cls_logits, mask_prob, params, query_feat, H, W, score_thr, mask_thr, overlap_thr) -> dict:
+    _chk(cls_logits, torch.float32); _chk(mask_prob, torch.float32); _chk(params, torch.float32); _chk(query_feat, torch.float32)
+    B, nq, _ = cls_logits.shape
+    _, h, w, nq2 = mask_prob.shape
+    assert nq2 == nq
+    D = query_feat.shape[-1]
+    dev = cls_logits.device
+    i32 = dict(device=dev, dtype=torch.int32)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {
+        "n_kept": torch.empty(B, **i32), "kept_idx": torch.empty(B, nq, **i32), "planes": torch.empty(B, nq, 3, **f32),
+        "feats": torch.empty(B, nq, D, **f32), "scores": torch.empty(B, nq, **f32), "areas": torch.empty(B, nq, **i32),
+        "centers": torch.empty(B, nq, 2, **f32), "winner": torch.zeros(B, H, W, device=dev, dtype=torch.uint8),
+        "flags": torch.empty(B, **i32),
+    }
+    work = torch.empty(B, 9 * nq + 8, **i32)
+    rc = _L().nopesac_postselect_planes(_p(cls_logits), _p(mask_prob), _p(params), _p(query_feat), B, nq, D, h, w, H, W,
+                                        score_thr, mask_thr, overlap_thr, _p(out["n_kept"]), _p(out["kept_idx"]),
+                                        _p(out["planes"]), _p(out["feats"]), _p(out["scores"]), _p(out["areas"]),
+                                        _p(out["centers"]), _p(out["winner"]), _p(out["flags"]), _p(work), _stream())
+    _lib.check(rc, "nopesac_postselect_planes")
+    return out
+
+
+def matcher_sinkhorn(desc_dot, planes1, planes2, cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr):
+    B, nq, _ = desc_dot.shape
+    for t in (desc_dot, planes1, planes2, cam7, bin_score):
+        _chk(t, torch.float32)
+    _chk(n1, torch.int32); _chk(n2, torch.int32)
+    log_scores = torch.empty(B, nq + 1, nq + 1, device=desc_dot.device, dtype=torch.float32)
+    assignment = torch.empty(B, nq, nq, device=desc_dot.device, dtype=torch.float32)
+    rc = _L().nopesac_matcher_sinkhorn(_p(desc_dot), _p(planes1), _p(planes2), _p(cam7), _p(n1), _p(n2), _p(bin_score),
+                                       offset_mult, normal_mult, iters, match_thr, B, nq, _p(log_scores), _p(assignment), _stream())
+    _lib.check(rc, "nopesac_matcher_sinkhorn")
+    return log_scores, assignment
+
+
+def geo_sequence(assignment, planes1, planes2, n1, n2, init_trans, init_rot, warp_in_ref=True):
+    B, nq, _ = assignment.shape
+    for t in (assignment, planes1, planes2, init_trans, init_rot):
+        _chk(t, torch.float32)
+    dev = assignment.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    geo_local, geo_global = torch.empty(B, nq, 6, **f32), torch.empty(B, nq, 6, **f32)
+    sig, geo_enc = torch.empty(B, nq, **f32), torch.empty(B, nq, 8, **f32)
+    m = torch.empty(B, device=dev, dtype=torch.int32)
+    rc = _L().nopesac_geo_sequence(_p(assignment), _p(planes1), _p(planes2), _p(n1), _p(n2), _p(init_trans), _p(init_rot), B, nq,
+                                   int(warp_in_ref), _p(geo_local), _p(geo_global), _p(sig), _p(geo_enc), _p(m), _stream())
+    _lib.check(rc, "nopesac_geo_sequence")
+    return geo_local, geo_global, sig, geo_enc, m
+
+
+def ransac_score_maps(geo_local, rot_raw, trans_raw, init_rot, init_trans, m, diagnostics=True):
+    B, nq, _ = geo_local.shape
+    for t in (geo_local, rot_raw, trans_raw, init_rot, init_trans):
+        _chk(t, torch.float32)
+    dev = geo_local.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"rots_all": torch.empty(B, nq + 1, 4, **f32), "trans_all": torch.empty(B, nq + 1, 3, **f32),
+           "normal_score": torch.empty(B, nq + 1, nq, **f32), "param_score": torch.empty(B, nq + 1, nq, **f32),
+           "dn_sum": torch.empty(B, nq + 1, **f32), "dl2_sum": torch.empty(B, nq + 1, **f32)}
+    if diagnostics:
+        for k in ("l2_dist", "normal_angle", "offset_dist"):
+            out[k] = torch.empty(B, nq + 1, nq, **f32)
+    rc = _L().nopesac_ransac_score_maps(_p(geo_local), _p(rot_raw), _p(trans_raw), _p(init_rot), _p(init_trans), _p(m), B, nq,
+                                        _p(out["rots_all"]), _p(out["trans_all"]), _p(out["normal_score"]), _p(out["param_score"]),
+                                        _p(out.get("l2_dist")), _p(out.get("normal_angle")), _p(out.get("offset_dist")),
+                                        _p(out["dn_sum"]), _p(out["dl2_sum"]), _stream())
+    _lib.check(rc, "nopesac_ransac_score_maps")
+    return out
+
+
+def ransac_soft_vote(sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat,
+                     fused_rot, fused_trans, rots_w, rots_b, trans_w, trans_b, maps, init_rot, init_trans, m, mode: int):
+    B, NH, _ = sf_rot.shape
+    nq = NH - 1
+    dev = sf_rot.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"pred_rot": torch.empty(B, 4, **f32), "pred_trans": torch.empty(B, 3, **f32), "avg_rot": torch.empty(B, 4, **f32),
+           "avg_trans": torch.empty(B, 3, **f32), "score_rot": torch.empty(B, NH, **f32), "score_trans": torch.empty(B, NH, **f32)}
+    args = [sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot,
+            fused_trans, rots_w, rots_b, trans_w, trans_b, maps["rots_all"], maps["trans_all"], maps["dn_sum"], maps["dl2_sum"],
+            init_rot, init_trans]
+    for t in args:
+        _chk(t, torch.float32)
+    rc = _L().nopesac_ransac_soft_vote(*[_p(t) for t in args], _p(m), B, nq, mode, _p(out["pred_rot"]), _p(out["pred_trans"]),
+                                       _p(out["avg_rot"]), _p(out["avg_trans"]), _p(out["score_rot"]), _p(out["score_trans"]), _stream())
+    _lib.check(rc, "nopesac_ransac_soft_vote")
+    return out
+
+
+def refilter_assignment(assignment, planes1, planes2, n1, n2, rot, trans):
+    B, nq, _ = assignment.shape
+    out = torch.empty_like(assignment)
+    rc = _L().nopesac_refilter_assignment(_p(_chk(assignment, torch.float32)), _p(planes1), _p(planes2), _p(n1), _p(n2), _p(_chk(rot, torch.float32)),
+                                          _p(_chk(trans, torch.float32)), B, nq, _p(out), _stream())
+    _lib.check(rc, "nopesac_refilter_assignment")
+    return out

@@ -1,0 +1,177 @@
+"""HIP kernels (through the C ABI) vs plain PyTorch fp32 CPU references of the same op."""
+import math
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, p
+    (2, 9, 11, 8, 70, 3, 1, 1),
+    (1, 16, 20, 64, 64, 1, 1, 0),
+    (2, 15, 20, 32, 130, 3, 2, 1),
+    (1, 23, 31, 4, 64, 7, 2, 3),
+    (2, 7, 5, 3, 17, 3, 1, 1),        # scalar K path (Cin % 4 != 0)
+    (1, 15, 20, 300, 128, 3, 1, 1),   # Cin = 300 (corr volume)
+    (3, 30, 40, 256, 256, 3, 1, 1),   # 128x128 tile path
+    (1, 60, 80, 128, 512, 1, 1, 0),
+    (2, 12, 16, 512, 128, 1, 2, 0),   # strided 1x1 shortcut
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d(device, case, dtype):
+    from nopesac_amd import ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        res = res.bfloat16().float()
+    ref = F.leaky_relu(ref + res, 0.01)
+    y = ops.conv2d(_nhwc(x).to(device, dtype), w.permute(0, 2, 3, 1).contiguous().to(device, dtype), scale.to(device),
+                   bias.to(device), _nhwc(res).to(device, dtype), stride=s, pad=p, act=ops.ACT_LEAKY)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert y.dtype == dtype
+    assert _rel(y.float().permute(0, 3, 1, 2), ref) < tol
+
+
+def test_conv2d_bf16_in_f32_out_and_slices(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 7, 48, generator=g).bfloat16()
+    w = (torch.randn(40, 1, 1, 16, generator=g) / 4).bfloat16()
+    xs = x.to(device)[..., 16:32]                       # channel slice of a wider buffer
+    out = torch.zeros(2, 6, 7, 100, device=device)
+    y = ops.conv2d(xs, w.to(device), out=out[..., 50:90], out_dtype=torch.float32, act=ops.ACT_RELU)
+    ref = F.relu(torch.einsum("bhwc,nc->bhwn", x[..., 16:32].float(), w.view(40, 16).float()))
+    assert _rel(out[..., 50:90], ref) < 1e-5
+    assert float(out[..., :50].abs().max()) == 0 and float(out[..., 90:].abs().max()) == 0
+
+
+def test_conv2d_batched_weights(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 10, 12, 256, generator=g)
+    w = torch.randn(3, 50, 1, 1, 256, generator=g) / 16
+    y = ops.conv2d(x.to(device), w.to(device), batched_weights=True, act=ops.ACT_SIGMOID)
+    ref = torch.sigmoid(torch.einsum("bhwc,bnc->bhwn", x, w.view(3, 50, 256)))
+    assert _rel(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("K,N", [(3, 256), (8, 1024), (50, 128), (1280, 1024), (768, 256)])
+def test_linear(device, K, N):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(K * 7 + N)
+    x = torch.randn(37, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    y = ops.linear(x.to(device), w.to(device), b.to(device), act=ops.ACT_RELU)
+    assert _rel(y, F.relu(F.linear(x, w, b))) < 2e-5
+
+
+def test_linear_concat_buffers(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(9)
+    buf = torch.randn(2, 50, 1280, generator=g)
+    w = torch.randn(256, 1024, generator=g) / 32
+    dbuf = buf.to(device)
+    y = ops.linear(dbuf[..., :1024], w.to(device), out=dbuf[..., 1024:])
+    ref = F.linear(buf[..., :1024], w)
+    assert _rel(dbuf[..., 1024:], ref) < 2e-5 and _rel(dbuf[..., :1024], buf[..., :1024]) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_and_upsample(device, dtype):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 24, 13, 17, generator=g).to(dtype).float()
+    xd = _nhwc(x).to(device, dtype)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert _rel(ops.maxpool(xd, 3, 2, 1).float().permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1)) < tol
+    assert _rel(ops.maxpool(xd, 2, 2, 0).float().permute(0, 3, 1, 2), F.max_pool2d(x, 2, 2)) < tol
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    add = torch.randn(up.shape, generator=g).to(dtype).float()
+    y = ops.upsample2x_bilinear(xd, _nhwc(add).to(device, dtype), act=ops.ACT_RELU)
+    assert _rel(y.float().permute(0, 3, 1, 2), F.relu(up) + add) < max(tol, 2e-6)
+    lat = torch.randn(2, 24, 26, 34, generator=g).to(dtype).float()
+    y = ops.upsample2x_nearest_add(xd, _nhwc(lat).to(device, dtype))
+    assert _rel(y.float().permute(0, 3, 1, 2), lat + F.interpolate(x, scale_factor=2, mode="nearest")) < tol
+
+
+def test_preprocess(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 256, (2, 3, 20, 24), generator=g).float()
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    y = ops.preprocess(x.to(device), mean.to(device), std.to(device), 4, torch.float32)
+    ref = (x - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    assert _rel(y[..., :3].permute(0, 3, 1, 2), ref) < 1e-6 and float(y[..., 3].abs().max()) == 0
+
+
+def test_norms_and_softmax(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 128, 15, 20, generator=g) * 3 + 1
+    ga, be = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    y = ops.groupnorm(_nhwc(x).to(device), ga.to(device), be.to(device), 32, 1e-5, act=ops.ACT_RELU)
+    assert _rel(y.permute(0, 3, 1, 2), F.relu(F.group_norm(x, 32, ga, be, 1e-5))) < 1e-5
+    t = torch.randn(77, 256, generator=g) * 2
+    r = torch.randn(77, 256, generator=g)
+    pos = torch.randn(11, 256, generator=g)
+    ga, be = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    y, y2 = ops.layernorm(t.to(device), ga.to(device), be.to(device), res=r.to(device), addend=pos.to(device))
+    ref = F.layer_norm(t + r, (256,), ga, be, 1e-5)
+    assert _rel(y, ref) < 1e-5
+    assert _rel(y2, ref + pos.repeat(7, 1)) < 1e-5
+    s = torch.randn(45, 300, generator=g) * 4
+    assert _rel(ops.softmax_rows(s.to(device)), F.softmax(s, -1)) < 1e-5
+    assert _rel(ops.add_rows(t.to(device), pos.to(device)), t + pos.repeat(7, 1)) == 0
+    q = torch.randn(9, 4, generator=g)
+    ref = F.normalize(q, dim=-1)
+    ref = torch.where(ref[:, :1] < 0, -ref, ref)
+    assert _rel(ops.normalize_rows(q.to(device), True), ref) < 1e-6
+    m = torch.randn(2, 15 * 20, 8, generator=g)
+    ref = m.view(2, 15, 20, 8).transpose(1, 2).reshape(2, 300, 8)
+    assert _rel(ops.transpose_hw_rows(m.to(device), 15, 20), ref) == 0
+
+
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 300, 300), (3, 50, 300), (4, 50, 50), (2, 7, 5)])
+def test_attention(device, B, Lq, Lk):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Lq)
+    qk = torch.randn(B * Lq, 512, generator=g)          # q in cols 0..255 of a wider buffer
+    k = torch.randn(B * Lk, 256, generator=g)
+    v = torch.randn(B * Lk, 256, generator=g)
+    qlen = torch.tensor([Lq - (i % 3) for i in range(B)], dtype=torch.int32)
+    klen = torch.tensor([Lk - (i % 2) * 2 for i in range(B)], dtype=torch.int32)
+    dq = qk.to(device)
+    o = ops.attention(dq[:, :256], k.to(device), v.to(device), B, Lq, Lk, 8, 32 ** -0.5, qlen.to(device), klen.to(device))
+    ref = torch.zeros(B * Lq, 256)
+    for b in range(B):
+        nq_, nk_ = int(qlen[b]), int(klen[b])
+        qq = qk[b * Lq: b * Lq + nq_, :256].view(nq_, 8, 32)
+        kk = k[b * Lk: b * Lk + nk_].view(nk_, 8, 32)
+        vv = v[b * Lk: b * Lk + nk_].view(nk_, 8, 32)
+        a = torch.softmax(torch.einsum("lhd,shd->hls", qq, kk) * 32 ** -0.5, -1)
+        ref[b * Lq: b * Lq + nq_] = torch.einsum("hls,shd->lhd", a, vv).reshape(nq_, 256)
+    assert _rel(o, ref) < 1e-5
