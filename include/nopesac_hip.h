@@ -35,6 +35,7 @@ extern "C" {
 #define NPS_ACT_RELU 1
 #define NPS_ACT_LEAKY 2   /* LeakyReLU(0.01), camera_modules.py:47 */
 #define NPS_ACT_SIGMOID 3
+#define NPS_ACT_RES_AFTER 0x100 /* OR-able flag: add `residual` AFTER the activation (planeTR_head.py:244-250) */
 
 #define NPS_E_ARG (-1)
 #define NPS_E_UNSUPPORTED (-2)
@@ -47,7 +48,7 @@ const char* nopesac_last_error(void);
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / linear layer with fused epilogue (MFMA).
  *   y[b,oh,ow,n] = act( (sum_{kh,kw,c} x[b, oh*s-p+kh, ow*s-p+kw, c] * w[n,kh,kw,c]) * scale[n] + bias[n]
- *                       + residual[b,oh,ow,n] )
+ *                       + residual[b,oh,ow,n] )        (or act(...) + residual with NPS_ACT_RES_AFTER)
  * Replaces every torch conv2d/linear(+BN/bias/residual/activation) on the path: d2 ResNet-50
  * (meta_arch/siamese_planeTR.py:456), planeTR_net/planeTR_head.py:126,148-162,209-215,
  * camera_net/camera_modules.py:36-48,271-321, camera_net/camera_head.py:957-962,983-990,

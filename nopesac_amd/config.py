@@ -101,7 +101,7 @@ class CfgNode(dict):
                     raise KeyError(f"config key {full} is not a node")
                 self[k]._merge(v, trail + [k])
             else:
-                self[k] = _coerce(v, self[k], full)
+                self[k] = _coerce(_decode(v), self[k], full)
 
     def merge_from_list(self, opts: Iterable[Any]):
         opts = list(opts)
@@ -115,12 +115,18 @@ class CfgNode(dict):
                 node = node[p]
             if parts[-1] not in node:
                 raise KeyError(f"Non-existent config key: {key}")
-            if isinstance(val, str):
-                try:
-                    val = ast.literal_eval(val)
-                except (ValueError, SyntaxError):
-                    pass
-            node[parts[-1]] = _coerce(val, node[parts[-1]], key)
+            node[parts[-1]] = _coerce(_decode(val), node[parts[-1]], key)
+
+
+def _decode(v):
+    """yacs `_decode_cfg_value`: strings that parse as Python literals become those literals
+    (e.g. the yaml scalar '("mp3d_test",)' -> tuple); everything else is kept."""
+    if not isinstance(v, str):
+        return v
+    try:
+        return ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
 
 
 def _merge_dicts(src: dict, dst: dict):

@@ -27,7 +27,7 @@ struct ConvParams {
     int M, N, K;       // M = rows per grid.y slice
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt;
+    int act, out_dt, res_after;
     int tiles_m, tiles_n;
 };
 
@@ -216,11 +216,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 if (m >= p.M) continue;
                 const long long pix = (long long)m + (long long)bz * p.rows_per_b;
                 float v = acc[i][j][r] * sc + bi;
+                float rv = 0.f;
                 if (p.res) {
-                    v += (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n]
+                    rv = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n]
                                                   : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n]);
                 }
-                v = apply_act(v, p.act);
+                if (p.res_after) v = apply_act(v, p.act) + rv;
+                else v = apply_act(v + rv, p.act);
                 if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n] = v;
                 else ((bf16_t*)p.y)[pix * p.y_cs + n] = f32_to_bf16(v);
             }
@@ -273,6 +275,8 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d: bad out_dt %d", out_dt);
     NPS_CHECK_ARG(x_cstride >= Cin && y_cstride >= Cout, "conv2d: channel stride smaller than channel count");
     NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d: residual stride");
+    const int res_after = (act & NPS_ACT_RES_AFTER) ? 1 : 0;
+    act &= 0xff;
     NPS_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad act %d", act);
     ConvParams p;
     memset(&p, 0, sizeof(p));
@@ -286,7 +290,7 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     p.batched = w_bstride != 0;
     p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
     p.N = Cout; p.K = KH * KW * Cin;
-    p.act = act; p.out_dt = out_dt;
+    p.act = act; p.out_dt = out_dt; p.res_after = res_after;
     if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t>(p, (hipStream_t)stream);
     else launch_dtype<float>(p, (hipStream_t)stream);
     NPS_LAUNCH_RET();

@@ -1,0 +1,85 @@
+"""ResNet-50 backbone on the HIP implicit-GEMM conv (detectron2 `build_resnet_backbone` semantics:
+configs/Base.yaml:2-12; call site meta_arch/siamese_planeTR.py:62,456).
+
+NHWC end to end; every conv carries its FrozenBN scale/shift, the residual add and the ReLU in the GEMM
+epilogue, so a bottleneck is 3 (4 with projection shortcut) kernel launches and no elementwise passes.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..registry import BACKBONE_REGISTRY
+from ..synth import RES_STAGES, state_dict_spec
+from .params import ParamModule, conv_bn
+
+
+class ShapeSpec:
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+
+class HipResNet50(ParamModule):
+    size_divisibility = 0
+    STEM_CIN_PAD = 4   # RGB padded to 4 channels so the stem's im2col vectors are 8/16-byte aligned
+
+    def __init__(self, cfg=None):
+        spec = {k[len("backbone."):]: v for k, v in state_dict_spec(50).items() if k.startswith("backbone.")}
+        super().__init__(spec)
+        if cfg is not None:
+            r = cfg.MODEL.RESNETS
+            assert r.DEPTH == 50 and not r.STRIDE_IN_1X1 and r.NORM == "FrozenBN" and r.NUM_GROUPS == 1, \
+                "only the ResNet-50 / FrozenBN / stride-in-3x3 configuration of configs/Base.yaml is implemented"
+            self.out_features = list(r.OUT_FEATURES)
+        else:
+            self.out_features = ["res2", "res3", "res4", "res5"]
+
+    def output_shape(self):
+        full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
+                "res5": ShapeSpec(2048, stride=32)}
+        return {k: full[k] for k in self.out_features}
+
+    def pack(self) -> dict:
+        P = {"stem": conv_bn(self, "stem.conv1.weight", "stem.conv1.norm", 1e-5, cin_pad=self.STEM_CIN_PAD)}
+        cin = 64
+        for name, n, cmid, cout in RES_STAGES:
+            for i in range(n):
+                p = f"{name}.{i}"
+                for c in ("conv1", "conv2", "conv3") + (("shortcut",) if cin != cout else ()):
+                    P[f"{p}.{c}"] = conv_bn(self, f"{p}.{c}.weight", f"{p}.{c}.norm", 1e-5)
+                cin = cout
+        return P
+
+    def forward(self, x: torch.Tensor) -> dict:
+        """x: NHWC [B,H,W,4] (normalised, channel-padded) in the compute dtype -> {res2..res5} NHWC."""
+        P, dt = self.packed, x.dtype
+
+        def cv(t, key, stride=1, pad=0, act=ops.ACT_RELU, residual=None):
+            c = P[key]
+            return ops.conv2d(t, c.w(dt), c.scale, c.bias, residual, stride=stride, pad=pad, act=act)
+
+        x = cv(x, "stem", 2, 3)
+        x = ops.maxpool(x, 3, 2, 1)
+        out = {}
+        cin = 64
+        for name, n, cmid, cout in RES_STAGES:
+            for i in range(n):
+                p = f"{name}.{i}"
+                stride = 2 if (i == 0 and name != "res2") else 1
+                y = cv(x, p + ".conv1")
+                y = cv(y, p + ".conv2", stride, 1)
+                sc = cv(x, p + ".shortcut", stride, 0, ops.ACT_NONE) if cin != cout else x
+                x = cv(y, p + ".conv3", residual=sc)
+                cin = cout
+            if name in self.out_features:
+                out[name] = x
+        return out
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape=None):
+    return HipResNet50(cfg)
+
+
+def build_backbone(cfg):
+    return BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)

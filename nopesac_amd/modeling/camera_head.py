@@ -1,0 +1,178 @@
+"""CAMERA_HEAD on HIP kernels (camera_net/camera_head.py:400-640 `inference_Joint`, batched over pairs):
+
+  (i)   pixel pose-regression net: pixel decoder (GN) -> 6 conv/BN/LeakyReLU -> 300x300 correlation softmax
+        -> 2 x 6 strided convs -> FC -> initial pose                                (:642-683, camera_modules.py:246-348)
+  (ii)  AIM re-embedding MLPs                                                        (:685-735)
+  (iii) plane matching (matching_head.MatchingHead) + mutual-NN assignment            (:493-501)
+  (iv)  neural one-plane RANSAC: geo encoding -> per-plane pose hypotheses (MFMA MLP stacks) -> (K+1)xK
+        scoring maps -> score MLPs -> masked softmax + soft aggregation -> final pose  (:512-583, 925-1115)
+  (v)   geometric re-filter of the assignment                                         (:605-629)
+
+The reference asserts batch == 1 pair; here every stage runs on B pairs at once with per-pair plane / match
+counts as device int32 vectors, and no stage synchronises with the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..registry import CAMERA_HEAD_REGISTRY
+from ..synth import state_dict_spec
+from .params import ConvW, ParamModule, conv_bias, conv_bn, mlp_layers
+from .plane_head import run_mlp
+
+CAM_MODES = {"soft": 0, "avg-all": 1, "min-cost": 2, "max-score": 3}
+
+
+@CAMERA_HEAD_REGISTRY.register()
+class PlaneCameraHead(ParamModule):
+    def __init__(self, cfg, input_shape=None):
+        C = cfg.MODEL.CAMERA_HEAD
+        self.num_queries = cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES
+        self.out_cam_type = C.INFERENCE_OUT_CAM_TYPE
+        self.warp_plane_in_cam_ref_on = bool(C.WARP_PLANE_IN_CAM_REF_ON)
+        self.matching_score_threshold = float(cfg.TEST.MATCHING_SCORE_THRESHOLD)
+        assert C.REFINE_ON and C.CAM_REC_ON and not C.INFERENCE_SP_TOPCAM_ON and cfg.MODEL.EMBEDDING_ON and cfg.MODEL.MASK_ON, \
+            "implemented: the shipped inference configuration (REFINE_ON, CAM_REC_ON, plane matcher on; inference_mp3d.yaml:17-23)"
+        assert not cfg.TEST.POSE_REFINEMENT_WITH_GT_MATCHERS, "GT matchers are an evaluation-only mode"
+        assert self.out_cam_type in CAM_MODES
+        assert cfg.MODEL.SEM_SEG_HEAD.NORM == "GN" and cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM == 128
+        spec = {k[len("camera_head_list.0."):]: v for k, v in state_dict_spec(self.num_queries).items()
+                if k.startswith("camera_head_list.0.")}
+        super().__init__(spec)
+
+    # ---------------------------------------------------------------- packing
+    def pack(self) -> dict:
+        P = {}
+        for nm in ("adapter_1", "adapter_2", "layer_1", "layer_2", "layer_3"):
+            P[nm] = ConvW(self.raw(f"pixel_decoder.{nm}.weight"))
+        P["mask_features"] = conv_bias(self, "pixel_decoder.mask_features")
+        for i in (0, 1, 3, 4, 6, 7):
+            P[f"cb{i}"] = conv_bn(self, f"convs_backbone.{i}.0.weight", f"convs_backbone.{i}.1", 1e-3)
+        for br in ("convs_trans", "convs_rots"):
+            for i in range(6):
+                P[f"{br}.{i}"] = conv_bn(self, f"{br}.{i}.0.weight", f"{br}.{i}.1", 1e-3)
+        for nm in ("fc_trans", "fc_rots"):
+            # the reference flattens NCHW (128,2,3) -> index c*6+hw; our activations are NHWC -> hw*128+c
+            w = self.raw(nm + ".weight").float().view(256, 128, 6).permute(0, 2, 1).reshape(256, 768)
+            P[nm] = ConvW(w.contiguous(), None, self.raw(nm + ".bias"))
+        for nm in ("trans", "rots", "rot_score_reg", "trans_score_reg"):
+            P[nm] = conv_bias(self, nm)
+        for nm in ("rot_emb_proj", "trans_emb_proj", "geo_encoder", "geo_proj_s1", "decoder_rot", "geo_proj_s2", "decoder_tran",
+                   "decoder_rot2", "decoder_tran2", "normal_score_proj", "param_score_proj"):
+            P[nm] = mlp_layers(self, nm)
+        return P
+
+    def _gn(self, x, nm, act):
+        return ops.groupnorm(x, self.raw(f"pixel_decoder.{nm}.norm.weight"), self.raw(f"pixel_decoder.{nm}.norm.bias"), 32, 1e-5, act)
+
+    # ---------------------------------------------------------------- (i) pixel pose net
+    def pixel_pose_net(self, feats: dict, B: int):
+        """feats: NHWC res3..res5 for 2B images (view-1 images first) -> trans0 [B,3], rot0 [B,4] (unit, w>=0),
+        trans_feat, rots_feat [B,256]."""
+        P = self.packed
+        r3, r4, r5 = feats["res3"], feats["res4"], feats["res5"]
+        cd = r5.dtype
+
+        def cv(x, nm, pad=0, stride=1, act=ops.ACT_NONE, out_dtype=None):
+            c = P[nm]
+            return ops.conv2d(x, c.w(x.dtype), c.scale, c.bias, stride=stride, pad=pad, act=act, out_dtype=out_dtype)
+
+        y = self._gn(cv(r5, "layer_3", 1), "layer_3", ops.ACT_RELU)
+        y = ops.upsample2x_nearest_add(y, self._gn(cv(r4, "adapter_2"), "adapter_2", ops.ACT_NONE))
+        y = self._gn(cv(y, "layer_2", 1), "layer_2", ops.ACT_RELU)
+        y = ops.upsample2x_nearest_add(y, self._gn(cv(r3, "adapter_1"), "adapter_1", ops.ACT_NONE))
+        y = self._gn(cv(y, "layer_1", 1), "layer_1", ops.ACT_RELU)
+        x = cv(y, "mask_features", 1)
+        x = cv(cv(x, "cb0", 1, act=ops.ACT_LEAKY), "cb1", 1, act=ops.ACT_LEAKY)
+        x = ops.maxpool(x, 2, 2, 0)
+        x = cv(cv(x, "cb3", 1, act=ops.ACT_LEAKY), "cb4", 1, act=ops.ACT_LEAKY)
+        x = ops.maxpool(x, 2, 2, 0)
+        x = cv(cv(x, "cb6", 1, act=ops.ACT_LEAKY), "cb7", 1, act=ops.ACT_LEAKY, out_dtype=torch.float32)   # [2B,h,w,256] f32
+        _, h, w, _ = x.shape
+        x1, x2 = x[:B], x[B:]
+        # correlation volume (:1117-1133): channel = view-2 position in (w,h) order, softmax over channels
+        x2t = ops.transpose_hw_rows(x2.reshape(B, h * w, 256), h, w)
+        corr = ops.conv2d(x1, x2t.view(B, h * w, 1, 1, 256), batched_weights=True)          # [B,h,w,h*w]
+        aff = ops.softmax_rows(corr)
+
+        def branch(name, fc):
+            t = aff
+            for i in range(6):
+                t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY)
+            return ops.linear(t.reshape(B, -1), P[fc].w2d(), P[fc].bias, act=ops.ACT_RELU)
+
+        trans_feat, rots_feat = branch("convs_trans", "fc_trans"), branch("convs_rots", "fc_rots")
+        trans0 = ops.linear(trans_feat, P["trans"].w2d(), P["trans"].bias)
+        rot0 = ops.normalize_rows(ops.linear(rots_feat, P["rots"].w2d(), P["rots"].bias), canonical_sign=True)  # :667, :436-437
+        return trans0, rot0, trans_feat, rots_feat
+
+    # ---------------------------------------------------------------- (ii) AIM
+    def aim(self, trans0, rot0):
+        P = self.packed
+        rot_feat = run_mlp(rot0, P["rot_emb_proj"], final_act=ops.ACT_RELU)                  # rot0 already has w >= 0 (:695-696)
+        rec_rot = ops.normalize_rows(ops.linear(rot_feat, P["rots"].w2d(), P["rots"].bias))
+        trans_feat = run_mlp(trans0 + 1e-10, P["trans_emb_proj"], final_act=ops.ACT_RELU)    # :718
+        rec_trans = ops.linear(trans_feat, P["trans"].w2d(), P["trans"].bias)
+        return rec_trans, rec_rot, trans_feat, rot_feat
+
+    # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
+    def refine(self, A0, planes1, planes2, n1, n2, rec_trans, rec_rot, trans_feat, rot_feat, diagnostics=False):
+        P, nq = self.packed, self.num_queries
+        B = A0.shape[0]
+        dev = A0.device
+        geo_local, geo_global, sig, geo_enc, m = ops.geo_sequence(A0, planes1, planes2, n1, n2, rec_trans, rec_rot,
+                                                                  self.warp_plane_in_cam_ref_on)
+        rows = B * nq
+        geo = run_mlp(geo_enc.view(rows, 8), P["geo_encoder"])
+        cat1280 = torch.empty(rows, 1280, device=dev, dtype=torch.float32)
+        cat_r = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
+        cat_t = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
+        cat_r[:, :, :256] = rot_feat[:, None, :]                                             # :980-983 broadcast of the initial feats
+        cat_t[:, :, :256] = trans_feat[:, None, :]
+        run_mlp(geo, P["geo_proj_s1"], out=cat1280[:, :1024])
+        f_rot = run_mlp(cat1280[:, :1024], P["decoder_rot"], out=cat1280[:, 1024:])
+        cat_r.view(rows, 512)[:, 256:] = f_rot                                               # geo_fea_rot_all feeds two consumers
+        s2 = run_mlp(cat1280, P["geo_proj_s2"])
+        run_mlp(s2, P["decoder_tran"], out=cat_t.view(rows, 512)[:, 256:])
+        fused_rot = run_mlp(cat_r.view(rows, 512), P["decoder_rot2"], final_act=ops.ACT_RELU)
+        fused_tran = run_mlp(cat_t.view(rows, 512), P["decoder_tran2"], final_act=ops.ACT_RELU)
+        rot_raw = ops.linear(fused_rot, P["rots"].w2d(), P["rots"].bias).view(B, nq, 4)
+        trans_raw = ops.linear(fused_tran, P["trans"].w2d(), P["trans"].bias).view(B, nq, 3)
+        maps = ops.ransac_score_maps(geo_local, rot_raw, trans_raw, rec_rot, rec_trans, m, diagnostics=diagnostics)
+        sf_rot = run_mlp(maps["normal_score"].view(B * (nq + 1), nq), P["normal_score_proj"]).view(B, nq + 1, 64)
+        sf_tran = run_mlp(maps["param_score"].view(B * (nq + 1), nq), P["param_score_proj"]).view(B, nq + 1, 64)
+        vote = ops.ransac_soft_vote(sf_rot, sf_tran, P["rot_score_reg"].w2d().view(-1), P["rot_score_reg"].bias,
+                                    P["trans_score_reg"].w2d().view(-1), P["trans_score_reg"].bias, rot_feat, trans_feat,
+                                    fused_rot.view(B, nq, 256), fused_tran.view(B, nq, 256), P["rots"].w2d(), P["rots"].bias,
+                                    P["trans"].w2d(), P["trans"].bias, maps, rec_rot, rec_trans, m, CAM_MODES[self.out_cam_type])
+        vote.update(m=m, geo_local=geo_local, geo_global=geo_global, sig=sig, maps=maps)
+        return vote
+
+    # ---------------------------------------------------------------- whole head
+    def forward(self, feats: dict, sel: dict, matching_net, B: int, diagnostics: bool = False) -> dict:
+        """feats: NHWC backbone maps of the 2B images (view-1 first); sel: output of plane post-selection for
+        the 2B images (planes [2B,nq,3], feats [2B,nq,256], n_kept int32[2B]).  Returns device tensors:
+        cameras {name: (tran [B,3], rot [B,4])}, assignments [B,nq,nq], log_scores [B,nq+1,nq+1], m [B] ..."""
+        trans0, rot0, tf0, rf0 = self.pixel_pose_net(feats, B)
+        rec_t, rec_r, rec_tf, rec_rf = self.aim(trans0, rot0)
+        n_all = sel["n_kept"]
+        n1, n2 = n_all[:B].contiguous(), n_all[B:].contiguous()
+        planes1, planes2 = sel["planes"][:B], sel["planes"][B:]
+        cam7 = torch.cat([rec_t, rec_r], dim=-1)                                             # :455
+        log_scores, A0 = matching_net(sel["feats"], n_all, cam7, planes1, planes2, self.matching_score_threshold)
+        ref = self.refine(A0, planes1, planes2, n1, n2, rec_t, rec_r, rec_tf, rec_rf, diagnostics)
+        A1 = ops.refilter_assignment(A0, planes1, planes2, n1, n2, ref["pred_rot"], ref["pred_trans"])
+        zero_t = torch.zeros_like(trans0)
+        zero_r = torch.zeros_like(rot0)
+        zero_r[:, 0] = 1.0
+        cams = {"camera_zero": (zero_t, zero_r), "camera_init": (trans0, rot0), "camera_initRec": (rec_t, rec_r),
+                "camera_avgRef0": (ref["avg_trans"], ref["avg_rot"]), "camera_softRef0": (ref["pred_trans"], ref["pred_rot"]),
+                "camera": (ref["pred_trans"], ref["pred_rot"])}                             # sign NOT canonicalised (:596-601)
+        return {"cameras": cams, "pred_assignment_beforeRef0": A0, "pred_assignment_afterRef0": A1, "pred_assignment": A1,
+                "log_scores_padded": log_scores, "m": ref["m"], "n1": n1, "n2": n2, "refine": ref,
+                "init_feats": (rec_tf, rec_rf)}
+
+
+def build_camera_head(cfg, input_shape=None):
+    return CAMERA_HEAD_REGISTRY.get(cfg.MODEL.CAMERA_HEAD.NAME)(cfg, input_shape)

@@ -1,0 +1,148 @@
+"""`PlaneTR_NopeSAC` — the drop-in META_ARCHITECTURE (meta_arch/siamese_planeTR.py:33-34, inference half
+:338-473).  Same registry name, same `model(batched_inputs: list[dict]) -> list[dict]` contract, same
+state-dict key names; the body runs on libnopesac_hip.so.
+
+Differences by design (MI355X-first):
+  * any number of pairs per call (the reference asserts batch == 1, :340): the 2B images of B pairs go
+    through backbone / plane head / post-selection as one batch, the B pairs through the camera head;
+  * no host synchronisation inside the forward: ragged plane / match counts stay on the device, results
+    are fetched once at the end when the per-pair dicts are built;
+  * training is out of scope (`forward` in training mode raises).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..registry import META_ARCH_REGISTRY, configurable
+from .backbone import build_backbone
+from .camera_head import build_camera_head
+from .matching_head import build_matching_head
+from .plane_head import build_planeTR_head, post_select
+
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+
+
+@META_ARCH_REGISTRY.register()
+class PlaneTR_NopeSAC(nn.Module):
+    @configurable
+    def __init__(self, *, num_queries: int, pixel_mean, pixel_std, device, cfg):
+        super().__init__()
+        self.cfg = cfg
+        assert cfg.MODEL.MASK_ON and cfg.MODEL.EMBEDDING_ON and cfg.MODEL.CAMERA_ON, \
+            "implemented: the inference configuration (MASK_ON, EMBEDDING_ON, CAMERA_ON; configs/inference_*.yaml)"
+        self.backbone = build_backbone(cfg)
+        self.sem_seg_head = build_planeTR_head(cfg, self.backbone.output_shape())
+        self.matching_head = build_matching_head(cfg)
+        self.camera_head_list = nn.ModuleList([build_camera_head(cfg, self.backbone.output_shape())])
+        self.num_queries = num_queries
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32), False)
+        self.compute_dtype = _DTYPES[cfg.MODEL.AMD.COMPUTE_DTYPE]
+        self.output_masks = bool(cfg.MODEL.AMD.OUTPUT_MASKS)
+        self.infer_iter = 0
+        # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
+
+    @classmethod
+    def from_config(cls, cfg):
+        return {"num_queries": cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES, "pixel_mean": cfg.MODEL.PIXEL_MEAN,
+                "pixel_std": cfg.MODEL.PIXEL_STD, "device": torch.device(cfg.MODEL.DEVICE), "cfg": cfg}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts a bare reference state dict or a detectron2 checkpoint {"model": sd}; the reference-only
+        `criterion.*` entries are ignored."""
+        if "model" in state_dict and isinstance(state_dict["model"], dict):
+            state_dict = state_dict["model"]
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("criterion.")}
+        return super().load_state_dict(sd, strict=strict)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, batched_inputs: List[dict]):
+        if self.training:
+            raise NotImplementedError("nopesac_amd implements the inference path only (call .eval())")
+        self.infer_iter += 1
+        with torch.no_grad():
+            dev_out = self.forward_device(batched_inputs)
+            return self.package(batched_inputs, dev_out)
+
+    def preprocess_image(self, batched_inputs: List[dict]) -> torch.Tensor:
+        """Stack the 2B images (all view-"0" images first), normalise, NCHW->NHWC (siamese_planeTR.py:534-542)."""
+        imgs = [x["0"]["image"] for x in batched_inputs] + [x["1"]["image"] for x in batched_inputs]
+        sizes = {tuple(i.shape) for i in imgs}
+        assert len(sizes) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
+        x = torch.stack([i.to(self.device, torch.float32, non_blocking=True) for i in imgs], 0).contiguous()
+        return ops.preprocess(x, self.pixel_mean, self.pixel_std, self.backbone.STEM_CIN_PAD, self.compute_dtype)
+
+    def forward_device(self, batched_inputs: List[dict], diagnostics: bool = False) -> dict:
+        """All device work for B pairs; returns device tensors only (no synchronisation)."""
+        B = len(batched_inputs)
+        H, W = batched_inputs[0]["0"]["image"].shape[-2:]
+        x = self.preprocess_image(batched_inputs)
+        return self.forward_tensors(x, B, H, W, diagnostics)
+
+    def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False) -> dict:
+        feats = self.backbone(x_nhwc)
+        head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
+        sel = post_select(head_out, query_feat, H, W, self.cfg)
+        cam = self.camera_head_list[0](feats, sel, self.matching_head, B, diagnostics)
+        return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
+                "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
+
+    # ------------------------------------------------------------------------------------------
+    def package(self, batched_inputs: List[dict], d: dict) -> List[dict]:
+        """Build the reference's per-pair result dicts (siamese_planeTR.py:384-450); the only host sync."""
+        B, sel, cam = d["B"], d["sel"], d["cam"]
+        H, W = d["H"], d["W"]
+        cpu = lambda t: t.detach().to("cpu")
+        n_kept, kept_idx = cpu(sel["n_kept"]).tolist(), cpu(sel["kept_idx"])
+        planes, centers, scores, areas = cpu(sel["planes"]), cpu(sel["centers"]), cpu(sel["scores"]), cpu(sel["areas"])
+        flags = cpu(sel["flags"]).tolist()
+        cams = {k: (cpu(t).numpy(), cpu(r).numpy()) for k, (t, r) in cam["cameras"].items()}
+        m = cpu(cam["m"]).tolist()
+        ass = {k: cpu(cam[k]) for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
+        onepp_t, onepp_r = cpu(cam["refine"]["maps"]["trans_all"]).numpy(), cpu(cam["refine"]["maps"]["rots_all"]).numpy()
+        results = []
+        for i in range(B):
+            res = {}
+            for v, j in (("0", i), ("1", B + i)):
+                n = n_kept[j]
+                idx = kept_idx[j, :n]
+                inp = batched_inputs[i][v]
+                view = {"image_id": inp.get("image_id"), "file_name": inp.get("file_name"),
+                        "pred_plane": planes[j, :n].clone(), "pred_plane_feats": sel["feats"][j:j + 1, :n],
+                        "pred_plane_oriIdxs": [int(q) for q in idx], "pred_plane_ins_center": centers[j, :n].clone(),
+                        "pred_plane_scores": scores[j, :n].clone(), "pred_plane_areas": areas[j, :n].clone(),
+                        "winner_map": sel["winner"][j], "fallback_mask": bool(flags[j] & 2)}
+                if self.output_masks:
+                    view["pred_plane_masks"] = decode_masks(sel["winner"][j], idx.to(sel["winner"].device), bool(flags[j] & 2))
+                view["instances"] = [{"image_id": inp.get("image_id"), "file_name": inp.get("file_name"), "category_id": 0,
+                                      "score": float(scores[j, k]), "bbox_mode": 1} for k in range(n)]
+                res[v] = view
+            res["pred_aff"] = None
+            res["depth"] = {"0": None, "1": None}
+            for k, (t, r) in cams.items():
+                res[k] = {"tran": t[i], "rot": r[i]}
+            if m[i] >= 2:        # camera_head.py:635-639: only present when the refine stage produced all hypotheses
+                res["camera_onePP"] = {"tran": onepp_t[i, :m[i] + 1], "rot": onepp_r[i, :m[i] + 1]}
+            n1, n2 = n_kept[i], n_kept[B + i]
+            for k, A in ass.items():
+                res[k] = A[i, :n1, :n2].clone()
+            res["matched_num"] = m[i]
+            results.append(res)
+        return results
+
+
+def decode_masks(winner: torch.Tensor, kept_idx: torch.Tensor, fallback: bool) -> torch.Tensor:
+    """winner uint8 [H,W] (low 7 bits = arg-max query, bit 7 = above mask threshold) -> bool [n,H,W]
+    (siamese_planeTR.py:685 / :743 in the fallback case)."""
+    ids = (winner & 0x7F).to(torch.int64)
+    eq = ids.unsqueeze(0) == kept_idx.view(-1, 1, 1).to(torch.int64)
+    return eq if fallback else eq & ((winner & 0x80) != 0).unsqueeze(0)

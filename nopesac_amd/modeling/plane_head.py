@@ -1,0 +1,183 @@
+"""PlaneTR head on HIP kernels (planeTR_net/planeTR_head.py:116-192; transformer/transformer.py;
+transformer/position_encoding.py) + fused plane post-selection (meta_arch/siamese_planeTR.py:625-803).
+
+Token matrices are batch-major [B*L, 256] fp32.  Per encoder layer: 4 GEMMs (fused q|k projection, v,
+out-proj with the residual in the epilogue, 2 FFN GEMMs with ReLU / residual epilogues), 1 attention
+launch, 2 LayerNorm launches (which also emit `x + pos` for the next layer's q/k).  Only the last decoder
+layer's heads are evaluated (the reference's deep-supervision outputs are training-only).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import ops
+from ..registry import SEM_SEG_HEADS_REGISTRY
+from ..synth import state_dict_spec
+from .params import ConvW, ParamModule, conv_bias, conv_bn, mlp_layers
+
+
+def sine_position_embedding(h: int, w: int, num_pos_feats: int = 128) -> torch.Tensor:
+    """[h*w, 2*num_pos_feats] table of transformer/position_encoding.py:29-52 (normalize=True, no mask);
+    input independent, built once on the host."""
+    eps, scale, temperature = 1e-6, 2 * math.pi, 10000.0
+    y = torch.arange(1, h + 1, dtype=torch.float32).view(h, 1).expand(h, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32).view(1, w).expand(h, w)
+    y = y / (y[-1:, :] + eps) * scale
+    x = x / (x[:, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, 2 * num_pos_feats).contiguous()
+
+
+def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE):
+    for i, l in enumerate(layers):
+        last = i == len(layers) - 1
+        x = ops.linear(x, l.w2d(), l.bias, act=final_act if last else ops.ACT_RELU, out=out if last else None)
+    return x
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class PlaneTRHead(ParamModule):
+    def __init__(self, cfg, input_shape=None):
+        H = cfg.MODEL.SEM_SEG_HEAD
+        self.num_queries = H.NUM_OBJECT_QUERIES
+        self.nheads = H.NHEADS
+        assert H.HIDDEN_DIM == 256 and H.MASK_DIM == 256 and H.NHEADS == 8 and H.ENC_LAYERS == 6 and H.DEC_LAYERS == 6, \
+            "PlaneTRHead kernels are specialised to hidden 256 / 8 heads / 6+6 layers (config/config.py:46-51)"
+        assert H.PARAM_ON and H.CENTER_ON and not cfg.MODEL.DEPTH_ON, "inference configs set PARAM_ON/CENTER_ON, no depth"
+        spec = {k[len("sem_seg_head."):]: v for k, v in state_dict_spec(self.num_queries).items()
+                if k.startswith("sem_seg_head.")}
+        super().__init__(spec)
+        self._pos_cache = {}
+
+    # ---------------------------------------------------------------- packing
+    def _mha(self, prefix: str, fuse_qk: bool):
+        w, b = self.raw(prefix + ".in_proj_weight").float(), self.raw(prefix + ".in_proj_bias").float()
+        E = 256
+        d = {"o": conv_bias(self, prefix + ".out_proj"), "v": ConvW(w[2 * E:], None, b[2 * E:])}
+        if fuse_qk:
+            d["qk"] = ConvW(w[:2 * E], None, b[:2 * E])
+        else:
+            d["q"], d["k"] = ConvW(w[:E], None, b[:E]), ConvW(w[E:2 * E], None, b[E:2 * E])
+        return d
+
+    def pack(self) -> dict:
+        P = {"input_proj": conv_bias(self, "input_proj")}
+        for i in range(6):
+            p = f"context_SA.layers.{i}"
+            P[p] = {"attn": self._mha(p + ".self_attn", True), "l1": conv_bias(self, p + ".linear1"),
+                    "l2": conv_bias(self, p + ".linear2")}
+            p = f"context2plane_decoder.layers.{i}"
+            P[p] = {"self": self._mha(p + ".self_attn", True), "cross": self._mha(p + ".multihead_attn", False),
+                    "l1": conv_bias(self, p + ".linear1"), "l2": conv_bias(self, p + ".linear2")}
+        for nm in ("up_conv3", "up_conv2", "up_conv1", "c4_conv", "c3_conv", "c2_conv", "c1_conv", "m_conv_dict.m4"):
+            P[nm] = conv_bn(self, f"top_down.{nm}.0.weight", f"top_down.{nm}.1", 1e-5)
+        for nm in ("plane_embedding", "plane_param", "plane_center"):
+            P[nm] = mlp_layers(self, nm)
+        P["pixel_embedding"] = conv_bias(self, "pixel_embedding")
+        P["pixel_plane_center"] = conv_bias(self, "pixel_plane_center")
+        P["plane_prob"] = conv_bias(self, "plane_prob")
+        return P
+
+    def _ln(self, x, prefix, **kw):
+        return ops.layernorm(x, self.raw(prefix + ".weight"), self.raw(prefix + ".bias"), **kw)
+
+    def _pos(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = sine_position_embedding(h, w).to(device)
+        return self._pos_cache[key]
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, features: dict, want_logits: bool = False):
+        """features: NHWC res2..res5 (compute dtype).  Returns (outputs, query_feat [B,nq,256]) where outputs
+        holds pred_logits [B,nq,2], pred_params [B,nq,3], pred_centers [B,nq,2], mask_prob [B,h,w,nq]
+        (= sigmoid(pred_mask_logits), NHWC) and, if `want_logits`, pred_mask_logits / pixel_centers."""
+        P = self.packed
+        c1, c2, c3, c4 = features["res2"], features["res3"], features["res4"], features["res5"]
+        cd = c4.dtype
+        B, hc, wc, _ = c4.shape
+        L, nq, nh = hc * wc, self.num_queries, self.nheads
+        scale = 32 ** -0.5
+        pos = self._pos(hc, wc, c4.device)
+        ip = P["input_proj"]
+        src = ops.conv2d(c4, ip.w(cd), None, ip.bias, out_dtype=torch.float32).view(B * L, 256)
+        q_in = ops.add_rows(src, pos)
+        # ---- encoder (post-norm; transformer.py:183-199)
+        for i in range(6):
+            p = f"context_SA.layers.{i}"
+            W = P[p]
+            qk = ops.linear(q_in, W["attn"]["qk"].w2d(), W["attn"]["qk"].bias)
+            v = ops.linear(src, W["attn"]["v"].w2d(), W["attn"]["v"].bias)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale)
+            s = ops.linear(o, W["attn"]["o"].w2d(), W["attn"]["o"].bias, residual=src)
+            src = self._ln(s, p + ".norm1")
+            hdn = ops.linear(src, W["l1"].w2d(), W["l1"].bias, act=ops.ACT_RELU)
+            s = ops.linear(hdn, W["l2"].w2d(), W["l2"].bias, residual=src)
+            src, q_in = self._ln(s, p + ".norm2", addend=pos)
+        memory, mem_k = self._ln(src, "context_SA.norm", addend=pos)
+        # ---- decoder (pre-norm; transformer.py:293-322), only hs[-1] is needed at inference
+        qpos = self.raw("query_embed.weight")
+        tgt = torch.zeros(B * nq, 256, device=c4.device, dtype=torch.float32)
+        for i in range(6):
+            p = f"context2plane_decoder.layers.{i}"
+            W = P[p]
+            t2, q_in = self._ln(tgt, p + ".norm1", addend=qpos)
+            qk = ops.linear(q_in, W["self"]["qk"].w2d(), W["self"]["qk"].bias)
+            v = ops.linear(t2, W["self"]["v"].w2d(), W["self"]["v"].bias)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale)
+            tgt = ops.linear(o, W["self"]["o"].w2d(), W["self"]["o"].bias, residual=tgt)
+            t2, q_in = self._ln(tgt, p + ".norm2", addend=qpos)
+            q = ops.linear(q_in, W["cross"]["q"].w2d(), W["cross"]["q"].bias)
+            k = ops.linear(mem_k, W["cross"]["k"].w2d(), W["cross"]["k"].bias)
+            v = ops.linear(memory, W["cross"]["v"].w2d(), W["cross"]["v"].bias)
+            o = ops.attention(q, k, v, B, nq, L, nh, scale)
+            tgt = ops.linear(o, W["cross"]["o"].w2d(), W["cross"]["o"].bias, residual=tgt)
+            t2 = self._ln(tgt, p + ".norm3")
+            hdn = ops.linear(t2, W["l1"].w2d(), W["l1"].bias, act=ops.ACT_RELU)
+            tgt = ops.linear(hdn, W["l2"].w2d(), W["l2"].bias, residual=tgt)
+        hs = self._ln(tgt, "context2plane_decoder.norm")             # [B*nq, 256]
+        # ---- top-down pyramid (planeTR_head.py:241-252): lateral + relu(bn(conv(up(.))))
+        RA = ops.ACT_RELU | ops.ACT_RES_AFTER
+
+        def cbr(x, nm, residual=None, out_dtype=None):
+            c = P[nm]
+            return ops.conv2d(x, c.w(x.dtype), c.scale, c.bias, residual, act=RA if residual is not None else ops.ACT_RELU,
+                              out_dtype=out_dtype)
+
+        p4 = cbr(memory.view(B, hc, wc, 256), "m_conv_dict.m4", residual=cbr(c4, "c4_conv"), out_dtype=cd)
+        p3 = cbr(ops.upsample2x_bilinear(p4), "up_conv3", residual=cbr(c3, "c3_conv"))
+        p2 = cbr(ops.upsample2x_bilinear(p3), "up_conv2", residual=cbr(c2, "c2_conv"))
+        p1 = cbr(ops.upsample2x_bilinear(p2), "up_conv1", residual=cbr(c1, "c1_conv"))
+        # ---- instance heads
+        pe = P["pixel_embedding"]
+        pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=torch.float32)            # [B,h,w,256] f32
+        plane_emb = run_mlp(hs, P["plane_embedding"]).view(B, nq, 1, 1, 256)
+        out = {
+            "pred_logits": ops.linear(hs, P["plane_prob"].w2d(), P["plane_prob"].bias).view(B, nq, 2),
+            "pred_params": run_mlp(hs, P["plane_param"]).view(B, nq, 3),
+            "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID).view(B, nq, 2),
+            "mask_prob": ops.conv2d(pix, plane_emb, batched_weights=True, act=ops.ACT_SIGMOID),
+        }
+        if want_logits:
+            out["pred_mask_logits"] = ops.conv2d(pix, plane_emb, batched_weights=True)
+            pc = P["pixel_plane_center"]
+            out["pixel_centers"] = ops.conv2d(p1, pc.w(cd), None, pc.bias, act=ops.ACT_SIGMOID, out_dtype=torch.float32)
+        return out, hs.view(B, nq, 256)
+
+
+def build_planeTR_head(cfg, input_shape=None):
+    return SEM_SEG_HEADS_REGISTRY.get(cfg.MODEL.SEM_SEG_HEAD.NAME)(cfg, input_shape)
+
+
+def post_select(head_out: dict, query_feat: torch.Tensor, height: int, width: int, cfg) -> dict:
+    """Fused plane post-selection for a batch of images (siamese_planeTR.py:625-803); thresholds from
+    cfg.TEST (config/config.py:92-94).  Everything stays on the device (no per-plane host sync)."""
+    return ops.postselect_planes(head_out["pred_logits"], head_out["mask_prob"], head_out["pred_params"], query_feat,
+                                 height, width, float(cfg.TEST.PLANE_SCORE_THRESHOLD), float(cfg.TEST.MASK_PROB_THRESHOLD),
+                                 float(cfg.TEST.OVERLAP_THRESHOLD))

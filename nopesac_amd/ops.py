@@ -13,6 +13,7 @@ from . import _lib
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+ACT_RES_AFTER = 0x100   # OR-able: residual is added after the activation
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 

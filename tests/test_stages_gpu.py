@@ -1,0 +1,222 @@
+"""Stage-level parity: the HIP product (through the C ABI) vs the CPU oracle on the same seeded inputs,
+and vs the golden fixtures captured from the imported reference (tests/golden/, oracle/gen_golden.py)."""
+import pytest
+import torch
+
+from tests import golden_inputs as GI
+from tests.util import gold, make_model, nchw, nhwc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import nopesac_oracle
+    return nopesac_oracle
+
+
+@pytest.fixture(scope="module")
+def model(device):
+    return make_model(device)
+
+
+def test_backbone_small(device, model, O, sd50):
+    from nopesac_amd.synth import synth_pair
+    img = synth_pair(11, 64, 96)["0"]["image"]
+    with torch.no_grad():
+        x = model.preprocess_image([{"0": {"image": img}, "1": {"image": img}}])[:1]
+        f = model.backbone(x)
+        ref = O.backbone(sd50, O.preprocess([img], O.OracleConfig()))
+    g = gold("A_backbone_64x96")
+    for k in ref:
+        assert rel_err(nchw(f[k].float()), ref[k]) < 2e-5, k
+        probe = nchw(f[k].float()).cpu().flatten()[:: max(ref[k].numel() // 64, 1)][:64]
+        assert rel_err(probe, g[k + "_probe"]) < 2e-5
+
+
+def test_plane_head(device, model, O, sd50):
+    feats = GI.feature_maps(21, 6, 8)
+    with torch.no_grad():
+        out, q = model.sem_seg_head({k: nhwc(v).to(device) for k, v in feats.items()}, want_logits=True)
+        ref, q_ref = O.plane_head(sd50, feats, O.OracleConfig())
+    g = gold("B_plane_head_6x8")
+    assert rel_err(q, q_ref) < 3e-4 and rel_err(q.cpu(), g["query_feat"]) < 3e-4
+    for k in ("pred_logits", "pred_params", "pred_centers"):
+        assert rel_err(out[k], ref[k]) < 3e-4, k
+        assert rel_err(out[k].cpu(), g[k]) < 3e-4, k
+    ml = out["pred_mask_logits"].permute(0, 3, 1, 2)          # [B,nq,h,w]
+    assert rel_err(ml, ref["pred_mask_logits"]) < 3e-4
+    assert rel_err(ml[0, :, ::4, ::4].cpu(), g["mask_logits_sub"]) < 3e-4
+    assert rel_err(out["mask_prob"].permute(0, 3, 1, 2), torch.sigmoid(ref["pred_mask_logits"])) < 1e-4
+    assert rel_err(out["pixel_centers"].permute(0, 3, 1, 2), ref["pixel_centers"]) < 1e-4
+
+
+@pytest.mark.parametrize("kind,seed", [("multi", 31), ("none_pass", 32), ("all_overlap_rejected", 33), ("full", 34)])
+def test_postselect(device, O, kind, seed):
+    from nopesac_amd import ops
+    from nopesac_amd.modeling import decode_masks
+    logits, params, mask, feat = GI.postselect_case(kind, seed)
+    cfg = O.OracleConfig()
+    ref = O.post_select(logits, params, mask, feat, cfg)
+    prob = torch.sigmoid(mask).permute(1, 2, 0).contiguous()[None]          # [1,h,w,nq]
+    # two images in one launch: the designed case and a copy with the "on" planes' scores flipped
+    out = ops.postselect_planes(torch.stack([logits, logits]).to(device), torch.cat([prob, prob]).to(device),
+                                torch.stack([params, params]).to(device), torch.stack([feat, feat]).to(device), 480, 640,
+                                cfg.plane_score_threshold, cfg.mask_prob_threshold, cfg.overlap_threshold)
+    g = gold(f"C_postselect_{kind}")
+    for b in range(2):
+        n = int(out["n_kept"][b])
+        idx = out["kept_idx"][b, :n].cpu().long()
+        assert idx.tolist() == ref["pred_plane_oriIdxs"].tolist() == g["idx"].tolist()
+        assert int(out["kept_idx"][b, n:].max() if n < 50 else -1) == -1
+        assert rel_err(out["planes"][b, :n], ref["pred_plane"]) == 0
+        assert rel_err(out["feats"][b, :n], ref["pred_plane_feats"][0]) == 0
+        assert float(out["feats"][b, n:].abs().max() if n < 50 else 0) == 0
+        assert rel_err(out["scores"][b, :n], ref["scores"]) < 1e-6
+        # discrete masks: identical up to float ties of the bilinear up-sampling (<= 0.02% of the pixels)
+        masks = decode_masks(out["winner"][b], idx.to(device), bool(int(out["flags"][b]) & 2)).cpu()
+        mism = int((masks != ref["pred_plane_masks"]).sum())
+        assert mism <= 64, mism
+        assert (out["areas"][b, :n].cpu() - g["areas"]).abs().max() <= 64
+        assert rel_err(out["centers"][b, :n], ref["pred_plane_ins_center"]) < 2e-4
+        assert rel_err(out["centers"][b, :n].cpu(), g["centers"]) < 2e-4
+
+
+def test_pixel_pose_net_and_aim(device, model, O, sd50):
+    fa, fb = GI.feature_maps(41), GI.feature_maps(42)
+    head = model.camera_head_list[0]
+    feats = {k: torch.cat([nhwc(fa[k]), nhwc(fb[k])]).to(device) for k in ("res3", "res4", "res5")}
+    with torch.no_grad():
+        t0, r0, tf, rf = head.pixel_pose_net(feats, 1)
+        rt, rr, rtf, rrf = head.aim(t0, r0)
+        t_ref, r_ref, tf_ref, rf_ref, _ = O.pixel_pose_net(sd50, fa, fb)
+    g = gold("D_posenet")
+    r_canon = r_ref if r_ref[0, 0] >= 0 else -r_ref
+    assert rel_err(t0, t_ref) < 5e-5 and rel_err(r0, r_canon) < 5e-5
+    assert rel_err(tf, tf_ref) < 5e-5 and rel_err(rf, rf_ref) < 5e-5
+    assert rel_err(t0.cpu(), g["trans"]) < 5e-5 and rel_err(tf.cpu(), g["trans_feat"]) < 5e-5
+    assert rel_err(rr.cpu(), g["aim_rot"]) < 5e-5 and rel_err(rt.cpu(), g["aim_trans"]) < 5e-5
+    assert rel_err(rrf.cpu(), g["aim_rot_feat"]) < 5e-5 and rel_err(rtf.cpu(), g["aim_trans_feat"]) < 5e-5
+
+
+MATCH_CASES = [(1, 1, 50), (5, 3, 51), (17, 40, 52), (32, 32, 53), (50, 50, 54)]
+
+
+def _pad(t, nq):
+    out = torch.zeros(nq, *t.shape[1:])
+    out[: t.shape[0]] = t
+    return out
+
+
+def test_matcher_ragged_batch(device, model, O, sd50):
+    """All five (n1, n2) cases in ONE ragged batch vs the per-pair oracle and the reference fixtures."""
+    nq, B = 50, len(MATCH_CASES)
+    cases = [GI.matcher_case(n1, n2, s) for n1, n2, s in MATCH_CASES]
+    app = torch.stack([_pad(c[0], nq) for c in cases] + [_pad(c[1], nq) for c in cases])          # [2B,nq,256]
+    n_all = torch.tensor([c[0].shape[0] for c in cases] + [c[1].shape[0] for c in cases], dtype=torch.int32)
+    cam7 = torch.stack([c[2] for c in cases])
+    p1 = torch.stack([_pad(c[3], nq) for c in cases])
+    p2 = torch.stack([_pad(c[4], nq) for c in cases])
+    with torch.no_grad():
+        ls, A = model.matching_head(app.to(device), n_all.to(device), cam7.to(device), p1.to(device), p2.to(device), 0.2)
+    ls, A = ls.cpu(), A.cpu()
+    cfg = O.OracleConfig()
+    for b, (n1, n2, _) in enumerate(MATCH_CASES):
+        ref = O.matcher(sd50, *cases[b], cfg)
+        got = torch.cat([torch.cat([ls[b, :n1, :n2], ls[b, :n1, nq:]], 1), torch.cat([ls[b, nq:, :n2], ls[b, nq:, nq:]], 1)], 0)
+        g = gold(f"E_matcher_{n1}x{n2}")
+        assert rel_err(got, ref) < 5e-5, (n1, n2)
+        assert rel_err(got, g["log_scores"]) < 5e-5, (n1, n2)
+        A_ref = O.assignment_matrix(ref, 0.2)
+        assert torch.equal(A[b, :n1, :n2], A_ref) and torch.equal(A_ref, g["assignment"]), (n1, n2)
+        assert float(A[b, n1:].abs().sum() + A[b, :, n2:].abs().sum()) == 0
+
+
+def _refine_batch(device, model, O, sd, nq, ms, seeds, cam_type="soft"):
+    head = model.camera_head_list[0]
+    cases = [GI.refine_case(nq, m, s) for m, s in zip(ms, seeds)]
+    B = len(cases)
+    A = torch.zeros(B, nq, nq)
+    for b, c in enumerate(cases):
+        A[b, : c["A"].shape[0], : c["A"].shape[1]] = c["A"]
+    p1 = torch.stack([_pad(c["planes1"], nq) for c in cases]).to(device)
+    p2 = torch.stack([_pad(c["planes2"], nq) for c in cases]).to(device)
+    n1 = torch.tensor([c["planes1"].shape[0] for c in cases], dtype=torch.int32, device=device)
+    n2 = torch.tensor([c["planes2"].shape[0] for c in cases], dtype=torch.int32, device=device)
+    st = lambda k: torch.stack([c[k] for c in cases]).to(device)
+    old = head.out_cam_type
+    head.out_cam_type = cam_type
+    try:
+        with torch.no_grad():
+            out = head.refine(A.to(device), p1, p2, n1, n2, st("init_trans"), st("init_rot"), st("trans_feat"), st("rot_feat"),
+                              diagnostics=True)
+    finally:
+        head.out_cam_type = old
+    cfg = O.OracleConfig(num_queries=nq, out_cam_type=cam_type)
+    for b, (c, m) in enumerate(zip(cases, ms)):
+        gl, mm = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq)
+        gg, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], c["init_trans"])
+        ga, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], torch.zeros(3))
+        sig = (((gg[:, 0:1] * ga[:, 0:1]) >= 0).float() - 0.5) * 2.0
+        assert int(out["m"][b]) == mm == m
+        assert rel_err(out["geo_local"][b], gl) < 1e-6 and rel_err(out["geo_global"][b], gg) < 1e-5
+        assert torch.equal(out["sig"][b].cpu(), sig[:, 0])
+        ref = O.ransac_refine(sd, c["trans_feat"], c["rot_feat"], gg, gl, sig, mm, c["init_trans"], c["init_rot"], cfg)
+        g = gold(f"F_refine_nq{nq}_m{m}_{cam_type}")
+        tag = (nq, m, cam_type)
+        for mine, key in (("pred_trans", "pred_trans"), ("pred_rot", "pred_rot"), ("avg_trans", "pred_trans_avg"), ("avg_rot", "pred_rot_avg")):
+            assert rel_err(out[mine][b], ref[key]) < 1e-4, (tag, key)
+            assert rel_err(out[mine][b].cpu(), g[key]) < 1e-4, (tag, key)
+        if m >= 2:
+            mp = out["maps"]
+            assert rel_err(mp["trans_all"][b, : m + 1], ref["all_pred_trans"]) < 1e-4
+            assert rel_err(mp["rots_all"][b, : m + 1], ref["all_pred_rots"]) < 1e-4
+            assert rel_err(out["score_rot"][b, : m + 1], ref["score_soft_rot"][:, 0]) < 2e-4
+            assert rel_err(out["score_trans"][b, : m + 1], ref["score_soft_offset"][:, 0]) < 2e-4
+            assert rel_err(mp["l2_dist"][b, : m + 1, :m], ref["l2_dist"]) < 1e-4
+            assert rel_err(mp["normal_angle"][b, : m + 1, :m], ref["normal_dist"]) < 1e-3   # acos near 0 amplifies rounding
+            assert rel_err(mp["offset_dist"][b, : m + 1, :m], ref["offset_dist"]) < 1e-4
+            assert rel_err(out["score_rot"][b, : m + 1].cpu(), g["score_soft_rot"][:, 0]) < 2e-4
+            assert float(out["score_rot"][b, m + 1:].abs().sum()) == 0
+
+
+def test_refine_ragged_batch(device, model, O, sd50):
+    ms = (0, 1, 2, 7, 32, 50)
+    _refine_batch(device, model, O, sd50, 50, ms, [60 + m for m in ms])
+
+
+@pytest.mark.parametrize("cam_type", ["avg-all", "min-cost", "max-score"])
+def test_refine_selection_modes(device, model, O, sd50, cam_type):
+    _refine_batch(device, model, O, sd50, 50, (7,), (67,), cam_type)
+
+
+def test_refine_nq64(device, O):
+    from nopesac_amd.synth import synth_state_dict
+    model64 = make_model(device, nq=64)
+    _refine_batch(device, model64, O, synth_state_dict(64), 64, (64, 33), (164, 133))
+
+
+def test_camera_head_ragged_batch(device, model, O, sd50):
+    """D->E->F for three pairs with (n1,n2) = (12,9), (32,32), (1,1) in one batch vs the reference fixtures."""
+    nq = 50
+    specs = [(12, 9, 70), (32, 32, 71), (1, 1, 72)]
+    B = len(specs)
+    mc = [GI.matcher_case(n1, n2, s) for n1, n2, s in specs]
+    fa = [GI.feature_maps(s + 100) for _, _, s in specs]
+    fb = [GI.feature_maps(s + 200) for _, _, s in specs]
+    feats = {k: torch.cat([nhwc(f[k]) for f in fa] + [nhwc(f[k]) for f in fb]).to(device) for k in ("res3", "res4", "res5")}
+    sel = {"planes": torch.stack([_pad(c[3], nq) for c in mc] + [_pad(c[4], nq) for c in mc]).to(device),
+           "feats": torch.stack([_pad(c[0], nq) for c in mc] + [_pad(c[1], nq) for c in mc]).to(device),
+           "n_kept": torch.tensor([c[0].shape[0] for c in mc] + [c[1].shape[0] for c in mc], dtype=torch.int32, device=device)}
+    with torch.no_grad():
+        out = model.camera_head_list[0](feats, sel, model.matching_head, B)
+    for b, (n1, n2, s) in enumerate(specs):
+        g = gold(f"DEF_camhead_{n1}x{n2}")
+        for k, (t, r) in out["cameras"].items():
+            assert rel_err(t[b].cpu(), g[k + "_tran"]) < 1e-4, (n1, n2, k)
+            assert rel_err(r[b].cpu(), g[k + "_rot"]) < 1e-4, (n1, n2, k)
+        for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment"):
+            assert torch.equal(out[k][b, :n1, :n2].cpu(), g[k]), (n1, n2, k)
+        m = int(out["m"][b])
+        if m >= 2:
+            assert rel_err(out["refine"]["maps"]["trans_all"][b, : m + 1].cpu(), g["camera_onePP_tran"]) < 1e-4

@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+LOOSE = ["TEST.OVERLAP_THRESHOLD", 0.0, "TEST.PLANE_SCORE_THRESHOLD", 0.5, "TEST.MATCHING_SCORE_THRESHOLD", 0.0,
+         "TEST.MASK_PROB_THRESHOLD", 0.3]
+
+
+def gold(name):
+    return {k: torch.from_numpy(v) if v.dtype.kind in "fiub" else v for k, v in np.load(os.path.join(GOLD, name + ".npz")).items()}
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def loose_oracle_cfg(nq=50):
+    from oracle.nopesac_oracle import OracleConfig
+    return OracleConfig(num_queries=nq, overlap_threshold=0.0, plane_score_threshold=0.5, matching_score_threshold=0.0,
+                        mask_prob_threshold=0.3)
+
+
+_MODELS = {}
+
+
+def make_model(device, overrides=(), nq=50, dtype="float32"):
+    """PlaneTR_NopeSAC (HIP) with the name-seeded synthetic checkpoint, cached per configuration."""
+    key = (str(device), tuple(overrides), nq, dtype)
+    if key not in _MODELS:
+        from nopesac_amd.config import get_cfg
+        from nopesac_amd.registry import build_model
+        from nopesac_amd.synth import synth_state_dict
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
+        cfg.merge_from_list(["MODEL.DEVICE", str(device), "MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES", nq,
+                             "MODEL.AMD.COMPUTE_DTYPE", dtype] + list(overrides))
+        cfg.freeze()
+        model = build_model(cfg).eval()
+        model.load_state_dict(synth_state_dict(nq))
+        _MODELS[key] = model
+    return _MODELS[key]
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
