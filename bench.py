@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""bench.py — image-pairs/s of the NopeSAC inference hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W              # single GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the whole hot path (preprocess -> ResNet-50 -> PlaneTR head -> plane post-selection
+-> pixel pose net -> matcher (GNN + 200-iter Sinkhorn) -> neural one-plane RANSAC -> results fetched) over
+one batch of `--pairs` synthetic 480x640 pairs per GPU, with the raw images already resident in HBM.
+Workload = BASELINE.json configs[1]: mp3d inference config, batch 32 pairs, ResNet-50 bf16 dense convs,
+K = 32 hypotheses (forced by construction, SURVEY.md §8d / PlaneTR_NopeSAC._force_k).
+
+Prints ONE JSON line (rank 0) with the driver contract fields + `roofline` (dominant kernel = the bf16 MFMA
+implicit-GEMM conv, timed live with HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed
+on this box's host cores over a bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+GFLOP_PER_PAIR = {32: 181.6, 64: 183.7, 128: 189.4}   # SURVEY.md §8d algorithmic work per pair
+
+
+def build_model(device, nq, dtype):
+    from nopesac_amd.config import get_cfg
+    from nopesac_amd.registry import build_model as _build
+    from nopesac_amd.synth import synth_state_dict
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", str(device), "MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES", nq,
+                         "MODEL.AMD.COMPUTE_DTYPE", dtype, "MODEL.AMD.OUTPUT_MASKS", False])
+    cfg.freeze()
+    model = _build(cfg).eval()
+    model.load_state_dict(synth_state_dict(nq))
+    return model
+
+
+def make_forced(B, K, nq, device, seed):
+    """Device-resident K control tensors (consistent plane pairs under a random pose, a K-permutation)."""
+    from tests import golden_inputs as GI
+    g = torch.Generator().manual_seed(seed)
+    planes = torch.zeros(2 * B, nq, 3)
+    A = torch.zeros(B, nq, nq)
+    perm = torch.zeros(B, K, dtype=torch.long)
+    for b in range(B):
+        p1, p2, pm, _ = GI.consistent_planes(K, K, K, g, noise=0.02)
+        planes[b, :K], planes[B + b, :K] = p1, p2
+        inv = torch.empty(K, dtype=torch.long)
+        inv[pm] = torch.arange(K)            # view-2 row j shows view-1 plane inv[j]
+        perm[b] = inv
+        A[b, torch.arange(K), pm] = 1.0
+    noise = 0.01 * torch.randn(B, K, 256, generator=g)
+    return {"K": K, "planes": planes.to(device), "assignment": A.to(device), "perm": perm.to(device), "noise": noise.to(device)}
+
+
+class ConvTimer:
+    """HIP-event timing of every conv/GEMM launch (torch events record on the stream the C ABI launches on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from nopesac_amd import ops
+        orig = ops.conv2d
+        timer = self
+
+        def timed(x, w, *a, **k):
+            if not timer.enabled:
+                return orig(x, w, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig(x, w, *a, **k)
+            e1.record()
+            kk = w.shape[-3] * w.shape[-2] * w.shape[-1]
+            flops = 2.0 * y.numel() * kk
+            nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + w.numel() * w.element_size()
+            if k.get("residual") is not None or (len(a) > 2 and a[2] is not None):
+                nbytes += y.numel() * y.element_size()
+            desc = "x%s w%s s%d" % (tuple(x.shape), tuple(w.shape), k.get("stride", 1))
+            timer.records.append((str(x.dtype), flops, e0, e1, nbytes, desc))
+            return y
+
+        ops.conv2d = timed
+        # modules imported `ops` as a module and call ops.conv2d / ops.linear, so the patch is seen everywhere
+        return self
+
+    def dump(self, path):
+        """Per-launch table: shape, ms, TFLOP/s, algorithmic GB/s (input+weights+output(+residual) once)."""
+        torch.cuda.synchronize()
+        with open(path, "w") as f:
+            f.write("dtype\tms\tTFLOPs\tGBs\tGFLOP\tMB\tdesc\n")
+            for dt, fl, e0, e1, nb, desc in self.records:
+                ms = e0.elapsed_time(e1)
+                f.write("%s\t%.4f\t%.1f\t%.0f\t%.2f\t%.1f\t%s\n" % (dt.replace("torch.", ""), ms, fl / ms / 1e9, nb / ms / 1e6,
+                                                                   fl / 1e9, nb / 1e6, desc))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for dt, fl, e0, e1, _, _ in self.records:
+            d = out.setdefault(dt, {"flops": 0.0, "ms": 0.0, "launches": 0})
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+        return out
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU oracle (restatement validated against the imported reference) on this host's cores."""
+    from nopesac_amd.synth import synth_pair, synth_state_dict
+    from oracle import nopesac_oracle as O
+    # small-batch CPU inference does not scale past a few tens of threads (256 hardware threads made
+    # it ~100x slower); use min(32, all) and say so in `cores`.
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    sd = synth_state_dict(50)
+    cfg = O.OracleConfig()
+    tw = time.perf_counter()
+    O.inference(sd, [synth_pair(100)], cfg)          # warm-up
+    tw = time.perf_counter() - tw
+    if tw > budget_s:                                # pathological host: report the single warm-up pair
+        return {"value": 1.0 / tw, "unit": "pairs/s", "cores": cores, "kind": "port",
+                "sample": f"1 synthetic 480x640 pair (warm-up only), fp32, batch 1, {tw:.1f}s"}
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.inference(sd, [synth_pair(101 + n)], cfg)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": n / el, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 480x640 pairs, fp32, batch 1, default thresholds (K data-dependent, ~1), {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step")
+    ap.add_argument("--k", type=int, default=32, help="hypotheses (matched planes) per pair")
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
+    args = ap.parse_args()
+
+    from nopesac_amd import runner
+    rank, world, local = runner.init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (nopesac_amd has no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    B, K = args.pairs, args.k
+    nq = 50 if K <= 50 else K
+    model = build_model(device, nq, args.dtype)
+    # synthetic inputs resident in HBM: uint8-valued fp32 RGB, seeds 1000+pair
+    g = torch.Generator().manual_seed(1000 + rank)
+    raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float().to(device)
+    forced = make_forced(B, K, nq, device, 7 + rank)
+    from nopesac_amd import ops
+
+    def step():
+        with torch.no_grad():
+            x = ops.preprocess(raw, model.pixel_mean, model.pixel_std, model.backbone.STEM_CIN_PAD, model.compute_dtype)
+            d = model.forward_tensors(x, B, 480, 640, forced=forced)
+            cam = d["cam"]
+            rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"],
+                                      rank * B)
+            allrows = runner.gather_metrics(rows)           # the only collective (RCCL all_gather, KBs)
+            host = allrows.cpu()                            # results leave the device once per step
+            return d, host
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d, host = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    pairs_per_s = world * B * args.steps / elapsed
+    m_mean = float(host[:, 9].mean())
+
+    # ---- roofline of the dominant kernel: one extra instrumented step (outside the timed region)
+    timer = ConvTimer().install()
+    timer.enabled = True
+    step()
+    timer.enabled = False
+    conv = timer.summary()
+    if args.layers and rank == 0:
+        timer.dump(args.layers)
+    key = "torch.bfloat16" if args.dtype == "bfloat16" else "torch.float32"
+    dom = conv.get(key, {"flops": 0.0, "ms": 1.0, "launches": 0})
+    peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bfloat16" else 157.3
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16>" if args.dtype == "bfloat16" else "conv_igemm_kernel<f32>",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
+                "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
+                "step_share": round(dom["ms"] / ms_per_step, 3),
+                "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
+                                          "launches": v["launches"]} for k, v in conv.items() if k != key}}
+
+    out = {"metric": "image-pairs/sec (480x640, K=%d hyp)" % K, "value": round(pairs_per_s, 3), "unit": "pairs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+           "config": {"workload": "configs/inference_mp3d.yaml, %d synthetic 480x640 pairs/GPU/step, ResNet-50 + pyramids in %s, "
+                                  "heads fp32, K=%d matched planes forced (m mean %.1f), nq=%d" % (B, args.dtype, K, m_mean, nq),
+                      "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
+                      "gflop_per_pair_algorithmic": GFLOP_PER_PAIR.get(K)},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_accuracy and args.dtype == "bfloat16":
+        out["pose_err_vs_fp32_path"] = accuracy_vs_fp32(model, device, nq)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def accuracy_vs_fp32(model16, device, nq, n_pairs=4):
+    """Pose error of the bf16 configuration against this implementation's fp32 path (itself within 1e-4 of
+    the reference, tests/test_e2e_gpu.py) on a few synthetic pairs (formulas: mp3d_evaluation.py:389-465)."""
+    import numpy as np
+    from nopesac_amd import runner
+    from nopesac_amd.synth import synth_pair
+    m32 = build_model(device, nq, "float32")
+    inp = [synth_pair(i) for i in range(n_pairs)]
+    a, b = m32(inp), model16(inp)
+    out = {}
+    for key in ("camera_init", "camera"):
+        t = np.stack([x[key]["tran"] for x in a]), np.stack([x[key]["tran"] for x in b])
+        r = np.stack([x[key]["rot"] for x in a]), np.stack([x[key]["rot"] for x in b])
+        out[key] = {"T_err_mean": float(runner.translation_error(t[1], t[0]).mean()),
+                    "R_err_deg_mean": float(runner.rotation_error_deg(r[1], r[0]).mean())}
+    del m32
+    torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ struct ConvParams {
     int M, N, K;       // M = rows per grid.y slice
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt, res_after;
+    int act, out_dt, res_after, epi_vec;
     int tiles_m, tiles_n;
 };
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
         } else {
             // v_mfma_f32_32x32x2_f32 (exact f32): lane l supplies A[row l&31][k = l>>5]; we feed it the
@@ -193,40 +193,97 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col_l = lane & 31, row_q = 4 * (lane >> 5);
+    // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
+    // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
+    // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
+    // 8-channel row chunks, so scale/shift, residual and the output are 16/32-byte accesses that cover whole
+    // 128/256-byte channel runs per row (the layers with small K are HBM-bound: this is what has to stream).
+    constexpr int EN = BN > 64 ? 64 : BN;
+    constexpr int ELD = EN + 4;
+    constexpr int NPASS = BN / EN;
+    static_assert(BM * ELD * 4 <= (int)sizeof(lds), "epilogue tile must fit in the staging LDS");
+    float* epi = reinterpret_cast<float*>(lds);
+    const bool vec_ok = p.epi_vec;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + col_l;
-        if (n >= p.N) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int c_wave = wn * WN - pass * EN;          // first column of this wave inside the pass window
+        if (c_wave >= 0 && c_wave < EN) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + row_q;
-                if (m >= p.M) continue;
-                const long long pix = (long long)m + (long long)bz * p.rows_per_b;
-                float v = acc[i][j][r] * sc + bi;
-                float rv = 0.f;
-                if (p.res) {
-                    rv = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n]
-                                                  : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n]);
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wm * WM + i * 32 + (lane & 31);
+                        const int c = c_wave + j * 32 + 8 * q + 4 * (lane >> 5);
+                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *(f32x4*)(epi + row * ELD + c) = v;
+                    }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BM * (EN / 8); idx += 256) {
+            const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
+            const int m = m0 + row, n = n0 + pass * EN + ch;
+            if (m >= p.M || n >= p.N) continue;
+            const long long pix = (long long)m + (long long)bz * p.rows_per_b;
+            float v[8];
+            *(f32x4*)(v) = *(const f32x4*)(epi + row * ELD + ch);
+            *(f32x4*)(v + 4) = *(const f32x4*)(epi + row * ELD + ch + 4);
+            if (vec_ok && n + 8 <= p.N) {
+                if (p.scale) {
+                    const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
                 }
-                if (p.res_after) v = apply_act(v, p.act) + rv;
-                else v = apply_act(v + rv, p.act);
-                if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n] = v;
-                else ((bf16_t*)p.y)[pix * p.y_cs + n] = f32_to_bf16(v);
+                if (p.bias) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    if (p.out_dt == NPS_DT_F32) {
+                        *(f32x4*)(rv) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n);
+                        *(f32x4*)(rv + 4) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n + 4);
+                    } else {
+                        const us8 r8 = *(const us8*)((const bf16_t*)p.res + pix * p.r_cs + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = bf16_to_f32(r8[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = p.res_after ? apply_act(v[e], p.act) + rv[e] : apply_act(v[e] + rv[e], p.act);
+                if (p.out_dt == NPS_DT_F32) {
+                    float* yp = (float*)p.y + pix * p.y_cs + n;
+                    *(f32x4*)(yp) = *(const f32x4*)(v);
+                    *(f32x4*)(yp + 4) = *(const f32x4*)(v + 4);
+                } else {
+                    us8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
+                    *(us8*)((bf16_t*)p.y + pix * p.y_cs + n) = o;
+                }
+            } else {
+                for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[n + e] : 0.f);
+                    float r = 0.f;
+                    if (p.res)
+                        r = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n + e]
+                                                     : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n + e]);
+                    x = p.res_after ? apply_act(x, p.act) + r : apply_act(x + r, p.act);
+                    if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n + e] = x;
+                    else ((bf16_t*)p.y)[pix * p.y_cs + n + e] = f32_to_bf16(x);
+                }
             }
         }
+        if (pass + 1 < NPASS) __syncthreads();
     }
 }
 
@@ -291,6 +348,16 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
     p.N = Cout; p.K = KH * KW * Cin;
     p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    {   // vectorised epilogue needs 8-channel runs that are 16-byte aligned in every buffer it touches
+        const size_t osz = out_dt == NPS_DT_F32 ? 4 : 2;
+        const int al = out_dt == NPS_DT_F32 ? 4 : 8;     // elements per 16 bytes
+        bool ok = (y_cstride % al == 0) && ((uintptr_t)y % 16 == 0);
+        if (residual) ok = ok && (r_cstride % al == 0) && ((uintptr_t)residual % 16 == 0);
+        if (scale) ok = ok && ((uintptr_t)scale % 16 == 0);
+        if (bias) ok = ok && ((uintptr_t)bias % 16 == 0);
+        (void)osz;
+        p.epi_vec = ok ? 1 : 0;
+    }
     if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t>(p, (hipStream_t)stream);
     else launch_dtype<float>(p, (hipStream_t)stream);
     NPS_LAUNCH_RET();

@@ -150,7 +150,8 @@ class PlaneCameraHead(ParamModule):
         return vote
 
     # ---------------------------------------------------------------- whole head
-    def forward(self, feats: dict, sel: dict, matching_net, B: int, diagnostics: bool = False) -> dict:
+    def forward(self, feats: dict, sel: dict, matching_net, B: int, diagnostics: bool = False,
+                forced_assignment: torch.Tensor = None) -> dict:
         """feats: NHWC backbone maps of the 2B images (view-1 first); sel: output of plane post-selection for
         the 2B images (planes [2B,nq,3], feats [2B,nq,256], n_kept int32[2B]).  Returns device tensors:
         cameras {name: (tran [B,3], rot [B,4])}, assignments [B,nq,nq], log_scores [B,nq+1,nq+1], m [B] ..."""
@@ -161,6 +162,8 @@ class PlaneCameraHead(ParamModule):
         planes1, planes2 = sel["planes"][:B], sel["planes"][B:]
         cam7 = torch.cat([rec_t, rec_r], dim=-1)                                             # :455
         log_scores, A0 = matching_net(sel["feats"], n_all, cam7, planes1, planes2, self.matching_score_threshold)
+        if forced_assignment is not None:       # benchmark-only K control, see PlaneTR_NopeSAC._force_k
+            A0 = forced_assignment
         ref = self.refine(A0, planes1, planes2, n1, n2, rec_t, rec_r, rec_tf, rec_rf, diagnostics)
         A1 = ops.refilter_assignment(A0, planes1, planes2, n1, n2, ref["pred_rot"], ref["pred_trans"])
         zero_t = torch.zeros_like(trans0)

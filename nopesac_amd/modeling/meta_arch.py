@@ -88,13 +88,35 @@ class PlaneTR_NopeSAC(nn.Module):
         x = self.preprocess_image(batched_inputs)
         return self.forward_tensors(x, B, H, W, diagnostics)
 
-    def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False) -> dict:
+    def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False,
+                        forced: dict = None) -> dict:
         feats = self.backbone(x_nhwc)
         head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
         sel = post_select(head_out, query_feat, H, W, self.cfg)
-        cam = self.camera_head_list[0](feats, sel, self.matching_head, B, diagnostics)
+        forced_A = None
+        if forced is not None:
+            sel, forced_A = self._force_k(sel, head_out, query_feat, forced, B)
+        cam = self.camera_head_list[0](feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A)
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
+
+    def _force_k(self, sel: dict, head_out: dict, query_feat: torch.Tensor, forced: dict, B: int):
+        """BENCHMARK-ONLY K control: with random weights the threshold-based selection keeps
+        ~1 plane per view, so the stages after post-selection would see K = 1.  The selection kernels still
+        run (their outputs are overwritten): every view gets its K highest-scoring queries, view-2 appearance
+        = permuted view-1 appearance + 1% noise, plane parameters and the K matches come from `forced`."""
+        K, nq = forced["K"], self.num_queries
+        score = head_out["pred_logits"][:B, :, 0] - head_out["pred_logits"][:B, :, 1]
+        idx = torch.topk(score, K, dim=1).indices.sort(dim=1).values                             # [B,K] ascending
+        f1 = torch.gather(query_feat[:B], 1, idx.unsqueeze(-1).expand(B, K, 256))
+        f2 = torch.gather(f1, 1, forced["perm"].unsqueeze(-1).expand(B, K, 256)) + forced["noise"]
+        feats = torch.zeros(2 * B, nq, 256, device=f1.device, dtype=torch.float32)
+        feats[:B, :K], feats[B:, :K] = f1, f2
+        out = dict(sel)
+        out["feats"] = feats
+        out["planes"] = forced["planes"]
+        out["n_kept"] = torch.full((2 * B,), K, device=f1.device, dtype=torch.int32)
+        return out, forced["assignment"]
 
     # ------------------------------------------------------------------------------------------
     def package(self, batched_inputs: List[dict], d: dict) -> List[dict]:

@@ -1,0 +1,85 @@
+"""Multi-GPU inference plumbing: one process per GPU, pairs sharded contiguously across ranks, and ONE
+collective — an all_gather of fixed-width fp32 per-pair metric rows over RCCL/xGMI — replacing the
+reference's `comm.synchronize(); comm.gather(pickled predictions)` on a Gloo group
+(evaluation/mp3d_evaluation.py:316-319; sharding = detectron2 InferenceSampler, test_NopeSAC.py:48-54).
+The model forward itself has no collective.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+METRIC_WIDTH = 16   # [t(3), q(4), n1, n2, m, T_err, R_err, pair_idx, pad(3)]
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Read RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun) and join the process group.  backend "nccl" is
+    RCCL on ROCm; "gloo" is used by the CPU tests."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of rank `rank` (InferenceSampler semantics: ceil(N/W) per rank)."""
+    per = int(math.ceil(n_items / world))
+    return min(rank * per, n_items), min((rank + 1) * per, n_items)
+
+
+def rotation_error_deg(q_pred: np.ndarray, q_ref: np.ndarray) -> np.ndarray:
+    """2*acos(|<q̂,q>|) in degrees (evaluation/mp3d_evaluation.py:463-465)."""
+    d = np.abs(np.sum(q_pred * q_ref, axis=-1))
+    return 2 * np.arccos(np.clip(d, -1.0, 1.0)) * 180.0 / np.pi
+
+
+def translation_error(t_pred: np.ndarray, t_ref: np.ndarray) -> np.ndarray:
+    """||t̂ - t||₂ (evaluation/mp3d_evaluation.py:389-391)."""
+    return np.linalg.norm(t_pred - t_ref, axis=-1)
+
+
+def metric_rows(trans: torch.Tensor, rot: torch.Tensor, n1: torch.Tensor, n2: torch.Tensor, m: torch.Tensor,
+                pair_idx0: int, t_err: Optional[torch.Tensor] = None, r_err: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pack per-pair results into [B, 16] fp32 rows on the tensors' device (no host sync)."""
+    B = trans.shape[0]
+    rows = torch.zeros(B, METRIC_WIDTH, device=trans.device, dtype=torch.float32)
+    rows[:, 0:3], rows[:, 3:7] = trans, rot
+    rows[:, 7], rows[:, 8], rows[:, 9] = n1.float(), n2.float(), m.float()
+    if t_err is not None:
+        rows[:, 10] = t_err
+    if r_err is not None:
+        rows[:, 11] = r_err
+    rows[:, 12] = torch.arange(pair_idx0, pair_idx0 + B, device=trans.device, dtype=torch.float32)
+    return rows
+
+
+def gather_metrics(rows: torch.Tensor) -> torch.Tensor:
+    """all_gather of equally-sized [B,16] blocks -> [world*B, 16] on every rank (single ring step; the
+    payload is KBs, i.e. latency bound)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    out = torch.empty(world * rows.shape[0], rows.shape[1], device=rows.device, dtype=rows.dtype)
+    if dist.get_backend() == "gloo":      # CPU test backend: list form of the same collective
+        dist.all_gather(list(out.chunk(world, 0)), rows.contiguous())
+    else:
+        dist.all_gather_into_tensor(out, rows.contiguous())
+    return out
+
+
+def summarize(rows: torch.Tensor) -> dict:
+    r = rows.detach().cpu().numpy()
+    return {"pairs": int(r.shape[0]), "mean_T_err": float(r[:, 10].mean()), "mean_R_err": float(r[:, 11].mean()),
+            "mean_planes": float((r[:, 7] + r[:, 8]).mean() / 2), "mean_matches": float(r[:, 9].mean())}

@@ -169,8 +169,11 @@ def synth_tensor(key: str, shape: tuple) -> torch.Tensor:
             w = 1.0 + 0.1 * torch.randn(shape, generator=g)
             if key.startswith("backbone.") and ".conv3.norm." in key:
                 w = 0.3 * w  # damp residual-branch growth through 16 bottlenecks
+            if ".convs_backbone.7.1." in key:
+                w = 0.3 * w  # keep the 300x300 correlation softmax of the pose net smooth (not arg-max-like)
             return w
-        return 0.05 * torch.randn(shape, generator=g)
+        b = 0.05 * torch.randn(shape, generator=g)
+        return 0.3 * b if ".convs_backbone.7.1." in key else b
     if key.endswith("query_embed.weight"):
         return 3.0 * torch.randn(shape, generator=g)
     if leaf in ("bias", "in_proj_bias"):

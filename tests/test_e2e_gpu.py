@@ -1,0 +1,87 @@
+"""End-to-end parity on the GPU: PlaneTR_NopeSAC (HIP, fp32 path) vs the CPU oracle and the golden
+vectors of the imported reference, on the same synthetic pairs; batching invariance; bf16 sanity."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import LOOSE, gold, loose_oracle_cfg, make_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: outputs within 1e-4 of the reference fp32 path (relative to the output scale)
+
+
+def _check_pair(res, ref, g=None, soft_masks=False):
+    """soft_masks: under the relaxed thresholds the synthetic checkpoint's masks are decided by ~1e-6
+    differences between queries, so mask-derived quantities (pixels, areas, centroids) get a looser,
+    explicit tolerance there; ids / plane parameters / cameras / assignments keep the strict gate."""
+    c_tol, px_tol = (5e-3, 3000) if soft_masks else (1e-3, 200)
+    for v in "01":
+        assert res[v]["pred_plane_oriIdxs"] == ref[v]["pred_plane_oriIdxs"].tolist()
+        assert rel_err(res[v]["pred_plane"], ref[v]["pred_plane"]) < TOL
+        assert rel_err(res[v]["pred_plane_feats"], ref[v]["pred_plane_feats"]) < 5e-4
+        assert rel_err(res[v]["pred_plane_ins_center"], ref[v]["pred_plane_ins_center"]) < c_tol
+        mism = int((res[v]["pred_plane_masks"].cpu() != ref[v]["pred_plane_masks"]).sum())
+        assert mism <= px_tol, mism       # 480x640xn booleans; float ties of the bilinear up-sampling only
+        if g is not None:
+            assert res[v]["pred_plane_oriIdxs"] == g[f"v{v}_idx"].tolist()
+            assert rel_err(res[v]["pred_plane"], g[f"v{v}_planes"]) < TOL
+            assert (res[v]["pred_plane_areas"].long() - g[f"v{v}_areas"].long()).abs().max() <= px_tol
+    for k in ref:
+        if "camera" in k:
+            assert k in res, k
+            assert rel_err(res[k]["tran"], ref[k]["tran"]) < TOL, k
+            assert rel_err(res[k]["rot"], ref[k]["rot"]) < TOL, k
+            if g is not None:
+                assert rel_err(res[k]["tran"], g[k + "_tran"]) < TOL and rel_err(res[k]["rot"], g[k + "_rot"]) < TOL, k
+        if "assignment" in k:
+            assert torch.equal(res[k], ref[k]), k
+    assert set(k for k in res if "camera" in k) == set(k for k in ref if "camera" in k)
+
+
+def test_e2e_default_config(device, sd50):
+    from nopesac_amd.synth import synth_pair
+    from oracle import nopesac_oracle as O
+    model = make_model(device)
+    inp = [synth_pair(0), synth_pair(3)]
+    res = model(inp)
+    ref = O.inference(sd50, inp, O.OracleConfig())
+    _check_pair(res[0], ref[0], gold("e2e_default_noise_0"))
+    _check_pair(res[1], ref[1])
+    for r in res:
+        assert r["pred_aff"] is None and r["depth"] == {"0": None, "1": None}
+        assert isinstance(r["camera"]["tran"], np.ndarray) and r["camera"]["rot"].shape == (4,)
+
+
+def test_e2e_loose_structured_batch(device, sd50):
+    """Three structured pairs in ONE batch under relaxed TEST.* thresholds (several planes per view)."""
+    from nopesac_amd.synth import synth_pair
+    from oracle import nopesac_oracle as O
+    model = make_model(device, LOOSE)
+    inp = [synth_pair(i, structured=True) for i in (0, 2, 1)]
+    res = model(inp)
+    ref = O.inference(sd50, inp, loose_oracle_cfg())
+    _check_pair(res[0], ref[0], gold("e2e_loose_structured_0"), soft_masks=True)
+    _check_pair(res[1], ref[1], gold("e2e_loose_structured_2"), soft_masks=True)
+    _check_pair(res[2], ref[2], soft_masks=True)
+    assert max(len(r["0"]["pred_plane_oriIdxs"]) for r in res) >= 3
+    # batching invariance: the same pair alone gives the same answer
+    solo = model([inp[1]])[0]
+    assert solo["0"]["pred_plane_oriIdxs"] == res[1]["0"]["pred_plane_oriIdxs"]
+    assert rel_err(solo["camera"]["tran"], res[1]["camera"]["tran"]) < 1e-5
+    assert torch.equal(solo["pred_assignment"], res[1]["pred_assignment"])
+
+
+def test_bf16_backbone_pose_error(device):
+    """bf16 dense convs: judged by pose error against the fp32 HIP path (discrete decisions may flip,
+    SURVEY.md §7 'hard parts'), not by the 1e-4 gate."""
+    from nopesac_amd.synth import synth_pair
+    m32, m16 = make_model(device), make_model(device, dtype="bfloat16")
+    inp = [synth_pair(i) for i in range(2)]
+    a, b = m32(inp), m16(inp)
+    for x, y in zip(a, b):
+        t_err = float(np.linalg.norm(x["camera_init"]["tran"] - y["camera_init"]["tran"]))
+        q = abs(float(np.dot(x["camera_init"]["rot"], y["camera_init"]["rot"])))
+        r_err = 2 * np.degrees(np.arccos(min(q, 1.0)))
+        assert t_err < 0.05 * (1 + np.linalg.norm(x["camera_init"]["tran"])) and r_err < 10.0, (t_err, r_err)
+        assert np.isfinite(y["camera"]["tran"]).all() and np.isfinite(y["camera"]["rot"]).all()

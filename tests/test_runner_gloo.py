@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: pair sharding + the single metrics all_gather of the multi-GPU path."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nopesac_amd import runner
+    r, w, _ = runner.init_distributed("gloo")
+    lo, hi = runner.shard_range(n_pairs, r, w)
+    B = hi - lo
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    trans = idx.view(-1, 1) * torch.tensor([1.0, 2.0, 3.0])
+    rot = torch.nn.functional.normalize(torch.ones(B, 4) + idx.view(-1, 1), dim=-1)
+    rows = runner.metric_rows(trans, rot, torch.full((B,), 5), torch.full((B,), 7), torch.full((B,), 3), lo,
+                              t_err=idx * 0.1, r_err=idx * 2.0)
+    allrows = runner.gather_metrics(rows)
+    torch.distributed.barrier()
+    q.put((rank, allrows.numpy(), runner.summarize(allrows)))
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    n_pairs, world = 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rows, summ in got:
+        assert rows.shape == (n_pairs, 16)
+        assert rows[:, 12].tolist() == list(range(n_pairs))            # contiguous shards, rank order
+        np.testing.assert_allclose(rows[:, 0], np.arange(n_pairs))
+        assert summ["pairs"] == n_pairs and abs(summ["mean_T_err"] - 0.35) < 1e-6 and summ["mean_matches"] == 3.0
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+
+
+def test_shard_range_covers_everything():
+    from nopesac_amd import runner
+    for n, w in ((256, 8), (10, 4), (3, 8), (1, 1)):
+        seen = []
+        for r in range(w):
+            lo, hi = runner.shard_range(n, r, w)
+            seen += list(range(lo, hi))
+        assert seen == list(range(n))
+
+
+def test_pose_error_formulas():
+    from nopesac_amd import runner
+    q = np.array([[1.0, 0, 0, 0], [np.cos(0.25), np.sin(0.25), 0, 0]])
+    assert np.allclose(runner.rotation_error_deg(q, q), 0, atol=1e-3)
+    assert np.allclose(runner.rotation_error_deg(q[:1], q[1:]), np.degrees(0.5), atol=1e-4)
+    assert np.allclose(runner.rotation_error_deg(q[:1], -q[1:]), np.degrees(0.5), atol=1e-4)   # sign invariant
+    assert np.allclose(runner.translation_error(np.array([[3.0, 4, 0]]), np.zeros((1, 3))), 5.0)
