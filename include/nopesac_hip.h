@@ -30,6 +30,7 @@ extern "C" {
 
 #define NPS_DT_F32 0
 #define NPS_DT_BF16 1
+#define NPS_DT_F32_BF16W 2 /* conv in_dt only: x is f32 in memory, w is bf16; x is rounded to bf16 while staged */
 
 #define NPS_ACT_NONE 0
 #define NPS_ACT_RELU 1
@@ -53,7 +54,7 @@ const char* nopesac_last_error(void);
  * (meta_arch/siamese_planeTR.py:456), planeTR_net/planeTR_head.py:126,148-162,209-215,
  * camera_net/camera_modules.py:36-48,271-321, camera_net/camera_head.py:957-962,983-990,
  * transformer linears, matching_net/matching_head.py:101-113.
- *   in_dt/out_dt : NPS_DT_*; weights have dtype in_dt.
+ *   in_dt/out_dt : NPS_DT_*; weights have dtype in_dt (bf16 for NPS_DT_F32_BF16W).
  *   x_cstride / y_cstride / r_cstride : elements between consecutive pixels (>= channels) so that
  *       inputs/outputs can live inside wider (concatenated) buffers.
  *   w_bstride : elements between per-image weight sets (0 = shared weights).  With w_bstride != 0

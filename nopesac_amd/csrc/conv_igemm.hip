@@ -42,7 +42,9 @@ template <> struct VecT<bf16_t, 1> { typedef unsigned short type; };
 template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<float, 1> { typedef float type; };
 
-template <typename T, int BM, int BN, int VEC>
+// TA = element type of x in memory (float with T = bf16_t is the mixed mode: f32 activations are rounded to
+// bf16 while being staged, weights are bf16, MFMA runs at the bf16 rate).
+template <typename TA, typename T, int BM, int BN, int VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BK = Cfg<T>::BK;
     constexpr int LDS_STRIDE = BK + Cfg<T>::VECW;          // elements; 80 bytes per row for both dtypes
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
     const int bz = p.batched ? blockIdx.y : 0;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const T* __restrict__ X = (const T*)p.x;
+    const TA* __restrict__ X = (const TA*)p.x;
     const T* __restrict__ Wt = (const T*)p.w + (long long)bz * p.w_bs;
 
     const int tid = threadIdx.x;
@@ -112,8 +114,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     ih += kh; iw += kw;
                 }
                 if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-                    const T* src = X + (a_base[i] + (long long)ih * p.W + iw) * p.x_cs + c;
-                    val = *(const vec_t*)src;
+                    const TA* src = X + (a_base[i] + (long long)ih * p.W + iw) * p.x_cs + c;
+                    if constexpr (sizeof(TA) == sizeof(T)) {
+                        val = *(const vec_t*)src;
+                    } else if constexpr (VEC == 1) {
+                        val = f32_to_bf16(*src);
+                    } else {
+#pragma unroll
+                        for (int e4 = 0; e4 < VEC / 4; ++e4) {
+                            const f32x4 f = *(const f32x4*)(src + 4 * e4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[4 * e4 + e] = f32_to_bf16(f[e]);
+                        }
+                    }
                 }
             }
             a_reg[i] = val;
@@ -287,34 +300,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <typename T, int BM, int BN>
+template <typename TA, typename T, int BM, int BN>
 static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
     ConvParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, p.batched ? p.B : 1, 1);
     constexpr int VW = Cfg<T>::VECW;
-    if (vec == VW) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, VW>), grid, dim3(256), 0, stream, p);
+    if (vec == VW) hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW>), grid, dim3(256), 0, stream, p);
     else if (sizeof(T) == 2 && vec == 4) {
-        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, 4>), grid, dim3(256), 0, stream, p);
-    } else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, 1>), grid, dim3(256), 0, stream, p);
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, 4>), grid, dim3(256), 0, stream, p);
+    } else hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, 1>), grid, dim3(256), 0, stream, p);
     return 0;
 }
 
-template <typename T>
+template <typename TA, typename T>
 static int launch_dtype(const ConvParams& p, hipStream_t stream) {
     // widest vector such that every vector stays inside one (kh,kw) tap and is 16/8-byte aligned
     int vec = 1;
     constexpr int VW = Cfg<T>::VECW;
     auto ok = [&](int v) {
-        return p.Cin % v == 0 && p.K % v == 0 && p.x_cs % v == 0 && p.w_bs % v == 0 &&
-               ((uintptr_t)p.x % (v * sizeof(T)) == 0) && ((uintptr_t)p.w % (v * sizeof(T)) == 0);
+        const size_t xa = sizeof(TA) == sizeof(T) ? v * sizeof(T) : (v >= 4 ? 16 : sizeof(TA));   // f32x4 pieces in mixed mode
+        const int xm = sizeof(TA) == sizeof(T) ? v : (v >= 4 ? 4 : 1);
+        return p.Cin % v == 0 && p.K % v == 0 && p.x_cs % xm == 0 && p.w_bs % v == 0 &&
+               ((uintptr_t)p.x % xa == 0) && ((uintptr_t)p.w % (v * sizeof(T)) == 0);
     };
     if (ok(VW)) vec = VW;
     else if (sizeof(T) == 2 && ok(4)) vec = 4;
     const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batched ? p.B : 1);
-    if (p.N > 64 && tiles128 >= 192) return launch_cfg<T, 128, 128>(p, stream, vec);
-    return launch_cfg<T, 64, 64>(p, stream, vec);
+    if (p.N > 64 && tiles128 >= 192) return launch_cfg<TA, T, 128, 128>(p, stream, vec);
+    return launch_cfg<TA, T, 64, 64>(p, stream, vec);
 }
 
 }  // namespace nps
@@ -328,7 +343,7 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     NPS_CHECK_ARG(x && w && y, "conv2d: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                   "conv2d: bad dims B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d", B, H, W, Cin, Cout, KH, KW, stride, pad);
-    NPS_CHECK_ARG(in_dt == NPS_DT_F32 || in_dt == NPS_DT_BF16, "conv2d: bad in_dt %d", in_dt);
+    NPS_CHECK_ARG(in_dt == NPS_DT_F32 || in_dt == NPS_DT_BF16 || in_dt == NPS_DT_F32_BF16W, "conv2d: bad in_dt %d", in_dt);
     NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d: bad out_dt %d", out_dt);
     NPS_CHECK_ARG(x_cstride >= Cin && y_cstride >= Cout, "conv2d: channel stride smaller than channel count");
     NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d: residual stride");
@@ -358,7 +373,8 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
         (void)osz;
         p.epi_vec = ok ? 1 : 0;
     }
-    if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t>(p, (hipStream_t)stream);
-    else launch_dtype<float>(p, (hipStream_t)stream);
+    if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t, bf16_t>(p, (hipStream_t)stream);
+    else if (in_dt == NPS_DT_F32_BF16W) launch_dtype<float, bf16_t>(p, (hipStream_t)stream);
+    else launch_dtype<float, float>(p, (hipStream_t)stream);
     NPS_LAUNCH_RET();
 }

@@ -22,41 +22,70 @@ __global__ void preprocess_kernel(const float* __restrict__ x, T* __restrict__ y
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// Vector helpers: V consecutive channels per thread (16 bytes for V = 8 bf16 / 4 f32).
+template <typename T, int V> struct Pack { T v[V]; };
+template <typename T, int V> __device__ __forceinline__ void load_vec(const T* p, float out[V]) {
+    if constexpr (V == 1) { out[0] = to_f32<T>(*p); }
+    else {
+        typedef Pack<T, V> __attribute__((aligned(sizeof(T) * V))) PV;
+        const PV pk = *reinterpret_cast<const PV*>(p);
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = to_f32<T>(pk.v[i]);
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void store_vec(T* p, const float in[V]) {
+    if constexpr (V == 1) { *p = from_f32<T>(in[0]); }
+    else {
+        typedef Pack<T, V> __attribute__((aligned(sizeof(T) * V))) PV;
+        PV pk;
+#pragma unroll
+        for (int i = 0; i < V; ++i) pk.v[i] = from_f32<T>(in[i]);
+        *reinterpret_cast<PV*>(p) = pk;
+    }
+}
+
+template <typename T, int V>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int K,
                                int stride, int pad, int OH, int OW) {
-    const long long total = (long long)B * OH * OW * C;
+    const int CV = C / V;
+    const long long total = (long long)B * OH * OW * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        long long pix = i / C;
+        const int c = (int)(i % CV) * V;
+        long long pix = i / CV;
         const int ow = pix % OW; pix /= OW;
         const int oh = pix % OH;
         const int b = pix / OH;
-        float m = -INFINITY;
+        float m[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = -INFINITY;
         for (int kh = 0; kh < K; ++kh) {
             const int ih = oh * stride - pad + kh;
             if ((unsigned)ih >= (unsigned)H) continue;
             for (int kw = 0; kw < K; ++kw) {
                 const int iw = ow * stride - pad + kw;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                m = fmaxf(m, to_f32<T>(x[(((long long)b * H + ih) * W + iw) * C + c]));
+                float t[V];
+                load_vec<T, V>(x + (((long long)b * H + ih) * W + iw) * C + c, t);
+#pragma unroll
+                for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], t[e]);
             }
         }
-        y[i] = from_f32<T>(m);
+        store_vec<T, V>(y + (i / CV) * C + c, m);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // bilinear x2, align_corners=False: src = 0.5*(dst+0.5)-0.5, clamped at 0 (PyTorch
 // area_pixel_compute_source_index), i1 = min(i0+1, size-1)
-template <typename T>
+template <typename T, int V>
 __global__ void upsample_bilinear2x_kernel(const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
                                            int B, int H, int W, int C, int act) {
-    const int OH = 2 * H, OW = 2 * W;
-    const long long total = (long long)B * OH * OW * C;
+    const int OH = 2 * H, OW = 2 * W, CV = C / V;
+    const long long total = (long long)B * OH * OW * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        long long pix = i / C;
+        const int c = (int)(i % CV) * V;
+        long long pix = i / CV;
+        const long long opix = pix;
         const int ow = pix % OW; pix /= OW;
         const int oh = pix % OH;
         const int b = pix / OH;
@@ -65,30 +94,41 @@ __global__ void upsample_bilinear2x_kernel(const T* __restrict__ x, const T* __r
         const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
         const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
         const long long base = (long long)b * H * W;
-        const float v00 = to_f32<T>(x[((base + (long long)y0 * W + x0)) * C + c]);
-        const float v01 = to_f32<T>(x[((base + (long long)y0 * W + x1)) * C + c]);
-        const float v10 = to_f32<T>(x[((base + (long long)y1 * W + x0)) * C + c]);
-        const float v11 = to_f32<T>(x[((base + (long long)y1 * W + x1)) * C + c]);
-        float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-        v = apply_act(v, act);
-        if (addend) v += to_f32<T>(addend[i]);
-        y[i] = from_f32<T>(v);
+        float v00[V], v01[V], v10[V], v11[V], o[V];
+        load_vec<T, V>(x + (base + (long long)y0 * W + x0) * C + c, v00);
+        load_vec<T, V>(x + (base + (long long)y0 * W + x1) * C + c, v01);
+        load_vec<T, V>(x + (base + (long long)y1 * W + x0) * C + c, v10);
+        load_vec<T, V>(x + (base + (long long)y1 * W + x1) * C + c, v11);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = apply_act(hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]), act);
+        if (addend) {
+            float a[V];
+            load_vec<T, V>(addend + opix * C + c, a);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] += a[e];
+        }
+        store_vec<T, V>(y + opix * C + c, o);
     }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void upsample_nearest2x_add_kernel(const T* __restrict__ x, const T* __restrict__ lat, T* __restrict__ y,
                                               int B, int H, int W, int C) {
-    const int OH = 2 * H, OW = 2 * W;
-    const long long total = (long long)B * OH * OW * C;
+    const int OH = 2 * H, OW = 2 * W, CV = C / V;
+    const long long total = (long long)B * OH * OW * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = i % C;
-        long long pix = i / C;
+        const int c = (int)(i % CV) * V;
+        long long pix = i / CV;
+        const long long opix = pix;
         const int ow = pix % OW; pix /= OW;
         const int oh = pix % OH;
         const int b = pix / OH;
-        const float v = to_f32<T>(lat[i]) + to_f32<T>(x[(((long long)b * H + (oh >> 1)) * W + (ow >> 1)) * C + c]);
-        y[i] = from_f32<T>(v);
+        float a[V], l[V];
+        load_vec<T, V>(x + (((long long)b * H + (oh >> 1)) * W + (ow >> 1)) * C + c, a);
+        load_vec<T, V>(lat + opix * C + c, l);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += l[e];
+        store_vec<T, V>(y + opix * C + c, a);
     }
 }
 
@@ -242,9 +282,13 @@ __global__ void normalize_rows_kernel(const float* __restrict__ x, float* __rest
     for (int d = 0; d < D; ++d) y[row * D + d] = sign * (x[row * D + d] / n);
 }
 
+static inline bool vec_aligned(const void* a, const void* b) {
+    return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+}
+
 static inline int grid_for(long long total, int block = 256) {
     long long g = (total + block - 1) / block;
-    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
 }  // namespace nps
@@ -266,33 +310,56 @@ extern "C" int nopesac_maxpool_nhwc(const void* x, void* y, int B, int H, int W,
                                     int dt, void* stream) {
     NPS_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && K > 0 && stride > 0, "maxpool: bad args");
     const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
-    const int g = grid_for((long long)B * OH * OW * C);
-    if (dt == NPS_DT_BF16)
-        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, K, stride, pad, OH, OW);
-    else
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, H, W, C, K, stride, pad, OH, OW);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == NPS_DT_BF16) {
+        if (C % 8 == 0 && vec_aligned(x, y))
+            hipLaunchKernelGGL((maxpool_kernel<bf16_t, 8>), dim3(grid_for((long long)B * OH * OW * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, K, stride, pad, OH, OW);
+        else
+            hipLaunchKernelGGL((maxpool_kernel<bf16_t, 1>), dim3(grid_for((long long)B * OH * OW * C)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, K, stride, pad, OH, OW);
+    } else {
+        if (C % 4 == 0 && vec_aligned(x, y))
+            hipLaunchKernelGGL((maxpool_kernel<float, 4>), dim3(grid_for((long long)B * OH * OW * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, K, stride, pad, OH, OW);
+        else
+            hipLaunchKernelGGL((maxpool_kernel<float, 1>), dim3(grid_for((long long)B * OH * OW * C)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, K, stride, pad, OH, OW);
+    }
     NPS_LAUNCH_RET();
 }
 
 extern "C" int nopesac_upsample2x_bilinear_nhwc(const void* x, const void* addend, void* y, int B, int H, int W,
                                                 int C, int act, int dt, void* stream) {
     NPS_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "upsample_bilinear: bad args");
-    const int g = grid_for((long long)B * 4 * H * W * C);
-    if (dt == NPS_DT_BF16)
-        hipLaunchKernelGGL(upsample_bilinear2x_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)y, B, H, W, C, act);
-    else
-        hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)addend, (float*)y, B, H, W, C, act);
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * 4 * H * W * C;
+    if (dt == NPS_DT_BF16) {
+        if (C % 8 == 0 && vec_aligned(x, y) && vec_aligned(addend, y))
+            hipLaunchKernelGGL((upsample_bilinear2x_kernel<bf16_t, 8>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)y, B, H, W, C, act);
+        else
+            hipLaunchKernelGGL((upsample_bilinear2x_kernel<bf16_t, 1>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)y, B, H, W, C, act);
+    } else {
+        if (C % 4 == 0 && vec_aligned(x, y) && vec_aligned(addend, y))
+            hipLaunchKernelGGL((upsample_bilinear2x_kernel<float, 4>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (const float*)addend, (float*)y, B, H, W, C, act);
+        else
+            hipLaunchKernelGGL((upsample_bilinear2x_kernel<float, 1>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (const float*)addend, (float*)y, B, H, W, C, act);
+    }
     NPS_LAUNCH_RET();
 }
 
 extern "C" int nopesac_upsample2x_nearest_add_nhwc(const void* x, const void* lateral, void* y, int B, int H, int W,
                                                    int C, int dt, void* stream) {
     NPS_CHECK_ARG(x && lateral && y && B > 0 && H > 0 && W > 0 && C > 0, "upsample_nearest: bad args");
-    const int g = grid_for((long long)B * 4 * H * W * C);
-    if (dt == NPS_DT_BF16)
-        hipLaunchKernelGGL(upsample_nearest2x_add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)lateral, (bf16_t*)y, B, H, W, C);
-    else
-        hipLaunchKernelGGL(upsample_nearest2x_add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)lateral, (float*)y, B, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * 4 * H * W * C;
+    if (dt == NPS_DT_BF16) {
+        if (C % 8 == 0 && vec_aligned(x, y) && vec_aligned(lateral, y))
+            hipLaunchKernelGGL((upsample_nearest2x_add_kernel<bf16_t, 8>), dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)lateral, (bf16_t*)y, B, H, W, C);
+        else
+            hipLaunchKernelGGL((upsample_nearest2x_add_kernel<bf16_t, 1>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)lateral, (bf16_t*)y, B, H, W, C);
+    } else {
+        if (C % 4 == 0 && vec_aligned(x, y) && vec_aligned(lateral, y))
+            hipLaunchKernelGGL((upsample_nearest2x_add_kernel<float, 4>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)x, (const float*)lateral, (float*)y, B, H, W, C);
+        else
+            hipLaunchKernelGGL((upsample_nearest2x_add_kernel<float, 1>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (const float*)lateral, (float*)y, B, H, W, C);
+    }
     NPS_LAUNCH_RET();
 }
 

@@ -70,13 +70,14 @@ class PlaneCameraHead(ParamModule):
     def pixel_pose_net(self, feats: dict, B: int):
         """feats: NHWC res3..res5 for 2B images (view-1 images first) -> trans0 [B,3], rot0 [B,4] (unit, w>=0),
         trans_feat, rots_feat [B,256]."""
-        P = self.packed
+        P, gd = self.packed, self.gemm_dtype
         r3, r4, r5 = feats["res3"], feats["res4"], feats["res5"]
         cd = r5.dtype
 
         def cv(x, nm, pad=0, stride=1, act=ops.ACT_NONE, out_dtype=None):
             c = P[nm]
-            return ops.conv2d(x, c.w(x.dtype), c.scale, c.bias, stride=stride, pad=pad, act=act, out_dtype=out_dtype)
+            return ops.conv2d(x, c.w(gd if x.dtype == torch.float32 else x.dtype), c.scale, c.bias, stride=stride, pad=pad, act=act,
+                              out_dtype=out_dtype)
 
         y = self._gn(cv(r5, "layer_3", 1), "layer_3", ops.ACT_RELU)
         y = ops.upsample2x_nearest_add(y, self._gn(cv(r4, "adapter_2"), "adapter_2", ops.ACT_NONE))
@@ -100,48 +101,48 @@ class PlaneCameraHead(ParamModule):
             t = aff
             for i in range(6):
                 t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY)
-            return ops.linear(t.reshape(B, -1), P[fc].w2d(), P[fc].bias, act=ops.ACT_RELU)
+            return ops.linear(t.reshape(B, -1), P[fc].w2d(gd), P[fc].bias, act=ops.ACT_RELU)
 
         trans_feat, rots_feat = branch("convs_trans", "fc_trans"), branch("convs_rots", "fc_rots")
-        trans0 = ops.linear(trans_feat, P["trans"].w2d(), P["trans"].bias)
-        rot0 = ops.normalize_rows(ops.linear(rots_feat, P["rots"].w2d(), P["rots"].bias), canonical_sign=True)  # :667, :436-437
+        trans0 = ops.linear(trans_feat, P["trans"].w2d(gd), P["trans"].bias)
+        rot0 = ops.normalize_rows(ops.linear(rots_feat, P["rots"].w2d(gd), P["rots"].bias), canonical_sign=True)  # :667, :436-437
         return trans0, rot0, trans_feat, rots_feat
 
     # ---------------------------------------------------------------- (ii) AIM
     def aim(self, trans0, rot0):
-        P = self.packed
-        rot_feat = run_mlp(rot0, P["rot_emb_proj"], final_act=ops.ACT_RELU)                  # rot0 already has w >= 0 (:695-696)
-        rec_rot = ops.normalize_rows(ops.linear(rot_feat, P["rots"].w2d(), P["rots"].bias))
-        trans_feat = run_mlp(trans0 + 1e-10, P["trans_emb_proj"], final_act=ops.ACT_RELU)    # :718
-        rec_trans = ops.linear(trans_feat, P["trans"].w2d(), P["trans"].bias)
+        P, gd = self.packed, self.gemm_dtype
+        rot_feat = run_mlp(rot0, P["rot_emb_proj"], final_act=ops.ACT_RELU, gd=gd)                  # rot0 already has w >= 0 (:695-696)
+        rec_rot = ops.normalize_rows(ops.linear(rot_feat, P["rots"].w2d(gd), P["rots"].bias))
+        trans_feat = run_mlp(trans0 + 1e-10, P["trans_emb_proj"], final_act=ops.ACT_RELU, gd=gd)    # :718
+        rec_trans = ops.linear(trans_feat, P["trans"].w2d(gd), P["trans"].bias)
         return rec_trans, rec_rot, trans_feat, rot_feat
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
     def refine(self, A0, planes1, planes2, n1, n2, rec_trans, rec_rot, trans_feat, rot_feat, diagnostics=False):
-        P, nq = self.packed, self.num_queries
+        P, nq, gd = self.packed, self.num_queries, self.gemm_dtype
         B = A0.shape[0]
         dev = A0.device
         geo_local, geo_global, sig, geo_enc, m = ops.geo_sequence(A0, planes1, planes2, n1, n2, rec_trans, rec_rot,
                                                                   self.warp_plane_in_cam_ref_on)
         rows = B * nq
-        geo = run_mlp(geo_enc.view(rows, 8), P["geo_encoder"])
+        geo = run_mlp(geo_enc.view(rows, 8), P["geo_encoder"], gd=gd)
         cat1280 = torch.empty(rows, 1280, device=dev, dtype=torch.float32)
         cat_r = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
         cat_t = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
         cat_r[:, :, :256] = rot_feat[:, None, :]                                             # :980-983 broadcast of the initial feats
         cat_t[:, :, :256] = trans_feat[:, None, :]
-        run_mlp(geo, P["geo_proj_s1"], out=cat1280[:, :1024])
-        f_rot = run_mlp(cat1280[:, :1024], P["decoder_rot"], out=cat1280[:, 1024:])
+        run_mlp(geo, P["geo_proj_s1"], out=cat1280[:, :1024], gd=gd)
+        f_rot = run_mlp(cat1280[:, :1024], P["decoder_rot"], out=cat1280[:, 1024:], gd=gd)
         cat_r.view(rows, 512)[:, 256:] = f_rot                                               # geo_fea_rot_all feeds two consumers
-        s2 = run_mlp(cat1280, P["geo_proj_s2"])
-        run_mlp(s2, P["decoder_tran"], out=cat_t.view(rows, 512)[:, 256:])
-        fused_rot = run_mlp(cat_r.view(rows, 512), P["decoder_rot2"], final_act=ops.ACT_RELU)
-        fused_tran = run_mlp(cat_t.view(rows, 512), P["decoder_tran2"], final_act=ops.ACT_RELU)
-        rot_raw = ops.linear(fused_rot, P["rots"].w2d(), P["rots"].bias).view(B, nq, 4)
-        trans_raw = ops.linear(fused_tran, P["trans"].w2d(), P["trans"].bias).view(B, nq, 3)
+        s2 = run_mlp(cat1280, P["geo_proj_s2"], gd=gd)
+        run_mlp(s2, P["decoder_tran"], out=cat_t.view(rows, 512)[:, 256:], gd=gd)
+        fused_rot = run_mlp(cat_r.view(rows, 512), P["decoder_rot2"], final_act=ops.ACT_RELU, gd=gd)
+        fused_tran = run_mlp(cat_t.view(rows, 512), P["decoder_tran2"], final_act=ops.ACT_RELU, gd=gd)
+        rot_raw = ops.linear(fused_rot, P["rots"].w2d(gd), P["rots"].bias).view(B, nq, 4)
+        trans_raw = ops.linear(fused_tran, P["trans"].w2d(gd), P["trans"].bias).view(B, nq, 3)
         maps = ops.ransac_score_maps(geo_local, rot_raw, trans_raw, rec_rot, rec_trans, m, diagnostics=diagnostics)
-        sf_rot = run_mlp(maps["normal_score"].view(B * (nq + 1), nq), P["normal_score_proj"]).view(B, nq + 1, 64)
-        sf_tran = run_mlp(maps["param_score"].view(B * (nq + 1), nq), P["param_score_proj"]).view(B, nq + 1, 64)
+        sf_rot = run_mlp(maps["normal_score"].view(B * (nq + 1), nq), P["normal_score_proj"], gd=gd).view(B, nq + 1, 64)
+        sf_tran = run_mlp(maps["param_score"].view(B * (nq + 1), nq), P["param_score_proj"], gd=gd).view(B, nq + 1, 64)
         vote = ops.ransac_soft_vote(sf_rot, sf_tran, P["rot_score_reg"].w2d().view(-1), P["rot_score_reg"].bias,
                                     P["trans_score_reg"].w2d().view(-1), P["trans_score_reg"].bias, rot_feat, trans_feat,
                                     fused_rot.view(B, nq, 256), fused_tran.view(B, nq, 256), P["rots"].w2d(), P["rots"].bias,

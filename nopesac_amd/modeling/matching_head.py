@@ -42,22 +42,22 @@ class MatchingHead(ParamModule):
 
     def _gnn_layer(self, W, x, src, nb, qlen, klen):
         """x [nb*nq,256], src [nb*nq,256] -> x + LN(mlp(cat[x, LN(merge(attn))]))   (gnn.py:73-96)."""
-        nq = self.num_queries
-        q = ops.linear(x, W["q"].w2d())
-        kv = ops.linear(src, W["kv"].w2d())
+        nq, gd = self.num_queries, self.gemm_dtype
+        q = ops.linear(x, W["q"].w2d(gd))
+        kv = ops.linear(src, W["kv"].w2d(gd))
         msg = ops.attention(q, kv[:, :256], kv[:, 256:], nb, nq, nq, 8, 32 ** -0.5, qlen, klen)
         p = W["prefix"]
-        msg = ops.layernorm(ops.linear(msg, W["merge"].w2d()), self.raw(p + ".norm1.weight"), self.raw(p + ".norm1.bias"))
-        h = ops.linear(x, W["mlp0_x"].w2d())
-        h = ops.linear(msg, W["mlp0_m"].w2d(), residual=h, act=ops.ACT_RELU)
-        out = ops.linear(h, W["mlp2"].w2d())
+        msg = ops.layernorm(ops.linear(msg, W["merge"].w2d(gd)), self.raw(p + ".norm1.weight"), self.raw(p + ".norm1.bias"))
+        h = ops.linear(x, W["mlp0_x"].w2d(gd))
+        h = ops.linear(msg, W["mlp0_m"].w2d(gd), residual=h, act=ops.ACT_RELU)
+        out = ops.linear(h, W["mlp2"].w2d(gd))
         _, y = ops.layernorm(out, self.raw(p + ".norm2.weight"), self.raw(p + ".norm2.bias"), addend=x)
         return y
 
     def descriptors(self, app: torch.Tensor, n_all: torch.Tensor, B: int):
         """app [2B,nq,256] (view-1 sets first), n_all int32[2B] -> GNN descriptors d0, d1 [B,nq,256]."""
-        P, nq = self.packed, self.num_queries
-        f = ops.linear(app.reshape(2 * B * nq, 256), P["app"].w2d(), P["app"].bias)
+        P, nq, gd = self.packed, self.num_queries, self.gemm_dtype
+        f = ops.linear(app.reshape(2 * B * nq, 256), P["app"].w2d(gd), P["app"].bias)
         n1, n2 = n_all[:B], n_all[B:]
         for i, W in enumerate(P["layers"]):
             if i % 2 == 0:                       # 'self' (gnn.py:128-130): both sets in one launch
@@ -66,7 +66,7 @@ class MatchingHead(ParamModule):
                 f0 = self._gnn_layer(W, f[:B * nq], f[B * nq:], B, n1, n2)
                 f1 = self._gnn_layer(W, f[B * nq:], f0, B, n2, n1)
                 f = torch.cat([f0, f1], 0)
-        d = ops.linear(f, P["desc"].w2d(), P["desc"].bias)
+        d = ops.linear(f, P["desc"].w2d(gd), P["desc"].bias)
         return d[:B * nq].view(B, nq, 256), d[B * nq:].view(B, nq, 256)
 
     def forward(self, app: torch.Tensor, n_all: torch.Tensor, cam7: torch.Tensor, planes1: torch.Tensor,

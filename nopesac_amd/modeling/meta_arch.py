@@ -44,6 +44,8 @@ class PlaneTR_NopeSAC(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32), False)
         self.compute_dtype = _DTYPES[cfg.MODEL.AMD.COMPUTE_DTYPE]
         self.output_masks = bool(cfg.MODEL.AMD.OUTPUT_MASKS)
+        for mod in (self.sem_seg_head, self.matching_head, self.camera_head_list[0]):
+            mod.gemm_dtype = self.compute_dtype     # bf16 => head GEMMs run f32-activation x bf16-weight MFMA
         self.infer_iter = 0
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 

@@ -38,6 +38,8 @@ class ParamModule(nn.Module):
             else:
                 mod.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
         self._packed: Optional[dict] = None
+        # dtype of the weight operand of head GEMMs whose activations are f32 (bf16 => mixed MFMA mode)
+        self.gemm_dtype = torch.float32
 
     # raw access by reference name
     def raw(self, key: str) -> torch.Tensor:

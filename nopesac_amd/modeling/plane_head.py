@@ -34,10 +34,10 @@ def sine_position_embedding(h: int, w: int, num_pos_feats: int = 128) -> torch.T
     return torch.cat((py, px), dim=2).reshape(h * w, 2 * num_pos_feats).contiguous()
 
 
-def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE):
+def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE, gd=torch.float32):
     for i, l in enumerate(layers):
         last = i == len(layers) - 1
-        x = ops.linear(x, l.w2d(), l.bias, act=final_act if last else ops.ACT_RELU, out=out if last else None)
+        x = ops.linear(x, l.w2d(gd), l.bias, act=final_act if last else ops.ACT_RELU, out=out if last else None)
     return x
 
 
@@ -98,7 +98,7 @@ class PlaneTRHead(ParamModule):
         """features: NHWC res2..res5 (compute dtype).  Returns (outputs, query_feat [B,nq,256]) where outputs
         holds pred_logits [B,nq,2], pred_params [B,nq,3], pred_centers [B,nq,2], mask_prob [B,h,w,nq]
         (= sigmoid(pred_mask_logits), NHWC) and, if `want_logits`, pred_mask_logits / pixel_centers."""
-        P = self.packed
+        P, gd = self.packed, self.gemm_dtype
         c1, c2, c3, c4 = features["res2"], features["res3"], features["res4"], features["res5"]
         cd = c4.dtype
         B, hc, wc, _ = c4.shape
@@ -112,13 +112,13 @@ class PlaneTRHead(ParamModule):
         for i in range(6):
             p = f"context_SA.layers.{i}"
             W = P[p]
-            qk = ops.linear(q_in, W["attn"]["qk"].w2d(), W["attn"]["qk"].bias)
-            v = ops.linear(src, W["attn"]["v"].w2d(), W["attn"]["v"].bias)
+            qk = ops.linear(q_in, W["attn"]["qk"].w2d(gd), W["attn"]["qk"].bias)
+            v = ops.linear(src, W["attn"]["v"].w2d(gd), W["attn"]["v"].bias)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale)
-            s = ops.linear(o, W["attn"]["o"].w2d(), W["attn"]["o"].bias, residual=src)
+            s = ops.linear(o, W["attn"]["o"].w2d(gd), W["attn"]["o"].bias, residual=src)
             src = self._ln(s, p + ".norm1")
-            hdn = ops.linear(src, W["l1"].w2d(), W["l1"].bias, act=ops.ACT_RELU)
-            s = ops.linear(hdn, W["l2"].w2d(), W["l2"].bias, residual=src)
+            hdn = ops.linear(src, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)
+            s = ops.linear(hdn, W["l2"].w2d(gd), W["l2"].bias, residual=src)
             src, q_in = self._ln(s, p + ".norm2", addend=pos)
         memory, mem_k = self._ln(src, "context_SA.norm", addend=pos)
         # ---- decoder (pre-norm; transformer.py:293-322), only hs[-1] is needed at inference
@@ -128,27 +128,27 @@ class PlaneTRHead(ParamModule):
             p = f"context2plane_decoder.layers.{i}"
             W = P[p]
             t2, q_in = self._ln(tgt, p + ".norm1", addend=qpos)
-            qk = ops.linear(q_in, W["self"]["qk"].w2d(), W["self"]["qk"].bias)
-            v = ops.linear(t2, W["self"]["v"].w2d(), W["self"]["v"].bias)
+            qk = ops.linear(q_in, W["self"]["qk"].w2d(gd), W["self"]["qk"].bias)
+            v = ops.linear(t2, W["self"]["v"].w2d(gd), W["self"]["v"].bias)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale)
-            tgt = ops.linear(o, W["self"]["o"].w2d(), W["self"]["o"].bias, residual=tgt)
+            tgt = ops.linear(o, W["self"]["o"].w2d(gd), W["self"]["o"].bias, residual=tgt)
             t2, q_in = self._ln(tgt, p + ".norm2", addend=qpos)
-            q = ops.linear(q_in, W["cross"]["q"].w2d(), W["cross"]["q"].bias)
-            k = ops.linear(mem_k, W["cross"]["k"].w2d(), W["cross"]["k"].bias)
-            v = ops.linear(memory, W["cross"]["v"].w2d(), W["cross"]["v"].bias)
+            q = ops.linear(q_in, W["cross"]["q"].w2d(gd), W["cross"]["q"].bias)
+            k = ops.linear(mem_k, W["cross"]["k"].w2d(gd), W["cross"]["k"].bias)
+            v = ops.linear(memory, W["cross"]["v"].w2d(gd), W["cross"]["v"].bias)
             o = ops.attention(q, k, v, B, nq, L, nh, scale)
-            tgt = ops.linear(o, W["cross"]["o"].w2d(), W["cross"]["o"].bias, residual=tgt)
+            tgt = ops.linear(o, W["cross"]["o"].w2d(gd), W["cross"]["o"].bias, residual=tgt)
             t2 = self._ln(tgt, p + ".norm3")
-            hdn = ops.linear(t2, W["l1"].w2d(), W["l1"].bias, act=ops.ACT_RELU)
-            tgt = ops.linear(hdn, W["l2"].w2d(), W["l2"].bias, residual=tgt)
+            hdn = ops.linear(t2, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)
+            tgt = ops.linear(hdn, W["l2"].w2d(gd), W["l2"].bias, residual=tgt)
         hs = self._ln(tgt, "context2plane_decoder.norm")             # [B*nq, 256]
         # ---- top-down pyramid (planeTR_head.py:241-252): lateral + relu(bn(conv(up(.))))
         RA = ops.ACT_RELU | ops.ACT_RES_AFTER
 
         def cbr(x, nm, residual=None, out_dtype=None):
             c = P[nm]
-            return ops.conv2d(x, c.w(x.dtype), c.scale, c.bias, residual, act=RA if residual is not None else ops.ACT_RELU,
-                              out_dtype=out_dtype)
+            return ops.conv2d(x, c.w(gd if x.dtype == torch.float32 else x.dtype), c.scale, c.bias, residual,
+                              act=RA if residual is not None else ops.ACT_RELU, out_dtype=out_dtype)
 
         p4 = cbr(memory.view(B, hc, wc, 256), "m_conv_dict.m4", residual=cbr(c4, "c4_conv"), out_dtype=cd)
         p3 = cbr(ops.upsample2x_bilinear(p4), "up_conv3", residual=cbr(c3, "c3_conv"))
@@ -156,16 +156,16 @@ class PlaneTRHead(ParamModule):
         p1 = cbr(ops.upsample2x_bilinear(p2), "up_conv1", residual=cbr(c1, "c1_conv"))
         # ---- instance heads
         pe = P["pixel_embedding"]
-        pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=torch.float32)            # [B,h,w,256] f32
-        plane_emb = run_mlp(hs, P["plane_embedding"]).view(B, nq, 1, 1, 256)
+        pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=gd)                       # [B,h,w,256]
+        plane_emb = run_mlp(hs, P["plane_embedding"], gd=gd).view(B, nq, 1, 1, 256).to(gd)
         out = {
-            "pred_logits": ops.linear(hs, P["plane_prob"].w2d(), P["plane_prob"].bias).view(B, nq, 2),
-            "pred_params": run_mlp(hs, P["plane_param"]).view(B, nq, 3),
-            "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID).view(B, nq, 2),
-            "mask_prob": ops.conv2d(pix, plane_emb, batched_weights=True, act=ops.ACT_SIGMOID),
+            "pred_logits": ops.linear(hs, P["plane_prob"].w2d(gd), P["plane_prob"].bias).view(B, nq, 2),
+            "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
+            "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
+            "mask_prob": ops.conv2d(pix, plane_emb, batched_weights=True, act=ops.ACT_SIGMOID, out_dtype=torch.float32),
         }
         if want_logits:
-            out["pred_mask_logits"] = ops.conv2d(pix, plane_emb, batched_weights=True)
+            out["pred_mask_logits"] = ops.conv2d(pix, plane_emb, batched_weights=True, out_dtype=torch.float32)
             pc = P["pixel_plane_center"]
             out["pixel_centers"] = ops.conv2d(p1, pc.w(cd), None, pc.bias, act=ops.ACT_SIGMOID, out_dtype=torch.float32)
         return out, hs.view(B, nq, 256)

@@ -60,7 +60,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         Cout, KH, KW, Cin = w.shape
         w_bs = 0
     assert Cin == (x_channels or Cx), (Cin, Cx)
-    assert w.dtype == x.dtype
+    mixed = x.dtype == torch.float32 and w.dtype == torch.bfloat16     # f32 activations x bf16 weights
+    assert w.dtype == x.dtype or mixed
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     out_dtype = out_dtype or (out.dtype if out is not None else x.dtype)
@@ -78,7 +79,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
             _chk(v, torch.float32)
             assert v.numel() == Cout
     rc = _L().nopesac_conv2d_nhwc(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,
-                                  stride, pad, x_cs, y_cs, r_cs, w_bs, act, _DT[x.dtype], _DT[out_dtype], _stream())
+                                  stride, pad, x_cs, y_cs, r_cs, w_bs, act, 2 if mixed else _DT[x.dtype], _DT[out_dtype], _stream())
     _lib.check(rc, "nopesac_conv2d_nhwc")
     return out
 
