@@ -84,9 +84,10 @@ int nopesac_upsample2x_bilinear_nhwc(const void* x, const void* addend, void* y,
 int nopesac_upsample2x_nearest_add_nhwc(const void* x, const void* lateral, void* y, int B, int H, int W,
                                         int C, int dt, void* stream);
 
-/* GroupNorm(G groups, eps) [+ReLU] on NHWC, per image; camera_modules.py:271-303 (d2 get_norm "GN"). */
+/* GroupNorm(G groups, eps) [+ReLU] on NHWC, per image; camera_modules.py:271-303 (d2 get_norm "GN").
+ * workspace: f32[B*16*G*2] scratch for the split statistics (NULL selects the slower single-kernel path). */
 int nopesac_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y,
-                           int B, int HW, int C, int G, float eps, int act, int dt, void* stream);
+                           int B, int HW, int C, int G, float eps, int act, int dt, float* workspace, void* stream);
 
 /* y = LayerNorm(x [+ res]) * gamma + beta over the last dim D (<= 1024, multiple of 64);
  * optional second output y2 = y + addend (addend row index = row % addend_rows), used for the

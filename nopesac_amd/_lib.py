@@ -25,7 +25,7 @@ SIGNATURES = {
     "nopesac_maxpool_nhwc": [P, P, I, I, I, I, I, I, I, I, P],
     "nopesac_upsample2x_bilinear_nhwc": [P, P, P, I, I, I, I, I, I, P],
     "nopesac_upsample2x_nearest_add_nhwc": [P, P, P, I, I, I, I, I, P],
-    "nopesac_groupnorm_nhwc": [P, P, P, P, I, I, I, I, F, I, I, P],
+    "nopesac_groupnorm_nhwc": [P, P, P, P, I, I, I, I, F, I, I, P, P],
     "nopesac_layernorm": [P, P, P, P, P, P, I, P, I, I, F, P],
     "nopesac_add_rows": [P, P, P, I, I, I, P],
     "nopesac_softmax_rows": [P, P, I, I, P],

@@ -10,6 +10,8 @@
 // The next K-tile's global loads are issued before the current tile's MFMAs (one barrier per K-tile).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous run of tiles that share
 // A rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nps {
@@ -27,7 +29,7 @@ struct ConvParams {
     int M, N, K;       // M = rows per grid.y slice
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt, res_after, epi_vec;
+    int act, out_dt, res_after, epi_vec, use_glds, force;
     int tiles_m, tiles_n;
 };
 
@@ -41,6 +43,96 @@ template <> struct VecT<bf16_t, 4> { typedef us4 type; };
 template <> struct VecT<bf16_t, 1> { typedef unsigned short type; };
 template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<float, 1> { typedef float type; };
+
+// Shared epilogue (see the comment inside): acc -> LDS (f32) -> 8-channel chunks -> scale/shift/residual/act -> store.
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi, int lds_bytes, const ConvParams& p, int m0, int n0,
+                                              int bz, int wm, int wn, int lane, int tid) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
+    // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
+    // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
+    // 8-channel row chunks, so scale/shift, residual and the output are 16/32-byte accesses that cover whole
+    // 128/256-byte channel runs per row (the layers with small K are HBM-bound: this is what has to stream).
+    constexpr int EN = BN > 64 ? 64 : BN;
+    constexpr int ELD = EN + 4;
+    constexpr int NPASS = BN / EN;
+    const bool vec_ok = p.epi_vec;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int c_wave = wn * WN - pass * EN;          // first column of this wave inside the pass window
+        if (c_wave >= 0 && c_wave < EN) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wm * WM + i * 32 + (lane & 31);
+                        const int c = c_wave + j * 32 + 8 * q + 4 * (lane >> 5);
+                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *(f32x4*)(epi + row * ELD + c) = v;
+                    }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BM * (EN / 8); idx += 256) {
+            const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
+            const int m = m0 + row, n = n0 + pass * EN + ch;
+            if (m >= p.M || n >= p.N) continue;
+            const long long pix = (long long)m + (long long)bz * p.rows_per_b;
+            float v[8];
+            *(f32x4*)(v) = *(const f32x4*)(epi + row * ELD + ch);
+            *(f32x4*)(v + 4) = *(const f32x4*)(epi + row * ELD + ch + 4);
+            if (vec_ok && n + 8 <= p.N) {
+                if (p.scale) {
+                    const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
+                }
+                if (p.bias) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    if (p.out_dt == NPS_DT_F32) {
+                        *(f32x4*)(rv) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n);
+                        *(f32x4*)(rv + 4) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n + 4);
+                    } else {
+                        const us8 r8 = *(const us8*)((const bf16_t*)p.res + pix * p.r_cs + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = bf16_to_f32(r8[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = p.res_after ? apply_act(v[e], p.act) + rv[e] : apply_act(v[e] + rv[e], p.act);
+                if (p.out_dt == NPS_DT_F32) {
+                    float* yp = (float*)p.y + pix * p.y_cs + n;
+                    *(f32x4*)(yp) = *(const f32x4*)(v);
+                    *(f32x4*)(yp + 4) = *(const f32x4*)(v + 4);
+                } else {
+                    us8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
+                    *(us8*)((bf16_t*)p.y + pix * p.y_cs + n) = o;
+                }
+            } else {
+                for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[n + e] : 0.f);
+                    float r = 0.f;
+                    if (p.res)
+                        r = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n + e]
+                                                     : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n + e]);
+                    x = p.res_after ? apply_act(x, p.act) + r : apply_act(x + r, p.act);
+                    if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n + e] = x;
+                    else ((bf16_t*)p.y)[pix * p.y_cs + n + e] = f32_to_bf16(x);
+                }
+            }
+        }
+        if (pass + 1 < NPASS) __syncthreads();
+    }
+}
 
 // TA = element type of x in memory (float with T = bf16_t is the mixed mode: f32 activations are rounded to
 // bf16 while being staged, weights are bf16, MFMA runs at the bf16 rate).
@@ -213,91 +305,132 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
-    // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
-    // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
-    // 8-channel row chunks, so scale/shift, residual and the output are 16/32-byte accesses that cover whole
-    // 128/256-byte channel runs per row (the layers with small K are HBM-bound: this is what has to stream).
-    constexpr int EN = BN > 64 ? 64 : BN;
-    constexpr int ELD = EN + 4;
-    constexpr int NPASS = BN / EN;
-    static_assert(BM * ELD * 4 <= (int)sizeof(lds), "epilogue tile must fit in the staging LDS");
-    float* epi = reinterpret_cast<float*>(lds);
-    const bool vec_ok = p.epi_vec;
+    conv_epilogue<BM, BN, TM, TN>(acc, reinterpret_cast<float*>(lds), (int)sizeof(lds), p, m0, n0, bz, wm, wn, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16, Cin % 64 == 0): both operand tiles go HBM -> LDS with global_load_lds_dwordx4
+// (no VGPR round trip, no ds_write pass), BK = 64, two stages, ONE barrier per K-tile: the next tile's
+// DMAs are issued before the current tile's MFMAs and drained (vmcnt(0)) at the barrier that follows them.
+// The LDS image is lane-linear per DMA (1 KB = 8 rows x 128 B); bank conflicts of the ds_read_b128
+// fragment reads are removed by an XOR swizzle applied on the SOURCE side (the lane that fills physical
+// 16-byte slot pc of row r fetches logical slot pc ^ ((r>>1)&7)) and again on the read.
+// Padding taps / rows beyond M / channels beyond N read a 16-byte zero word instead of branching.
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvParams p) {
+    typedef bf16_t T;
+    constexpr int BK = 64, ROWB = BK * 2;                       // 128 bytes per tile row
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_DMA = BM / 8 / 4, B_DMA = BN / 8 / 4;        // 1-KB DMAs per wave per stage
+    constexpr int EPI_BYTES = BM * ((BN > 64 ? 64 : BN) + 4) * 4;
+    constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int bz = p.batched ? blockIdx.y : 0;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ Wt = (const T*)p.w + (long long)bz * p.w_bs;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
+
+    // ---- per-lane DMA sources.  DMA j of this wave fills physical rows (wave*A_DMA + j)*8 + (lane>>3), slot lane&7.
+    const int slot = lane & 7, rsub = lane >> 3;
+    long long a_pix[A_DMA];      // pixel index of (b, 0, 0) ; -1 if the row is beyond M
+    int a_ih0[A_DMA], a_iw0[A_DMA], a_coff[A_DMA];
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int c_wave = wn * WN - pass * EN;          // first column of this wave inside the pass window
-        if (c_wave >= 0 && c_wave < EN) {
+    for (int j = 0; j < A_DMA; ++j) {
+        const int pr = (wave * A_DMA + j) * 8 + rsub;
+        const int m = m0 + pr;
+        a_coff[j] = (slot ^ ((pr >> 1) & 7)) * 8;                // logical 8-channel chunk this lane fetches
+        if (m < p.M) {
+            const int mg = m + bz * p.rows_per_b;
+            const int b = mg / p.rows_per_b, rem = mg % p.rows_per_b;
+            const int oh = rem / p.OW, ow = rem % p.OW;
+            a_ih0[j] = oh * p.stride - p.pad;
+            a_iw0[j] = ow * p.stride - p.pad;
+            a_pix[j] = (long long)b * p.H * p.W;
+        } else {
+            a_ih0[j] = 0; a_iw0[j] = 0; a_pix[j] = -1;
+        }
+    }
+    const T* b_src[B_DMA];
+#pragma unroll
+    for (int j = 0; j < B_DMA; ++j) {
+        const int pr = (wave * B_DMA + j) * 8 + rsub;
+        const int n = n0 + pr;
+        b_src[j] = n < p.N ? Wt + (long long)n * p.K + (slot ^ ((pr >> 1) & 7)) * 8 : nullptr;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        // Cin % 64 == 0: the whole K-tile lies inside one (kh,kw) tap -> the decode is wave-uniform (SALU)
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        unsigned char* sbase = lds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) {
+            const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+            const bool ok = a_pix[j] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const T* src = ok ? X + (a_pix[j] + (long long)ih * p.W + iw) * p.x_cs + c0 + a_coff[j] : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * A_DMA + j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_DMA; ++j) {
+            const T* src = b_src[j] ? b_src[j] + k0 : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + A_BYTES + (wave * B_DMA + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const int sw = (lane >> 1) & 7;                              // ((row >> 1) & 7) of this lane's fragment rows
+    const int a_row_off = (wm * WM + (lane & 31)) * ROWB;
+    const int b_row_off = A_BYTES + (wn * WN + (lane & 31)) * ROWB;
+    issue(0, 0);
+    __syncthreads();                                             // carries the vmcnt(0) for the pending LDS-DMAs
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        const unsigned char* sb = lds + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[TM], bfr[TN];
+            const int so = ((kk * 2 + (lane >> 5)) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * ROWB + so);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *(const bf16x8*)(sb + b_row_off + j * 32 * ROWB + so);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = wm * WM + i * 32 + (lane & 31);
-                        const int c = c_wave + j * 32 + 8 * q + 4 * (lane >> 5);
-                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        *(f32x4*)(epi + row * ELD + c) = v;
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        for (int idx = tid; idx < BM * (EN / 8); idx += 256) {
-            const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
-            const int m = m0 + row, n = n0 + pass * EN + ch;
-            if (m >= p.M || n >= p.N) continue;
-            const long long pix = (long long)m + (long long)bz * p.rows_per_b;
-            float v[8];
-            *(f32x4*)(v) = *(const f32x4*)(epi + row * ELD + ch);
-            *(f32x4*)(v + 4) = *(const f32x4*)(epi + row * ELD + ch + 4);
-            if (vec_ok && n + 8 <= p.N) {
-                if (p.scale) {
-                    const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
-                }
-                if (p.bias) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (p.res) {
-                    if (p.out_dt == NPS_DT_F32) {
-                        *(f32x4*)(rv) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n);
-                        *(f32x4*)(rv + 4) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n + 4);
-                    } else {
-                        const us8 r8 = *(const us8*)((const bf16_t*)p.res + pix * p.r_cs + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rv[e] = bf16_to_f32(r8[e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = p.res_after ? apply_act(v[e], p.act) + rv[e] : apply_act(v[e] + rv[e], p.act);
-                if (p.out_dt == NPS_DT_F32) {
-                    float* yp = (float*)p.y + pix * p.y_cs + n;
-                    *(f32x4*)(yp) = *(const f32x4*)(v);
-                    *(f32x4*)(yp + 4) = *(const f32x4*)(v + 4);
-                } else {
-                    us8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
-                    *(us8*)((bf16_t*)p.y + pix * p.y_cs + n) = o;
-                }
-            } else {
-                for (int e = 0; e < 8 && n + e < p.N; ++e) {
-                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[n + e] : 0.f);
-                    float r = 0.f;
-                    if (p.res)
-                        r = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n + e]
-                                                     : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n + e]);
-                    x = p.res_after ? apply_act(x, p.act) + r : apply_act(x + r, p.act);
-                    if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n + e] = x;
-                    else ((bf16_t*)p.y)[pix * p.y_cs + n + e] = f32_to_bf16(x);
-                }
-            }
-        }
-        if (pass + 1 < NPASS) __syncthreads();
+        __syncthreads();      // next tile landed (vmcnt(0)) and every wave is done reading this stage
     }
+    conv_epilogue<BM, BN, TM, TN>(acc, reinterpret_cast<float*>(lds), LDS_BYTES, p, m0, n0, bz, wm, wn, lane, tid);
 }
 
 template <typename TA, typename T, int BM, int BN>
@@ -328,7 +461,29 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
     if (ok(VW)) vec = VW;
     else if (sizeof(T) == 2 && ok(4)) vec = 4;
     const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batched ? p.B : 1);
-    if (p.N > 64 && tiles128 >= 192) return launch_cfg<TA, T, 128, 128>(p, stream, vec);
+    if constexpr (sizeof(TA) == 2 && sizeof(T) == 2) {
+        // LDS-DMA kernel: bf16, every K-tile of 64 inside one tap, 16-byte aligned 8-channel chunks
+        // measured: the DMA kernel wins on 3x3 (K >= 576) layers, loses on the HBM-bound 1x1 layers (2 blocks/CU)
+        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.force == 3);
+        if (dma_ok) {
+            ConvParams q = p;
+            q.tiles_m = (q.M + 127) / 128;
+            if (p.N > 64) {
+                q.tiles_n = (q.N + 127) / 128;
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
+            } else {
+                q.tiles_n = (q.N + 63) / 64;
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 64>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
+            }
+            return 0;
+        }
+    }
+    if (p.force == 1) return launch_cfg<TA, T, 128, 128>(p, stream, vec);
+    if (p.force == 2) return launch_cfg<TA, T, 64, 64>(p, stream, vec);
+    // measured (scripts/conv_microbench.py): 1x1 layers with K <= 256 are HBM-bound streaming ops; the 64x64 tile
+    // (8 waves/SIMD, 8 blocks/CU) keeps more bytes in flight than the 128x128 tile (3.8 vs 2.6 TB/s on 64->256+res)
+    const bool small_k_stream = p.KH * p.KW == 1 && p.K <= 256;
+    if (p.N > 64 && tiles128 >= 192 && !small_k_stream) return launch_cfg<TA, T, 128, 128>(p, stream, vec);
     return launch_cfg<TA, T, 64, 64>(p, stream, vec);
 }
 
@@ -363,6 +518,17 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
     p.N = Cout; p.K = KH * KW * Cin;
     p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    {
+        // NOPESAC_CONV_FORCE (tuning aid, read per call): t128 | t64 | glds | unset = heuristic
+        const char* e = getenv("NOPESAC_CONV_FORCE");
+        p.use_glds = 1;
+        p.force = 0;
+        if (e) {
+            if (!strcmp(e, "t128")) { p.force = 1; p.use_glds = 0; }
+            else if (!strcmp(e, "t64")) { p.force = 2; p.use_glds = 0; }
+            else if (!strcmp(e, "glds")) { p.force = 3; }
+        }
+    }
     {   // vectorised epilogue needs 8-channel runs that are 16-byte aligned in every buffer it touches
         const size_t osz = out_dt == NPS_DT_F32 ? 4 : 2;
         const int al = out_dt == NPS_DT_F32 ? 4 : 8;     // elements per 16 bytes

@@ -1,6 +1,8 @@
 // HBM-bound NHWC / row kernels around the GEMMs: preprocessing, pooling, up-sampling, GroupNorm,
 // LayerNorm, row softmax, small re-layouts.  All are streaming kernels: channels are the fastest
 // dimension, so a wave touches contiguous bytes; reductions use wave shuffles (+LDS across waves).
+#include <algorithm>
+
 #include "common.h"
 
 namespace nps {
@@ -189,6 +191,84 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fast GroupNorm path (C % 8 == 0, C/8 divides 256): split statistics + apply, both with 16-byte channel
+// vectors.  Partial sums go to a caller-provided workspace [B][GN_SPLITS][G][2] and are combined in a fixed
+// order (deterministic, no float atomics).
+constexpr int GN_SPLITS = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C, int G) {
+    const int cv = C / 8, rows_per_iter = 256 / cv;
+    const int c8 = threadIdx.x % cv, prow = threadIdx.x / cv;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int p0 = (int)((long long)HW * sp / GN_SPLITS), p1 = (int)((long long)HW * (sp + 1) / GN_SPLITS);
+    const T* xb = x + (long long)b * HW * C;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+        float v[8];
+        load_vec<T, 8>(xb + (long long)p * C + c8 * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+    }
+    __shared__ float red[2][256][8 + 1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s[e]; red[1][threadIdx.x][e] = ss[e]; }
+    __syncthreads();
+    __shared__ float chs[2][2048];
+    for (int c = threadIdx.x; c < C; c += 256) {     // per-channel totals over the pixel rows of this block
+        float a = 0.f, q = 0.f;
+        for (int r = 0; r < rows_per_iter; ++r) { a += red[0][r * cv + c / 8][c % 8]; q += red[1][r * cv + c / 8][c % 8]; }
+        chs[0][c] = a; chs[1][c] = q;
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float a = 0.f, q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[0][c]; q += chs[1][c]; }
+        float* o = part + (((long long)b * GN_SPLITS + sp) * G + g) * 2;
+        o[0] = a; o[1] = q;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, int HW, int C, int G, float eps, int act) {
+    __shared__ float s_mean[256], s_rstd[256];
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float a = 0.f, q = 0.f;
+        for (int sp = 0; sp < GN_SPLITS; ++sp) {
+            const float* o = part + (((long long)b * GN_SPLITS + sp) * G + g) * 2;
+            a += o[0]; q += o[1];
+        }
+        const float cnt = (float)HW * cpg;
+        const float mean = a / cnt;
+        const float var = fmaxf(q / cnt - mean * mean, 0.f);
+        s_mean[g] = mean; s_rstd[g] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int cv = C / 8;
+    const long long total = (long long)HW * cv;
+    const T* xb = x + (long long)b * HW * C;
+    T* yb = y + (long long)b * HW * C;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 8;
+        float v[8];
+        load_vec<T, 8>(xb + (i / cv) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / cpg;
+            v[e] = apply_act((v[e] - s_mean[g]) * s_rstd[g] * gamma[c + e] + beta[c + e], act);
+        }
+        store_vec<T, 8>(yb + (i / cv) * C + c, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm over D (one wave per row), optional residual, optional second output y + addend
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -364,9 +444,21 @@ extern "C" int nopesac_upsample2x_nearest_add_nhwc(const void* x, const void* la
 }
 
 extern "C" int nopesac_groupnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y, int B, int HW,
-                                      int C, int G, float eps, int act, int dt, void* stream) {
+                                      int C, int G, float eps, int act, int dt, float* workspace, void* stream) {
     NPS_CHECK_ARG(x && gamma && beta && y && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm: bad args");
     const int cpg = C / G;
+    if (workspace && C % 8 == 0 && 256 % (C / 8) == 0 && C <= 2048 && G <= 256 && vec_aligned(x, y)) {
+        hipStream_t st = (hipStream_t)stream;
+        dim3 g1(GN_SPLITS, B), g2((unsigned)std::min<long long>(((long long)HW * (C / 8) + 255) / 256, 1024), B);
+        if (dt == NPS_DT_BF16) {
+            hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, workspace, HW, C, G);
+            hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, HW, C, G, eps, act);
+        } else {
+            hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), 0, st, (const float*)x, workspace, HW, C, G);
+            hipLaunchKernelGGL(gn_apply_kernel<float>, g2, dim3(256), 0, st, (const float*)x, workspace, gamma, beta, (float*)y, HW, C, G, eps, act);
+        }
+        NPS_LAUNCH_RET();
+    }
     NPS_CHECK_ARG(cpg <= 256 && 256 % cpg == 0, "groupnorm: channels/group %d must divide 256", cpg);
     int gpb = 256 / cpg / 16;  // 16 pixel rows per block
     if (gpb < 1) gpb = 1;

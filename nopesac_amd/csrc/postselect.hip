@@ -54,49 +54,73 @@ __global__ __launch_bounds__(64) void ps_classify_kernel(const float* __restrict
     if (lane == 0) wk[9 * nq] = any ? 0 : 1;
 }
 
+__device__ __forceinline__ int wave_isum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Each workgroup walks `rows_per_block` image rows (256 pixels per iteration), keeping its per-query area /
+// centroid sums in LDS, and flushes them with a handful of global integer atomics at the end (60 workgroups
+// per 480x640 image instead of 1200: the global atomics on the same few words were the bottleneck).
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
-                                                        int W, float mask_thr, int* __restrict__ work,
-                                                        uint8_t* __restrict__ winner) {
+                                                        int W, float mask_thr, int rows_per_block,
+                                                        int* __restrict__ work, uint8_t* __restrict__ winner) {
     extern __shared__ int sh[];   // [0,nq) valid, [nq,2nq) score, then 7*nq accumulators
     const int b = blockIdx.y;
     int* wk = work + (long long)b * work_words(nq);
     for (int i = threadIdx.x; i < 9 * nq; i += 256) sh[i] = i < 2 * nq ? wk[i] : 0;
     __syncthreads();
-    const long long pid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool in = pid < (long long)H * W;
-    const int Y = in ? (int)(pid / W) : 0, X = in ? (int)(pid % W) : 0;
     const float sch = (float)h / (float)H, scw = (float)w / (float)W;
-    const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
-    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
-    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
     const float* pb = prob + (long long)b * h * w * nq;
-    const float* p00 = pb + ((long long)y0 * w + x0) * nq;
-    const float* p01 = pb + ((long long)y0 * w + x1) * nq;
-    const float* p10 = pb + ((long long)y1 * w + x0) * nq;
-    const float* p11 = pb + ((long long)y1 * w + x1) * nq;
-    float best = -INFINITY;
-    int win = -1;
-    for (int q = 0; q < nq; ++q) {
-        if (!sh[q]) continue;   // block-uniform
-        float p = 0.f;
-        if (in) p = hy * (hx * p00[q] + lx * p01[q]) + ly * (hx * p10[q] + lx * p11[q]);
-        const float wgt = __int_as_float(sh[nq + q]) * p;
-        if (in && wgt > best) { best = wgt; win = q; }
-        const unsigned long long bal = __ballot(in && p >= mask_thr);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
-    }
-    if (in && win >= 0) {
-        const int pass = best > mask_thr;
-        atomicAdd(&sh[6 * nq + win], 1);
-        atomicAdd(&sh[7 * nq + win], X);
-        atomicAdd(&sh[8 * nq + win], Y);
-        if (pass) {
-            atomicAdd(&sh[3 * nq + win], 1);
-            atomicAdd(&sh[4 * nq + win], X);
-            atomicAdd(&sh[5 * nq + win], Y);
+    const long long p_begin = (long long)blockIdx.x * rows_per_block * W;
+    const long long p_end = min(p_begin + (long long)rows_per_block * W, (long long)H * W);
+    for (long long base = p_begin; base < p_end; base += 256) {
+        const long long pid = base + threadIdx.x;
+        const bool in = pid < p_end;
+        const int Y = in ? (int)(pid / W) : 0, X = in ? (int)(pid % W) : 0;
+        const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* p00 = pb + ((long long)y0 * w + x0) * nq;
+        const float* p01 = pb + ((long long)y0 * w + x1) * nq;
+        const float* p10 = pb + ((long long)y1 * w + x0) * nq;
+        const float* p11 = pb + ((long long)y1 * w + x1) * nq;
+        float best = -INFINITY;
+        int win = -1;
+        for (int q = 0; q < nq; ++q) {
+            if (!sh[q]) continue;   // block-uniform
+            float p = 0.f;
+            if (in) p = hy * (hx * p00[q] + lx * p01[q]) + ly * (hx * p10[q] + lx * p11[q]);
+            const float wgt = __int_as_float(sh[nq + q]) * p;
+            if (in && wgt > best) { best = wgt; win = q; }
+            const unsigned long long bal = __ballot(in && p >= mask_thr);
+            if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
         }
-        winner[(long long)b * H * W + pid] = (uint8_t)(win | (pass ? 0x80 : 0));
+        const int pass = in && win >= 0 && best > mask_thr;
+        if (in && win >= 0) winner[(long long)b * H * W + pid] = (uint8_t)(win | (pass ? 0x80 : 0));
+        // wave-level aggregation: in the common case every lane of the wave has the same winner
+        const int w0 = __builtin_amdgcn_readfirstlane(win);
+        if (__all(win == w0)) {
+            if (w0 >= 0) {
+                const int cnt = wave_isum(in ? 1 : 0), sxs = wave_isum(in ? X : 0), sys = wave_isum(in ? Y : 0);
+                const int cp = wave_isum(pass), sxp = wave_isum(pass ? X : 0), syp = wave_isum(pass ? Y : 0);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&sh[6 * nq + w0], cnt); atomicAdd(&sh[7 * nq + w0], sxs); atomicAdd(&sh[8 * nq + w0], sys);
+                    if (cp) { atomicAdd(&sh[3 * nq + w0], cp); atomicAdd(&sh[4 * nq + w0], sxp); atomicAdd(&sh[5 * nq + w0], syp); }
+                }
+            }
+        } else if (in && win >= 0) {
+            atomicAdd(&sh[6 * nq + win], 1);
+            atomicAdd(&sh[7 * nq + win], X);
+            atomicAdd(&sh[8 * nq + win], Y);
+            if (pass) {
+                atomicAdd(&sh[3 * nq + win], 1);
+                atomicAdd(&sh[4 * nq + win], X);
+                atomicAdd(&sh[5 * nq + win], Y);
+            }
+        }
     }
     __syncthreads();
     for (int i = 2 * nq + threadIdx.x; i < 9 * nq; i += 256)
@@ -197,8 +221,10 @@ extern "C" int nopesac_postselect_planes(const float* cls_logits, const float* m
     hipError_t e = hipMemsetAsync(work, 0, (size_t)B * work_words(nq) * sizeof(int), st);
     if (e != hipSuccess) { set_error("postselect: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(ps_classify_kernel, dim3(B), dim3(64), 0, st, cls_logits, nq, score_thr, work);
-    dim3 grid((unsigned)(((long long)H * W + 255) / 256), B);
-    hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), 9 * nq * sizeof(int), st, mask_prob, nq, h, w, H, W, mask_thr, work, winner);
+    const int rows_per_block = 8;
+    dim3 grid((unsigned)((H + rows_per_block - 1) / rows_per_block), B);
+    hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), 9 * nq * sizeof(int), st, mask_prob, nq, h, w, H, W, mask_thr,
+                       rows_per_block, work, winner);
     hipLaunchKernelGGL(ps_finalize_kernel, dim3(B), dim3(64), 0, st, params, query_feat, nq, D, H, W, overlap_thr, work,
                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags);
     NPS_LAUNCH_RET();

@@ -152,8 +152,9 @@ def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, act=ACT_NON
     _chk(x)
     B, H, W, C = x.shape
     y = torch.empty_like(x)
+    ws = torch.empty(B * 16 * groups * 2, device=x.device, dtype=torch.float32)
     _lib.check(_L().nopesac_groupnorm_nhwc(_p(x), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(y), B, H * W, C,
-                                           groups, eps, act, _DT[x.dtype], _stream()), "nopesac_groupnorm_nhwc")
+                                           groups, eps, act, _DT[x.dtype], _p(ws), _stream()), "nopesac_groupnorm_nhwc")
     return y
 
 

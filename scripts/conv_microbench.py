@@ -1,0 +1,63 @@
+"""Time individual conv shapes under each kernel configuration (NOPESAC_CONV_FORCE) on the GPU box."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nopesac_amd import ops  # noqa: E402
+
+SHAPES = [  # B,H,W,Cin,Cout,k,s, residual
+    (64, 120, 160, 64, 256, 1, 1, True),
+    (64, 120, 160, 256, 64, 1, 1, False),
+    (64, 120, 160, 256, 256, 1, 1, True),
+    (64, 60, 80, 128, 512, 1, 1, True),
+    (64, 60, 80, 512, 128, 1, 1, False),
+    (64, 30, 40, 256, 1024, 1, 1, True),
+    (64, 30, 40, 1024, 256, 1, 1, False),
+    (64, 15, 20, 2048, 512, 1, 1, False),
+    (64, 120, 160, 64, 64, 3, 1, False),
+    (64, 60, 80, 128, 128, 3, 1, False),
+    (64, 30, 40, 256, 256, 3, 1, False),
+    (64, 15, 20, 512, 512, 3, 1, False),
+    (64, 60, 80, 256, 256, 3, 1, False),
+]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    modes = sys.argv[1:] or ["", "t128", "t64", "glds"]
+    print("shape".ljust(44) + "".join(m.rjust(26) if m else "auto".rjust(26) for m in modes))
+    for (B, H, W, Cin, Cout, k, s, res) in SHAPES:
+        x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
+        w = (torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5).bfloat16()
+        sc, bi = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        OH = (H + 2 * (k // 2) - k) // s + 1
+        OW = (W + 2 * (k // 2) - k) // s + 1
+        r = torch.randn(B, OH, OW, Cout, device=dev).bfloat16() if res else None
+        y = torch.empty(B, OH, OW, Cout, device=dev, dtype=torch.bfloat16)
+        flops = 2.0 * B * OH * OW * Cout * Cin * k * k
+        nbytes = 2 * (x.numel() + w.numel() + y.numel() * (2 if res else 1))
+        line = f"{B}x{H}x{W}x{Cin}->{Cout} k{k} s{s}{' +res' if res else ''}".ljust(44)
+        for m in modes:
+            if m:
+                os.environ["NOPESAC_CONV_FORCE"] = m
+            else:
+                os.environ.pop("NOPESAC_CONV_FORCE", None)
+            for _ in range(3):
+                ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU, out=y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n = 20
+            for _ in range(n):
+                ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            line += f"{ms:7.3f}ms {flops / ms / 1e9:5.0f}TF {nbytes / ms / 1e6:5.0f}GB/s".rjust(26)
+        print(line)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,12 @@ CONV_CASES = [
     (3, 30, 40, 256, 256, 3, 1, 1),   # 128x128 tile path
     (1, 60, 80, 128, 512, 1, 1, 0),
     (2, 12, 16, 512, 128, 1, 2, 0),   # strided 1x1 shortcut
+    # >= 192 tiles of 128x128 and Cin % 64 == 0: the LDS-DMA (global_load_lds) kernel in bf16
+    (4, 60, 80, 128, 256, 3, 1, 1),
+    (5, 61, 79, 64, 256, 1, 1, 0),    # M tail (M % 128 != 0), K = 64 (single K-tile)
+    (6, 64, 80, 256, 64, 1, 1, 0),    # BN = 64 variant
+    (4, 62, 82, 128, 192, 3, 2, 1),   # stride 2 + N tail inside a 128-wide tile
+    (8, 60, 80, 64, 64, 3, 1, 1),     # BN = 64, 3x3
 ]
 
 
