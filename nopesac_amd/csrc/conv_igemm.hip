@@ -29,7 +29,7 @@ struct ConvParams {
     int M, N, K;       // M = rows per grid.y slice
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt, res_after, epi_vec, use_glds, force;
+    int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1;
     int tiles_m, tiles_n;
 };
 
@@ -136,9 +136,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
 
 // TA = element type of x in memory (float with T = bf16_t is the mixed mode: f32 activations are rounded to
 // bf16 while being staged, weights are bf16, MFMA runs at the bf16 rate).
-template <typename TA, typename T, int BM, int BN, int VEC>
+template <typename TA, typename T, int BM, int BN, int VEC, int KMUL = 1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int BK = Cfg<T>::BK;
+    // KMUL > 1: deeper K-tile (fewer, fatter pipeline steps) for the small latency-bound head GEMMs
+    constexpr int BK = Cfg<T>::BK * KMUL;
     constexpr int LDS_STRIDE = BK + Cfg<T>::VECW;          // elements; 80 bytes per row for both dtypes
     constexpr int VPR = BK / VEC;                           // vectors per tile row
     constexpr int A_VECS = BM * VPR / 256;                  // vectors per thread (A)
@@ -180,11 +181,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_ok[i] = m < p.M;
         if (!a_ok[i]) m = 0;
         const int mg = m + bz * p.rows_per_b;          // global pixel index
-        const int b = mg / p.rows_per_b, rem = mg % p.rows_per_b;
-        const int oh = rem / p.OW, ow = rem % p.OW;
-        a_ih0[i] = oh * p.stride - p.pad;
-        a_iw0[i] = ow * p.stride - p.pad;
-        a_base[i] = (long long)b * p.H * p.W;
+        if (p.dense1x1) {                              // 1x1 / stride 1 / no padding: pixel index == row index
+            a_ih0[i] = 0; a_iw0[i] = 0; a_base[i] = mg;
+        } else {
+            const int b = mg / p.rows_per_b, rem = mg % p.rows_per_b;
+            const int oh = rem / p.OW, ow = rem % p.OW;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+            a_base[i] = (long long)b * p.H * p.W;
+        }
     }
     const bool is1x1 = (p.KH == 1 && p.KW == 1);
 
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     const int kh = tap / p.KW, kw = tap - kh * p.KW;
                     ih += kh; iw += kw;
                 }
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-                    const TA* src = X + (a_base[i] + (long long)ih * p.W + iw) * p.x_cs + c;
+                if (p.dense1x1 || ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)) {
+                    const TA* src = X + (a_base[i] + (p.dense1x1 ? 0ll : (long long)ih * p.W + iw)) * p.x_cs + c;
                     if constexpr (sizeof(TA) == sizeof(T)) {
                         val = *(const vec_t*)src;
                     } else if constexpr (VEC == 1) {
@@ -440,6 +445,13 @@ static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
     p.tiles_n = (p.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, p.batched ? p.B : 1, 1);
     constexpr int VW = Cfg<T>::VECW;
+    if constexpr (sizeof(T) == 2 && BM == 64) {
+        // head GEMMs (a few hundred blocks, K >= 128): BK = 128 halves/quarters the number of exposed-latency steps
+        if (vec == VW && p.K % 128 == 0 && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048) {
+            hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 4>), grid, dim3(256), 0, stream, p);
+            return 0;
+        }
+    }
     if (vec == VW) hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW>), grid, dim3(256), 0, stream, p);
     else if (sizeof(T) == 2 && vec == 4) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, 4>), grid, dim3(256), 0, stream, p);
@@ -518,6 +530,7 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
     p.N = Cout; p.K = KH * KW * Cin;
     p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    p.dense1x1 = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
     {
         // NOPESAC_CONV_FORCE (tuning aid, read per call): t128 | t64 | glds | unset = heuristic
         const char* e = getenv("NOPESAC_CONV_FORCE");

@@ -60,33 +60,47 @@ __device__ __forceinline__ int wave_isum(int v) {
     return v;
 }
 
-// Each workgroup walks `rows_per_block` image rows (256 pixels per iteration), keeping its per-query area /
-// centroid sums in LDS, and flushes them with a handful of global integer atomics at the end (60 workgroups
-// per 480x640 image instead of 1200: the global atomics on the same few words were the bottleneck).
+// One workgroup = one TW x TH tile of output pixels.  The (few) source rows x columns of the 1/4-resolution
+// probability map that the tile's bilinear taps touch are first copied into LDS with coalesced loads ([row][col][q],
+// q contiguous as in memory); the per-pixel loop over the valid queries then reads LDS only (bank = (nq*x + q) % 32:
+// distinct for the 16 source columns a wave touches).  Area / centroid sums are aggregated per wave, then per
+// workgroup in LDS, then flushed with a few integer global atomics.
+constexpr int PS_TW = 64, PS_TH = 8;
+
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
-                                                        int W, float mask_thr, int rows_per_block,
+                                                        int W, float mask_thr, int src_rows, int src_cols,
                                                         int* __restrict__ work, uint8_t* __restrict__ winner) {
-    extern __shared__ int sh[];   // [0,nq) valid, [nq,2nq) score, then 7*nq accumulators
-    const int b = blockIdx.y;
+    extern __shared__ int sh[];   // [0,nq) valid, [nq,2nq) score, 7*nq accumulators, then the f32 source tile
+    float* tile = reinterpret_cast<float*>(sh + 9 * nq);
+    const int b = blockIdx.z;
     int* wk = work + (long long)b * work_words(nq);
     for (int i = threadIdx.x; i < 9 * nq; i += 256) sh[i] = i < 2 * nq ? wk[i] : 0;
-    __syncthreads();
     const float sch = (float)h / (float)H, scw = (float)w / (float)W;
+    const int X0 = blockIdx.x * PS_TW, Y0 = blockIdx.y * PS_TH;
+    const int ry0 = min((int)fmaxf(sch * (Y0 + 0.5f) - 0.5f, 0.f), h - 1);
+    const int cx0 = min((int)fmaxf(scw * (X0 + 0.5f) - 0.5f, 0.f), w - 1);
+    const int nrows = min(src_rows, h - ry0), ncols = min(src_cols, w - cx0);
     const float* pb = prob + (long long)b * h * w * nq;
-    const long long p_begin = (long long)blockIdx.x * rows_per_block * W;
-    const long long p_end = min(p_begin + (long long)rows_per_block * W, (long long)H * W);
-    for (long long base = p_begin; base < p_end; base += 256) {
-        const long long pid = base + threadIdx.x;
-        const bool in = pid < p_end;
-        const int Y = in ? (int)(pid / W) : 0, X = in ? (int)(pid % W) : 0;
+    for (int r = 0; r < nrows; ++r) {
+        const float* srow = pb + ((long long)(ry0 + r) * w + cx0) * nq;
+        for (int i = threadIdx.x; i < ncols * nq; i += 256) tile[r * src_cols * nq + i] = srow[i];
+    }
+    __syncthreads();
+    for (int it = 0; it < PS_TW * PS_TH / 256; ++it) {
+        const int lp = it * 256 + threadIdx.x;
+        const int X = X0 + (lp % PS_TW), Y = Y0 + (lp / PS_TW);
+        const bool in = X < W && Y < H;
         const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
         const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
         const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-        const float* p00 = pb + ((long long)y0 * w + x0) * nq;
-        const float* p01 = pb + ((long long)y0 * w + x1) * nq;
-        const float* p10 = pb + ((long long)y1 * w + x0) * nq;
-        const float* p11 = pb + ((long long)y1 * w + x1) * nq;
+        // clamp the local indices so that out-of-image lanes still read inside the tile
+        const int r0 = min(max(y0 - ry0, 0), nrows - 1), r1 = min(max(y1 - ry0, 0), nrows - 1);
+        const int c0 = min(max(x0 - cx0, 0), ncols - 1), c1 = min(max(x1 - cx0, 0), ncols - 1);
+        const float* p00 = tile + (r0 * src_cols + c0) * nq;
+        const float* p01 = tile + (r0 * src_cols + c1) * nq;
+        const float* p10 = tile + (r1 * src_cols + c0) * nq;
+        const float* p11 = tile + (r1 * src_cols + c1) * nq;
         float best = -INFINITY;
         int win = -1;
         for (int q = 0; q < nq; ++q) {
@@ -99,12 +113,13 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
             if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
         }
         const int pass = in && win >= 0 && best > mask_thr;
-        if (in && win >= 0) winner[(long long)b * H * W + pid] = (uint8_t)(win | (pass ? 0x80 : 0));
+        if (in && win >= 0) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win | (pass ? 0x80 : 0));
         // wave-level aggregation: in the common case every lane of the wave has the same winner
         const int w0 = __builtin_amdgcn_readfirstlane(win);
-        if (__all(win == w0)) {
+        if (__all(win == w0 || !in)) {
             if (w0 >= 0) {
-                const int cnt = wave_isum(in ? 1 : 0), sxs = wave_isum(in ? X : 0), sys = wave_isum(in ? Y : 0);
+                const int ok = in && win >= 0;
+                const int cnt = wave_isum(ok), sxs = wave_isum(ok ? X : 0), sys = wave_isum(ok ? Y : 0);
                 const int cp = wave_isum(pass), sxp = wave_isum(pass ? X : 0), syp = wave_isum(pass ? Y : 0);
                 if ((threadIdx.x & 63) == 0) {
                     atomicAdd(&sh[6 * nq + w0], cnt); atomicAdd(&sh[7 * nq + w0], sxs); atomicAdd(&sh[8 * nq + w0], sys);
@@ -221,10 +236,13 @@ extern "C" int nopesac_postselect_planes(const float* cls_logits, const float* m
     hipError_t e = hipMemsetAsync(work, 0, (size_t)B * work_words(nq) * sizeof(int), st);
     if (e != hipSuccess) { set_error("postselect: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(ps_classify_kernel, dim3(B), dim3(64), 0, st, cls_logits, nq, score_thr, work);
-    const int rows_per_block = 8;
-    dim3 grid((unsigned)((H + rows_per_block - 1) / rows_per_block), B);
-    hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), 9 * nq * sizeof(int), st, mask_prob, nq, h, w, H, W, mask_thr,
-                       rows_per_block, work, winner);
+    // source extent touched by one PS_TW x PS_TH output tile (+2 for the second tap and the start rounding)
+    const int src_rows = (int)(((long long)PS_TH * h + H - 1) / H) + 2, src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
+    const size_t lds = (size_t)9 * nq * sizeof(int) + (size_t)src_rows * src_cols * nq * sizeof(float);
+    NPS_CHECK_ARG(lds <= 64 * 1024, "postselect: up-sampling ratio too small for the LDS tile (%zu bytes)", lds);
+    dim3 grid((W + PS_TW - 1) / PS_TW, (H + PS_TH - 1) / PS_TH, B);
+    hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols,
+                       work, winner);
     hipLaunchKernelGGL(ps_finalize_kernel, dim3(B), dim3(64), 0, st, params, query_feat, nq, D, H, W, overlap_thr, work,
                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags);
     NPS_LAUNCH_RET();

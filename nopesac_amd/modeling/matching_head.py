@@ -33,6 +33,8 @@ class MatchingHead(ParamModule):
             P["layers"].append({
                 "q": ConvW(self.raw(p + ".q_proj.weight")),
                 "kv": ConvW(torch.cat([self.raw(p + ".k_proj.weight").float(), self.raw(p + ".v_proj.weight").float()], 0)),
+                "qkv": ConvW(torch.cat([self.raw(p + ".q_proj.weight").float(), self.raw(p + ".k_proj.weight").float(),
+                                        self.raw(p + ".v_proj.weight").float()], 0)),
                 "merge": ConvW(self.raw(p + ".merge.weight")),
                 "mlp0_x": ConvW(w0[:, :256].contiguous()), "mlp0_m": ConvW(w0[:, 256:].contiguous()),
                 "mlp2": ConvW(self.raw(p + ".mlp.2.weight")), "prefix": p})
@@ -43,9 +45,14 @@ class MatchingHead(ParamModule):
     def _gnn_layer(self, W, x, src, nb, qlen, klen):
         """x [nb*nq,256], src [nb*nq,256] -> x + LN(mlp(cat[x, LN(merge(attn))]))   (gnn.py:73-96)."""
         nq, gd = self.num_queries, self.gemm_dtype
-        q = ops.linear(x, W["q"].w2d(gd))
-        kv = ops.linear(src, W["kv"].w2d(gd))
-        msg = ops.attention(q, kv[:, :256], kv[:, 256:], nb, nq, nq, 8, 32 ** -0.5, qlen, klen)
+        if x is src:                                   # self layer: one fused q|k|v projection
+            qkv = ops.linear(x, W["qkv"].w2d(gd))
+            q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
+        else:
+            q = ops.linear(x, W["q"].w2d(gd))
+            kv = ops.linear(src, W["kv"].w2d(gd))
+            k, v = kv[:, :256], kv[:, 256:]
+        msg = ops.attention(q, k, v, nb, nq, nq, 8, 32 ** -0.5, qlen, klen)
         p = W["prefix"]
         msg = ops.layernorm(ops.linear(msg, W["merge"].w2d(gd)), self.raw(p + ".norm1.weight"), self.raw(p + ".norm1.bias"))
         h = ops.linear(x, W["mlp0_x"].w2d(gd))

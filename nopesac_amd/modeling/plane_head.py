@@ -151,9 +151,18 @@ class PlaneTRHead(ParamModule):
                               act=RA if residual is not None else ops.ACT_RELU, out_dtype=out_dtype)
 
         p4 = cbr(memory.view(B, hc, wc, 256), "m_conv_dict.m4", residual=cbr(c4, "c4_conv"), out_dtype=cd)
-        p3 = cbr(ops.upsample2x_bilinear(p4), "up_conv3", residual=cbr(c3, "c3_conv"))
-        p2 = cbr(ops.upsample2x_bilinear(p3), "up_conv2", residual=cbr(c2, "c2_conv"))
-        p1 = cbr(ops.upsample2x_bilinear(p2), "up_conv1", residual=cbr(c1, "c1_conv"))
+
+        def up_stage(x, nm, lateral):
+            """relu(bn(conv1x1(up2(x)))) + lateral, evaluated as relu(up2(bn(conv1x1(x)))) + lateral: the 1x1 conv and
+            the BN affine are linear and the bilinear weights sum to 1, so they commute with the up-sampling
+            exactly in real arithmetic (fp rounding only) - 4x fewer conv FLOPs and bytes (planeTR_head.py:246-250)."""
+            c = P[nm]
+            t = ops.conv2d(x, c.w(x.dtype), c.scale, c.bias, act=ops.ACT_NONE)
+            return ops.upsample2x_bilinear(t, lateral, act=ops.ACT_RELU)
+
+        p3 = up_stage(p4, "up_conv3", cbr(c3, "c3_conv"))
+        p2 = up_stage(p3, "up_conv2", cbr(c2, "c2_conv"))
+        p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
         # ---- instance heads
         pe = P["pixel_embedding"]
         pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=gd)                       # [B,h,w,256]
