@@ -114,6 +114,13 @@ int nopesac_attention_small(const float* q, int64_t q_stride, const float* k, in
                             int B, int Lq, int Lk, int heads, float scale,
                             const int32_t* qlen, const int32_t* klen, void* stream);
 
+/* Same contract, mixed-precision MFMA kernel: q/k/v are rounded to bf16 while staged, scores / softmax
+ * statistics / output accumulate in f32 (used when MODEL.AMD.COMPUTE_DTYPE = bfloat16). Rows 16-byte aligned. */
+int nopesac_attention_small_bf16(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                                 const float* v, int64_t v_stride, float* o, int64_t o_stride,
+                                 int B, int Lq, int Lk, int heads, float scale,
+                                 const int32_t* qlen, const int32_t* klen, void* stream);
+
 /* gather rows of a [B, H*W, C] map into (w,h) order: y[b, w*H + h, :] = x[b, h*W + w, :]
  * (camera_head.py:1120-1124). f32. */
 int nopesac_transpose_hw_rows(const float* x, float* y, int B, int H, int W, int C, void* stream);

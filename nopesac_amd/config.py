@@ -251,6 +251,7 @@ def add_amd_defaults(cfg: CfgNode) -> CfgNode:
         COMPUTE_DTYPE="float32",      # "float32" (parity path) or "bfloat16" (dense convs on bf16 MFMA)
         OUTPUT_MASKS=True,            # decode pred_plane_masks [n,H,W] from the winner map for every image
         USE_HIP_GRAPH=False,          # capture the static-shape forward in a hipGraph
+        TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
     ))
     return cfg
 

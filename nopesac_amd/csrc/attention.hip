@@ -82,6 +82,147 @@ __global__ __launch_bounds__(256) void attention_small_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA variant (mixed-precision mode): same interface, q/k/v are f32 in memory and are rounded to bf16
+// while being staged; scores, softmax statistics and the output accumulate in f32.
+//
+// One workgroup = 128 query rows of one (batch, head); each wave owns 32 rows.  K ([key][d]) and V^T ([d][key])
+// of the (batch, head) are staged once in LDS as bf16.  Per 32-key tile a wave issues
+//     S^T = K_tile . Q^T      (2 x v_mfma_f32_32x32x16_bf16; operands swapped so that lane l holds, for query
+//                              row l&31, 16 of the 32 scores -> the row max / sum are in-lane reductions plus ONE
+//                              exchange with lane l^32)
+//     online softmax (running max / sum, rescale of the O accumulator)
+//     P -> bf16 pairs, 4 x v_permlane32_swap to turn the accumulator layout into the B-operand layout
+//     O^T += V^T_tile . P^T   (2 x MFMA)
+// so no score matrix ever touches LDS or HBM.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+constexpr int ATT_KSTRIDE = 40;   // bf16 elements per K row in LDS (32 + 8 pad = 80 bytes: conflict-free b128 reads)
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(
+    const float* __restrict__ q, long long q_stride, const float* __restrict__ k, long long k_stride,
+    const float* __restrict__ v, long long v_stride, float* __restrict__ o, long long o_stride, int Lq, int Lk,
+    int Lk_pad, float scale, const int* __restrict__ qlen, const int* __restrict__ klen) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(att_smem);                    // [Lk_pad][ATT_KSTRIDE]
+    const int vt_stride = Lk_pad + 8;                                    // bf16 elements per V^T row
+    bf16_t* Vt = Ks + Lk_pad * ATT_KSTRIDE;                              // [32][vt_stride]
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = qlen ? min(qlen[b], Lq) : Lq;
+    const int nk = klen ? min(klen[b], Lk) : Lk;
+    // ---- stage K (row-major) and V^T as bf16; rows >= nk are zero
+    const float* kb = k + (long long)b * Lk * k_stride + h * HD;
+    const float* vb = v + (long long)b * Lk * v_stride + h * HD;
+    for (int idx = tid; idx < Lk_pad * 4; idx += 256) {                  // 8 floats per chunk
+        const int j = idx >> 2, c = (idx & 3) * 8;
+        float kv[8], vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+        if (j < nk) {
+            *(f32x4*)(kv) = *(const f32x4*)(kb + (long long)j * k_stride + c);
+            *(f32x4*)(kv + 4) = *(const f32x4*)(kb + (long long)j * k_stride + c + 4);
+            *(f32x4*)(vv) = *(const f32x4*)(vb + (long long)j * v_stride + c);
+            *(f32x4*)(vv + 4) = *(const f32x4*)(vb + (long long)j * v_stride + c + 4);
+        }
+        u32x4 pk = {pack_bf16x2(kv[0], kv[1]), pack_bf16x2(kv[2], kv[3]), pack_bf16x2(kv[4], kv[5]), pack_bf16x2(kv[6], kv[7])};
+        *(u32x4*)(Ks + j * ATT_KSTRIDE + c) = pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(c + e) * vt_stride + j] = f32_to_bf16(vv[e]);
+    }
+    __syncthreads();
+    // ---- this wave's 32 query rows; lane l: row = l&31, k-half = l>>5
+    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool row_ok = row < nq;
+    const int half = lane >> 5;
+    bf16x8 qf[2];
+    {
+        const float* qp = q + ((long long)b * Lq + (row_ok ? row : 0)) * q_stride + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float t[8];
+            *(f32x4*)(t) = *(const f32x4*)(qp + ks * 16 + half * 8);
+            *(f32x4*)(t + 4) = *(const f32x4*)(qp + ks * 16 + half * 8 + 4);
+            u32x4 pk = {pack_bf16x2(t[0] * scale, t[1] * scale), pack_bf16x2(t[2] * scale, t[3] * scale),
+                        pack_bf16x2(t[4] * scale, t[5] * scale), pack_bf16x2(t[6] * scale, t[7] * scale)};
+            qf[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (nk + 31) / 32;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 32 + (lane & 31)) * ATT_KSTRIDE + ks * 16 + half * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        // s[r] = score(query row, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= nk) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        // accumulator layout -> B-operand layout (see header comment): pairs d[i] = keys (2i&3 .. ) of group i>>1
+        unsigned int d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = pack_bf16x2(s[2 * i], s[2 * i + 1]);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                      // k-step g: keys 16g .. 16g+15 of the tile
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+            auto r0 = __builtin_amdgcn_permlane32_swap(d[4 * g + 0], d[4 * g + 2], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(d[4 * g + 1], d[4 * g + 3], false, false);
+            u32x4 pk = {r0[0], r1[0], r0[1], r1[1]};
+#else
+            // portable fallback: exchange through ds_bpermute-style shuffles
+            const unsigned int a0 = d[4 * g + 0], a1 = d[4 * g + 1], a2 = d[4 * g + 2], a3 = d[4 * g + 3];
+            const unsigned int x0 = __shfl_xor(half ? a0 : a2, 32, 64), x1 = __shfl_xor(half ? a1 : a3, 32, 64);
+            u32x4 pk = half ? u32x4{x0, x1, a2, a3} : u32x4{a0, a1, x0, x1};
+#endif
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
+            const bf16x8 vf = *(const bf16x8*)(Vt + (lane & 31) * vt_stride + kt * 32 + g * 16 + half * 8);
+            oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+        }
+    }
+    // oacc[r] = O(query row, d = (r&3) + 8*(r>>2) + 4*half)
+    if (row < Lq) {
+        float* op = o + ((long long)b * Lq + row) * o_stride + h * HD;
+        const float inv = (row_ok && nk > 0) ? 1.f / l_run : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 ov = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
+            if (!(row_ok && nk > 0)) ov = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(op + 8 * g + 4 * half) = ov;
+        }
+    }
+}
+
 }  // namespace nps
 
 extern "C" int nopesac_attention_small(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
@@ -96,5 +237,28 @@ extern "C" int nopesac_attention_small(const float* q, int64_t q_stride, const f
     dim3 grid((Lq + 63) / 64, heads, B);
     hipLaunchKernelGGL(attention_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, (long long)q_stride, k,
                        (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, scale, qlen, klen);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_attention_small_bf16(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                                            const float* v, int64_t v_stride, float* o, int64_t o_stride, int B, int Lq,
+                                            int Lk, int heads, float scale, const int32_t* qlen, const int32_t* klen,
+                                            void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(q && k && v && o, "attention_bf16: null pointer");
+    NPS_CHECK_ARG(B > 0 && Lq > 0 && Lk > 0 && Lk <= 512 && heads > 0, "attention_bf16: bad dims B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, heads);
+    NPS_CHECK_ARG(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0 &&
+                      (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)o % 16 == 0,
+                  "attention_bf16: rows must be 16-byte aligned");
+    const int Lk_pad = ((Lk + 31) / 32) * 32;
+    const size_t lds = (size_t)Lk_pad * ATT_KSTRIDE * 2 + (size_t)32 * (Lk_pad + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((Lq + 127) / 128, heads, B);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, q, (long long)q_stride, k,
+                       (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad, scale, qlen, klen);
     NPS_LAUNCH_RET();
 }

@@ -151,13 +151,18 @@ class PlaneCameraHead(ParamModule):
         return vote
 
     # ---------------------------------------------------------------- whole head
+    def initial_pose(self, feats: dict, B: int):
+        """(i) + (ii): everything that depends only on the backbone maps (can run on a side stream while the
+        plane head works on the main stream)."""
+        trans0, rot0, tf0, rf0 = self.pixel_pose_net(feats, B)
+        return (trans0, rot0) + self.aim(trans0, rot0)
+
     def forward(self, feats: dict, sel: dict, matching_net, B: int, diagnostics: bool = False,
-                forced_assignment: torch.Tensor = None) -> dict:
+                forced_assignment: torch.Tensor = None, pose=None) -> dict:
         """feats: NHWC backbone maps of the 2B images (view-1 first); sel: output of plane post-selection for
         the 2B images (planes [2B,nq,3], feats [2B,nq,256], n_kept int32[2B]).  Returns device tensors:
         cameras {name: (tran [B,3], rot [B,4])}, assignments [B,nq,nq], log_scores [B,nq+1,nq+1], m [B] ..."""
-        trans0, rot0, tf0, rf0 = self.pixel_pose_net(feats, B)
-        rec_t, rec_r, rec_tf, rec_rf = self.aim(trans0, rot0)
+        trans0, rot0, rec_t, rec_r, rec_tf, rec_rf = pose if pose is not None else self.initial_pose(feats, B)
         n_all = sel["n_kept"]
         n1, n2 = n_all[:B].contiguous(), n_all[B:].contiguous()
         planes1, planes2 = sel["planes"][:B], sel["planes"][B:]

@@ -52,7 +52,7 @@ class MatchingHead(ParamModule):
             q = ops.linear(x, W["q"].w2d(gd))
             kv = ops.linear(src, W["kv"].w2d(gd))
             k, v = kv[:, :256], kv[:, 256:]
-        msg = ops.attention(q, k, v, nb, nq, nq, 8, 32 ** -0.5, qlen, klen)
+        msg = ops.attention(q, k, v, nb, nq, nq, 8, 32 ** -0.5, qlen, klen, mfma_bf16=(gd == torch.bfloat16))
         p = W["prefix"]
         msg = ops.layernorm(ops.linear(msg, W["merge"].w2d(gd)), self.raw(p + ".norm1.weight"), self.raw(p + ".norm1.bias"))
         h = ops.linear(x, W["mlp0_x"].w2d(gd))

@@ -47,6 +47,8 @@ class PlaneTR_NopeSAC(nn.Module):
         for mod in (self.sem_seg_head, self.matching_head, self.camera_head_list[0]):
             mod.gemm_dtype = self.compute_dtype     # bf16 => head GEMMs run f32-activation x bf16-weight MFMA
         self.infer_iter = 0
+        self.two_streams = bool(cfg.MODEL.AMD.TWO_STREAMS)
+        self._side_stream = None
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 
     @classmethod
@@ -93,12 +95,28 @@ class PlaneTR_NopeSAC(nn.Module):
     def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False,
                         forced: dict = None) -> dict:
         feats = self.backbone(x_nhwc)
+        head = self.camera_head_list[0]
+        pose = None
+        if self.two_streams and x_nhwc.is_cuda:
+            # the pixel pose net depends only on the backbone maps: run it on a side HIP stream, concurrently
+            # with the (launch-latency-bound) transformer of the plane head
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=x_nhwc.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pose = head.initial_pose(feats, B)
+                for t in pose:
+                    t.record_stream(main)
         head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
         sel = post_select(head_out, query_feat, H, W, self.cfg)
         forced_A = None
         if forced is not None:
             sel, forced_A = self._force_k(sel, head_out, query_feat, forced, B)
-        cam = self.camera_head_list[0](feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A)
+        if pose is not None:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+        cam = head(feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A, pose=pose)
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
 

@@ -104,6 +104,7 @@ class PlaneTRHead(ParamModule):
         B, hc, wc, _ = c4.shape
         L, nq, nh = hc * wc, self.num_queries, self.nheads
         scale = 32 ** -0.5
+        mf = gd == torch.bfloat16          # bf16 mode: MFMA attention kernel
         pos = self._pos(hc, wc, c4.device)
         ip = P["input_proj"]
         src = ops.conv2d(c4, ip.w(cd), None, ip.bias, out_dtype=torch.float32).view(B * L, 256)
@@ -114,7 +115,7 @@ class PlaneTRHead(ParamModule):
             W = P[p]
             qk = ops.linear(q_in, W["attn"]["qk"].w2d(gd), W["attn"]["qk"].bias)
             v = ops.linear(src, W["attn"]["v"].w2d(gd), W["attn"]["v"].bias)
-            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale, mfma_bf16=mf)
             s = ops.linear(o, W["attn"]["o"].w2d(gd), W["attn"]["o"].bias, residual=src)
             src = self._ln(s, p + ".norm1")
             hdn = ops.linear(src, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)
@@ -130,13 +131,13 @@ class PlaneTRHead(ParamModule):
             t2, q_in = self._ln(tgt, p + ".norm1", addend=qpos)
             qk = ops.linear(q_in, W["self"]["qk"].w2d(gd), W["self"]["qk"].bias)
             v = ops.linear(t2, W["self"]["v"].w2d(gd), W["self"]["v"].bias)
-            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale, mfma_bf16=mf)
             tgt = ops.linear(o, W["self"]["o"].w2d(gd), W["self"]["o"].bias, residual=tgt)
             t2, q_in = self._ln(tgt, p + ".norm2", addend=qpos)
             q = ops.linear(q_in, W["cross"]["q"].w2d(gd), W["cross"]["q"].bias)
             k = ops.linear(mem_k, W["cross"]["k"].w2d(gd), W["cross"]["k"].bias)
             v = ops.linear(memory, W["cross"]["v"].w2d(gd), W["cross"]["v"].bias)
-            o = ops.attention(q, k, v, B, nq, L, nh, scale)
+            o = ops.attention(q, k, v, B, nq, L, nh, scale, mfma_bf16=mf)
             tgt = ops.linear(o, W["cross"]["o"].w2d(gd), W["cross"]["o"].bias, residual=tgt)
             t2 = self._ln(tgt, p + ".norm3")
             hdn = ops.linear(t2, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)

@@ -191,15 +191,16 @@ def softmax_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Lq: int, Lk: int, heads: int, scale: float,
-              qlen=None, klen=None) -> torch.Tensor:
+              qlen=None, klen=None, mfma_bf16: bool = False) -> torch.Tensor:
     """q [B*Lq, >=heads*32] etc. as (possibly column-sliced) row-major matrices -> o [B*Lq, heads*32]."""
     for t in (q, k, v):
         assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
     assert q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk
     o = torch.empty((B * Lq, heads * 32), device=q.device, dtype=torch.float32)
-    rc = _L().nopesac_attention_small(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), B, Lq, Lk,
-                                      heads, scale, _p(qlen), _p(klen), _stream())
-    _lib.check(rc, "nopesac_attention_small")
+    fn = _L().nopesac_attention_small_bf16 if mfma_bf16 else _L().nopesac_attention_small
+    rc = fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), B, Lq, Lk,
+            heads, scale, _p(qlen), _p(klen), _stream())
+    _lib.check(rc, "nopesac_attention_small" + ("_bf16" if mfma_bf16 else ""))
     return o
 
 
