@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
+    ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
     args = ap.parse_args()
 
     from nopesac_amd import runner
@@ -224,6 +225,14 @@ def main():
                 "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
                                           "launches": v["launches"]} for k, v in conv.items() if k != key}}
 
+    stage_ms = None
+    if args.stages:
+        model.stage_events = []
+        step()
+        torch.cuda.synchronize()
+        ev = model.stage_events
+        model.stage_events = None
+        stage_ms = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(ev[:-1], ev[1:])}
     out = {"metric": "image-pairs/sec (480x640, K=%d hyp)" % K, "value": round(pairs_per_s, 3), "unit": "pairs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -233,6 +242,8 @@ def main():
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
                       "gflop_per_pair_algorithmic": GFLOP_PER_PAIR.get(K)},
            "roofline": roofline}
+    if stage_ms:
+        out["stage_ms_main_stream"] = stage_ms
     if rank == 0 and world == 1 and not args.no_accuracy and args.dtype == "bfloat16":
         out["pose_err_vs_fp32_path"] = accuracy_vs_fp32(model, device, nq)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

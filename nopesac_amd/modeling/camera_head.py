@@ -158,11 +158,13 @@ class PlaneCameraHead(ParamModule):
         return (trans0, rot0) + self.aim(trans0, rot0)
 
     def forward(self, feats: dict, sel: dict, matching_net, B: int, diagnostics: bool = False,
-                forced_assignment: torch.Tensor = None, pose=None) -> dict:
+                forced_assignment: torch.Tensor = None, pose=None, mark=None) -> dict:
         """feats: NHWC backbone maps of the 2B images (view-1 first); sel: output of plane post-selection for
         the 2B images (planes [2B,nq,3], feats [2B,nq,256], n_kept int32[2B]).  Returns device tensors:
         cameras {name: (tran [B,3], rot [B,4])}, assignments [B,nq,nq], log_scores [B,nq+1,nq+1], m [B] ..."""
+        mark = mark or (lambda name: None)
         trans0, rot0, rec_t, rec_r, rec_tf, rec_rf = pose if pose is not None else self.initial_pose(feats, B)
+        mark("pose_net(main-stream part)")
         n_all = sel["n_kept"]
         n1, n2 = n_all[:B].contiguous(), n_all[B:].contiguous()
         planes1, planes2 = sel["planes"][:B], sel["planes"][B:]
@@ -170,6 +172,7 @@ class PlaneCameraHead(ParamModule):
         log_scores, A0 = matching_net(sel["feats"], n_all, cam7, planes1, planes2, self.matching_score_threshold)
         if forced_assignment is not None:       # benchmark-only K control, see PlaneTR_NopeSAC._force_k
             A0 = forced_assignment
+        mark("matcher")
         ref = self.refine(A0, planes1, planes2, n1, n2, rec_t, rec_r, rec_tf, rec_rf, diagnostics)
         A1 = ops.refilter_assignment(A0, planes1, planes2, n1, n2, ref["pred_rot"], ref["pred_trans"])
         zero_t = torch.zeros_like(trans0)

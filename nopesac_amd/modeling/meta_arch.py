@@ -94,7 +94,10 @@ class PlaneTR_NopeSAC(nn.Module):
 
     def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False,
                         forced: dict = None) -> dict:
+        mark = self._mark
+        mark("start")
         feats = self.backbone(x_nhwc)
+        mark("backbone")
         head = self.camera_head_list[0]
         pose = None
         if self.two_streams and x_nhwc.is_cuda:
@@ -110,15 +113,27 @@ class PlaneTR_NopeSAC(nn.Module):
                 for t in pose:
                     t.record_stream(main)
         head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
+        mark("plane_head")
         sel = post_select(head_out, query_feat, H, W, self.cfg)
+        mark("post_select")
         forced_A = None
         if forced is not None:
             sel, forced_A = self._force_k(sel, head_out, query_feat, forced, B)
         if pose is not None:
             torch.cuda.current_stream().wait_stream(self._side_stream)
-        cam = head(feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A, pose=pose)
+        cam = head(feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A, pose=pose, mark=mark)
+        mark("refine")
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
+
+    def _mark(self, name: str):
+        """Stage boundary marker: records a HIP event on the current stream when `self.stage_events` is a list
+        (bench.py --stages); a no-op otherwise."""
+        ev = getattr(self, "stage_events", None)
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
 
     def _force_k(self, sel: dict, head_out: dict, query_feat: torch.Tensor, forced: dict, B: int):
         """BENCHMARK-ONLY K control: with random weights the threshold-based selection keeps
