@@ -326,15 +326,15 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvParams p) {
+template <int BM, int BN, int NSTAGE = 2>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_igemm_glds_kernel(const ConvParams p) {
     typedef bf16_t T;
     constexpr int BK = 64, ROWB = BK * 2;                       // 128 bytes per tile row
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_DMA = BM / 8 / 4, B_DMA = BN / 8 / 4;        // 1-KB DMAs per wave per stage
     constexpr int EPI_BYTES = BM * ((BN > 64 ? 64 : BN) + 4) * 4;
-    constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -413,11 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvParam
     const int sw = (lane >> 1) & 7;                              // ((row >> 1) & 7) of this lane's fragment rows
     const int a_row_off = (wm * WM + (lane & 31)) * ROWB;
     const int b_row_off = A_BYTES + (wn * WN + (lane & 31)) * ROWB;
-    issue(0, 0);
-    __syncthreads();                                             // carries the vmcnt(0) for the pending LDS-DMAs
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+    auto compute = [&](int stage) {
         const unsigned char* sb = lds + stage * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -433,7 +429,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvParam
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();      // next tile landed (vmcnt(0)) and every wave is done reading this stage
+    };
+    if constexpr (NSTAGE == 2) {
+        issue(0, 0);
+        __syncthreads();                                         // carries the vmcnt(0) for the pending LDS-DMAs
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+            compute(stage);
+            __syncthreads();  // next tile landed (vmcnt(0)) and every wave is done reading this stage
+        }
+    } else {
+        // NSTAGE-deep ring, NSTAGE-1 tiles of DMA in flight across the barrier: counted vmcnt (each tile = DPT DMAs
+        // per wave, retired in issue order) + raw s_barrier, never vmcnt(0) in the steady state.  At iteration kt:
+        //   wait until tile kt has landed (<= (NSTAGE-2)*DPT newer DMAs may stay outstanding)  -> barrier
+        //   (all waves' pieces of tile kt are visible AND everyone finished reading tile kt-1's stage)
+        //   -> refill that stage with tile kt+NSTAGE-1 -> MFMAs on tile kt.
+        constexpr int DPT = A_DMA + B_DMA;
+        for (int t = 0; t < NSTAGE - 1; ++t)
+            if (t < nk) issue(t, t);
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(nk - 1 - kt, NSTAGE - 2);      // tiles issued after tile kt that may stay in flight
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NSTAGE - 1 < nk) {
+                int st = stage + NSTAGE - 1;
+                if (st >= NSTAGE) st -= NSTAGE;
+                issue(kt + NSTAGE - 1, st);
+            }
+            compute(stage);
+            if (++stage == NSTAGE) stage = 0;
+        }
+        __syncthreads();
     }
     conv_epilogue<BM, BN, TM, TN>(acc, reinterpret_cast<float*>(lds), LDS_BYTES, p, m0, n0, bz, wm, wn, lane, tid);
 }
@@ -476,12 +507,20 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
     if constexpr (sizeof(TA) == 2 && sizeof(T) == 2) {
         // LDS-DMA kernel: bf16, every K-tile of 64 inside one tap, 16-byte aligned 8-channel chunks
         // measured: the DMA kernel wins on 3x3 (K >= 576) layers, loses on the HBM-bound 1x1 layers (2 blocks/CU)
-        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.force == 3);
+        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.force >= 3);
         if (dma_ok) {
             ConvParams q = p;
             q.tiles_m = (q.M + 127) / 128;
             if (p.N > 64) {
                 q.tiles_n = (q.N + 127) / 128;
+                const dim3 g(q.tiles_m * q.tiles_n, q.batched ? q.B : 1);
+                if (p.force == 4) {
+                    static bool a3 = false;
+                    if (!a3) { hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<128, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 0); a3 = true; }
+                    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 3>), g, dim3(256), 0, stream, q);
+                } else if (p.force == 5) {
+                    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 4>), g, dim3(256), 0, stream, q);
+                } else
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
             } else {
                 q.tiles_n = (q.N + 63) / 64;
@@ -540,6 +579,8 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
             if (!strcmp(e, "t128")) { p.force = 1; p.use_glds = 0; }
             else if (!strcmp(e, "t64")) { p.force = 2; p.use_glds = 0; }
             else if (!strcmp(e, "glds")) { p.force = 3; }
+            else if (!strcmp(e, "glds3")) { p.force = 4; }
+            else if (!strcmp(e, "glds4")) { p.force = 5; }
         }
     }
     {   // vectorised epilogue needs 8-channel runs that are 16-byte aligned in every buffer it touches

@@ -105,8 +105,10 @@ class PlaneTR_NopeSAC(nn.Module):
             # with the (launch-latency-bound) transformer of the plane head
             main = torch.cuda.current_stream()
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=x_nhwc.device)
-            side = self._side_stream
+                self._side_stream = {}
+            if main.cuda_stream not in self._side_stream:      # one side stream per caller stream (batches may be pipelined)
+                self._side_stream[main.cuda_stream] = torch.cuda.Stream(device=x_nhwc.device)
+            side = self._side_stream[main.cuda_stream]
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pose = head.initial_pose(feats, B)
@@ -120,7 +122,7 @@ class PlaneTR_NopeSAC(nn.Module):
         if forced is not None:
             sel, forced_A = self._force_k(sel, head_out, query_feat, forced, B)
         if pose is not None:
-            torch.cuda.current_stream().wait_stream(self._side_stream)
+            torch.cuda.current_stream().wait_stream(side)
         cam = head(feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A, pose=pose, mark=mark)
         mark("refine")
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,

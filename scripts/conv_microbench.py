@@ -21,12 +21,14 @@ SHAPES = [  # B,H,W,Cin,Cout,k,s, residual
     (64, 30, 40, 256, 256, 3, 1, False),
     (64, 15, 20, 512, 512, 3, 1, False),
     (64, 60, 80, 256, 256, 3, 1, False),
+    (64, 60, 80, 512, 256, 1, 1, False),
 ]
 
 
 def main():
     dev = torch.device("cuda:0")
-    modes = sys.argv[1:] or ["", "t128", "t64", "glds"]
+    modes = sys.argv[1:] or ["", "t128", "t64", "glds", "glds3", "glds4"]
+    modes = ["" if m == "auto" else m for m in modes]
     print("shape".ljust(44) + "".join(m.rjust(26) if m else "auto".rjust(26) for m in modes))
     for (B, H, W, Cin, Cout, k, s, res) in SHAPES:
         x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
@@ -39,6 +41,8 @@ def main():
         flops = 2.0 * B * OH * OW * Cout * Cin * k * k
         nbytes = 2 * (x.numel() + w.numel() + y.numel() * (2 if res else 1))
         line = f"{B}x{H}x{W}x{Cin}->{Cout} k{k} s{s}{' +res' if res else ''}".ljust(44)
+        os.environ["NOPESAC_CONV_FORCE"] = "t128"
+        ref = ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU).float()
         for m in modes:
             if m:
                 os.environ["NOPESAC_CONV_FORCE"] = m
@@ -55,7 +59,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
-            line += f"{ms:7.3f}ms {flops / ms / 1e9:5.0f}TF {nbytes / ms / 1e6:5.0f}GB/s".rjust(26)
+            err = float((y.float() - ref).abs().max())
+            line += f"{ms:7.3f}ms {flops / ms / 1e9:5.0f}TF {nbytes / ms / 1e6:5.0f}GB/s{'' if err < 1e-6 else ' ERR%.2g' % err}".rjust(26)
         print(line)
 
 
