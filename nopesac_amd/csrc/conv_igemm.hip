@@ -45,10 +45,11 @@ template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<float, 1> { typedef float type; };
 
 // Shared epilogue (see the comment inside): acc -> LDS (f32) -> 8-channel chunks -> scale/shift/residual/act -> store.
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int WAVES_M = 2>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi, int lds_bytes, const ConvParams& p, int m0, int n0,
                                               int bz, int wm, int wn, int lane, int tid) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / 2;
+    constexpr int NTHREADS = WAVES_M * 2 * 64;
     // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
     // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
     // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
@@ -75,7 +76,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                     }
         }
         __syncthreads();
-        for (int idx = tid; idx < BM * (EN / 8); idx += 256) {
+        for (int idx = tid; idx < BM * (EN / 8); idx += NTHREADS) {
             const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
             const int m = m0 + row, n = n0 + pass * EN + ch;
             if (m >= p.M || n >= p.N) continue;
@@ -320,19 +321,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // The LDS image is lane-linear per DMA (1 KB = 8 rows x 128 B); bank conflicts of the ds_read_b128
 // fragment reads are removed by an XOR swizzle applied on the SOURCE side (the lane that fills physical
 // 16-byte slot pc of row r fetches logical slot pc ^ ((r>>1)&7)) and again on the read.
-// Padding taps / rows beyond M / channels beyond N read a 16-byte zero word instead of branching.
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
+// Padding taps / rows beyond M / channels beyond N get an out-of-range buffer offset (the load returns zeros).
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int NSTAGE = 2>
-__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_igemm_glds_kernel(const ConvParams p) {
+template <int BM, int BN, int NSTAGE = 2, int WAVES_M = 2>
+__global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 1) void conv_igemm_glds_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins below exist only in the device pass
     typedef bf16_t T;
     constexpr int BK = 64, ROWB = BK * 2;                       // 128 bytes per tile row
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_DMA = BM / 8 / 4, B_DMA = BN / 8 / 4;        // 1-KB DMAs per wave per stage
+    constexpr int NWAVES = WAVES_M * 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_DMA = BM / 8 / NWAVES, B_DMA = BN / 8 / NWAVES;   // 1-KB DMAs per wave per stage
     constexpr int EPI_BYTES = BM * ((BN > 64 ? 64 : BN) + 4) * 4;
     constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -351,53 +351,70 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_igemm_glds_kern
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const T* zsrc = reinterpret_cast<const T*>(g_zero16);
 
     // ---- per-lane DMA sources.  DMA j of this wave fills physical rows (wave*A_DMA + j)*8 + (lane>>3), slot lane&7.
+    // Addressing is split so that the K-loop does almost no VALU work (PMC: the first version spent 8.6 VALU
+    // instructions per MFMA on 64-bit im2col address math):
+    //   buffer resource  = x shifted back by the padding offset (so every tap offset is >= 0), bounds-checked
+    //   voffset (VGPR)   = byte offset of the lane's output pixel + its swizzled 8-channel chunk   (loop invariant)
+    //   soffset (SGPR)   = byte offset of the K-tile's tap (kh,kw) and channel base                  (wave uniform)
+    //   out-of-image taps / rows >= M / channels >= N: voffset = OOB  ->  the buffer load returns zeros
     const int slot = lane & 7, rsub = lane >> 3;
-    long long a_pix[A_DMA];      // pixel index of (b, 0, 0) ; -1 if the row is beyond M
-    int a_ih0[A_DMA], a_iw0[A_DMA], a_coff[A_DMA];
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const long long padb = ((long long)p.pad * p.W + p.pad) * p.x_cs * 2;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x - padb), 0, (int)(((long long)p.B * p.H * p.W * p.x_cs) * 2 + padb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)Wt, 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    unsigned a_voff[A_DMA], a_mask[A_DMA];
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
         const int pr = (wave * A_DMA + j) * 8 + rsub;
         const int m = m0 + pr;
-        a_coff[j] = (slot ^ ((pr >> 1) & 7)) * 8;                // logical 8-channel chunk this lane fetches
+        const int coff = (slot ^ ((pr >> 1) & 7)) * 8;           // logical 8-channel chunk this lane fetches
+        a_voff[j] = OOB; a_mask[j] = 0u;
         if (m < p.M) {
             const int mg = m + bz * p.rows_per_b;
             const int b = mg / p.rows_per_b, rem = mg % p.rows_per_b;
             const int oh = rem / p.OW, ow = rem % p.OW;
-            a_ih0[j] = oh * p.stride - p.pad;
-            a_iw0[j] = ow * p.stride - p.pad;
-            a_pix[j] = (long long)b * p.H * p.W;
-        } else {
-            a_ih0[j] = 0; a_iw0[j] = 0; a_pix[j] = -1;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            a_voff[j] = (unsigned)((((long long)b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + coff) * 2u;
+            unsigned mk = 0u;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= 1u << (kh * p.KW + kw);
+            a_mask[j] = mk;
         }
     }
-    const T* b_src[B_DMA];
+    unsigned b_voff[B_DMA];
 #pragma unroll
     for (int j = 0; j < B_DMA; ++j) {
         const int pr = (wave * B_DMA + j) * 8 + rsub;
         const int n = n0 + pr;
-        b_src[j] = n < p.N ? Wt + (long long)n * p.K + (slot ^ ((pr >> 1) & 7)) * 8 : nullptr;
+        b_voff[j] = n < p.N ? (unsigned)((long long)n * p.K + (slot ^ ((pr >> 1) & 7)) * 8) * 2u : OOB;
     }
-
-    auto issue = [&](int kt, int stage) {
-        // Cin % 64 == 0: the whole K-tile lies inside one (kh,kw) tap -> the decode is wave-uniform (SALU)
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    // wave-uniform K-tile cursor (no integer division in the loop): tap index, its byte offset, channel base
+    int cur_tap = 0, cur_kw = 0, cur_c0 = 0;
+    unsigned cur_tapoff = 0u;                                    // ((kh*W + kw) * x_cs) * 2
+    unsigned cur_k0b = 0u;                                       // k0 * 2
+    auto issue = [&](int /*kt*/, int stage) {
         unsigned char* sbase = lds + stage * STAGE;
+        const unsigned a_soff = cur_tapoff + (unsigned)cur_c0 * 2u;
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
-            const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-            const bool ok = a_pix[j] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const T* src = ok ? X + (a_pix[j] + (long long)ih * p.W + iw) * p.x_cs + c0 + a_coff[j] : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (wave * A_DMA + j) * 1024), 16, 0, 0);
+            const unsigned vo = ((a_mask[j] >> cur_tap) & 1u) ? a_voff[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)(sbase + (wave * A_DMA + j) * 1024), 16, vo, a_soff, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < B_DMA; ++j) {
-            const T* src = b_src[j] ? b_src[j] + k0 : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + A_BYTES + (wave * B_DMA + j) * 1024), 16, 0, 0);
+        for (int j = 0; j < B_DMA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)(sbase + A_BYTES + (wave * B_DMA + j) * 1024), 16, b_voff[j], cur_k0b, 0, 0);
+        // advance the cursor to the next K-tile (tiles are always issued in order)
+        cur_k0b += BK * 2;
+        cur_c0 += BK;
+        if (cur_c0 >= p.Cin) {
+            cur_c0 = 0; ++cur_tap; ++cur_kw;
+            cur_tapoff += (unsigned)p.x_cs * 2u;
+            if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * 2u; }
         }
     };
 
@@ -466,7 +483,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_igemm_glds_kern
         }
         __syncthreads();
     }
-    conv_epilogue<BM, BN, TM, TN>(acc, reinterpret_cast<float*>(lds), LDS_BYTES, p, m0, n0, bz, wm, wn, lane, tid);
+    conv_epilogue<BM, BN, TM, TN, WAVES_M>(acc, reinterpret_cast<float*>(lds), LDS_BYTES, p, m0, n0, bz, wm, wn, lane, tid);
+#endif
 }
 
 template <typename TA, typename T, int BM, int BN>
@@ -506,21 +524,16 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
     const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batched ? p.B : 1);
     if constexpr (sizeof(TA) == 2 && sizeof(T) == 2) {
         // LDS-DMA kernel: bf16, every K-tile of 64 inside one tap, 16-byte aligned 8-channel chunks
-        // measured: the DMA kernel wins on 3x3 (K >= 576) layers, loses on the HBM-bound 1x1 layers (2 blocks/CU)
-        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.force >= 3);
+        // measured (scripts/conv_microbench.py): the DMA kernel wins on 3x3 layers and on 1x1 layers with K >= 1024,
+        // loses on the HBM-bound small-K 1x1 layers (2 blocks/CU keep too few bytes in flight)
+        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
+                            (long long)p.B * p.H * p.W * p.x_cs * 2 + ((long long)p.pad * p.W + p.pad) * p.x_cs * 2 < (1ll << 31) && (long long)p.N * p.K * 2 < (1ll << 31);
         if (dma_ok) {
             ConvParams q = p;
             q.tiles_m = (q.M + 127) / 128;
             if (p.N > 64) {
                 q.tiles_n = (q.N + 127) / 128;
                 const dim3 g(q.tiles_m * q.tiles_n, q.batched ? q.B : 1);
-                if (p.force == 4) {
-                    static bool a3 = false;
-                    if (!a3) { hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<128, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 0); a3 = true; }
-                    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 3>), g, dim3(256), 0, stream, q);
-                } else if (p.force == 5) {
-                    hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 4>), g, dim3(256), 0, stream, q);
-                } else
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
             } else {
                 q.tiles_n = (q.N + 63) / 64;
@@ -579,8 +592,6 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
             if (!strcmp(e, "t128")) { p.force = 1; p.use_glds = 0; }
             else if (!strcmp(e, "t64")) { p.force = 2; p.use_glds = 0; }
             else if (!strcmp(e, "glds")) { p.force = 3; }
-            else if (!strcmp(e, "glds3")) { p.force = 4; }
-            else if (!strcmp(e, "glds4")) { p.force = 5; }
         }
     }
     {   // vectorised epilogue needs 8-channel runs that are 16-byte aligned in every buffer it touches
