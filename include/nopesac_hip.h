@@ -68,6 +68,21 @@ int nopesac_conv2d_nhwc(const void* x, const void* w, const float* scale, const 
                         int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int64_t w_bstride,
                         int act, int in_dt, int out_dt, void* stream);
 
+/* Same, with an explicit kernel configuration (chosen per layer shape by the load-time autotuner of
+ * nopesac_amd/ops.py; every configuration computes the same result): NPS_CONV_AUTO = built-in heuristic,
+ * T128 / T64 = register-staged 128x128 / 64x64 tiles, DMA64 / DMA32 = LDS-DMA kernel with BK = 64 / 32
+ * (bf16 with Cin % 64 == 0 only; silently falls back to the heuristic when not applicable). */
+#define NPS_CONV_AUTO 0
+#define NPS_CONV_T128 1
+#define NPS_CONV_T64 2
+#define NPS_CONV_DMA64 3
+#define NPS_CONV_DMA32 4
+int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, const float* bias,
+                           const void* residual, void* y,
+                           int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int64_t w_bstride,
+                           int act, int in_dt, int out_dt, int kernel_cfg, void* stream);
+
 /* (x - mean[c]) / std[c], NCHW f32 -> NHWC (C padded with zeros to Cpad), out_dt f32/bf16.
  * siamese_planeTR.py:85-89,534-542. */
 int nopesac_preprocess_nchw_to_nhwc(const float* x, void* y, const float* mean, const float* std,

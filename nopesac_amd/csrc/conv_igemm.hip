@@ -324,15 +324,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // Padding taps / rows beyond M / channels beyond N get an out-of-range buffer offset (the load returns zeros).
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int NSTAGE = 2, int WAVES_M = 2>
-__global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 1) void conv_igemm_glds_kernel(const ConvParams p) {
+template <int BM, int BN, int NSTAGE = 2, int WAVES_M = 2, int BKT = 64>
+__global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? (BKT == 32 ? 4 : 2) : 1) void conv_igemm_glds_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins below exist only in the device pass
     typedef bf16_t T;
-    constexpr int BK = 64, ROWB = BK * 2;                       // 128 bytes per tile row
+    constexpr int BK = BKT, ROWB = BK * 2;                      // 128 (64) bytes per tile row
+    constexpr int CPR = BK / 8;                                  // 16-byte chunks per row
+    constexpr int RPD = 64 / CPR;                                // tile rows per 1-KB DMA
+    constexpr int SWSH = BK == 64 ? 1 : 2;                       // rows per 256-byte bank row = 1 << SWSH
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NWAVES = WAVES_M * 2;
     constexpr int WM = BM / WAVES_M, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_DMA = BM / 8 / NWAVES, B_DMA = BN / 8 / NWAVES;   // 1-KB DMAs per wave per stage
+    constexpr int A_DMA = BM / RPD / NWAVES, B_DMA = BN / RPD / NWAVES;   // 1-KB DMAs per wave per stage
     constexpr int EPI_BYTES = BM * ((BN > 64 ? 64 : BN) + 4) * 4;
     constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 
     //   voffset (VGPR)   = byte offset of the lane's output pixel + its swizzled 8-channel chunk   (loop invariant)
     //   soffset (SGPR)   = byte offset of the K-tile's tap (kh,kw) and channel base                  (wave uniform)
     //   out-of-image taps / rows >= M / channels >= N: voffset = OOB  ->  the buffer load returns zeros
-    const int slot = lane & 7, rsub = lane >> 3;
+    const int slot = lane % CPR, rsub = lane / CPR;
     constexpr unsigned OOB = 0xFFFFFF00u;
     const long long padb = ((long long)p.pad * p.W + p.pad) * p.x_cs * 2;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -369,9 +372,9 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 
     unsigned a_voff[A_DMA], a_mask[A_DMA];
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
-        const int pr = (wave * A_DMA + j) * 8 + rsub;
+        const int pr = (wave * A_DMA + j) * RPD + rsub;
         const int m = m0 + pr;
-        const int coff = (slot ^ ((pr >> 1) & 7)) * 8;           // logical 8-channel chunk this lane fetches
+        const int coff = (slot ^ ((pr >> SWSH) & (CPR - 1))) * 8;           // logical 8-channel chunk this lane fetches
         a_voff[j] = OOB; a_mask[j] = 0u;
         if (m < p.M) {
             const int mg = m + bz * p.rows_per_b;
@@ -389,9 +392,9 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 
     unsigned b_voff[B_DMA];
 #pragma unroll
     for (int j = 0; j < B_DMA; ++j) {
-        const int pr = (wave * B_DMA + j) * 8 + rsub;
+        const int pr = (wave * B_DMA + j) * RPD + rsub;
         const int n = n0 + pr;
-        b_voff[j] = n < p.N ? (unsigned)((long long)n * p.K + (slot ^ ((pr >> 1) & 7)) * 8) * 2u : OOB;
+        b_voff[j] = n < p.N ? (unsigned)((long long)n * p.K + (slot ^ ((pr >> SWSH) & (CPR - 1))) * 8) * 2u : OOB;
     }
     // wave-uniform K-tile cursor (no integer division in the loop): tap index, its byte offset, channel base
     int cur_tap = 0, cur_kw = 0, cur_c0 = 0;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? 2 : 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
-    const int sw = (lane >> 1) & 7;                              // ((row >> 1) & 7) of this lane's fragment rows
+    const int sw = (lane >> SWSH) & (CPR - 1);                   // swizzle key of this lane's fragment rows
     const int a_row_off = (wm * WM + (lane & 31)) * ROWB;
     const int b_row_off = A_BYTES + (wn * WN + (lane & 31)) * ROWB;
     auto compute = [&](int stage) {
@@ -534,7 +537,8 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
             if (p.N > 64) {
                 q.tiles_n = (q.N + 127) / 128;
                 const dim3 g(q.tiles_m * q.tiles_n, q.batched ? q.B : 1);
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
+                if (p.force == 4) hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 2, 2, 32>), g, dim3(256), 0, stream, q);
+                else hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128>), g, dim3(256), 0, stream, q);
             } else {
                 q.tiles_n = (q.N + 63) / 64;
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 64>), dim3(q.tiles_m * q.tiles_n, q.batched ? q.B : 1), dim3(256), 0, stream, q);
@@ -553,11 +557,26 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
 
 }  // namespace nps
 
+extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, const float* bias,
+                                      const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                      int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride,
+                                      int64_t r_cstride, int64_t w_bstride, int act, int in_dt, int out_dt,
+                                      int kernel_cfg, void* stream);
+
 extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* scale, const float* bias,
                                    const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
                                    int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride,
                                    int64_t r_cstride, int64_t w_bstride, int act, int in_dt, int out_dt,
                                    void* stream) {
+    return nopesac_conv2d_nhwc_ex(x, w, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride,
+                                  y_cstride, r_cstride, w_bstride, act, in_dt, out_dt, NPS_CONV_AUTO, stream);
+}
+
+extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, const float* bias,
+                                      const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                      int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride,
+                                      int64_t r_cstride, int64_t w_bstride, int act, int in_dt, int out_dt,
+                                      int kernel_cfg, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && w && y, "conv2d: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
@@ -584,14 +603,21 @@ extern "C" int nopesac_conv2d_nhwc(const void* x, const void* w, const float* sc
     p.act = act; p.out_dt = out_dt; p.res_after = res_after;
     p.dense1x1 = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
     {
-        // NOPESAC_CONV_FORCE (tuning aid, read per call): t128 | t64 | glds | unset = heuristic
+        // kernel_cfg (per call, e.g. from the load-time autotuner) or NOPESAC_CONV_FORCE (tuning aid):
+        // t128 | t64 | glds | glds32 | unset = heuristic
         const char* e = getenv("NOPESAC_CONV_FORCE");
         p.use_glds = 1;
         p.force = 0;
+        NPS_CHECK_ARG(kernel_cfg >= 0 && kernel_cfg <= 4, "conv2d: bad kernel_cfg %d", kernel_cfg);
+        if (kernel_cfg == NPS_CONV_T128) { p.force = 1; p.use_glds = 0; }
+        else if (kernel_cfg == NPS_CONV_T64) { p.force = 2; p.use_glds = 0; }
+        else if (kernel_cfg == NPS_CONV_DMA64) p.force = 3;
+        else if (kernel_cfg == NPS_CONV_DMA32) p.force = 4;
         if (e) {
             if (!strcmp(e, "t128")) { p.force = 1; p.use_glds = 0; }
             else if (!strcmp(e, "t64")) { p.force = 2; p.use_glds = 0; }
             else if (!strcmp(e, "glds")) { p.force = 3; }
+            else if (!strcmp(e, "glds32")) { p.force = 4; }
         }
     }
     {   // vectorised epilogue needs 8-channel runs that are 16-byte aligned in every buffer it touches

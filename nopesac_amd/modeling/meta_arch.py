@@ -128,6 +128,23 @@ class PlaneTR_NopeSAC(nn.Module):
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
 
+    def autotune(self, pairs: int, height: int = 480, width: int = 640) -> int:
+        """One dedicated single-stream forward on zeros that lets ops.TUNER pick, per conv/GEMM shape of this
+        (batch, resolution), the fastest of the library's equivalent kernel configurations.  Returns the number of
+        shapes whose choice differs from the built-in heuristic."""
+        dev = self.device
+        x = torch.zeros(2 * pairs, height, width, self.backbone.STEM_CIN_PAD, device=dev, dtype=self.compute_dtype)
+        two, self.two_streams = self.two_streams, False
+        ops.TUNER.measuring = True
+        try:
+            with torch.no_grad():
+                self.forward_tensors(x, pairs, height, width)
+            torch.cuda.synchronize(dev)
+        finally:
+            ops.TUNER.measuring = False
+            self.two_streams = two
+        return sum(1 for v in ops.TUNER.best.values() if v)
+
     def _mark(self, name: str):
         """Stage boundary marker: records a HIP event on the current stream when `self.stage_events` is a list
         (bench.py --stages); a no-op otherwise."""

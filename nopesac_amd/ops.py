@@ -41,6 +41,42 @@ def _chk(t: torch.Tensor, dtype=None, contiguous=True):
     return t
 
 
+class ConvTuner:
+    """Load-time autotuner: for every distinct conv/GEMM problem signature, time the kernel configurations the
+    library offers (they all compute the same result) and remember the fastest.  Off by default; a model turns
+    it on for one dedicated, single-stream pass (PlaneTR_NopeSAC.autotune) and then freezes it."""
+    CANDIDATES = (0, 1, 2, 3, 4)
+
+    def __init__(self):
+        self.best = {}
+        self.measuring = False
+        self.log = []
+
+    def choose(self, key, launch):
+        cfg = self.best.get(key)
+        if cfg is not None or not self.measuring:
+            return cfg or 0
+        times = {}
+        for c in self.CANDIDATES:
+            launch(c)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(c)
+            e1.record()
+            e1.synchronize()
+            times[c] = e0.elapsed_time(e1) / 3
+        cfg = min(times, key=times.get)
+        if times[cfg] > 0.97 * times[0]:      # keep the heuristic unless a candidate is clearly faster
+            cfg = 0
+        self.best[key] = cfg
+        self.log.append((key, cfg, times))
+        return cfg
+
+
+TUNER = ConvTuner()
+
+
 def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=None, *, stride=1, pad=0, act=ACT_NONE,
            out: Optional[torch.Tensor] = None, out_dtype=None, x_channels: Optional[int] = None,
            batched_weights: bool = False) -> torch.Tensor:
@@ -78,9 +114,17 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         if v is not None:
             _chk(v, torch.float32)
             assert v.numel() == Cout
-    rc = _L().nopesac_conv2d_nhwc(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,
-                                  stride, pad, x_cs, y_cs, r_cs, w_bs, act, 2 if mixed else _DT[x.dtype], _DT[out_dtype], _stream())
-    _lib.check(rc, "nopesac_conv2d_nhwc")
+    def launch(cfg):
+        rc = _L().nopesac_conv2d_nhwc_ex(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,
+                                         stride, pad, x_cs, y_cs, r_cs, w_bs, act, 2 if mixed else _DT[x.dtype], _DT[out_dtype],
+                                         cfg, _stream())
+        _lib.check(rc, "nopesac_conv2d_nhwc_ex")
+
+    cfg = 0
+    if TUNER.measuring or TUNER.best:
+        key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0)
+        cfg = TUNER.choose(key, launch)
+    launch(cfg)
     return out
 
 
