@@ -1,0 +1,96 @@
+"""Camera-pose evaluator counterpart of `MP3DEvaluator` (evaluation/mp3d_evaluation.py), restricted to the part
+that consumes the hot path's outputs: per-pair pose errors and their summary table.
+
+  * process(inputs, outputs)  ~ mp3d_evaluation.py:184-257: collects every output key containing "camera"
+    together with the ground truth `input["rel_pose"]{"position","rotation"}`;
+  * evaluate()                ~ :315-366 + `_eval_camera_reg` :382-425: gathers across ranks (ONE all_gather of
+    fixed-width fp32 rows over RCCL instead of pickled predictions over Gloo), then
+    T err = ||t - t_gt||2, R err = 2 acos|<q, q_gt>| 180/pi, medians / means / accuracy at 1.0|0.5|0.2 m, 30|15|10 deg.
+Plane AP and matching P/R (COCO tooling, pycocotools) stay out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import runner
+
+
+def camera_metrics(pred_tran: np.ndarray, pred_rot: np.ndarray, gt_tran: np.ndarray, gt_rot: np.ndarray) -> Dict[str, float]:
+    """The reference's camera table (mp3d_evaluation.py:382-418), same keys."""
+    t_err = runner.translation_error(pred_tran, gt_tran)
+    r_err = runner.rotation_error_deg(pred_rot, gt_rot)
+    n = max(len(t_err), 1)
+    return {
+        "T median err": float(np.median(t_err)), "T mean err": float(np.mean(t_err)),
+        "T err < 1.0": 100.0 * float((t_err < 1.0).sum()) / n, "T err < 0.5": 100.0 * float((t_err < 0.5).sum()) / n,
+        "T err < 0.2": 100.0 * float((t_err < 0.2).sum()) / n,
+        "R median err": float(np.median(r_err)), "R mean err": float(np.mean(r_err)),
+        "R err < 30": 100.0 * float((r_err < 30).sum()) / n, "R err < 15": 100.0 * float((r_err < 15).sum()) / n,
+        "R err < 10": 100.0 * float((r_err < 10).sum()) / n,
+    }
+
+
+class PoseEvaluator:
+    """DatasetEvaluator-style: reset() / process(inputs, outputs) / evaluate()."""
+
+    def __init__(self, camera_keys=("camera", "camera_init", "camera_initRec", "camera_avgRef0", "camera_softRef0"),
+                 device: Optional[torch.device] = None):
+        self.camera_keys = tuple(camera_keys)
+        self.device = device
+        self.reset()
+
+    def reset(self):
+        self._rows: List[np.ndarray] = []
+
+    def process(self, inputs: List[dict], outputs: List[dict]):
+        for inp, out in zip(inputs, outputs):
+            gt = inp.get("rel_pose")
+            gt_t = np.asarray(gt["position"], dtype=np.float32) if gt else np.zeros(3, np.float32)
+            gt_q = np.asarray(gt["rotation"], dtype=np.float32) if gt else np.array([1, 0, 0, 0], np.float32)
+            row = [gt_t, gt_q, np.array([1.0 if gt else 0.0, len(out["0"]["pred_plane"]), len(out["1"]["pred_plane"]),
+                                          float(out.get("matched_num", 0))], np.float32)]
+            for k in self.camera_keys:
+                cam = out.get(k)
+                row.append(np.asarray(cam["tran"], np.float32).reshape(-1)[:3] if cam else np.zeros(3, np.float32))
+                row.append(np.asarray(cam["rot"], np.float32).reshape(-1)[:4] if cam else np.array([1, 0, 0, 0], np.float32))
+            self._rows.append(np.concatenate(row))
+
+    @property
+    def row_width(self) -> int:
+        return 3 + 4 + 4 + 7 * len(self.camera_keys)
+
+    def evaluate(self) -> Dict[str, dict]:
+        local = np.stack(self._rows) if self._rows else np.zeros((0, self.row_width), np.float32)
+        rows = torch.from_numpy(local)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            dev = self.device or (torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl"
+                                  else torch.device("cpu"))
+            # ranks may hold different pair counts (ceil sharding): pad to the max, gather, drop the padding
+            n = torch.tensor([rows.shape[0]], device=dev)
+            counts = [torch.zeros_like(n) for _ in range(torch.distributed.get_world_size())]
+            torch.distributed.all_gather(counts, n)
+            nmax = int(max(c.item() for c in counts))
+            padded = torch.zeros(nmax, self.row_width, device=dev)
+            padded[: rows.shape[0]] = rows.to(dev)
+            allrows = runner.gather_metrics(padded).cpu()
+            rows = torch.cat([allrows[r * nmax: r * nmax + int(c.item())] for r, c in enumerate(counts)], 0)
+        r = rows.numpy()
+        res: Dict[str, dict] = {"pairs": {"count": int(r.shape[0]), "mean planes/view": float(r[:, 8:10].mean()) if len(r) else 0.0,
+                                          "mean matches": float(r[:, 10].mean()) if len(r) else 0.0}}
+        has_gt = r[:, 7] > 0 if len(r) else np.zeros(0, bool)
+        for i, k in enumerate(self.camera_keys):
+            o = 11 + 7 * i
+            if has_gt.any():
+                res[k] = camera_metrics(r[has_gt, o:o + 3], r[has_gt, o + 3:o + 7], r[has_gt, 0:3], r[has_gt, 3:7])
+        return res
+
+
+def create_small_table(d: Dict[str, float]) -> str:
+    keys, vals = list(d), ["%.4f" % d[k] for k in d]
+    w = [max(len(k), len(v)) for k, v in zip(keys, vals)]
+    return "\n".join(["| " + " | ".join(k.ljust(x) for k, x in zip(keys, w)) + " |",
+                      "|" + "|".join("-" * (x + 2) for x in w) + "|",
+                      "| " + " | ".join(v.ljust(x) for v, x in zip(vals, w)) + " |"])

@@ -1,0 +1,132 @@
+"""Inference CLI: the counterpart of the reference's `test_NopeSAC.py` + detectron2 `inference_on_dataset`.
+
+    python -m nopesac_amd.run --config-file configs/inference_mp3d.yaml --eval-only [--num-gpus N] KEY VALUE ...
+    python -m torch.distributed.run --nproc-per-node N -m nopesac_amd.run --config-file ... --num-gpus N ...
+
+Reproduces: cfg = defaults -> NopeSAC defaults -> merge_from_file -> merge_from_list -> freeze
+(test_NopeSAC.py:182-192); build_model + checkpoint load by state-dict key names (:198-201; `{"model": sd}` or a
+bare state dict); per-rank contiguous sharding of the pair list (InferenceSampler, :48-54); the batch loop
+`outputs = model(inputs); evaluator.process(inputs, outputs)` with a s/pair log (:157-179); evaluator.evaluate()
+with the single RCCL gather.  Dataset I/O is out of scope: pairs come from `--pairs-file`
+(a torch-saved list of reference-format input dicts) or are synthetic (`--synthetic-pairs N`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+import torch
+
+from . import runner
+from .config import get_cfg
+from .evaluation import PoseEvaluator, create_small_table
+from .registry import build_model
+from .synth import synth_pair, synth_state_dict
+
+logger = logging.getLogger("nopesac_amd")
+
+
+def default_argument_parser():
+    ap = argparse.ArgumentParser(description="NopeSAC inference on MI355X (nopesac_amd)")
+    ap.add_argument("--config-file", default="", metavar="FILE")
+    ap.add_argument("--eval-only", action="store_true")
+    ap.add_argument("--num-gpus", type=int, default=1)
+    ap.add_argument("--pairs-per-batch", type=int, default=8)
+    ap.add_argument("--pairs-file", default="", help="torch-saved list of input dicts (reference mapper format)")
+    ap.add_argument("--synthetic-pairs", type=int, default=0)
+    ap.add_argument("--structured", action="store_true", help="structured synthetic images instead of noise")
+    ap.add_argument("--synthetic-weights", action="store_true", help="name-seeded checkpoint instead of cfg.MODEL.WEIGHTS")
+    ap.add_argument("--output", default="", help="write the result summary JSON here")
+    ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides")
+    return ap
+
+
+def setup(args):
+    cfg = get_cfg()
+    if args.config_file:
+        cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts)
+    cfg.freeze()
+    return cfg
+
+
+def load_checkpoint(model, cfg, synthetic: bool):
+    if synthetic:
+        model.load_state_dict(synth_state_dict(cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES))
+        return "synthetic(name-seeded)"
+    path = cfg.MODEL.WEIGHTS
+    if not path or not os.path.exists(path):
+        raise FileNotFoundError(f"MODEL.WEIGHTS={path!r} not found (pass --synthetic-weights for the name-seeded checkpoint)")
+    ckpt = torch.load(path, map_location="cpu")
+    model.load_state_dict(ckpt)
+    return path
+
+
+def load_pairs(args):
+    if args.pairs_file:
+        return torch.load(args.pairs_file)
+    n = args.synthetic_pairs or 8
+    pairs = []
+    for i in range(n):
+        p = synth_pair(i, structured=args.structured)
+        pairs.append(p)
+    return pairs
+
+
+def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int):
+    """Batch loop of detectron2's inference_on_dataset (eval mode, no_grad, timing log)."""
+    evaluator.reset()
+    model.eval()
+    t0, n_done, t_compute = time.perf_counter(), 0, 0.0
+    with torch.no_grad():
+        for i in range(0, len(pairs), pairs_per_batch):
+            batch = pairs[i:i + pairs_per_batch]
+            t1 = time.perf_counter()
+            outputs = model(batch)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t_compute += time.perf_counter() - t1
+            evaluator.process(batch, outputs)
+            n_done += len(batch)
+            if (i // pairs_per_batch) % 10 == 0:
+                logger.info("Inference done %d/%d pairs. %.4f s / pair", n_done, len(pairs), t_compute / max(n_done, 1))
+    total = time.perf_counter() - t0
+    return {"pairs": n_done, "total_s": total, "compute_s": t_compute, "s_per_pair": t_compute / max(n_done, 1)}
+
+
+def main(argv=None):
+    args = default_argument_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s %(name)s]: %(message)s")
+    rank, world, local = runner.init_distributed()
+    cfg = setup(args)
+    if cfg.MODEL.DEVICE == "cuda" and torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    model = build_model(cfg)
+    src = load_checkpoint(model, cfg, args.synthetic_weights)
+    pairs = load_pairs(args)
+    lo, hi = runner.shard_range(len(pairs), rank, world)
+    logger.info("rank %d/%d: weights=%s pairs [%d,%d) of %d", rank, world, src, lo, hi, len(pairs))
+    evaluator = PoseEvaluator()
+    timing = inference_on_dataset(model, pairs[lo:hi], evaluator, args.pairs_per_batch)
+    results = evaluator.evaluate()
+    results["timing(rank0)"] = timing
+    if rank == 0:
+        for k, v in results.items():
+            if isinstance(v, dict) and v and all(isinstance(x, (int, float)) for x in v.values()):
+                logger.info("%s metrics (final output mode -> %s):\n%s", k, cfg.MODEL.CAMERA_HEAD.INFERENCE_OUT_CAM_TYPE,
+                            create_small_table({kk: float(vv) for kk, vv in v.items()}))
+        if args.output:
+            os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
+            with open(args.output, "w") as f:
+                json.dump(results, f, indent=1)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -85,3 +85,16 @@ def test_bf16_backbone_pose_error(device):
         r_err = 2 * np.degrees(np.arccos(min(q, 1.0)))
         assert t_err < 0.05 * (1 + np.linalg.norm(x["camera_init"]["tran"])) and r_err < 10.0, (t_err, r_err)
         assert np.isfinite(y["camera"]["tran"]).all() and np.isfinite(y["camera"]["rot"]).all()
+
+
+def test_cli_runner_end_to_end(device, tmp_path):
+    """`python -m nopesac_amd.run` flow (cfg -> build_model -> checkpoint -> batch loop -> evaluator) on the GPU."""
+    import json
+    from nopesac_amd import run
+    from tests.util import ROOT
+    import os
+    out = tmp_path / "res.json"
+    res = run.main(["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights",
+                    "--synthetic-pairs", "3", "--pairs-per-batch", "2", "--output", str(out), "MODEL.DEVICE", str(device)])
+    assert res["pairs"]["count"] == 3 and res["timing(rank0)"]["pairs"] == 3
+    assert json.load(open(out))["pairs"]["count"] == 3

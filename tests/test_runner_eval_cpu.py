@@ -1,0 +1,95 @@
+"""CPU: the evaluator / CLI host logic (no GPU): metric formulas vs hand values, process/evaluate bookkeeping,
+config -> CLI wiring, ragged multi-rank gather (gloo, world size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.util import ROOT
+
+
+def _out(t, q, n1=2, n2=3, m=1):
+    cam = {"tran": np.asarray(t, np.float32), "rot": np.asarray(q, np.float32)}
+    return {"0": {"pred_plane": torch.zeros(n1, 3)}, "1": {"pred_plane": torch.zeros(n2, 3)}, "matched_num": m,
+            "camera": cam, "camera_init": cam}
+
+
+def test_camera_metrics_table():
+    from nopesac_amd.evaluation import camera_metrics, create_small_table
+    gt_t = np.zeros((4, 3), np.float32)
+    gt_q = np.tile(np.array([1, 0, 0, 0], np.float32), (4, 1))
+    pt = np.array([[0.1, 0, 0], [0.4, 0, 0], [0.9, 0, 0], [3, 0, 0]], np.float32)
+    ang = np.radians([4.0, 12.0, 28.0, 90.0]) / 2
+    pq = np.stack([np.cos(ang), np.sin(ang), 0 * ang, 0 * ang], 1).astype(np.float32)
+    pq[1] *= -1                                                     # q and -q are the same rotation
+    m = camera_metrics(pt, pq, gt_t, gt_q)
+    assert m["T err < 0.2"] == 25.0 and m["T err < 0.5"] == 50.0 and m["T err < 1.0"] == 75.0
+    assert m["R err < 10"] == 25.0 and m["R err < 15"] == 50.0 and m["R err < 30"] == 75.0
+    assert abs(m["T median err"] - 0.65) < 1e-6 and abs(m["R median err"] - 20.0) < 1e-3
+    assert create_small_table(m).count("\n") == 2
+
+
+def test_pose_evaluator_single_process():
+    from nopesac_amd.evaluation import PoseEvaluator
+    ev = PoseEvaluator(camera_keys=("camera", "camera_init"))
+    inputs = [{"rel_pose": {"position": [0.0, 0, 0], "rotation": [1.0, 0, 0, 0]}}, {}]
+    outputs = [_out([0.3, 0.4, 0.0], [1, 0, 0, 0]), _out([9, 9, 9], [0, 1, 0, 0])]
+    ev.process(inputs, outputs)
+    res = ev.evaluate()
+    assert res["pairs"]["count"] == 2 and res["pairs"]["mean planes/view"] == 2.5
+    assert abs(res["camera"]["T mean err"] - 0.5) < 1e-6 and res["camera"]["R mean err"] < 1e-3   # only the pair with GT counts
+
+
+def test_cli_setup_and_synthetic_dataset():
+    from nopesac_amd import run
+    args = run.default_argument_parser().parse_args(
+        ["--config-file", os.path.join(ROOT, "configs", "inference_scannet.yaml"), "--eval-only", "--synthetic-pairs", "3",
+         "MODEL.DEVICE", "cpu", "TEST.PLANE_SCORE_THRESHOLD", "0.7"])
+    cfg = run.setup(args)
+    assert cfg.MODEL.DEVICE == "cpu" and cfg.TEST.PLANE_SCORE_THRESHOLD == 0.7 and cfg.DATASETS.TEST == ("scannet_test",)
+    pairs = run.load_pairs(args)
+    assert len(pairs) == 3 and pairs[0]["0"]["image"].shape == (3, 480, 640)
+    with pytest.raises(FileNotFoundError):
+        run.load_checkpoint(torch.nn.Linear(1, 1), cfg, synthetic=False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nopesac_amd import runner
+    from nopesac_amd.evaluation import PoseEvaluator
+    runner.init_distributed("gloo")
+    lo, hi = runner.shard_range(5, rank, world)                       # ragged: 3 + 2 pairs
+    ev = PoseEvaluator(camera_keys=("camera",), device=torch.device("cpu"))
+    for i in range(lo, hi):
+        ev.process([{"rel_pose": {"position": [0.0, 0, 0], "rotation": [1.0, 0, 0, 0]}}], [_out([float(i), 0, 0], [1, 0, 0, 0])])
+    res = ev.evaluate()
+    torch.distributed.barrier()
+    q.put((rank, res))
+    torch.distributed.destroy_process_group()
+
+
+def test_ragged_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, res in got:
+        assert res["pairs"]["count"] == 5
+        assert abs(res["camera"]["T mean err"] - 2.0) < 1e-6 and abs(res["camera"]["T median err"] - 2.0) < 1e-6
