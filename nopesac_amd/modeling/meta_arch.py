@@ -112,8 +112,9 @@ class PlaneTR_NopeSAC(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pose = head.initial_pose(feats, B)
-                for t in pose:
-                    t.record_stream(main)
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in pose:
+                        t.record_stream(main)
         head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
         mark("plane_head")
         sel = post_select(head_out, query_feat, H, W, self.cfg)
