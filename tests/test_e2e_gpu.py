@@ -98,3 +98,15 @@ def test_cli_runner_end_to_end(device, tmp_path):
                     "--synthetic-pairs", "3", "--pairs-per-batch", "2", "--output", str(out), "MODEL.DEVICE", str(device)])
     assert res["pairs"]["count"] == 3 and res["timing(rank0)"]["pairs"] == 3
     assert json.load(open(out))["pairs"]["count"] == 3
+
+
+@pytest.mark.parametrize("nq", [64, 128])
+def test_e2e_more_queries(device, nq):
+    """BASELINE configs 3/5 need NUM_OBJECT_QUERIES = 64 / 128: end-to-end parity at those sizes."""
+    from nopesac_amd.synth import synth_pair, synth_state_dict
+    from oracle import nopesac_oracle as O
+    model = make_model(device, nq=nq)
+    inp = [synth_pair(7)]
+    res = model(inp)
+    ref = O.inference(synth_state_dict(nq), inp, O.OracleConfig(num_queries=nq))
+    _check_pair(res[0], ref[0])
