@@ -83,6 +83,12 @@ int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, con
                            int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int64_t w_bstride,
                            int act, int in_dt, int out_dt, int kernel_cfg, void* stream);
 
+/* Fused bf16 ResNet stem: y = maxpool3x3/s2/p1( relu( bn( conv7x7/s2/p3(x) ) ) ) in one kernel (d2 BasicStem).
+ *   x bf16 NHWC [B,H,W,4] (RGB + zero pad channel); w bf16 [64][7][8][4] (kw padded 7 -> 8 with zeros, i.e. 224 per
+ *   output channel); scale/bias f32[64] (folded FrozenBN); y bf16 NHWC [B,PH,PW,64]. */
+int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, const float* bias, void* y,
+                            int B, int H, int W, void* stream);
+
 /* (x - mean[c]) / std[c], NCHW f32 -> NHWC (C padded with zeros to Cpad), out_dt f32/bf16.
  * siamese_planeTR.py:85-89,534-542. */
 int nopesac_preprocess_nchw_to_nhwc(const float* x, void* y, const float* mean, const float* std,

@@ -1,0 +1,155 @@
+// Fused ResNet stem for the bf16 path: conv 7x7/s2/p3 (3->64, input padded to 4 channels) + FrozenBN + ReLU +
+// max-pool 3x3/s2/p1 in ONE kernel (detectron2 BasicStem; call site meta_arch/siamese_planeTR.py:456).
+//
+// The un-fused path writes the 64 x 240 x 320 x 64 conv output (629 MB at 64 images) and reads it back for the pool;
+// here a workgroup owns a 4 x 20 tile of POOLED pixels:
+//   * the 23 x 88 input-pixel patch it needs (8 bytes / pixel) and the 64 x 224 weight matrix go to LDS once;
+//   * the 9 x 41 conv outputs under the pooled tile are an implicit GEMM straight out of the LDS patch:
+//     K index = (kh*8 + kw)*4 + c with kw padded 7 -> 8 (zero weights), so 8 consecutive k = 2 horizontally adjacent
+//     input pixels = one aligned 16-byte ds_read_b128 A fragment - no im2col buffer;
+//     M = 369 pixels -> 12 row tiles of 32 (3 per wave), N = 64, K = 224 -> 14 x v_mfma_f32_32x32x16_bf16 per tile pair;
+//   * BN + ReLU in registers, conv tile -> LDS (bf16, pool-padding positions = -inf), 3x3/s2 max from LDS,
+//     16-byte stores of the pooled NHWC rows.
+// HBM traffic per image: 2.4 MB in + 2.4 MB out (instead of 2.4 + 9.8 + 9.8 + 2.4).
+#include "common.h"
+
+namespace nps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+constexpr int ST_PH = 4, ST_PW = 20;                 // pooled tile
+constexpr int ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1;   // conv tile 9 x 41
+constexpr int ST_M = ST_CH * ST_CW;                  // 369 conv pixels
+constexpr int ST_IH = 2 * (ST_CH - 1) + 7;           // 23 input rows
+constexpr int ST_IW = 88;                            // 2*(41-1)+7 = 87 -> 88 (row = 704 bytes, 16-byte multiple)
+constexpr int ST_K = 224, ST_WLD = 232;              // weight row: 224 + 8 pad elements (464 bytes)
+constexpr int ST_CLD = 72;                           // conv tile row: 64 + 8 pad elements (144 bytes)
+constexpr int ST_PATCH_BYTES = ST_IH * ST_IW * 8 + 64;          // + slack for the padded kw = 7 tap
+constexpr int ST_W_BYTES = 64 * ST_WLD * 2;
+constexpr int ST_CONV_BYTES = 384 * ST_CLD * 2;
+constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH_BYTES + ST_W_BYTES) : ST_CONV_BYTES;
+
+__global__ __launch_bounds__(256) void stem_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ bias,
+                                                         bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
+    unsigned char* patch = lds;
+    bf16_t* wl = reinterpret_cast<bf16_t*>(lds + ST_PATCH_BYTES);
+    bf16_t* ctile = reinterpret_cast<bf16_t*>(lds);
+    const int b = blockIdx.z;
+    const int py0 = blockIdx.y * ST_PH, px0 = blockIdx.x * ST_PW;
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;          // first conv row / col under this pooled tile
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / col
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- stage the input patch (zero outside the image) and the weights
+    const bf16_t* xb = x + (long long)b * H * W * 4;
+    for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
+        const int r = i / ST_IW, c = i % ST_IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        uint2 v = make_uint2(0u, 0u);
+        if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = *reinterpret_cast<const uint2*>(xb + ((long long)iy * W + ix) * 4);
+        *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
+    }
+    for (int i = tid; i < 64 * (ST_K / 8); i += 256) {
+        const int n = i / (ST_K / 8), c = i % (ST_K / 8);
+        *reinterpret_cast<us8*>(wl + n * ST_WLD + c * 8) = *reinterpret_cast<const us8*>(w + n * ST_K + c * 8);
+    }
+    __syncthreads();
+    // ---- implicit GEMM: wave owns row tiles t = wave*3 .. +3 (32 conv pixels each), both 32-channel halves
+    const int half = lane >> 5;
+    int a_base[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int p = (wave * 3 + t) * 32 + (lane & 31);
+        if (p >= ST_M) p = 0;                                   // padded rows compute garbage that is never stored
+        const int cy = p / ST_CW, cx = p % ST_CW;
+        a_base[t] = ((2 * cy) * ST_IW + 2 * cx + 2 * half) * 8;
+    }
+    const int b_off = ((lane & 31) * ST_WLD + 8 * half) * 2;
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks) {
+        const int kh = ks >> 1, kw0 = (ks & 1) * 4;
+        bf16x8 af[3], bf[2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(patch + a_base[t] + (kh * ST_IW + kw0) * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bf[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wl) + b_off + (j * 32 * ST_WLD + ks * 16) * 2);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[t], acc[t][j], 0, 0, 0);
+    }
+    __syncthreads();                                            // patch / weights are dead: reuse LDS for the conv tile
+    // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 8q + 4*half + {0..3}
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int p = (wave * 3 + t) * 32 + (lane & 31);
+        const int cy = p / ST_CW, cx = p % ST_CW;
+        const int gy = cy0 + cy, gx = cx0 + cx;
+        const bool inside = p < ST_M && (unsigned)gy < (unsigned)CH && (unsigned)gx < (unsigned)CW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = j * 32 + 8 * q + 4 * half;
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(acc[t][j][4 * q + e] * scale[n + e] + bias[n + e], 0.f);
+                    o[e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
+                }
+                if (p < 384) *reinterpret_cast<us4*>(ctile + p * ST_CLD + n) = o;
+            }
+    }
+    __syncthreads();
+    // ---- 3x3 / s2 max-pool out of LDS; 8 channels (16 bytes) per work item
+    for (int i = tid; i < ST_PH * ST_PW * 8; i += 256) {
+        const int c8 = (i & 7) * 8, pp = i >> 3;
+        const int ly = pp / ST_PW, lx = pp % ST_PW;
+        const int py = py0 + ly, px = px0 + lx;
+        if (py >= PH || px >= PW) continue;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const us8 v = *reinterpret_cast<const us8*>(ctile + ((2 * ly + dy) * ST_CW + 2 * lx + dx) * ST_CLD + c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf16_to_f32(v[e]));
+            }
+        us8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(m[e]);
+        *reinterpret_cast<us8*>(y + (((long long)b * PH + py) * PW + px) * 64 + c8) = o;
+    }
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, const float* bias, void* y, int B,
+                                       int H, int W, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && w && scale && bias && y && B > 0 && H >= 7 && W >= 7, "stem_fused: bad args");
+    NPS_CHECK_ARG(((uintptr_t)x % 8 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "stem_fused: alignment");
+    const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
+    const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
+    dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
+    hipLaunchKernelGGL(stem_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, scale, bias,
+                       (bf16_t*)y, H, W, CH, CW, PH, PW);
+    NPS_LAUNCH_RET();
+}

@@ -33,6 +33,7 @@ class HipResNet50(ParamModule):
             self.out_features = list(r.OUT_FEATURES)
         else:
             self.out_features = ["res2", "res3", "res4", "res5"]
+        self.fused_stem = True
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -41,6 +42,11 @@ class HipResNet50(ParamModule):
 
     def pack(self) -> dict:
         P = {"stem": conv_bn(self, "stem.conv1.weight", "stem.conv1.norm", 1e-5, cin_pad=self.STEM_CIN_PAD)}
+        # fused bf16 stem: [64][kh 7][kw 8 (zero padded)][c 4] -> 224 K per output channel
+        w = self.raw("stem.conv1.weight").float().permute(0, 2, 3, 1)                   # [64,7,7,3]
+        w8 = w.new_zeros(64, 7, 8, 4)
+        w8[:, :, :7, :3] = w
+        P["stem_fused_w"] = w8.reshape(64, 224).to(torch.bfloat16).contiguous()
         cin = 64
         for name, n, cmid, cout in RES_STAGES:
             for i in range(n):
@@ -58,8 +64,11 @@ class HipResNet50(ParamModule):
             c = P[key]
             return ops.conv2d(t, c.w(dt), c.scale, c.bias, residual, stride=stride, pad=pad, act=act)
 
-        x = cv(x, "stem", 2, 3)
-        x = ops.maxpool(x, 3, 2, 1)
+        if dt == torch.bfloat16 and self.fused_stem:
+            x = ops.stem_fused(x, P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
+        else:
+            x = cv(x, "stem", 2, 3)
+            x = ops.maxpool(x, 3, 2, 1)
         out = {}
         cin = 64
         for name, n, cmid, cout in RES_STAGES:

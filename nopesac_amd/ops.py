@@ -161,6 +161,18 @@ def preprocess(images_nchw: torch.Tensor, mean: torch.Tensor, std: torch.Tensor,
     return y
 
 
+def stem_fused(x: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """bf16 conv7x7/s2 + BN + ReLU + maxpool3x3/s2 in one kernel.  x [B,H,W,4] bf16, w224 [64,224] bf16."""
+    _chk(x, torch.bfloat16); _chk(w224, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
+    B, H, W, C = x.shape
+    assert C == 4 and w224.shape == (64, 224)
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    y = torch.empty((B, PH, PW, 64), device=x.device, dtype=torch.bfloat16)
+    _lib.check(_L().nopesac_stem_fused_bf16(_p(x), _p(w224), _p(scale), _p(bias), _p(y), B, H, W, _stream()), "nopesac_stem_fused_bf16")
+    return y
+
+
 def maxpool(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
     _chk(x)
     B, H, W, C = x.shape

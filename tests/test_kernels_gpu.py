@@ -183,3 +183,21 @@ def test_attention(device, B, Lq, Lk, mfma):
         a = torch.softmax(torch.einsum("lhd,shd->hls", qq, kk) * 32 ** -0.5, -1)
         ref[b * Lq: b * Lq + nq_] = torch.einsum("hls,shd->lhd", a, vv).reshape(nq_, 256)
     assert _rel(o, ref) < (2e-2 if mfma else 1e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 480, 640), (1, 64, 96), (3, 70, 90)])
+def test_stem_fused(device, B, H, W):
+    """Fused bf16 stem (conv7x7/s2 + BN + ReLU + maxpool) vs the PyTorch fp32 ops on bf16-rounded operands."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)), 3, 2, 1)
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    w8 = torch.zeros(64, 7, 8, 4)
+    w8[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    y = ops.stem_fused(x4.to(device, torch.bfloat16), w8.reshape(64, 224).to(device, torch.bfloat16), scale.to(device), bias.to(device))
+    assert y.shape == (B, ref.shape[2], ref.shape[3], 64)
+    assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1e-2
