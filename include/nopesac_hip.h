@@ -238,6 +238,21 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
  * optionally flip the sign so that component 0 >= 0 (camera_head.py:436-437,695-696). */
 int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream);
 
+/* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
+ *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
+ * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)
+ *   -> uint8[V,W,H] COLUMN-major map of kept-plane ordinals (0xFF = none; bit-7 test skipped when flags bit1 = fallback). */
+int nopesac_rle_labels(const uint8_t* winner, const int32_t* kept_idx, const int32_t* n_kept, const int32_t* flags,
+                       uint8_t* labels, int V, int H, int W, int nq, void* stream);
+/* transitions: counts int32[V,nq] = number of 0<->1 flips of plane p's mask along the column-major scan (N = H*W);
+ *   if positions != NULL the ascending flip positions of (v,p) are written at positions[offsets[v*nq+p] ...]
+ *   (call once with NULLs to size, exclusive-scan the counts, call again). */
+int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_kept, const int64_t* offsets, int32_t* counts,
+                            uint32_t* positions, int V, int N, int nq, void* stream);
+/* HOST function (no device work): one mask's flip positions -> COCO compressed "counts" string (not NUL terminated,
+ *   returns its length or < 0) and bbox4 = [x, y, w, h] (cocoapi rleToString / rleToBbox). */
+int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W, char* out, int cap, double* bbox4);
+
 #ifdef __cplusplus
 }
 #endif

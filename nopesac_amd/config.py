@@ -250,6 +250,7 @@ def add_amd_defaults(cfg: CfgNode) -> CfgNode:
     cfg.MODEL.AMD = CN(dict(
         COMPUTE_DTYPE="float32",      # "float32" (parity path) or "bfloat16" (dense convs on bf16 MFMA)
         OUTPUT_MASKS=True,            # decode pred_plane_masks [n,H,W] from the winner map for every image
+        OUTPUT_RLE=True,              # COCO RLE "segmentation" + "bbox" in every `instances` entry (siamese_planeTR.py:703-720)
         USE_HIP_GRAPH=False,          # capture the static-shape forward in a hipGraph
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
     ))

@@ -1,0 +1,184 @@
+// COCO run-length encoding of the kept plane masks, straight from the post-selection winner map.
+//
+// The reference packs every kept plane into an `instances` entry whose "segmentation" is
+// pycocotools.mask.encode(np.asfortranarray(mask)) and whose "bbox" is mask.toBbox(rle)
+// (meta_arch/siamese_planeTR.py:685-720, 741-766).  pycocotools is a third-party dependency that is not in the
+// reference tree; its published algorithm (cocoapi maskApi.c rleEncode / rleToString / rleToBbox) is:
+//   * scan the mask in COLUMN-major order, emit alternating run lengths starting with a run of zeros;
+//   * string form: each count (from the 4th on, minus the count two places earlier) as 5-bit groups, LSB first,
+//     bit 5 = "more", + 48 to land in printable ASCII;
+//   * bbox = tight box of the ones, [x, y, w, h]; zeros when there are fewer than two runs.
+//
+// Device side (this file): the n masks of a view are never materialised.  One pass turns the row-major winner map
+// into a column-major map of plane ordinals (0xFF = no kept plane); then one workgroup per (view, plane) streams that
+// 300 KB map (L2 resident) 16 bytes per lane and compacts the positions where "pixel belongs to plane p" flips.
+// Host side: nopesac_rle_compress_host turns one plane's flip positions into the COCO string + bbox.
+#include "common.h"
+
+namespace nps {
+
+__global__ __launch_bounds__(256) void rle_labels_kernel(const uint8_t* __restrict__ winner, const int* __restrict__ kept_idx,
+                                                         const int* __restrict__ n_kept, const int* __restrict__ flags,
+                                                         uint8_t* __restrict__ labels, int H, int W, int nq) {
+    __shared__ uint8_t lut[128];
+    __shared__ uint8_t tile[32][33];
+    const int v = blockIdx.z, tx = threadIdx.x, ty = threadIdx.y, tid = ty * 32 + tx;
+    if (tid < 128) lut[tid] = 0xFF;
+    __syncthreads();
+    const int n = n_kept[v];
+    if (tid < n) {
+        const int q = kept_idx[(long long)v * nq + tid];
+        if (q >= 0 && q < 128) lut[q] = (uint8_t)tid;
+    }
+    __syncthreads();
+    const bool fallback = (flags[v] & 2) != 0;      // :743 fallback mask = arg-max only, no probability test
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const uint8_t* wv = winner + (long long)v * H * W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + ty + 8 * i, x = x0 + tx;
+        uint8_t l = 0xFF;
+        if (y < H && x < W) {
+            const uint8_t w8 = wv[(long long)y * W + x];
+            if (fallback || (w8 & 0x80)) l = lut[w8 & 0x7F];
+        }
+        tile[ty + 8 * i][tx] = l;
+    }
+    __syncthreads();
+    uint8_t* lv = labels + (long long)v * H * W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x0 + ty + 8 * i, y = y0 + tx;
+        if (x < W && y < H) lv[(long long)x * H + y] = tile[tx][ty + 8 * i];
+    }
+}
+
+// grid (nq, V).  counts[v*nq+p] = number of flips of plane p; when positions != nullptr the flip positions are
+// written (ascending) at positions[offsets[v*nq+p] ...].
+__global__ __launch_bounds__(256) void rle_transitions_kernel(const uint8_t* __restrict__ labels, const int* __restrict__ n_kept,
+                                                              const long long* __restrict__ offsets, int* __restrict__ counts,
+                                                              uint32_t* __restrict__ positions, int N, int nq) {
+    __shared__ int wave_tot[4];
+    const int p = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p >= n_kept[v]) {
+        if (tid == 0) counts[v * nq + p] = 0;
+        return;
+    }
+    const uint8_t* lv = labels + (long long)v * N;
+    const bool vec_ok = (N % 16 == 0) && (((uintptr_t)lv & 15) == 0);
+    uint32_t* out = positions ? positions + offsets[v * nq + p] : nullptr;
+    int base = 0;
+    for (int k0 = 0; k0 < N; k0 += 4096) {
+        const int k = k0 + tid * 16;
+        uint32_t m = 0;
+        if (k < N) {
+            if (vec_ok) {
+                const uint4 q = *reinterpret_cast<const uint4*>(lv + k);
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) m |= (uint32_t)(((wd[j >> 2] >> (8 * (j & 3))) & 0xFF) == (uint32_t)p) << j;
+            } else {
+                for (int j = 0; j < 16 && k + j < N; ++j) m |= (uint32_t)(lv[k + j] == (uint8_t)p) << j;
+            }
+        }
+        const uint32_t prev = (k > 0 && k < N) ? (uint32_t)(lv[k - 1] == (uint8_t)p) : 0u;
+        uint32_t tr = (m ^ ((m << 1) | prev)) & 0xFFFFu;
+        if (k + 16 > N) tr &= (k < N) ? ((1u << (N - k)) - 1u) : 0u;
+        const int c = __popc(tr);
+        int incl = c;                                       // wave inclusive scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int t = wave_tot[w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        if (out) {
+            int o = base + wbase + incl - c;
+            while (tr) {
+                const int j = __ffs(tr) - 1;
+                tr &= tr - 1;
+                out[o++] = (uint32_t)(k + j);
+            }
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[v * nq + p] = base;
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_rle_labels(const uint8_t* winner, const int32_t* kept_idx, const int32_t* n_kept, const int32_t* flags,
+                                  uint8_t* labels, int V, int H, int W, int nq, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(winner && kept_idx && n_kept && flags && labels, "rle_labels: null pointer");
+    NPS_CHECK_ARG(V > 0 && H > 0 && W > 0 && nq > 0 && nq <= 128, "rle_labels: bad sizes (nq <= 128)");
+    dim3 grid((W + 31) / 32, (H + 31) / 32, V);
+    hipLaunchKernelGGL(rle_labels_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, winner, kept_idx, n_kept, flags, labels, H, W, nq);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_kept, const int64_t* offsets, int32_t* counts,
+                                       uint32_t* positions, int V, int N, int nq, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(labels && n_kept && counts, "rle_transitions: null pointer");
+    NPS_CHECK_ARG((positions == nullptr) == (offsets == nullptr), "rle_transitions: offsets and positions go together");
+    NPS_CHECK_ARG(V > 0 && N > 0 && nq > 0 && nq <= 128, "rle_transitions: bad sizes");
+    hipLaunchKernelGGL(rle_transitions_kernel, dim3(nq, V), dim3(256), 0, (hipStream_t)stream, labels, n_kept,
+                       (const long long*)offsets, counts, positions, N, nq);
+    NPS_LAUNCH_RET();
+}
+
+// Host-only: flip positions of ONE mask (ascending, column-major pixel indices) -> COCO compressed counts string
+// (not NUL-terminated) + bbox [x, y, w, h].  Returns the string length, or a negative error code.
+extern "C" int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W, char* out, int cap, double* bbox4) {
+    using namespace nps;
+    NPS_CHECK_ARG((positions || n_pos == 0) && n_pos >= 0 && H > 0 && W > 0 && out && bbox4, "rle_compress: bad args");
+    const long long N = (long long)H * W;
+    const int m = n_pos + 1;                                  // runs: [pos0, pos1-pos0, ..., N-pos_last]
+    auto run = [&](int i) -> long long {
+        const long long lo = i == 0 ? 0 : positions[i - 1];
+        const long long hi = i == n_pos ? N : positions[i];
+        return hi - lo;
+    };
+    int len = 0;
+    for (int i = 0; i < m; ++i) {
+        long long x = run(i);
+        NPS_CHECK_ARG(x >= 0, "rle_compress: positions not ascending");
+        if (i > 2) x -= run(i - 2);
+        bool more = true;
+        while (more) {
+            char c = (char)(x & 0x1f);
+            x >>= 5;
+            more = (c & 0x10) ? x != -1 : x != 0;
+            if (more) c |= 0x20;
+            NPS_CHECK_ARG(len < cap, "rle_compress: output buffer too small");
+            out[len++] = (char)(c + 48);
+        }
+    }
+    // tight box of the ones (rleToBbox): runs 1, 3, 5, ... are ones
+    const int me = (m / 2) * 2;
+    if (me == 0) {
+        bbox4[0] = bbox4[1] = bbox4[2] = bbox4[3] = 0.0;
+        return len;
+    }
+    long long xs = W, ys = H, xe = 0, ye = 0, xp = 0, cc = 0;
+    for (int j = 0; j < me; ++j) {
+        cc += run(j);
+        const long long t = cc - (j % 2), y = t % H, x = (t - y) / H;
+        if (j % 2 == 0) xp = x;
+        else if (xp < x) { ys = 0; ye = H - 1; }
+        xs = x < xs ? x : xs; xe = x > xe ? x : xe;
+        ys = y < ys ? y : ys; ye = y > ye ? y : ye;
+    }
+    bbox4[0] = (double)xs; bbox4[1] = (double)ys; bbox4[2] = (double)(xe - xs + 1); bbox4[3] = (double)(ye - ys + 1);
+    return len;
+}

@@ -6,10 +6,15 @@ that consumes the hot path's outputs: per-pair pose errors and their summary tab
   * evaluate()                ~ :315-366 + `_eval_camera_reg` :382-425: gathers across ranks (ONE all_gather of
     fixed-width fp32 rows over RCCL instead of pickled predictions over Gloo), then
     T err = ||t - t_gt||2, R err = 2 acos|<q, q_gt>| 180/pi, medians / means / accuracy at 1.0|0.5|0.2 m, 30|15|10 deg.
+  * dump(output_dir)          ~ :330-341 (`eval_full_scene`): `NopeSAC_instances_predictions.pth` (torch.save of the
+    per-pair prediction dicts, schema of :193-257) and `continuous.pkl` (`get_optimized_dict` :259-313 + `save_dict`
+    :852-860) - the two files the reference's offline eval.py / vis tools read.
 Plane AP and matching P/R (COCO tooling, pycocotools) stay out of scope.
 """
 from __future__ import annotations
 
+import os
+import pickle
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -37,13 +42,35 @@ class PoseEvaluator:
     """DatasetEvaluator-style: reset() / process(inputs, outputs) / evaluate()."""
 
     def __init__(self, camera_keys=("camera", "camera_init", "camera_initRec", "camera_avgRef0", "camera_softRef0"),
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, keep_predictions: bool = False):
         self.camera_keys = tuple(camera_keys)
         self.device = device
+        self.keep_predictions = keep_predictions
         self.reset()
 
     def reset(self):
         self._rows: List[np.ndarray] = []
+        self._predictions: List[dict] = []
+
+    @staticmethod
+    def prediction_record(inp: dict, out: dict) -> dict:
+        """One entry of the reference's `self._predictions` (mp3d_evaluation.py:193-257), CPU-only objects."""
+        gt = inp.get("rel_pose") or {}
+        gt_cam = {"tran": gt.get("position"), "rot": gt.get("rotation"), "tran_cls": gt.get("tran_cls"), "rot_cls": gt.get("rot_cls")}
+        pred = {"0": {}, "1": {}}
+        for v in "01":
+            pred[v]["image_id"] = inp[v].get("image_id")
+            pred[v]["file_name"] = inp[v].get("file_name")
+            if out[v] is not None and "instances" in out[v]:
+                pred[v]["instances"] = out[v]["instances"]
+            pred[v]["pred_plane"] = out[v]["pred_plane"].detach().cpu()
+        for k, val in out.items():
+            if "camera" in k and "cls" not in k:
+                pred[k] = {"pred": val, "gts": gt_cam}
+            elif "assignment" in k:
+                pred[k] = val.detach().cpu()
+        pred["corrs"] = {"0": {}, "1": {}}
+        return pred
 
     def process(self, inputs: List[dict], outputs: List[dict]):
         for inp, out in zip(inputs, outputs):
@@ -57,6 +84,8 @@ class PoseEvaluator:
                 row.append(np.asarray(cam["tran"], np.float32).reshape(-1)[:3] if cam else np.zeros(3, np.float32))
                 row.append(np.asarray(cam["rot"], np.float32).reshape(-1)[:4] if cam else np.array([1, 0, 0, 0], np.float32))
             self._rows.append(np.concatenate(row))
+            if self.keep_predictions:
+                self._predictions.append(self.prediction_record(inp, out))
 
     @property
     def row_width(self) -> int:
@@ -86,6 +115,42 @@ class PoseEvaluator:
             if has_gt.any():
                 res[k] = camera_metrics(r[has_gt, o:o + 3], r[has_gt, o + 3:o + 7], r[has_gt, 0:3], r[has_gt, 3:7])
         return res
+
+
+def optimized_dict(predictions: List[dict]) -> Dict[int, dict]:
+    """`get_optimized_dict` (mp3d_evaluation.py:259-313): the `continuous.pkl` schema read by eval.py:1027-1038."""
+    ret = {}
+    for idx, p in enumerate(predictions):
+        best = p["pred_assignment"].numpy()
+        cam = p["camera"]
+        ret[idx] = {
+            "n_corr": best.sum(), "cost": 0.1,
+            "best_camera": {"position": cam["pred"]["tran"], "rotation": cam["pred"]["rot"]},
+            "gt_camera": {"position": cam["gts"]["tran"], "rotation": cam["gts"]["rot"]},
+            "best_assignment": best,
+            "plane_param_override": {"0": p["0"]["pred_plane"].cpu().numpy(), "1": p["1"]["pred_plane"].cpu().numpy()},
+            "image_ids": {"0": p["0"]["image_id"], "1": p["1"]["image_id"]},
+        }
+    return ret
+
+
+def dump_predictions(predictions: List[dict], output_dir: str) -> Dict[str, str]:
+    """Rank-0 side of `eval_full_scene` (mp3d_evaluation.py:330-341).  With a process group the per-rank lists are
+    concatenated in rank order first (comm.gather semantics, :317-319); non-zero ranks return {}."""
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, predictions)
+        if dist.get_rank() != 0:
+            return {}
+        predictions = [p for part in parts for p in part]
+    os.makedirs(output_dir, exist_ok=True)
+    inst = os.path.join(output_dir, "NopeSAC_instances_predictions.pth")
+    torch.save(predictions, inst)
+    cont = os.path.join(output_dir, "continuous.pkl")
+    with open(cont, "wb") as f:
+        pickle.dump(optimized_dict(predictions), f)
+    return {"instances_predictions": inst, "continuous": cont}
 
 
 def create_small_table(d: Dict[str, float]) -> str:

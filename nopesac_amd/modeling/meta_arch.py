@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, rle
 from ..registry import META_ARCH_REGISTRY, configurable
 from .backbone import build_backbone
 from .camera_head import build_camera_head
@@ -44,6 +44,7 @@ class PlaneTR_NopeSAC(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32), False)
         self.compute_dtype = _DTYPES[cfg.MODEL.AMD.COMPUTE_DTYPE]
         self.output_masks = bool(cfg.MODEL.AMD.OUTPUT_MASKS)
+        self.output_rle = bool(cfg.MODEL.AMD.get("OUTPUT_RLE", True))
         for mod in (self.sem_seg_head, self.matching_head, self.camera_head_list[0]):
             mod.gemm_dtype = self.compute_dtype     # bf16 => head GEMMs run f32-activation x bf16-weight MFMA
         self.infer_iter = 0
@@ -186,6 +187,7 @@ class PlaneTR_NopeSAC(nn.Module):
         m = cpu(cam["m"]).tolist()
         ass = {k: cpu(cam[k]) for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
         onepp_t, onepp_r = cpu(cam["refine"]["maps"]["trans_all"]).numpy(), cpu(cam["refine"]["maps"]["rots_all"]).numpy()
+        rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]) if self.output_rle else None
         results = []
         for i in range(B):
             res = {}
@@ -200,8 +202,14 @@ class PlaneTR_NopeSAC(nn.Module):
                         "winner_map": sel["winner"][j], "fallback_mask": bool(flags[j] & 2)}
                 if self.output_masks:
                     view["pred_plane_masks"] = decode_masks(sel["winner"][j], idx.to(sel["winner"].device), bool(flags[j] & 2))
-                view["instances"] = [{"image_id": inp.get("image_id"), "file_name": inp.get("file_name"), "category_id": 0,
-                                      "score": float(scores[j, k]), "bbox_mode": 1} for k in range(n)]
+                view["instances"] = []
+                for k in range(n):       # siamese_planeTR.py:705-720 (bbox_mode 1 = XYWH_ABS)
+                    ins = {"image_id": inp.get("image_id"), "file_name": inp.get("file_name"), "category_id": 0,
+                           "score": float(scores[j, k])}
+                    if rles is not None:
+                        ins["segmentation"], ins["bbox"] = rles[j][k]["segmentation"], rles[j][k]["bbox"]
+                    ins["bbox_mode"] = 1
+                    view["instances"].append(ins)
                 res[v] = view
             res["pred_aff"] = None
             res["depth"] = {"0": None, "1": None}

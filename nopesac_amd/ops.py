@@ -374,3 +374,28 @@ def refilter_assignment(assignment, planes1, planes2, n1, n2, rot, trans):
                                           _p(_chk(trans, torch.float32)), B, nq, _p(out), _stream())
     _lib.check(rc, "nopesac_refilter_assignment")
     return out
+
+
+def rle_labels(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:
+    """winner uint8 [V,H,W] -> column-major uint8 [V,W,H] map of kept-plane ordinals (0xFF = none)."""
+    _chk(winner, torch.uint8); _chk(kept_idx, torch.int32); _chk(n_kept, torch.int32); _chk(flags, torch.int32)
+    V, H, W = winner.shape
+    labels = torch.empty((V, W, H), device=winner.device, dtype=torch.uint8)
+    _lib.check(_L().nopesac_rle_labels(_p(winner), _p(kept_idx), _p(n_kept), _p(flags), _p(labels), V, H, W, kept_idx.shape[1],
+                                       _stream()), "nopesac_rle_labels")
+    return labels
+
+
+def rle_transitions(labels: torch.Tensor, n_kept: torch.Tensor, nq: int, offsets: torch.Tensor = None,
+                    positions: torch.Tensor = None) -> torch.Tensor:
+    """counts int32 [V,nq] of mask flips per (view, plane); with offsets (int64 [V,nq]) + positions (int32 buffer) also
+    writes the ascending flip positions."""
+    _chk(labels, torch.uint8); _chk(n_kept, torch.int32)
+    V, W, H = labels.shape
+    counts = torch.empty((V, nq), device=labels.device, dtype=torch.int32)
+    if positions is not None:
+        _chk(offsets, torch.int64); _chk(positions, torch.int32)
+    _lib.check(_L().nopesac_rle_transitions(_p(labels), _p(n_kept), _p(offsets) if positions is not None else None, _p(counts),
+                                            _p(positions) if positions is not None else None, V, W * H, nq, _stream()),
+               "nopesac_rle_transitions")
+    return counts

@@ -23,7 +23,7 @@ import torch
 
 from . import runner
 from .config import get_cfg
-from .evaluation import PoseEvaluator, create_small_table
+from .evaluation import PoseEvaluator, create_small_table, dump_predictions
 from .registry import build_model
 from .synth import synth_pair, synth_state_dict
 
@@ -41,6 +41,7 @@ def default_argument_parser():
     ap.add_argument("--structured", action="store_true", help="structured synthetic images instead of noise")
     ap.add_argument("--synthetic-weights", action="store_true", help="name-seeded checkpoint instead of cfg.MODEL.WEIGHTS")
     ap.add_argument("--output", default="", help="write the result summary JSON here")
+    ap.add_argument("--dump-dir", default="", help="write NopeSAC_instances_predictions.pth + continuous.pkl here (eval_full_scene)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides")
     return ap
 
@@ -110,10 +111,14 @@ def main(argv=None):
     pairs = load_pairs(args)
     lo, hi = runner.shard_range(len(pairs), rank, world)
     logger.info("rank %d/%d: weights=%s pairs [%d,%d) of %d", rank, world, src, lo, hi, len(pairs))
-    evaluator = PoseEvaluator()
+    evaluator = PoseEvaluator(keep_predictions=bool(args.dump_dir))
     timing = inference_on_dataset(model, pairs[lo:hi], evaluator, args.pairs_per_batch)
     results = evaluator.evaluate()
     results["timing(rank0)"] = timing
+    if args.dump_dir:            # eval_full_scene dumps (mp3d_evaluation.py:330-341)
+        files = dump_predictions(evaluator._predictions, args.dump_dir)
+        if rank == 0:
+            logger.info("wrote %s", files)
     if rank == 0:
         for k, v in results.items():
             if isinstance(v, dict) and v and all(isinstance(x, (int, float)) for x in v.values()):

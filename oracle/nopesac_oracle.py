@@ -25,6 +25,8 @@ import numpy as np
 import torch
 from torch.nn import functional as F
 
+from . import rle_oracle
+
 Tensor = torch.Tensor
 
 
@@ -287,7 +289,14 @@ def post_select(logits: Tensor, params: Tensor, mask_logits: Tensor, query_feat:
         keep.append(pi); masks.append(m); areas.append(int(n_pix))
         centers.append(torch.stack([(xs.double() * mf).sum() / n_pix, (ys.double() * mf).sum() / n_pix]).float())
     k = torch.tensor(keep)
+    instances = []                                                                   # :703-720 / :747-766
+    for j, m in enumerate(masks):
+        rle = rle_oracle.encode(m.numpy())
+        instances.append({"category_id": 0, "score": float(v_score[k[j]]),
+                          "segmentation": {"size": [height, width], "counts": rle["counts"]},
+                          "bbox": rle_oracle.to_bbox(rle).tolist(), "bbox_mode": 1})
     return {
+        "instances": instances,
         "pred_plane": v_param[k], "pred_plane_feats": v_feat[k].unsqueeze(0).contiguous(),
         "pred_plane_masks": torch.stack(masks, 0), "pred_plane_oriIdxs": ori_idx[k],
         "pred_plane_ins_center": torch.stack(centers, 0), "scores": v_score[k],

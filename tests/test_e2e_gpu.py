@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import rle_oracle as R
 from tests.util import LOOSE, gold, loose_oracle_cfg, make_model, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +24,15 @@ def _check_pair(res, ref, g=None, soft_masks=False):
         assert rel_err(res[v]["pred_plane_ins_center"], ref[v]["pred_plane_ins_center"]) < c_tol
         mism = int((res[v]["pred_plane_masks"].cpu() != ref[v]["pred_plane_masks"]).sum())
         assert mism <= px_tol, mism       # 480x640xn booleans; float ties of the bilinear up-sampling only
+        # `instances` (siamese_planeTR.py:703-720): COCO RLE + bbox describe exactly the masks returned, scores match
+        assert len(res[v]["instances"]) == len(ref[v]["instances"])
+        for k, (ins, rins) in enumerate(zip(res[v]["instances"], ref[v]["instances"])):
+            own = R.encode(res[v]["pred_plane_masks"][k].cpu().numpy())
+            assert ins["segmentation"] == {"size": list(res[v]["pred_plane_masks"].shape[1:]), "counts": own["counts"]}
+            assert ins["bbox"] == R.to_bbox(own).tolist() and ins["bbox_mode"] == 1 and ins["category_id"] == 0
+            assert abs(ins["score"] - rins["score"]) < TOL
+            if mism == 0:
+                assert ins["segmentation"] == rins["segmentation"] and ins["bbox"] == rins["bbox"]
         if g is not None:
             assert res[v]["pred_plane_oriIdxs"] == g[f"v{v}_idx"].tolist()
             assert rel_err(res[v]["pred_plane"], g[f"v{v}_planes"]) < TOL

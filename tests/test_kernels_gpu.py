@@ -201,3 +201,36 @@ def test_stem_fused(device, B, H, W):
     y = ops.stem_fused(x4.to(device, torch.bfloat16), w8.reshape(64, 224).to(device, torch.bfloat16), scale.to(device), bias.to(device))
     assert y.shape == (B, ref.shape[2], ref.shape[3], 64)
     assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1e-2
+
+
+@pytest.mark.parametrize("V,H,W,nq,seed", [(3, 48, 64, 50, 0), (2, 37, 53, 50, 1), (2, 480, 640, 128, 2), (1, 5, 3, 50, 3)])
+def test_rle_from_winner_map(device, V, H, W, nq, seed):
+    """RLE kernels + host compressor vs the numpy COCO restatement on blocky synthetic winner maps
+    (ragged n_kept, a fallback view, sizes with H*W not a multiple of 16, ids up to 127)."""
+    from nopesac_amd import rle
+    from oracle import rle_oracle as R
+    g = torch.Generator().manual_seed(seed)
+    bh, bw = max(H // 6, 1), max(W // 5, 1)
+    coarse = torch.randint(0, nq, (V, (H + bh - 1) // bh, (W + bw - 1) // bw), generator=g)
+    ids = coarse.repeat_interleave(bh, 1).repeat_interleave(bw, 2)[:, :H, :W]
+    passed = torch.rand(V, H, W, generator=g) < 0.8
+    winner = (ids | (passed.long() << 7)).to(torch.uint8)
+    n_kept = torch.tensor([min(nq, 1 + 7 * v) for v in range(V)], dtype=torch.int32)
+    kept = torch.full((V, nq), -1, dtype=torch.int32)
+    for v in range(V):
+        present = torch.unique(ids[v])
+        extra = torch.tensor([q for q in range(nq) if q not in set(present.tolist())], dtype=torch.long)
+        pool = torch.cat([present, extra])[: int(n_kept[v])]
+        kept[v, : int(n_kept[v])] = pool.sort().values.int()
+    flags = torch.zeros(V, dtype=torch.int32)
+    flags[V - 1] = 2                                                   # last view: fallback mask (no probability test)
+    out = rle.encode_views(winner.to(device), kept.to(device), n_kept.to(device), flags.to(device))
+    for v in range(V):
+        assert len(out[v]) == int(n_kept[v])
+        for p in range(int(n_kept[v])):
+            m = ids[v] == int(kept[v, p])
+            if not (int(flags[v]) & 2):
+                m = m & passed[v]
+            ref = R.encode(m.numpy())
+            assert out[v][p]["segmentation"] == {"size": [H, W], "counts": ref["counts"]}, (v, p)
+            assert out[v][p]["bbox"] == R.to_bbox(ref).tolist()

@@ -93,3 +93,29 @@ def test_ragged_gather_world2():
     for _, res in got:
         assert res["pairs"]["count"] == 5
         assert abs(res["camera"]["T mean err"] - 2.0) < 1e-6 and abs(res["camera"]["T median err"] - 2.0) < 1e-6
+
+
+def test_prediction_dumps(tmp_path):
+    """`eval_full_scene` artefacts: NopeSAC_instances_predictions.pth (prediction schema of mp3d_evaluation.py:193-257)
+    and continuous.pkl (get_optimized_dict :259-313)."""
+    import pickle
+    from nopesac_amd.evaluation import PoseEvaluator, dump_predictions
+    ev = PoseEvaluator(camera_keys=("camera",), keep_predictions=True)
+    inp = {"0": {"image_id": "a_0", "file_name": "a0.png"}, "1": {"image_id": "a_1", "file_name": "a1.png"},
+           "rel_pose": {"position": [0.0, 0, 1], "rotation": [1.0, 0, 0, 0], "tran_cls": 3, "rot_cls": 4}}
+    out = _out([0.3, 0.4, 0.0], [1, 0, 0, 0])
+    seg = {"size": [2, 2], "counts": b"04"}
+    out["0"]["instances"] = [{"image_id": "a_0", "file_name": "a0.png", "category_id": 0, "score": 0.9, "segmentation": seg,
+                              "bbox": [0.0, 0.0, 2.0, 2.0], "bbox_mode": 1}] * 2
+    out["1"]["instances"] = []
+    out["pred_assignment"] = torch.tensor([[0., 1, 0], [0, 0, 0]])
+    out["camera_onePP"] = {"tran": np.zeros((2, 3), np.float32), "rot": np.zeros((2, 4), np.float32)}
+    ev.process([inp], [out])
+    files = dump_predictions(ev._predictions, str(tmp_path))
+    preds = torch.load(files["instances_predictions"], weights_only=False)
+    assert len(preds) == 1 and preds[0]["0"]["instances"][0]["segmentation"] == seg
+    assert preds[0]["camera"]["gts"]["tran_cls"] == 3 and "camera_onePP" in preds[0] and preds[0]["corrs"] == {"0": {}, "1": {}}
+    cont = pickle.load(open(files["continuous"], "rb"))
+    assert set(cont[0]) == {"n_corr", "cost", "best_camera", "gt_camera", "best_assignment", "plane_param_override", "image_ids"}
+    assert cont[0]["n_corr"] == 1 and cont[0]["image_ids"] == {"0": "a_0", "1": "a_1"}
+    assert cont[0]["plane_param_override"]["1"].shape == (3, 3) and cont[0]["gt_camera"]["position"] == [0.0, 0, 1]
