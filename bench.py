@@ -92,6 +92,44 @@ class ConvTimer:
             return y
 
         ops.conv2d = timed
+        # the two fused backbone kernels are conv work too: stem (conv7x7 + pool) and bottleneck tail (conv3 + shortcut [+ conv1'])
+        orig_stem, orig_tail = ops.stem_fused, ops.bottleneck_tail
+
+        def timed_stem(x, w224, scale, bias):
+            if not timer.enabled:
+                return orig_stem(x, w224, scale, bias)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_stem(x, w224, scale, bias)
+            e1.record()
+            B, H, W, _ = x.shape
+            flops = 2.0 * B * (H // 2) * (W // 2) * 64 * 147              # algorithmic: 7x7x3 taps (padding lanes not counted)
+            timer.records.append((str(x.dtype), flops, e0, e1, x.numel() * 2 + y.numel() * 2, "stem_fused x%s" % (tuple(x.shape),)))
+            return y
+
+        def timed_tail(b, w3, s3, b3, **k):
+            if not timer.enabled:
+                return orig_tail(b, w3, s3, b3, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y, o = orig_tail(b, w3, s3, b3, **k)
+            e1.record()
+            px = y.numel() // y.shape[-1]
+            flops = 2.0 * px * w3.shape[0] * w3.shape[1]
+            nbytes = 2 * (b.numel() + y.numel())
+            if k.get("x2") is not None:
+                flops += 2.0 * px * k["wsc"].shape[0] * k["wsc"].shape[1]
+                nbytes += 2 * px * k["x2"].shape[-1]
+            else:
+                nbytes += 2 * y.numel()
+            if o is not None:
+                flops += 2.0 * px * k["w1"].shape[0] * k["w1"].shape[1]
+                nbytes += 2 * o.numel()
+            timer.records.append((str(b.dtype), flops, e0, e1, nbytes, "bottleneck_tail b%s C4=%d CN=%d proj=%d" % (
+                tuple(b.shape), w3.shape[0], 0 if o is None else o.shape[-1], int(k.get("x2") is not None))))
+            return y, o
+
+        ops.stem_fused, ops.bottleneck_tail = timed_stem, timed_tail
         # modules imported `ops` as a module and call ops.conv2d / ops.linear, so the patch is seen everywhere
         return self
 
@@ -158,6 +196,10 @@ def main():
     ap.add_argument("--no-autotune", dest="autotune", action="store_false", help="skip the load-time conv kernel autotuning")
     ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward in a hipGraph and replay it")
     ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
+    ap.add_argument("--ablate", default="", choices=["", "backbone", "head", "nocam"],
+                    help="ANALYSIS ONLY (the JSON line is marked invalid): time a truncated pipeline - backbone only / "
+                         "backbone + plane head + post-selection / everything but the camera head - to see what each stage "
+                         "costs once batches overlap")
     args = ap.parse_args()
 
     from nopesac_amd import runner
@@ -197,8 +239,19 @@ def main():
     graphs = [None] * n_slots          # optional: one captured hipGraph per slot (static shapes, static buffers)
     graph_rows = [None] * n_slots
 
+    zero_rows = torch.zeros(B, runner.METRIC_WIDTH, device=device)
+
     def device_step(slot):
         x = ops.preprocess(raws[slot], model.pixel_mean, model.pixel_std, model.backbone.STEM_CIN_PAD, model.compute_dtype)
+        if args.ablate:
+            from nopesac_amd.modeling.plane_head import post_select
+            feats = model.backbone(x)
+            if args.ablate in ("head", "nocam"):
+                head_out, qf = model.sem_seg_head(feats)
+                post_select(head_out, qf, 480, 640, model.cfg)
+            if args.ablate == "nocam":
+                model.camera_head_list[0].initial_pose(feats, B)
+            return None, zero_rows
         d = model.forward_tensors(x, B, 480, 640, forced=forced)
         cam = d["cam"]
         rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B)
@@ -272,6 +325,10 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pairs_per_s = world * B * args.steps / elapsed
     m_mean = float(host[:, 9].mean())
+    if args.ablate:
+        if rank == 0:
+            print(json.dumps({"INVALID_ablation": args.ablate, "ms_per_step": round(ms_per_step, 3)}))
+        return
 
     # ---- roofline of the dominant kernel: one extra instrumented step (outside the timed region)
     timer = ConvTimer().install()

@@ -89,6 +89,23 @@ int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, con
 int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, const float* bias, void* y,
                             int B, int H, int W, void* stream);
 
+/* Fused tail of a bf16 ResNet bottleneck (d2 BottleneckBlock.forward: conv3 + shortcut + ReLU) plus, optionally, the NEXT
+ * block's 1x1 reduce conv, in one launch (all tensors bf16 NHWC, pixel-dense; FrozenBN as f32 scale/bias):
+ *   y = relu(scale3 * (w3 . b) + bias3 + shortcut),  shortcut = residual [B,OH,OW,C4]                      (identity block)
+ *                                                    or scale_sc * (wsc . x2[:, ::s, ::s]) + bias_sc        (projection block)
+ *   o = relu(scale1 * (w1 . y) + bias1)  if CN > 0   [B,OH,OW,CN]
+ * b [B,OH,OW,C], x2 [B,x2_H,x2_W,C2].  Exactly one of residual / x2 is non-NULL.
+ * The three weight matrices w3 [C4][C], wsc [C4][C2], w1 [CN][C4] are passed FRAGMENT-MAJOR: a [N][K] matrix is stored as
+ * [N/32][K/16][2][32][8], i.e. element (n, k) at ((((n/32)*(K/16) + k/16)*2 + (k%16)/8)*32 + n%32)*8 + k%8 - the order in which
+ * the 64 lanes of a wave consume it as MFMA operands, so every weight load is 1 KB contiguous (nopesac_amd.ops.mfma_fragment_major).
+ * Supported (C, C4, CN, C2): (64,256,{0,64,128},0), (64,256,{0,64},64), (128,512,{0,128,256},0), (128,512,{0,128},256);
+ * anything else returns an error (the caller then uses
+ * nopesac_conv2d_nhwc per layer). */
+int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,
+                                 const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH, int OW,
+                                 int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
+                                 const float* scale1, const float* bias1, int CN, void* o, void* stream);
+
 /* (x - mean[c]) / std[c], NCHW f32 -> NHWC (C padded with zeros to Cpad), out_dt f32/bf16.
  * siamese_planeTR.py:85-89,534-542. */
 int nopesac_preprocess_nchw_to_nhwc(const float* x, void* y, const float* mean, const float* std,

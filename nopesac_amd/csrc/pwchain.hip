@@ -1,0 +1,308 @@
+// Fused tail of a ResNet bottleneck for the bf16 path (d2 BottleneckBlock, STRIDE_IN_1X1 = False):
+//
+//     y  = relu( bn3(W3 . b) + shortcut )          shortcut = x            (identity blocks)
+//                                                           = bn_sc(Wsc . x[:, ::s, ::s])   (first block of a stage)
+//     a' = relu( bn1'(W1' . y) )                   the NEXT block's 1x1 reduce conv (optional)
+//
+// Un-fused, these are 2-3 HBM-bound launches: the expand conv reads b and the residual and writes y in 128-byte
+// segments, the projection shortcut writes and re-reads a full-width tensor, and the next block's conv1 reads y again.
+// Here a workgroup owns 64 consecutive pixels and the FULL channel width:
+//   * b (64 x C), the optional second source x (64 x C2) and the residual rows (64 x C4) are fetched with every load in
+//     flight at once and parked in LDS (one exposed HBM latency per workgroup instead of one per K-step);
+//   * phase 1: per wave, 32-channel column tiles; weight fragments come straight from L2 in MFMA operand layout (each
+//     wave reads different rows of W3: no redundancy, no LDS), activations from LDS; BN / shortcut / ReLU in registers;
+//     the bf16 result overwrites the residual in LDS, so the y tile is complete on chip;
+//   * y leaves as whole 2*C4-byte rows (16 B per lane, fully coalesced) and is, at the same time, the A operand of
+//   * phase 2: a' = relu(bn(y . W1'^T)) with K = C4, again with register-streamed weight fragments.
+// HBM bytes per pixel (res2, C = 64): 128 + 512 in, 512 + 128 out, instead of (128+512+512) + (512+128) un-fused.
+// The arithmetic (MFMA K order, f32 epilogue order, bf16 rounding points) is the same as the generic kernels', so the
+// identity-block results are bit-identical to the un-fused path; the projection block keeps the shortcut in f32
+// instead of rounding it to bf16 in between.
+#include "common.h"
+
+namespace nps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+struct PwArgs {
+    const bf16_t* a1; const bf16_t* w3; const float* s3; const float* b3;      // expand conv: a1 [M][C], w3 [C4][C] (all weights fragment-major)
+    const bf16_t* res;                                                         // identity shortcut [M][C4] or null
+    const bf16_t* a2; const bf16_t* wsc; const float* ssc; const float* bsc;   // projection shortcut source [B][H2][W2][C2], wsc [C4][C2]
+    int a2_H, a2_W, a2_stride, OH, OW;                                         // pixel m = (b, oy, ox) reads a2[b][oy*s][ox*s]
+    bf16_t* y;                                                                 // [M][C4]
+    const bf16_t* w1; const float* s1; const float* b1; bf16_t* o;             // next conv1: w1 [CN][C4], o [M][CN]
+    long long M;
+};
+
+template <int BM, int K>
+__device__ __forceinline__ void pw_load_tile(const bf16_t* __restrict__ src, long long row0, long long M, int tid, us8 (&reg)[BM * K / 8 / 256]) {
+    constexpr int CPR = K / 8;                       // 16-byte chunks per row
+    static_assert(BM * CPR % 256 == 0, "tile chunking");
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 256; ++i) {
+        const int c = tid + i * 256, row = c / CPR, col = c % CPR;
+        us8 v = us8{};
+        if (row0 + row < M) v = *reinterpret_cast<const us8*>(src + (row0 + row) * K + col * 8);
+        reg[i] = v;
+    }
+}
+template <int BM, int K, int LD>
+__device__ __forceinline__ void pw_store_tile(bf16_t* lds, int tid, const us8 (&reg)[BM * K / 8 / 256]) {
+    constexpr int CPR = K / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 256; ++i) {
+        const int c = tid + i * 256, row = c / CPR, col = c % CPR;
+        *reinterpret_cast<us8*>(lds + row * LD + col * 8) = reg[i];
+    }
+}
+
+// LDS: region 0 = the phase-1 operands (b tile, then the projection source tile), re-used for the a' staging tile once phase 1
+// is over; region 1 = the residual / y tile.
+template <int C, int C4, int CN, int C2, int BM>
+struct PwLds {
+    static constexpr int A_LD = C + 8, A2_LD = C2 + 8, Y_LD = C4 + 8, O_LD = CN + 8;
+    static constexpr int OPER = BM * A_LD + (C2 ? BM * A2_LD : 0), OUT = CN ? BM * O_LD : 0;
+    static constexpr int R0 = OPER > OUT ? OPER : OUT;
+    static constexpr size_t BYTES = 2 * (size_t)(R0 + BM * Y_LD);
+    static constexpr int WAVES_PER_SIMD = 3 * BYTES <= 160 * 1024 ? 3 : 2;     // workgroups (4 waves) that fit one CU's LDS
+};
+
+template <int C, int C4, int CN, int C2, int BM>
+__global__ __launch_bounds__(256, (PwLds<C, C4, CN, C2, BM>::WAVES_PER_SIMD)) void pw_chain_kernel(const PwArgs p) {
+    typedef PwLds<C, C4, CN, C2, BM> L;
+    constexpr int RT = BM / 32;                              // 32-pixel row tiles per workgroup
+    constexpr int A_LD = L::A_LD, A2_LD = L::A2_LD, Y_LD = L::Y_LD, O_LD = L::O_LD;
+    constexpr int KF1 = C / 16, KF1S = C2 / 16;              // weight fragments per column tile (expand / shortcut)
+    constexpr int NT1 = C4 / 128;                            // column tiles per wave in phase 1
+    static_assert(C % 32 == 0 && C4 % 128 == 0 && (CN == 0 || CN % 64 == 0) && C2 % 32 == 0, "channel counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* A2 = A1 + BM * A_LD;
+    bf16_t* O = A1;                                          // aliases the operands (dead after phase 1)
+    bf16_t* Y = A1 + L::R0;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+
+    // ---- every global read of the activations goes out first
+    us8 ra1[BM * C / 8 / 256];
+    pw_load_tile<BM, C>(p.a1, m0, p.M, tid, ra1);
+    us8 rres[BM * C4 / 8 / 256];
+    const bool has_res = p.res != nullptr;
+    if (has_res) pw_load_tile<BM, C4>(p.res, m0, p.M, tid, rres);
+    us8 ra2[C2 ? BM * C2 / 8 / 256 : 1];
+    if constexpr (C2 > 0) {
+        constexpr int CPR = C2 / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int c = tid + i * 256, row = c / CPR, col = c % CPR;
+            us8 v = us8{};
+            const long long m = m0 + row;
+            if (m < p.M) {
+                long long pix = m;
+                if (p.a2_stride != 1 || p.a2_H != p.OH || p.a2_W != p.OW) {
+                    const int per = p.OH * p.OW;
+                    const int b = (int)(m / per), rem = (int)(m % per), oy = rem / p.OW, ox = rem % p.OW;
+                    pix = ((long long)b * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
+                }
+                v = *reinterpret_cast<const us8*>(p.a2 + pix * C2 + col * 8);
+            }
+            ra2[i] = v;
+        }
+    }
+    // weight fragments of this wave's first column tile (L2 resident)
+    bf16x8 wf[2][KF1];
+    bf16x8 wsf[2][C2 ? KF1S : 1];
+    auto load_w1frags = [&](int j, int buf) {
+        // fragment-major weights (see the header): one load instruction = 1 KB contiguous = 8 whole cache lines
+        const int nt = wave * NT1 + j;
+#pragma unroll
+        for (int kk = 0; kk < KF1; ++kk) wf[buf][kk] = *reinterpret_cast<const bf16x8*>(p.w3 + ((long long)(nt * KF1 + kk) * 64 + lane) * 8);
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int kk = 0; kk < KF1S; ++kk) wsf[buf][kk] = *reinterpret_cast<const bf16x8*>(p.wsc + ((long long)(nt * KF1S + kk) * 64 + lane) * 8);
+        }
+    };
+    load_w1frags(0, 0);
+    pw_store_tile<BM, C, A_LD>(A1, tid, ra1);
+    if (has_res) pw_store_tile<BM, C4, Y_LD>(Y, tid, rres);
+    if constexpr (C2 > 0) pw_store_tile<BM, C2, A2_LD>(A2, tid, ra2);
+    __syncthreads();
+
+    // ---- phase 1: y tile = relu(bn3(W3 b) + shortcut), column tiles (wave*NT1 + j), both 32-pixel row tiles
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < NT1) load_w1frags(j + 1, buf ^ 1);
+        const int n0 = (wave * NT1 + j) * 32;
+        // one 32-pixel row tile at a time (the weight fragments stay in registers, the accumulators are re-used)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            f32x16 acc, accs;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KF1; ++kk) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(A1 + (r * 32 + l31) * A_LD + kk * 16 + half * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][kk], af, acc, 0, 0, 0);
+            }
+            if constexpr (C2 > 0) {
+#pragma unroll
+                for (int kk = 0; kk < KF1S; ++kk) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(A2 + (r * 32 + l31) * A2_LD + kk * 16 + half * 8);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wsf[buf][kk], af, accs, 0, 0, 0);
+                }
+            }
+            // lane holds, for pixel r*32 + l31, channels n0 + 8q + 4*half + {0..3}
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 8 * q + 4 * half;
+                const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + n), b3 = *reinterpret_cast<const f32x4*>(p.b3 + n);
+                f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(p.ssc + n); bs = *reinterpret_cast<const f32x4*>(p.bsc + n); }
+                bf16_t* yp = Y + (r * 32 + l31) * Y_LD + n;
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_res) {
+                    const us4 r4 = *reinterpret_cast<const us4*>(yp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = bf16_to_f32(r4[e]);
+                }
+                us4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[4 * q + e] * s3[e];
+                    v += b3[e];
+                    if constexpr (C2 > 0) {
+                        float sc = accs[4 * q + e] * ss[e];
+                        sc += bs[e];
+                        rv[e] = sc;
+                    }
+                    v += rv[e];
+                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(yp) = o4;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- y leaves as whole rows
+    {
+        constexpr int CPR = C4 / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int c = tid + i * 256, row = c / CPR, col = c % CPR;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.y + (m0 + row) * C4 + col * 8) = *reinterpret_cast<const us8*>(Y + row * Y_LD + col * 8);
+        }
+    }
+    if constexpr (CN > 0) {
+        // ---- phase 2: a' = relu(bn1(y W1'^T)), K = C4.  CN = 64: wave -> (column tile w&1, row tile w>>1); CN >= 128: wave -> column
+        // tiles {w, w+4, ..}, both row tiles.  Weight fragments stream through a two-deep register ring, 8 k-steps per chunk.
+        static_assert(CN >= 128 || BM == 64, "CN = 64 needs two row tiles to occupy four waves");
+        constexpr int NR2 = CN >= 128 ? RT : 1;
+        constexpr int NT2 = CN >= 128 ? CN / 128 : 1;
+        constexpr int KCH = 8, NCH = C4 / 16 / KCH;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int nt = CN >= 128 ? wave + 4 * j : (wave & 1);
+            const int r0 = CN >= 128 ? 0 : (wave >> 1);
+            const bf16_t* wrow = p.w1 + ((long long)nt * (C4 / 16) * 64 + lane) * 8;      // fragment-major: [nt][kk][lane][8]
+            bf16x8 wq[2][KCH];
+#pragma unroll
+            for (int kk = 0; kk < KCH; ++kk) wq[0][kk] = *reinterpret_cast<const bf16x8*>(wrow + kk * 512);
+            f32x16 acc[NR2];
+#pragma unroll
+            for (int r = 0; r < NR2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int buf = ch & 1;
+                if (ch + 1 < NCH) {
+#pragma unroll
+                    for (int kk = 0; kk < KCH; ++kk) wq[buf ^ 1][kk] = *reinterpret_cast<const bf16x8*>(wrow + ((ch + 1) * KCH + kk) * 512);
+                }
+#pragma unroll
+                for (int kk = 0; kk < KCH; ++kk)
+#pragma unroll
+                    for (int r = 0; r < NR2; ++r) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Y + ((r0 + r) * 32 + l31) * Y_LD + (ch * KCH + kk) * 16 + half * 8);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[buf][kk], af, acc[r], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nt * 32 + 8 * q + 4 * half;
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+#pragma unroll
+                for (int r = 0; r < NR2; ++r) {
+                    us4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[r][4 * q + e] * s1[e];
+                        v += b1[e];
+                        o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                    *reinterpret_cast<us4*>(O + ((r0 + r) * 32 + l31) * O_LD + n) = o4;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = CN / 8;
+        static_assert(BM * CPR % 256 == 0, "a' tile chunking");
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int c = tid + i * 256, row = c / CPR, col = c % CPR;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+        }
+    }
+}
+
+template <int C, int C4, int CN, int C2, int BM>
+static int pw_launch(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)pw_chain_kernel<C, C4, CN, C2, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)((a.M + BM - 1) / BM);
+    hipLaunchKernelGGL((pw_chain_kernel<C, C4, CN, C2, BM>), dim3(blocks), dim3(256), lds, stream, a);
+    return 0;
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,
+                                            const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH,
+                                            int OW, int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
+                                            const float* scale1, const float* bias1, int CN, void* o, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(b && w3 && scale3 && bias3 && y && B > 0 && OH > 0 && OW > 0, "bottleneck_tail: bad args");
+    NPS_CHECK_ARG((residual != nullptr) != (x2 != nullptr), "bottleneck_tail: exactly one of residual / x2 (projection shortcut)");
+    NPS_CHECK_ARG(!x2 || (wsc && scale_sc && bias_sc && C2 > 0 && x2_stride >= 1 && (OH - 1) * x2_stride < x2_H && (OW - 1) * x2_stride < x2_W),
+                  "bottleneck_tail: projection shortcut arguments");
+    NPS_CHECK_ARG(CN == 0 || (w1 && scale1 && bias1 && o), "bottleneck_tail: next-conv1 arguments");
+    const void* ptrs[] = {b, w3, scale3, bias3, residual, x2, wsc, scale_sc, bias_sc, y, w1, scale1, bias1, o};
+    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "bottleneck_tail: pointers must be 16-byte aligned");
+    PwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a1 = (const bf16_t*)b; a.w3 = (const bf16_t*)w3; a.s3 = scale3; a.b3 = bias3; a.res = (const bf16_t*)residual;
+    a.a2 = (const bf16_t*)x2; a.wsc = (const bf16_t*)wsc; a.ssc = scale_sc; a.bsc = bias_sc;
+    a.a2_H = x2_H; a.a2_W = x2_W; a.a2_stride = x2_stride; a.OH = OH; a.OW = OW;
+    a.y = (bf16_t*)y; a.w1 = (const bf16_t*)w1; a.s1 = scale1; a.b1 = bias1; a.o = (bf16_t*)o;
+    a.M = (long long)B * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    const int c2 = x2 ? C2 : 0;
+#define PW_CASE(c, c4, cn, cc2, bm) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch<c, c4, cn, cc2, bm>(a, st); NPS_LAUNCH_RET(); }
+    PW_CASE(64, 256, 64, 0, 64) PW_CASE(64, 256, 128, 0, 64) PW_CASE(64, 256, 64, 64, 64) PW_CASE(64, 256, 0, 0, 64) PW_CASE(64, 256, 0, 64, 64)
+    PW_CASE(128, 512, 128, 0, 32) PW_CASE(128, 512, 256, 0, 32) PW_CASE(128, 512, 128, 256, 32) PW_CASE(128, 512, 0, 0, 32) PW_CASE(128, 512, 0, 256, 32)
+#undef PW_CASE
+    set_error("bottleneck_tail: unsupported channel configuration C=%d C4=%d CN=%d C2=%d", C, C4, CN, c2);
+    return NPS_E_ARG;
+}

@@ -34,6 +34,7 @@ class HipResNet50(ParamModule):
         else:
             self.out_features = ["res2", "res3", "res4", "res5"]
         self.fused_stem = True
+        self.fused_tail = True
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -71,16 +72,40 @@ class HipResNet50(ParamModule):
             x = ops.maxpool(x, 3, 2, 1)
         out = {}
         cin = 64
-        for name, n, cmid, cout in RES_STAGES:
-            for i in range(n):
-                p = f"{name}.{i}"
-                stride = 2 if (i == 0 and name != "res2") else 1
-                y = cv(x, p + ".conv1")
-                y = cv(y, p + ".conv2", stride, 1)
-                sc = cv(x, p + ".shortcut", stride, 0, ops.ACT_NONE) if cin != cout else x
+        fuse = dt == torch.bfloat16 and self.fused_tail
+        blocks = [(name, i, n, cmid, cout) for name, n, cmid, cout in RES_STAGES for i in range(n)]
+        a_pre = None                                  # conv1 output of the current block, when the previous tail produced it
+        for bi, (name, i, n, cmid, cout) in enumerate(blocks):
+            p = f"{name}.{i}"
+            stride = 2 if (i == 0 and name != "res2") else 1
+            proj = cin != cout
+            y = a_pre if a_pre is not None else cv(x, p + ".conv1")
+            y = cv(y, p + ".conv2", stride, 1)
+            a_pre = None
+            nxt = None
+            if bi + 1 < len(blocks):
+                nn_, ni = blocks[bi + 1][0], blocks[bi + 1][1]
+                nxt = P[f"{nn_}.{ni}.conv1"]
+            c3 = P[p + ".conv3"]
+            cfg_next = (cmid, cout, nxt.cout if nxt is not None else 0, cin if proj else 0)
+            cfg_solo = (cmid, cout, 0, cin if proj else 0)
+            if fuse and (cfg_next in ops.BOTTLENECK_TAIL_CONFIGS or cfg_solo in ops.BOTTLENECK_TAIL_CONFIGS):
+                # conv3 + shortcut + ReLU (+ the next block's conv1) in one launch (csrc/pwchain.hip)
+                use_next = cfg_next in ops.BOTTLENECK_TAIL_CONFIGS and nxt is not None
+                kw = {}
+                if proj:
+                    sc = P[p + ".shortcut"]
+                    kw.update(x2=x, wsc=sc.wfrag(dt), ssc=sc.scale, bsc=sc.bias, stride=stride)
+                else:
+                    kw.update(residual=x)
+                if use_next:
+                    kw.update(w1=nxt.wfrag(dt), s1=nxt.scale, b1=nxt.bias)
+                x, a_pre = ops.bottleneck_tail(y, c3.wfrag(dt), c3.scale, c3.bias, **kw)
+            else:
+                sc = cv(x, p + ".shortcut", stride, 0, ops.ACT_NONE) if proj else x
                 x = cv(y, p + ".conv3", residual=sc)
-                cin = cout
-            if name in self.out_features:
+            cin = cout
+            if i == n - 1 and name in self.out_features:
                 out[name] = x
         return out
 

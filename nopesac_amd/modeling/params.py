@@ -107,6 +107,15 @@ class ConvW:
     def w2d(self, dtype=torch.float32) -> torch.Tensor:
         return self.w(dtype).view(self.cout, -1)
 
+    def wfrag(self, dtype=torch.bfloat16) -> torch.Tensor:
+        """1x1 weights in MFMA fragment-major order (ops.mfma_fragment_major), for the fused bottleneck tail."""
+        key = ("frag", dtype)
+        if key not in self._w:
+            from .. import ops
+            assert self.kh == 1 and self.kw == 1
+            self._w[key] = ops.mfma_fragment_major(self.w2d(dtype))
+        return self._w[key]
+
 
 def fold_bn(pm: ParamModule, prefix: str, eps: float):
     """(scale, shift) of an inference-mode BatchNorm: y = x*scale + shift."""

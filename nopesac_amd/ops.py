@@ -173,6 +173,42 @@ def stem_fused(x: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor, bias: t
     return y
 
 
+BOTTLENECK_TAIL_CONFIGS = {(64, 256, 0, 0), (64, 256, 64, 0), (64, 256, 128, 0), (64, 256, 0, 64), (64, 256, 64, 64),          # (C, C4, CN, C2)
+                           (128, 512, 0, 0), (128, 512, 128, 0), (128, 512, 256, 0), (128, 512, 0, 256), (128, 512, 128, 256)}
+
+
+def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:
+    """[N,K] (N % 32 == 0, K % 16 == 0) -> same shape, re-ordered [N/32][K/16][2][32][8]: the order in which a wave's 64 lanes
+    consume the matrix as v_mfma_f32_32x32x16_bf16 operands (lane = 32*(k%16 >= 8) + n%32 holds 8 consecutive k)."""
+    N, K = w2d.shape
+    assert N % 32 == 0 and K % 16 == 0
+    return w2d.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
+def bottleneck_tail(b, w3, s3, b3, *, residual=None, x2=None, wsc=None, ssc=None, bsc=None, stride=1, w1=None, s1=None, b1=None):
+    """Fused conv3 + shortcut + ReLU (+ the next block's conv1) of a bf16 bottleneck; returns (y, o or None).
+    b [B,OH,OW,C]; residual [B,OH,OW,C4] or projection source x2 [B,H2,W2,C2] with wsc [C4,C2]; w1 [CN,C4].
+    The weight matrices are expected in `mfma_fragment_major` order."""
+    _chk(b, torch.bfloat16); _chk(w3, torch.bfloat16)
+    B, OH, OW, C = b.shape
+    C4 = w3.shape[0]
+    CN = 0 if w1 is None else w1.shape[0]
+    C2 = 0 if x2 is None else x2.shape[3]
+    assert (C, C4, CN, C2) in BOTTLENECK_TAIL_CONFIGS, (C, C4, CN, C2)
+    y = torch.empty((B, OH, OW, C4), device=b.device, dtype=torch.bfloat16)
+    o = torch.empty((B, OH, OW, CN), device=b.device, dtype=torch.bfloat16) if CN else None
+    if residual is not None:
+        _chk(residual, torch.bfloat16)
+        assert residual.shape == y.shape
+    if x2 is not None:
+        _chk(x2, torch.bfloat16); _chk(wsc, torch.bfloat16)
+    H2, W2 = (x2.shape[1], x2.shape[2]) if x2 is not None else (0, 0)
+    rc = _L().nopesac_bottleneck_tail_bf16(_p(b), _p(w3), _p(s3), _p(b3), _p(residual), _p(x2), _p(wsc), _p(ssc), _p(bsc), B, OH, OW,
+                                           H2, W2, stride, C, C4, C2, _p(y), _p(w1), _p(s1), _p(b1), CN, _p(o), _stream())
+    _lib.check(rc, "nopesac_bottleneck_tail_bf16")
+    return y, o
+
+
 def maxpool(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
     _chk(x)
     B, H, W, C = x.shape

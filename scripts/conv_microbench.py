@@ -16,6 +16,7 @@ SHAPES = [  # B,H,W,Cin,Cout,k,s, residual
     (64, 30, 40, 256, 1024, 1, 1, True),
     (64, 30, 40, 1024, 256, 1, 1, False),
     (64, 15, 20, 2048, 512, 1, 1, False),
+    (64, 15, 20, 512, 2048, 1, 1, True),
     (64, 120, 160, 64, 64, 3, 1, False),
     (64, 60, 80, 128, 128, 3, 1, False),
     (64, 30, 40, 256, 256, 3, 1, False),

@@ -19,5 +19,5 @@ for f in glob.glob("gpurun_out/pmc_conv/*/*counter_collection.csv"):
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
 for k,v in agg.items():
     print(k)
-    for c,val in sorted(v.items()): print("   %-28s %.4g"%(c, val/5))
+    for c,val in sorted(v.items()): print("   %-28s %.4g"%(c, val/25))
 PY

@@ -234,3 +234,62 @@ def test_rle_from_winner_map(device, V, H, W, nq, seed):
             ref = R.encode(m.numpy())
             assert out[v][p]["segmentation"] == {"size": [H, W], "counts": ref["counts"]}, (v, p)
             assert out[v][p]["bbox"] == R.to_bbox(ref).tolist()
+
+
+@pytest.mark.parametrize("C,proj,CN,stride,M_odd", [
+    (64, False, 64, 1, False), (64, False, 128, 1, True), (64, True, 64, 1, False), (64, False, 0, 1, False), (64, True, 0, 1, True),
+    (128, False, 128, 1, True), (128, False, 256, 1, False), (128, True, 128, 2, True), (128, True, 0, 2, False), (128, False, 0, 1, False)])
+def test_bottleneck_tail(device, C, proj, CN, stride, M_odd):
+    """Fused conv3 + shortcut + ReLU (+ next conv1) vs the per-layer bf16 kernels: identity blocks bit-exact, projection
+    blocks within bf16 rounding (the fused kernel does not round the shortcut to bf16 in between)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(11 + CN + proj + C)
+    B, H, W = (3, 9, 13) if M_odd else (2, 16, 24)          # 351 pixels: a ragged last tile
+    C4, C2 = 4 * C, (64 if C == 64 else 2 * C)
+    bf = lambda t: t.to(device, torch.bfloat16).contiguous()
+    f = lambda t: t.to(device).contiguous()
+    b = bf(torch.randn(B, H, W, C, generator=g))
+    w3 = bf(torch.randn(C4, 1, 1, C, generator=g) / C ** 0.5)
+    s3, b3 = f(1 + 0.1 * torch.randn(C4, generator=g)), f(0.1 * torch.randn(C4, generator=g))
+    kw, sc = {}, None
+    if proj:
+        H2, W2 = (H - 1) * stride + 1 + (stride - 1), (W - 1) * stride + 1      # odd/even source sizes both occur
+        x = bf(torch.randn(B, H2, W2, C2, generator=g))
+        wsc = bf(torch.randn(C4, 1, 1, C2, generator=g) / C2 ** 0.5)
+        ssc, bsc = f(1 + 0.1 * torch.randn(C4, generator=g)), f(0.1 * torch.randn(C4, generator=g))
+        kw.update(x2=x, wsc=ops.mfma_fragment_major(wsc.view(C4, C2)), ssc=ssc, bsc=bsc, stride=stride)
+        sc = ops.conv2d(x, wsc, ssc, bsc, stride=stride)
+        assert sc.shape == (B, H, W, C4)
+    else:
+        sc = bf(torch.randn(B, H, W, C4, generator=g))
+        kw.update(residual=sc)
+    y_ref = ops.conv2d(b, w3, s3, b3, sc, act=ops.ACT_RELU)
+    if CN:
+        w1 = bf(torch.randn(CN, 1, 1, C4, generator=g) / C4 ** 0.5)
+        s1, b1 = f(1 + 0.1 * torch.randn(CN, generator=g)), f(0.1 * torch.randn(CN, generator=g))
+        kw.update(w1=ops.mfma_fragment_major(w1.view(CN, C4)), s1=s1, b1=b1)
+    y, o = ops.bottleneck_tail(b, ops.mfma_fragment_major(w3.view(C4, C)), s3, b3, **kw)
+    if proj:
+        assert _rel(y.float(), y_ref.float()) < 1e-2
+    else:
+        assert torch.equal(y, y_ref)
+    if CN:
+        o_ref = ops.conv2d(y, w1, s1, b1, act=ops.ACT_RELU)      # from the fused y: isolates phase 2
+        assert torch.equal(o, o_ref)
+    else:
+        assert o is None
+
+
+def test_backbone_fused_tail_matches_unfused(device, sd50):
+    """bf16 backbone with the fused bottleneck tails / stem vs the same model with per-layer kernels."""
+    from tests.util import make_model
+    model = make_model(device, dtype="bfloat16")
+    x = torch.randn(2, 96, 128, 4, device=device).bfloat16()
+    x[..., 3] = 0
+    bb = model.backbone
+    fused = bb(x)
+    bb.fused_tail = False
+    plain = bb(x)
+    bb.fused_tail = True
+    for k in plain:
+        assert _rel(fused[k].float(), plain[k].float()) < 2e-2, k
