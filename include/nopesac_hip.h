@@ -134,6 +134,12 @@ int nopesac_layernorm(const float* x, const float* res, const float* gamma, cons
                       float* y, const float* addend, int addend_rows, float* y2,
                       int rows, int D, float eps, void* stream);
 
+/* Same, with optional bf16 copies of both results (y_bf16, y2_bf16) for the GEMMs that consume them; any of the four
+ * outputs may be NULL (at least one must not be). */
+int nopesac_layernorm_ex(const float* x, const float* res, const float* gamma, const float* beta,
+                         float* y, const float* addend, int addend_rows, float* y2, void* y_bf16, void* y2_bf16,
+                         int rows, int D, float eps, void* stream);
+
 /* out = a + b (b row index = row % b_rows); f32. */
 int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream);
 
@@ -158,6 +164,13 @@ int nopesac_attention_small_bf16(const float* q, int64_t q_stride, const float* 
                                  const float* v, int64_t v_stride, float* o, int64_t o_stride,
                                  int B, int Lq, int Lk, int heads, float scale,
                                  const int32_t* qlen, const int32_t* klen, void* stream);
+
+/* Same kernel with q/k/v/o stored as bf16 (strides in elements, rows 16-byte aligned): the producing / consuming GEMMs round
+ * to bf16 anyway, so this only halves the traffic. */
+int nopesac_attention_small_bf16io(const void* q, int64_t q_stride, const void* k, int64_t k_stride,
+                                   const void* v, int64_t v_stride, void* o, int64_t o_stride,
+                                   int B, int Lq, int Lk, int heads, float scale,
+                                   const int32_t* qlen, const int32_t* klen, void* stream);
 
 /* gather rows of a [B, H*W, C] map into (w,h) order: y[b, w*H + h, :] = x[b, h*W + w, :]
  * (camera_head.py:1120-1124). f32. */

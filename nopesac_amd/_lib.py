@@ -33,10 +33,12 @@ SIGNATURES = {
     "nopesac_upsample2x_nearest_add_nhwc": [P, P, P, I, I, I, I, I, P],
     "nopesac_groupnorm_nhwc": [P, P, P, P, I, I, I, I, F, I, I, P, P],
     "nopesac_layernorm": [P, P, P, P, P, P, I, P, I, I, F, P],
+    "nopesac_layernorm_ex": [P, P, P, P, P, P, I, P, P, P, I, I, F, P],
     "nopesac_add_rows": [P, P, P, I, I, I, P],
     "nopesac_softmax_rows": [P, P, I, I, P],
     "nopesac_attention_small": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
+    "nopesac_attention_small_bf16io": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_transpose_hw_rows": [P, P, I, I, I, I, P],
     "nopesac_postselect_planes": [P, P, P, P, I, I, I, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P, P, P, P],
     "nopesac_matcher_sinkhorn": [P, P, P, P, P, P, P, F, F, I, F, I, I, P, P, P],

@@ -106,9 +106,29 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 
 constexpr int ATT_KSTRIDE = 40;   // bf16 elements per K row in LDS (32 + 8 pad = 80 bytes: conflict-free b128 reads)
 
+// TIO = float: f32 q/k/v/o (operands rounded to bf16 while staged); TIO = bf16_t: q/k/v/o are bf16 in memory (the GEMMs
+// that produce / consume them round to bf16 anyway, so this only halves the traffic).
+template <typename TIO>
+__device__ __forceinline__ void att_load8(const TIO* p, float (&t)[8]);
+template <>
+__device__ __forceinline__ void att_load8<float>(const float* p, float (&t)[8]) {
+    *(f32x4*)(t) = *(const f32x4*)(p);
+    *(f32x4*)(t + 4) = *(const f32x4*)(p + 4);
+}
+template <>
+__device__ __forceinline__ void att_load8<bf16_t>(const bf16_t* p, float (&t)[8]) {
+    const u32x4 r = *(const u32x4*)(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        t[2 * e] = __uint_as_float(r[e] << 16);
+        t[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u);
+    }
+}
+
+template <typename TIO>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(
-    const float* __restrict__ q, long long q_stride, const float* __restrict__ k, long long k_stride,
-    const float* __restrict__ v, long long v_stride, float* __restrict__ o, long long o_stride, int Lq, int Lk,
+    const TIO* __restrict__ q, long long q_stride, const TIO* __restrict__ k, long long k_stride,
+    const TIO* __restrict__ v, long long v_stride, TIO* __restrict__ o, long long o_stride, int Lq, int Lk,
     int Lk_pad, float scale, const int* __restrict__ qlen, const int* __restrict__ klen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char att_smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(att_smem);                    // [Lk_pad][ATT_KSTRIDE]
@@ -120,18 +140,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
     const int nq = qlen ? min(qlen[b], Lq) : Lq;
     const int nk = klen ? min(klen[b], Lk) : Lk;
     // ---- stage K (row-major) and V^T as bf16; rows >= nk are zero
-    const float* kb = k + (long long)b * Lk * k_stride + h * HD;
-    const float* vb = v + (long long)b * Lk * v_stride + h * HD;
+    const TIO* kb = k + (long long)b * Lk * k_stride + h * HD;
+    const TIO* vb = v + (long long)b * Lk * v_stride + h * HD;
     for (int idx = tid; idx < Lk_pad * 4; idx += 256) {                  // 8 floats per chunk
         const int j = idx >> 2, c = (idx & 3) * 8;
         float kv[8], vv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
         if (j < nk) {
-            *(f32x4*)(kv) = *(const f32x4*)(kb + (long long)j * k_stride + c);
-            *(f32x4*)(kv + 4) = *(const f32x4*)(kb + (long long)j * k_stride + c + 4);
-            *(f32x4*)(vv) = *(const f32x4*)(vb + (long long)j * v_stride + c);
-            *(f32x4*)(vv + 4) = *(const f32x4*)(vb + (long long)j * v_stride + c + 4);
+            att_load8<TIO>(kb + (long long)j * k_stride + c, kv);
+            att_load8<TIO>(vb + (long long)j * v_stride + c, vv);
         }
         u32x4 pk = {pack_bf16x2(kv[0], kv[1]), pack_bf16x2(kv[2], kv[3]), pack_bf16x2(kv[4], kv[5]), pack_bf16x2(kv[6], kv[7])};
         *(u32x4*)(Ks + j * ATT_KSTRIDE + c) = pk;
@@ -145,12 +163,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
     const int half = lane >> 5;
     bf16x8 qf[2];
     {
-        const float* qp = q + ((long long)b * Lq + (row_ok ? row : 0)) * q_stride + h * HD;
+        const TIO* qp = q + ((long long)b * Lq + (row_ok ? row : 0)) * q_stride + h * HD;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float t[8];
-            *(f32x4*)(t) = *(const f32x4*)(qp + ks * 16 + half * 8);
-            *(f32x4*)(t + 4) = *(const f32x4*)(qp + ks * 16 + half * 8 + 4);
+            att_load8<TIO>(qp + ks * 16 + half * 8, t);
             u32x4 pk = {pack_bf16x2(t[0] * scale, t[1] * scale), pack_bf16x2(t[2] * scale, t[3] * scale),
                         pack_bf16x2(t[4] * scale, t[5] * scale), pack_bf16x2(t[6] * scale, t[7] * scale)};
             qf[ks] = __builtin_bit_cast(bf16x8, pk);
@@ -212,13 +229,18 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
     }
     // oacc[r] = O(query row, d = (r&3) + 8*(r>>2) + 4*half)
     if (row < Lq) {
-        float* op = o + ((long long)b * Lq + row) * o_stride + h * HD;
+        TIO* op = o + ((long long)b * Lq + row) * o_stride + h * HD;
         const float inv = (row_ok && nk > 0) ? 1.f / l_run : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 ov = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
             if (!(row_ok && nk > 0)) ov = f32x4{0.f, 0.f, 0.f, 0.f};
-            *(f32x4*)(op + 8 * g + 4 * half) = ov;
+            if constexpr (sizeof(TIO) == 4) {
+                *(f32x4*)(op + 8 * g + 4 * half) = ov;
+            } else {
+                uint2 pk = make_uint2(pack_bf16x2(ov[0], ov[1]), pack_bf16x2(ov[2], ov[3]));
+                *(uint2*)(op + 8 * g + 4 * half) = pk;
+            }
         }
     }
 }
@@ -240,25 +262,43 @@ extern "C" int nopesac_attention_small(const float* q, int64_t q_stride, const f
     NPS_LAUNCH_RET();
 }
 
-extern "C" int nopesac_attention_small_bf16(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
-                                            const float* v, int64_t v_stride, float* o, int64_t o_stride, int B, int Lq,
-                                            int Lk, int heads, float scale, const int32_t* qlen, const int32_t* klen,
-                                            void* stream) {
+template <typename TIO>
+static int launch_attention_mfma(const TIO* q, int64_t q_stride, const TIO* k, int64_t k_stride, const TIO* v, int64_t v_stride, TIO* o,
+                                 int64_t o_stride, int B, int Lq, int Lk, int heads, float scale, const int32_t* qlen,
+                                 const int32_t* klen, void* stream) {
     using namespace nps;
+    constexpr int AL = 16 / sizeof(TIO);      // elements per 16 bytes
     NPS_CHECK_ARG(q && k && v && o, "attention_bf16: null pointer");
     NPS_CHECK_ARG(B > 0 && Lq > 0 && Lk > 0 && Lk <= 512 && heads > 0, "attention_bf16: bad dims B=%d Lq=%d Lk=%d heads=%d", B, Lq, Lk, heads);
-    NPS_CHECK_ARG(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0 &&
+    NPS_CHECK_ARG(q_stride >= heads * HD && k_stride >= heads * HD && v_stride >= heads * HD && o_stride >= heads * HD,
+                  "attention_bf16: row stride smaller than heads*32");
+    NPS_CHECK_ARG(q_stride % AL == 0 && k_stride % AL == 0 && v_stride % AL == 0 && o_stride % AL == 0 &&
                       (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)o % 16 == 0,
                   "attention_bf16: rows must be 16-byte aligned");
     const int Lk_pad = ((Lk + 31) / 32) * 32;
     const size_t lds = (size_t)Lk_pad * ATT_KSTRIDE * 2 + (size_t)32 * (Lk_pad + 8) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<TIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     dim3 grid((Lq + 127) / 128, heads, B);
-    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, q, (long long)q_stride, k,
+    hipLaunchKernelGGL(attention_mfma_kernel<TIO>, grid, dim3(256), lds, (hipStream_t)stream, q, (long long)q_stride, k,
                        (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad, scale, qlen, klen);
     NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_attention_small_bf16(const float* q, int64_t q_stride, const float* k, int64_t k_stride,
+                                            const float* v, int64_t v_stride, float* o, int64_t o_stride, int B, int Lq,
+                                            int Lk, int heads, float scale, const int32_t* qlen, const int32_t* klen,
+                                            void* stream) {
+    return launch_attention_mfma<float>(q, q_stride, k, k_stride, v, v_stride, o, o_stride, B, Lq, Lk, heads, scale, qlen, klen, stream);
+}
+
+extern "C" int nopesac_attention_small_bf16io(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* v,
+                                              int64_t v_stride, void* o, int64_t o_stride, int B, int Lq, int Lk, int heads,
+                                              float scale, const int32_t* qlen, const int32_t* klen, void* stream) {
+    using nps::bf16_t;
+    return launch_attention_mfma<bf16_t>((const bf16_t*)q, q_stride, (const bf16_t*)k, k_stride, (const bf16_t*)v, v_stride, (bf16_t*)o,
+                                         o_stride, B, Lq, Lk, heads, scale, qlen, klen, stream);
 }

@@ -270,11 +270,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over D (one wave per row), optional residual, optional second output y + addend
+// (y16 / y2_16: the same two results rounded to bf16 for the GEMMs that consume them - nullable, like y / y2)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, const float* __restrict__ addend,
-                                                        int addend_rows, float* __restrict__ y2, int rows, int D,
-                                                        float eps) {
+                                                        int addend_rows, float* __restrict__ y2, bf16_t* __restrict__ y16,
+                                                        bf16_t* __restrict__ y2_16, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -298,8 +299,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < per; ++i) {
         const int d = lane + i * 64;
         const float o = (v[i] - mean) * rstd * gamma[d] + beta[d];
-        y[(long long)row * D + d] = o;
-        if (y2) y2[(long long)row * D + d] = o + addend[(long long)(row % addend_rows) * D + d];
+        if (y) y[(long long)row * D + d] = o;
+        if (y16) y16[(long long)row * D + d] = f32_to_bf16(o);
+        if (y2 || y2_16) {
+            const float o2 = o + addend[(long long)(row % addend_rows) * D + d];
+            if (y2) y2[(long long)row * D + d] = o2;
+            if (y2_16) y2_16[(long long)row * D + d] = f32_to_bf16(o2);
+        }
     }
 }
 
@@ -478,7 +484,18 @@ extern "C" int nopesac_layernorm(const float* x, const float* res, const float* 
                                  void* stream) {
     NPS_CHECK_ARG(x && gamma && beta && y && rows > 0 && D > 0 && D % 64 == 0 && D <= 1024, "layernorm: bad args (D=%d)", D);
     NPS_CHECK_ARG(!y2 || (addend && addend_rows > 0), "layernorm: y2 needs addend");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, addend, addend_rows, y2, rows, D, eps);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, addend, addend_rows, y2,
+                       (nps::bf16_t*)nullptr, (nps::bf16_t*)nullptr, rows, D, eps);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_layernorm_ex(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                    const float* addend, int addend_rows, float* y2, void* y_bf16, void* y2_bf16, int rows, int D,
+                                    float eps, void* stream) {
+    NPS_CHECK_ARG(x && gamma && beta && (y || y2 || y_bf16 || y2_bf16) && rows > 0 && D > 0 && D % 64 == 0 && D <= 1024, "layernorm_ex: bad args (D=%d)", D);
+    NPS_CHECK_ARG(!(y2 || y2_bf16) || (addend && addend_rows > 0), "layernorm_ex: y2 needs addend");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, y, addend, addend_rows, y2,
+                       (nps::bf16_t*)y_bf16, (nps::bf16_t*)y2_bf16, rows, D, eps);
     NPS_LAUNCH_RET();
 }
 

@@ -75,6 +75,14 @@ class PlaneTRHead(ParamModule):
             p = f"context2plane_decoder.layers.{i}"
             P[p] = {"self": self._mha(p + ".self_attn", True), "cross": self._mha(p + ".multihead_attn", False),
                     "l1": conv_bias(self, p + ".linear1"), "l2": conv_bias(self, p + ".linear2")}
+        # decoder cross-attention K / V projections of all six layers act on the same encoder memory: one GEMM each
+        # (N = 6 x 256) instead of twelve M = B*L, N = 256 launches
+        wk = [self.raw(f"context2plane_decoder.layers.{i}.multihead_attn.in_proj_weight").float()[256:512] for i in range(6)]
+        bk = [self.raw(f"context2plane_decoder.layers.{i}.multihead_attn.in_proj_bias").float()[256:512] for i in range(6)]
+        wv = [self.raw(f"context2plane_decoder.layers.{i}.multihead_attn.in_proj_weight").float()[512:768] for i in range(6)]
+        bv = [self.raw(f"context2plane_decoder.layers.{i}.multihead_attn.in_proj_bias").float()[512:768] for i in range(6)]
+        P["cross_k_all"] = ConvW(torch.cat(wk, 0), None, torch.cat(bk, 0))
+        P["cross_v_all"] = ConvW(torch.cat(wv, 0), None, torch.cat(bv, 0))
         for nm in ("up_conv3", "up_conv2", "up_conv1", "c4_conv", "c3_conv", "c2_conv", "c1_conv", "m_conv_dict.m4"):
             P[nm] = conv_bn(self, f"top_down.{nm}.0.weight", f"top_down.{nm}.1", 1e-5)
         for nm in ("plane_embedding", "plane_param", "plane_center"):
@@ -108,6 +116,9 @@ class PlaneTRHead(ParamModule):
         pos = self._pos(hc, wc, c4.device)
         ip = P["input_proj"]
         src = ops.conv2d(c4, ip.w(cd), None, ip.bias, out_dtype=torch.float32).view(B * L, 256)
+        if mf:
+            hs, memory = self._transformer_bf16(src, pos, B, L, nq, nh, scale)
+            return self._heads(features, hs, memory, B, hc, wc, nq, want_logits)
         q_in = ops.add_rows(src, pos)
         # ---- encoder (post-norm; transformer.py:183-199)
         for i in range(6):
@@ -143,6 +154,63 @@ class PlaneTRHead(ParamModule):
             hdn = ops.linear(t2, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)
             tgt = ops.linear(hdn, W["l2"].w2d(gd), W["l2"].bias, residual=tgt)
         hs = self._ln(tgt, "context2plane_decoder.norm")             # [B*nq, 256]
+        return self._heads(features, hs, memory, B, hc, wc, nq, want_logits)
+
+    def _transformer_bf16(self, src, pos, B, L, nq, nh, scale):
+        """bf16-mode encoder/decoder.  Same arithmetic as the fp32-activation path above run in mixed mode - every GEMM / attention
+        operand was rounded to bf16 when staged there - but the tensors that only feed GEMMs or attention (q|k, v, attention
+        output, FFN hidden, the LayerNorm outputs) are now WRITTEN as bf16, halving their HBM traffic; the residual stream, the
+        LayerNorm statistics and all accumulation stay f32.  The decoder's cross-attention K / V of all six layers come from two
+        N = 1536 GEMMs over the encoder memory."""
+        P, bf, f32 = self.packed, torch.bfloat16, torch.float32
+        lin = ops.linear
+
+        def ln(x, prefix, addend=None, want=("y",)):
+            return ops.layernorm_ex(x, self.raw(prefix + ".weight"), self.raw(prefix + ".bias"), addend=addend, want=want)
+
+        src16 = src.to(bf)
+        q_in16 = ops.add_rows(src, pos).to(bf)
+        for i in range(6):
+            p = f"context_SA.layers.{i}"
+            W = P[p]
+            qk = lin(q_in16, W["attn"]["qk"].w2d(bf), W["attn"]["qk"].bias, out_dtype=bf)
+            v = lin(src16, W["attn"]["v"].w2d(bf), W["attn"]["v"].bias, out_dtype=bf)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale, mfma_bf16=True)
+            s = lin(o, W["attn"]["o"].w2d(bf), W["attn"]["o"].bias, residual=src, out_dtype=f32)
+            r = ln(s, p + ".norm1", want=("y", "y16"))
+            src, src16 = r["y"], r["y16"]
+            hdn = lin(src16, W["l1"].w2d(bf), W["l1"].bias, act=ops.ACT_RELU, out_dtype=bf)
+            s = lin(hdn, W["l2"].w2d(bf), W["l2"].bias, residual=src, out_dtype=f32)
+            r = ln(s, p + ".norm2", addend=pos, want=("y", "y16", "y2_16"))
+            src, src16, q_in16 = r["y"], r["y16"], r["y2_16"]
+        r = ln(src, "context_SA.norm", addend=pos, want=("y", "y16", "y2_16"))
+        memory, mem16, memk16 = r["y"], r["y16"], r["y2_16"]
+        k_all = lin(memk16, P["cross_k_all"].w2d(bf), P["cross_k_all"].bias, out_dtype=bf)          # [B*L, 6*256]
+        v_all = lin(mem16, P["cross_v_all"].w2d(bf), P["cross_v_all"].bias, out_dtype=bf)
+        qpos = self.raw("query_embed.weight")
+        tgt = torch.zeros(B * nq, 256, device=src.device, dtype=f32)
+        for i in range(6):
+            p = f"context2plane_decoder.layers.{i}"
+            W = P[p]
+            r = ln(tgt, p + ".norm1", addend=qpos, want=("y16", "y2_16"))
+            qk = lin(r["y2_16"], W["self"]["qk"].w2d(bf), W["self"]["qk"].bias, out_dtype=bf)
+            v = lin(r["y16"], W["self"]["v"].w2d(bf), W["self"]["v"].bias, out_dtype=bf)
+            o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale, mfma_bf16=True)
+            tgt = lin(o, W["self"]["o"].w2d(bf), W["self"]["o"].bias, residual=tgt, out_dtype=f32)
+            r = ln(tgt, p + ".norm2", addend=qpos, want=("y2_16",))
+            q = lin(r["y2_16"], W["cross"]["q"].w2d(bf), W["cross"]["q"].bias, out_dtype=bf)
+            o = ops.attention(q, k_all[:, 256 * i:256 * (i + 1)], v_all[:, 256 * i:256 * (i + 1)], B, nq, L, nh, scale, mfma_bf16=True)
+            tgt = lin(o, W["cross"]["o"].w2d(bf), W["cross"]["o"].bias, residual=tgt, out_dtype=f32)
+            r = ln(tgt, p + ".norm3", want=("y16",))
+            hdn = lin(r["y16"], W["l1"].w2d(bf), W["l1"].bias, act=ops.ACT_RELU, out_dtype=bf)
+            tgt = lin(hdn, W["l2"].w2d(bf), W["l2"].bias, residual=tgt, out_dtype=f32)
+        hs = self._ln(tgt, "context2plane_decoder.norm")
+        return hs, memory
+
+    def _heads(self, features, hs, memory, B, hc, wc, nq, want_logits):
+        P, gd = self.packed, self.gemm_dtype
+        c1, c2, c3, c4 = features["res2"], features["res3"], features["res4"], features["res5"]
+        cd = c4.dtype
         # ---- top-down pyramid (planeTR_head.py:241-252): lateral + relu(bn(conv(up(.))))
         RA = ops.ACT_RELU | ops.ACT_RES_AFTER
 

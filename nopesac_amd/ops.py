@@ -266,6 +266,25 @@ def layernorm(x: torch.Tensor, gamma, beta, res=None, addend=None, eps=1e-5):
     return (y, y2) if addend is not None else y
 
 
+def layernorm_ex(x: torch.Tensor, gamma, beta, res=None, addend=None, eps=1e-5, want=("y",)):
+    """LayerNorm with a chosen set of outputs: "y" (f32), "y16" (bf16 copy), "y2" (y + addend, f32), "y2_16" (bf16).
+    Returns a dict with exactly the requested tensors (one launch)."""
+    _chk(x, torch.float32)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out = {k: torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if k.endswith("16") else torch.float32) for k in want}
+    assert set(want) <= {"y", "y16", "y2", "y2_16"} and want
+    if res is not None:
+        _chk(res, torch.float32)
+        assert res.shape == x.shape
+    a_rows = 0 if addend is None else _chk(addend, torch.float32).numel() // D
+    assert addend is not None or not ({"y2", "y2_16"} & set(want))
+    _lib.check(_L().nopesac_layernorm_ex(_p(x), _p(res), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(out.get("y")),
+                                         _p(addend), a_rows, _p(out.get("y2")), _p(out.get("y16")), _p(out.get("y2_16")), rows, D, eps,
+                                         _stream()), "nopesac_layernorm_ex")
+    return out
+
+
 def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _chk(a, torch.float32); _chk(b, torch.float32)
     D = a.shape[-1]
@@ -285,11 +304,13 @@ def softmax_rows(x: torch.Tensor) -> torch.Tensor:
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Lq: int, Lk: int, heads: int, scale: float,
               qlen=None, klen=None, mfma_bf16: bool = False) -> torch.Tensor:
     """q [B*Lq, >=heads*32] etc. as (possibly column-sliced) row-major matrices -> o [B*Lq, heads*32]."""
+    io16 = q.dtype == torch.bfloat16          # bf16 q/k/v in memory -> bf16 o (MFMA kernel only)
     for t in (q, k, v):
-        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+        assert t.is_cuda and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1
+    assert q.dtype == torch.float32 or (io16 and mfma_bf16)
     assert q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk
-    o = torch.empty((B * Lq, heads * 32), device=q.device, dtype=torch.float32)
-    fn = _L().nopesac_attention_small_bf16 if mfma_bf16 else _L().nopesac_attention_small
+    o = torch.empty((B * Lq, heads * 32), device=q.device, dtype=q.dtype)
+    fn = _L().nopesac_attention_small_bf16io if io16 else (_L().nopesac_attention_small_bf16 if mfma_bf16 else _L().nopesac_attention_small)
     rc = fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), B, Lq, Lk,
             heads, scale, _p(qlen), _p(klen), _stream())
     _lib.check(rc, "nopesac_attention_small" + ("_bf16" if mfma_bf16 else ""))

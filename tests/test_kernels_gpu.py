@@ -293,3 +293,25 @@ def test_backbone_fused_tail_matches_unfused(device, sd50):
     bb.fused_tail = True
     for k in plain:
         assert _rel(fused[k].float(), plain[k].float()) < 2e-2, k
+
+
+def test_layernorm_ex_and_attention_bf16io(device):
+    """bf16-output LayerNorm and bf16 I/O attention are the f32 kernels' results rounded once (same statistics)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 256, generator=g).to(device)
+    gamma, beta = (1 + 0.1 * torch.randn(256, generator=g)).to(device), (0.1 * torch.randn(256, generator=g)).to(device)
+    pos = torch.randn(100, 256, generator=g).to(device)
+    y, y2 = ops.layernorm(x, gamma, beta, addend=pos)
+    r = ops.layernorm_ex(x, gamma, beta, addend=pos, want=("y", "y16", "y2", "y2_16"))
+    assert torch.equal(r["y"], y) and torch.equal(r["y2"], y2)
+    assert torch.equal(r["y16"], y.bfloat16()) and torch.equal(r["y2_16"], y2.bfloat16())
+    r = ops.layernorm_ex(x, gamma, beta, want=("y16",))
+    assert set(r) == {"y16"} and torch.equal(r["y16"], y.bfloat16())
+    B, Lq, Lk, H = 3, 50, 300, 8
+    q = torch.randn(B * Lq, 256, generator=g).to(device).bfloat16()
+    kv = torch.randn(B * Lk, 1536, generator=g).to(device).bfloat16()          # column slices of a wide buffer
+    k, v = kv[:, 256:512], kv[:, 768:1024]
+    o16 = ops.attention(q, k, v, B, Lq, Lk, H, 0.25, mfma_bf16=True)           # scale 2^-2: the q scaling is exact in bf16
+    o32 = ops.attention(q.float(), k.float().contiguous(), v.float().contiguous(), B, Lq, Lk, H, 0.25, mfma_bf16=True)
+    assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.bfloat16())
