@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-autotune", dest="autotune", action="store_false", help="skip the load-time conv kernel autotuning")
     ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward in a hipGraph and replay it")
     ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
+    ap.add_argument("--single-stream", action="store_true", help="ANALYSIS: pose net on the main stream (clean per-stage times)")
     ap.add_argument("--ablate", default="", choices=["", "backbone", "head", "nocam"],
                     help="ANALYSIS ONLY (the JSON line is marked invalid): time a truncated pipeline - backbone only / "
                          "backbone + plane head + post-selection / everything but the camera head - to see what each stage "
@@ -212,6 +213,8 @@ def main():
     B, K = args.pairs, args.k
     nq = 50 if K <= 50 else K
     model = build_model(device, nq, args.dtype)
+    if args.single_stream:
+        model.two_streams = False
     # synthetic inputs resident in HBM: uint8-valued fp32 RGB, seeds 1000+pair
     g = torch.Generator().manual_seed(1000 + rank)
     raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float().to(device)

@@ -268,6 +268,17 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
  * optionally flip the sign so that component 0 >= 0 (camera_head.py:436-437,695-696). */
 int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream);
 
+/* One GNN layer of the plane matcher (transformer/gnn.py:73-96) for n_sets plane sets, one workgroup per set, bf16 MFMA
+ * operands / f32 residual stream (csrc/gnn_layer.hip).  Feature buffers are f32 [sets][nq][256] (nq <= 64); workgroup b updates
+ * set x_off + b attending to set src_off + b (same buffer and offset = 'self' layer) and writes set out_off + b of `out`
+ * (out may share a buffer with x / src only for disjoint set ranges).  qlen / klen: int32 valid rows per set, indexed like
+ * x / src (NULL = nq).  All six weight matrices are bf16 in MFMA fragment-major order (see nopesac_bottleneck_tail_bf16):
+ * wq (pre-multiplied by 1/sqrt(32)), wk, wv, wmerge [256][256]; w0 = mlp.0 [512][512] (input = [x | msg]); w2 = mlp.2 [256][512]. */
+int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_off, float* out, int out_off, int n_sets, int nq,
+                           const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
+                           const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
+                           const float* ln2_g, const float* ln2_b, void* stream);
+
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
  * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)

@@ -21,6 +21,7 @@ class MatchingHead(ParamModule):
         self.normal_multiplier = float(cfg.MODEL.MATCHING_HEAD.NORMAL_MULTIPLIER)
         self.sinkhorn_iterations = 200                                    # matching_head.py:38
         self.num_queries = cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES
+        self.fused_gnn = True
         spec = {k[len("matching_head."):]: v for k, v in state_dict_spec(self.num_queries).items()
                 if k.startswith("matching_head.")}
         super().__init__(spec)
@@ -61,10 +62,36 @@ class MatchingHead(ParamModule):
         _, y = ops.layernorm(out, self.raw(p + ".norm2.weight"), self.raw(p + ".norm2.bias"), addend=x)
         return y
 
+    def _fused_weights(self, i: int) -> dict:
+        """Layer i's weights for the fused kernel: bf16, MFMA fragment-major, 1/sqrt(32) folded into Wq."""
+        cache = self.__dict__.setdefault("_fused_w", {})
+        if i not in cache:
+            p = f"gnn.layers.{i}"
+            fm = lambda w: ops.mfma_fragment_major(w.float().to(torch.bfloat16).contiguous())
+            cache[i] = {"wq": fm(self.raw(p + ".q_proj.weight").float() * (32 ** -0.5)), "wk": fm(self.raw(p + ".k_proj.weight")),
+                        "wv": fm(self.raw(p + ".v_proj.weight")), "wm": fm(self.raw(p + ".merge.weight")),
+                        "w0": fm(self.raw(p + ".mlp.0.weight")), "w2": fm(self.raw(p + ".mlp.2.weight")),
+                        "g1": self.raw(p + ".norm1.weight").float().contiguous(), "b1": self.raw(p + ".norm1.bias").float().contiguous(),
+                        "g2": self.raw(p + ".norm2.weight").float().contiguous(), "b2": self.raw(p + ".norm2.bias").float().contiguous()}
+        return cache[i]
+
     def descriptors(self, app: torch.Tensor, n_all: torch.Tensor, B: int):
         """app [2B,nq,256] (view-1 sets first), n_all int32[2B] -> GNN descriptors d0, d1 [B,nq,256]."""
         P, nq, gd = self.packed, self.num_queries, self.gemm_dtype
         f = ops.linear(app.reshape(2 * B * nq, 256), P["app"].w2d(gd), P["app"].bias)
+        if gd == torch.bfloat16 and nq <= 64 and self.fused_gnn:
+            # one launch per layer step, one workgroup per plane set (csrc/gnn_layer.hip): 27 launches instead of 234
+            cur, nxt = f.view(2 * B, nq, 256), torch.empty(2 * B, nq, 256, device=f.device, dtype=torch.float32)
+            for i in range(18):
+                W = self._fused_weights(i)
+                if i % 2 == 0:
+                    ops.gnn_layer(cur, 0, cur, 0, nxt, 0, 2 * B, n_all, W)
+                else:                            # feat1 attends to the UPDATED feat0 (gnn.py:131-133)
+                    ops.gnn_layer(cur, 0, cur, B, nxt, 0, B, n_all, W)
+                    ops.gnn_layer(cur, B, nxt, 0, nxt, B, B, n_all, W)
+                cur, nxt = nxt, cur
+            d = ops.linear(cur.view(2 * B * nq, 256), P["desc"].w2d(gd), P["desc"].bias)
+            return d[:B * nq].view(B, nq, 256), d[B * nq:].view(B, nq, 256)
         n1, n2 = n_all[:B], n_all[B:]
         for i, W in enumerate(P["layers"]):
             if i % 2 == 0:                       # 'self' (gnn.py:128-130): both sets in one launch

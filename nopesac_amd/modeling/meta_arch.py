@@ -116,6 +116,7 @@ class PlaneTR_NopeSAC(nn.Module):
                 if not torch.cuda.is_current_stream_capturing():
                     for t in pose:
                         t.record_stream(main)
+        self.sem_seg_head.mark = mark if getattr(self, "stage_events", None) is not None else None
         head_out, query_feat = self.sem_seg_head(feats, want_logits=diagnostics)
         mark("plane_head")
         sel = post_select(head_out, query_feat, H, W, self.cfg)

@@ -116,9 +116,12 @@ class PlaneTRHead(ParamModule):
         pos = self._pos(hc, wc, c4.device)
         ip = P["input_proj"]
         src = ops.conv2d(c4, ip.w(cd), None, ip.bias, out_dtype=torch.float32).view(B * L, 256)
+        mark = getattr(self, "mark", None) or (lambda name: None)
+        mark("ph.input_proj")
         if mf:
-            hs, memory = self._transformer_bf16(src, pos, B, L, nq, nh, scale)
-            return self._heads(features, hs, memory, B, hc, wc, nq, want_logits)
+            hs, memory = self._transformer_bf16(src, pos, B, L, nq, nh, scale, mark)
+            mark("ph.decoder")
+            return self._heads(features, hs, memory, B, hc, wc, nq, want_logits, mark)
         q_in = ops.add_rows(src, pos)
         # ---- encoder (post-norm; transformer.py:183-199)
         for i in range(6):
@@ -133,6 +136,7 @@ class PlaneTRHead(ParamModule):
             s = ops.linear(hdn, W["l2"].w2d(gd), W["l2"].bias, residual=src)
             src, q_in = self._ln(s, p + ".norm2", addend=pos)
         memory, mem_k = self._ln(src, "context_SA.norm", addend=pos)
+        mark("ph.encoder")
         # ---- decoder (pre-norm; transformer.py:293-322), only hs[-1] is needed at inference
         qpos = self.raw("query_embed.weight")
         tgt = torch.zeros(B * nq, 256, device=c4.device, dtype=torch.float32)
@@ -154,9 +158,10 @@ class PlaneTRHead(ParamModule):
             hdn = ops.linear(t2, W["l1"].w2d(gd), W["l1"].bias, act=ops.ACT_RELU)
             tgt = ops.linear(hdn, W["l2"].w2d(gd), W["l2"].bias, residual=tgt)
         hs = self._ln(tgt, "context2plane_decoder.norm")             # [B*nq, 256]
-        return self._heads(features, hs, memory, B, hc, wc, nq, want_logits)
+        mark("ph.decoder")
+        return self._heads(features, hs, memory, B, hc, wc, nq, want_logits, mark)
 
-    def _transformer_bf16(self, src, pos, B, L, nq, nh, scale):
+    def _transformer_bf16(self, src, pos, B, L, nq, nh, scale, mark):
         """bf16-mode encoder/decoder.  Same arithmetic as the fp32-activation path above run in mixed mode - every GEMM / attention
         operand was rounded to bf16 when staged there - but the tensors that only feed GEMMs or attention (q|k, v, attention
         output, FFN hidden, the LayerNorm outputs) are now WRITTEN as bf16, halving their HBM traffic; the residual stream, the
@@ -185,6 +190,7 @@ class PlaneTRHead(ParamModule):
             src, src16, q_in16 = r["y"], r["y16"], r["y2_16"]
         r = ln(src, "context_SA.norm", addend=pos, want=("y", "y16", "y2_16"))
         memory, mem16, memk16 = r["y"], r["y16"], r["y2_16"]
+        mark("ph.encoder")
         k_all = lin(memk16, P["cross_k_all"].w2d(bf), P["cross_k_all"].bias, out_dtype=bf)          # [B*L, 6*256]
         v_all = lin(mem16, P["cross_v_all"].w2d(bf), P["cross_v_all"].bias, out_dtype=bf)
         qpos = self.raw("query_embed.weight")
@@ -207,7 +213,7 @@ class PlaneTRHead(ParamModule):
         hs = self._ln(tgt, "context2plane_decoder.norm")
         return hs, memory
 
-    def _heads(self, features, hs, memory, B, hc, wc, nq, want_logits):
+    def _heads(self, features, hs, memory, B, hc, wc, nq, want_logits, mark):
         P, gd = self.packed, self.gemm_dtype
         c1, c2, c3, c4 = features["res2"], features["res3"], features["res4"], features["res5"]
         cd = c4.dtype
@@ -232,6 +238,7 @@ class PlaneTRHead(ParamModule):
         p3 = up_stage(p4, "up_conv3", cbr(c3, "c3_conv"))
         p2 = up_stage(p3, "up_conv2", cbr(c2, "c2_conv"))
         p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
+        mark("ph.top_down")
         # ---- instance heads
         pe = P["pixel_embedding"]
         pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=gd)                       # [B,h,w,256]

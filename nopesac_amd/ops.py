@@ -456,3 +456,21 @@ def rle_transitions(labels: torch.Tensor, n_kept: torch.Tensor, nq: int, offsets
                                             _p(positions) if positions is not None else None, V, W * H, nq, _stream()),
                "nopesac_rle_transitions")
     return counts
+
+
+def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict):
+    """One fused GNN layer (csrc/gnn_layer.hip): x/src/out f32 [sets, nq, 256]; lens int32 [sets] (indexed like x / src);
+    W: fragment-major bf16 weights "wq" (pre-scaled), "wk", "wv", "wm", "w0", "w2" and f32 "g1", "b1", "g2", "b2"."""
+    for t in (x, src, out):
+        _chk(t, torch.float32)
+        assert t.dim() == 3 and t.shape[2] == 256
+    nq = x.shape[1]
+    assert nq <= 64 and src.shape[1] == nq and out.shape[1] == nq
+    assert x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0]
+    if lens is not None:
+        _chk(lens, torch.int32)
+    rc = _L().nopesac_gnn_layer_bf16(_p(x), x_off, _p(src), src_off, _p(out), out_off, n_sets, nq, _p(lens), _p(lens),
+                                     _p(W["wq"]), _p(W["wk"]), _p(W["wv"]), _p(W["wm"]), _p(W["w0"]), _p(W["w2"]),
+                                     _p(W["g1"]), _p(W["b1"]), _p(W["g2"]), _p(W["b2"]), _stream())
+    _lib.check(rc, "nopesac_gnn_layer_bf16")
+    return out

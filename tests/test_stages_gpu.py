@@ -220,3 +220,32 @@ def test_camera_head_ragged_batch(device, model, O, sd50):
         m = int(out["m"][b])
         if m >= 2:
             assert rel_err(out["refine"]["maps"]["trans_all"][b, : m + 1].cpu(), g["camera_onePP_tran"]) < 1e-4
+
+
+def test_fused_gnn_layers_match_per_launch_bf16_path(device):
+    """bf16 mode: the fused one-workgroup-per-set GNN layer kernel (csrc/gnn_layer.hip) vs the per-launch bf16 path on ragged
+    plane sets, all 18 layers chained.  The two differ only in rounding (1/sqrt(32) folded into Wq, LayerNorm summation
+    order), so each is judged against the fp32 path (itself parity-tested against the oracle): the fused kernel must be as
+    close to fp32 as the per-launch bf16 path is."""
+    from tests.util import make_model
+    model = make_model(device, dtype="bfloat16")
+    mh, mh32 = model.matching_head, make_model(device).matching_head
+    B, nq = 5, mh.num_queries
+    g = torch.Generator().manual_seed(3)
+    app = torch.randn(2 * B, nq, 256, generator=g).to(device)
+    n_all = torch.tensor([50, 1, 7, 32, 50, 3, 50, 20, 32, 9], dtype=torch.int32, device=device)
+    mh.fused_gnn = True
+    d0, d1 = mh.descriptors(app, n_all, B)
+    mh.fused_gnn = False
+    r0, r1 = mh.descriptors(app, n_all, B)
+    mh.fused_gnn = True
+    f0, f1 = mh32.descriptors(app, n_all, B)
+    worst_fused = worst_plain = 0.0
+    for b in range(B):
+        n1, n2 = int(n_all[b]), int(n_all[B + b])
+        for d, r, f, n in ((d0, r0, f0, n1), (d1, r1, f1, n2)):
+            worst_fused = max(worst_fused, rel_err(d[b, :n], f[b, :n]))
+            worst_plain = max(worst_plain, rel_err(r[b, :n], f[b, :n]))
+            assert rel_err(d[b, :n], r[b, :n]) < 6e-2
+    assert worst_fused < 1.25 * worst_plain + 5e-3, (worst_fused, worst_plain)
+    assert torch.isfinite(d0).all() and torch.isfinite(d1).all()
