@@ -529,12 +529,15 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
         // LDS-DMA kernel: bf16, every K-tile of 64 inside one tap, 16-byte aligned 8-channel chunks
         // measured (scripts/conv_microbench.py): the DMA kernel wins on 3x3 layers and on 1x1 layers with K >= 1024,
         // loses on the HBM-bound small-K 1x1 layers (2 blocks/CU keep too few bytes in flight)
-        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && tiles128 >= 192 && (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
+        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && (tiles128 >= 192 || p.K >= 4096) && (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
                             (long long)p.B * p.H * p.W * p.x_cs * 2 + ((long long)p.pad * p.W + p.pad) * p.x_cs * 2 < (1ll << 31) && (long long)p.N * p.K * 2 < (1ll << 31);
         if (dma_ok) {
             ConvParams q = p;
             q.tiles_m = (q.M + 127) / 128;
-            if (p.N > 64) {
+            // few 128x128 tiles but a long K loop (e.g. 2048 -> 128, 3x3 at 15x20: 150 tiles, K = 18432): 128x64 tiles double the
+            // number of workgroups
+            const bool narrow = p.N <= 64 || (tiles128 < 256 && p.N % 64 == 0);
+            if (!narrow) {
                 q.tiles_n = (q.N + 127) / 128;
                 const dim3 g(q.tiles_m * q.tiles_n, q.batched ? q.B : 1);
                 if (p.force == 4) hipLaunchKernelGGL((conv_igemm_glds_kernel<128, 128, 2, 2, 32>), g, dim3(256), 0, stream, q);

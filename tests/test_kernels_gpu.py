@@ -34,6 +34,7 @@ CONV_CASES = [
     (6, 64, 80, 256, 64, 1, 1, 0),    # BN = 64 variant
     (4, 62, 82, 128, 192, 3, 2, 1),   # stride 2 + N tail inside a 128-wide tile
     (8, 60, 80, 64, 64, 3, 1, 1),     # BN = 64, 3x3
+    (3, 15, 20, 512, 128, 3, 1, 1),   # few tiles, K = 4608 >= 4096: DMA kernel with 128x64 tiles, two tile columns, M tail
 ]
 
 
