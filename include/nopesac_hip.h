@@ -37,6 +37,7 @@ extern "C" {
 #define NPS_ACT_LEAKY 2   /* LeakyReLU(0.01), camera_modules.py:47 */
 #define NPS_ACT_SIGMOID 3
 #define NPS_ACT_RES_AFTER 0x100 /* OR-able flag: add `residual` AFTER the activation (planeTR_head.py:244-250) */
+#define NPS_ACT_BIAS_BATCHED 0x200 /* OR-able flag, batched weights only: `bias` is [B][Cout] (one row per batch entry) */
 
 #define NPS_E_ARG (-1)
 #define NPS_E_UNSUPPORTED (-2)

@@ -29,7 +29,7 @@ struct ConvParams {
     int M, N, K;       // M = rows per grid.y slice
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1;
+    int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1, bias_bs;
     int tiles_m, tiles_n;
 };
 
@@ -91,7 +91,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                     for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
                 }
                 if (p.bias) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+                    const float* bp = p.bias + (long long)bz * p.bias_bs + n;
+                    const f32x4 b0 = *(const f32x4*)(bp), b1 = *(const f32x4*)(bp + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                 }
@@ -120,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                 }
             } else {
                 for (int e = 0; e < 8 && n + e < p.N; ++e) {
-                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[n + e] : 0.f);
+                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[(long long)bz * p.bias_bs + n + e] : 0.f);
                     float r = 0.f;
                     if (p.res)
                         r = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n + e]
@@ -589,6 +590,8 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
     NPS_CHECK_ARG(x_cstride >= Cin && y_cstride >= Cout, "conv2d: channel stride smaller than channel count");
     NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d: residual stride");
     const int res_after = (act & NPS_ACT_RES_AFTER) ? 1 : 0;
+    const int bias_batched = (act & NPS_ACT_BIAS_BATCHED) ? 1 : 0;
+    NPS_CHECK_ARG(!bias_batched || (w_bstride != 0 && bias), "conv2d: NPS_ACT_BIAS_BATCHED needs batched weights and a bias");
     act &= 0xff;
     NPS_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad act %d", act);
     ConvParams p;
@@ -603,7 +606,7 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
     p.batched = w_bstride != 0;
     p.M = p.batched ? p.rows_per_b : B * p.rows_per_b;
     p.N = Cout; p.K = KH * KW * Cin;
-    p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    p.act = act; p.out_dt = out_dt; p.res_after = res_after; p.bias_bs = bias_batched ? Cout : 0;
     p.dense1x1 = (KH == 1 && KW == 1 && stride == 1 && pad == 0) ? 1 : 0;
     {
         // kernel_cfg (per call, e.g. from the load-time autotuner) or NOPESAC_CONV_FORCE (tuning aid):
@@ -629,7 +632,7 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
         bool ok = (y_cstride % al == 0) && ((uintptr_t)y % 16 == 0);
         if (residual) ok = ok && (r_cstride % al == 0) && ((uintptr_t)residual % 16 == 0);
         if (scale) ok = ok && ((uintptr_t)scale % 16 == 0);
-        if (bias) ok = ok && ((uintptr_t)bias % 16 == 0);
+        if (bias) ok = ok && ((uintptr_t)bias % 16 == 0) && (!bias_batched || Cout % 4 == 0);
         (void)osz;
         p.epi_vec = ok ? 1 : 0;
     }

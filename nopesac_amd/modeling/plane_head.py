@@ -88,6 +88,13 @@ class PlaneTRHead(ParamModule):
         for nm in ("plane_embedding", "plane_param", "plane_center"):
             P[nm] = mlp_layers(self, nm)
         P["pixel_embedding"] = conv_bias(self, "pixel_embedding")
+        # mask logit = plane_emb . (W_pe p1 + b_pe) = (W_pe^T plane_emb) . p1 + plane_emb . b_pe: the 256x256 pixel-embedding conv
+        # over the full 120x160 map folds into the per-image 50x256 mask weights (rows 0..255 = W_pe^T, row 256 = b_pe)
+        w_pe = self.raw("pixel_embedding.weight").float().reshape(256, 256)
+        fold = torch.zeros(264, 256, device=w_pe.device)
+        fold[:256] = w_pe.t()
+        fold[256] = self.raw("pixel_embedding.bias").float()
+        P["pe_fold"] = ConvW(fold)
         P["pixel_plane_center"] = conv_bias(self, "pixel_plane_center")
         P["plane_prob"] = conv_bias(self, "plane_prob")
         return P
@@ -240,17 +247,18 @@ class PlaneTRHead(ParamModule):
         p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
         mark("ph.top_down")
         # ---- instance heads
-        pe = P["pixel_embedding"]
-        pix = ops.conv2d(p1, pe.w(cd), None, pe.bias, out_dtype=gd)                       # [B,h,w,256]
-        plane_emb = run_mlp(hs, P["plane_embedding"], gd=gd).view(B, nq, 1, 1, 256).to(gd)
+        emb = run_mlp(hs, P["plane_embedding"], gd=gd)                                    # [B*nq, 256]
+        fold = ops.linear(emb, P["pe_fold"].w2d(gd))                                      # [B*nq, 264]: mask weights | bias | pad
+        mw = fold[:, :256].to(cd).contiguous().view(B, nq, 1, 1, 256)
+        mb = fold[:, 256].contiguous().view(B, nq)
         out = {
             "pred_logits": ops.linear(hs, P["plane_prob"].w2d(gd), P["plane_prob"].bias).view(B, nq, 2),
             "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
             "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
-            "mask_prob": ops.conv2d(pix, plane_emb, batched_weights=True, act=ops.ACT_SIGMOID, out_dtype=torch.float32),
+            "mask_prob": ops.conv2d(p1, mw, None, mb, batched_weights=True, act=ops.ACT_SIGMOID, out_dtype=torch.float32),
         }
         if want_logits:
-            out["pred_mask_logits"] = ops.conv2d(pix, plane_emb, batched_weights=True, out_dtype=torch.float32)
+            out["pred_mask_logits"] = ops.conv2d(p1, mw, None, mb, batched_weights=True, out_dtype=torch.float32)
             pc = P["pixel_plane_center"]
             out["pixel_centers"] = ops.conv2d(p1, pc.w(cd), None, pc.bias, act=ops.ACT_SIGMOID, out_dtype=torch.float32)
         return out, hs.view(B, nq, 256)

@@ -13,7 +13,8 @@ from . import _lib
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
-ACT_RES_AFTER = 0x100   # OR-able: residual is added after the activation
+ACT_RES_AFTER = 0x100      # OR-able: residual is added after the activation
+ACT_BIAS_BATCHED = 0x200   # OR-able (set by conv2d): with batched weights, bias is [B, Cout]
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
@@ -110,10 +111,12 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == out_dtype and residual.stride(3) == 1
         r_cs = residual.stride(2)
+    if batched_weights and bias is not None and bias.numel() == B * Cout and B > 1:
+        act |= ACT_BIAS_BATCHED                                   # per-batch bias rows [B, Cout]
     for v in (scale, bias):
         if v is not None:
             _chk(v, torch.float32)
-            assert v.numel() == Cout
+            assert v.numel() == Cout or (v is bias and (act & ACT_BIAS_BATCHED))
     def launch(cfg):
         rc = _L().nopesac_conv2d_nhwc_ex(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,
                                          stride, pad, x_cs, y_cs, r_cs, w_bs, act, 2 if mixed else _DT[x.dtype], _DT[out_dtype],
