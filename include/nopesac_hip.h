@@ -280,6 +280,15 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
                            const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
                            const float* ln2_g, const float* ln2_b, void* stream);
 
+/* Tail of one post-norm transformer encoder layer (transformer/transformer.py:183-199) for M tokens of width 256, FFN 1024:
+ *   y1 = LN1(src + attn . wo^T + bo);  y2 = LN2(y1 + relu(y1 . w1^T + b1) . w2^T + b2)
+ * attn bf16 [M][256] (attention output), src f32 [M][256]; wo [256][256], w1 [1024][256], w2 [256][1024] bf16 in MFMA
+ * fragment-major order; outputs (each nullable): y f32, y_bf16, ypos_bf16 = bf16(y2 + pos[token % pos_rows]). */
+int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* ln1_g,
+                              const float* ln1_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                              const float* ln2_g, const float* ln2_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                              void* ypos_bf16, int M, void* stream);
+
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
  * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)

@@ -1,0 +1,237 @@
+// Tail of one post-norm transformer encoder layer of the PlaneTR head in ONE launch (bf16 mode;
+// transformer/transformer.py:183-199 TransformerEncoderLayer.forward_post):
+//
+//     s   = src + out_proj(attn)              attn = multi-head attention output (separate kernel, bf16)
+//     y1  = LayerNorm1(s)
+//     y2  = LayerNorm2(y1 + linear2(relu(linear1(y1))))
+//     outputs: y2 (f32 residual stream), bf16(y2) and bf16(y2 + pos) (the next layer's GEMM operands)
+//
+// Un-fused this is 5 launches per layer (out-proj GEMM, LN, two FFN GEMMs, LN) and the 1024-wide hidden tensor makes a
+// round trip through HBM.  Here a workgroup (8 waves) owns 32 consecutive tokens and the full width: the attention rows
+// sit in LDS as the bf16 A tile, every GEMM is "LDS tile x fragment-major weights streamed from L2" (pwchain.hip /
+// gnn_layer.hip), LayerNorm reduces across the waves through LDS, y1 stays in registers (f32) for the second residual
+// and in LDS (bf16) as the FFN operand, the 32 x 1024 hidden tile never leaves the CU.
+#include "common.h"
+
+namespace nps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+constexpr int ET_D = 256, ET_FF = 1024, ET_BM = 32;
+constexpr int ET_LD = ET_D + 8, ET_HLD = ET_FF + 8;
+constexpr int ET_A = ET_BM * ET_LD;                      // elements of one [32][264] bf16 tile
+constexpr size_t ET_LDS_BYTES = 2 * (size_t)(2 * ET_A + ET_BM * ET_HLD) + 2 * 8 * 32 * sizeof(float);
+static_assert((size_t)ET_BM * ET_D * 4 <= 2 * (size_t)ET_BM * ET_HLD, "f32 staging tile must fit the hidden tile");
+
+struct EncTailArgs {
+    const bf16_t* attn; const float* src;                 // [M][256]
+    const bf16_t* wo; const float* bo; const float* g1; const float* be1;
+    const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2; const float* g2; const float* be2;
+    const float* pos; int pos_rows;                       // [pos_rows][256], row index = token % pos_rows (may be null)
+    float* y; bf16_t* y16; bf16_t* ypos16;                // outputs [M][256] (each nullable)
+    int M;
+};
+
+struct EtRing {
+    bf16x8 f[2][16];
+};
+__device__ __forceinline__ void et_issue(EtRing& ring, int buf, const bf16_t* __restrict__ w, int kf_total, int kf_off, int nt, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        ring.f[buf][kk] = *reinterpret_cast<const bf16x8*>(w + ((long long)(nt * kf_total + kf_off + kk) * 64 + lane) * 8);
+}
+// acc += A[row][k] * W[tile][k] over the 16 k-steps held in ring.f[buf]; lane holds token l&31 x 4-channel runs
+__device__ __forceinline__ void et_gemm(const EtRing& ring, int buf, const bf16_t* A, int lda, f32x16& acc, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + l31 * lda + kk * 16 + half * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[buf][kk], af, acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void et_zero(f32x16& acc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+}
+// two-pass LayerNorm over 256 channels spread over the 8 waves (32 each); normalised + affine values stay in acc
+__device__ __forceinline__ void et_layernorm(f32x16& acc, const float* __restrict__ gamma, const float* __restrict__ beta, float* red,
+                                             int wave, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* rp = red + pass * 8 * 32;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float d = pass == 0 ? acc[e] : acc[e] - mean;
+            s += pass == 0 ? d : d * d;
+        }
+        s += __shfl_xor(s, 32, 64);
+        if (half == 0) rp[wave * 32 + l31] = s;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += rp[w * 32 + l31];
+        if (pass == 0) mean = t / ET_D;
+        else rstd = rsqrtf(t / ET_D + 1e-5f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n), b = *reinterpret_cast<const f32x4*>(beta + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = (acc[4 * q + e] - mean) * rstd * g[e] + b[e];
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char et_smem[];
+    bf16_t* At = reinterpret_cast<bf16_t*>(et_smem);         // attention rows [32][264]
+    bf16_t* Yt = At + ET_A;                                  // bf16(y1) [32][264]; later bf16(y2)
+    bf16_t* Ht = Yt + ET_A;                                  // hidden [32][1032]; later the f32 / bf16 output staging
+    float* red = reinterpret_cast<float*>(Ht + ET_BM * ET_HLD);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * ET_BM;
+    const long long row = m0 + l31;
+    const bool row_ok = row < p.M;
+    EtRing ring;
+
+    et_issue(ring, 0, p.wo, 16, 0, wave, lane);                                   // step 0: out-proj tile `wave`
+#pragma unroll
+    for (int i = 0; i < ET_BM * 32 / 512; ++i) {                                  // attention rows -> LDS
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        us8 v = us8{};
+        if (m0 + r < p.M) v = *reinterpret_cast<const us8*>(p.attn + (m0 + r) * ET_D + col);
+        *reinterpret_cast<us8*>(At + r * ET_LD + col) = v;
+    }
+    __syncthreads();
+
+    // ---- y1 = LN1(src + out_proj(attn)); wave owns channels wave*32 .. +32
+    et_issue(ring, 1, p.w1, 16, 0, 4 * wave, lane);                               // step 1: linear1 tile 4w
+    f32x16 y1;
+    et_zero(y1);
+    et_gemm(ring, 0, At, ET_LD, y1, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + n);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok) s = *reinterpret_cast<const f32x4*>(p.src + row * ET_D + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y1[4 * q + e] = (y1[4 * q + e] + b[e]) + s[e];
+    }
+    et_layernorm(y1, p.g1, p.be1, red, wave, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        us4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y1[4 * q + e]);
+        *reinterpret_cast<us4*>(Yt + l31 * ET_LD + wave * 32 + 8 * q + 4 * half) = o;
+    }
+    __syncthreads();
+
+    // ---- hidden = relu(linear1(y1)): tiles 4w .. 4w+3 of 32
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int buf = (1 + j) & 1;
+        if (j < 3) et_issue(ring, buf ^ 1, p.w1, 16, 0, 4 * wave + j + 1, lane);  // steps 2..4
+        else et_issue(ring, buf ^ 1, p.w2, 64, 0, wave, lane);                    // step 5: linear2, hidden 0..255
+        f32x16 h;
+        et_zero(h);
+        et_gemm(ring, buf, Yt, ET_LD, h, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = (4 * wave + j) * 32 + 8 * q + 4 * half;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + n);
+            us4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = h[4 * q + e] + b[e];
+                o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+            }
+            *reinterpret_cast<us4*>(Ht + l31 * ET_HLD + n) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- y2 = LN2(y1 + linear2(hidden)): K = 1024 in four ring steps
+    f32x16 y2;
+    et_zero(y2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int buf = (5 + c) & 1;
+        if (c < 3) et_issue(ring, buf ^ 1, p.w2, 64, 16 * (c + 1), wave, lane);   // steps 6..8
+        et_gemm(ring, buf, Ht + 256 * c, ET_HLD, y2, lane);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y2[4 * q + e] = (y2[4 * q + e] + b[e]) + y1[4 * q + e];
+    }
+    et_layernorm(y2, p.g2, p.be2, red, wave, lane);           // its barriers also retire every read of Ht / Yt
+
+    // ---- outputs through LDS so that they leave as whole rows: f32 tile in the hidden region, bf16 tiles in At / Yt
+    float* Yf = reinterpret_cast<float*>(Ht);                 // [32][256] f32
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        f32x4 v = {y2[4 * q], y2[4 * q + 1], y2[4 * q + 2], y2[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = v;
+        us4 o, op;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (p.pos && row_ok) pv = *reinterpret_cast<const f32x4*>(p.pos + (row % p.pos_rows) * ET_D + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = f32_to_bf16(v[e]); op[e] = f32_to_bf16(v[e] + pv[e]); }
+        *reinterpret_cast<us4*>(Yt + l31 * ET_LD + n) = o;
+        *reinterpret_cast<us4*>(At + l31 * ET_LD + n) = op;
+    }
+    __syncthreads();
+    if (p.y) {
+#pragma unroll
+        for (int i = 0; i < ET_BM * 64 / 512; ++i) {          // 64 16-byte chunks per f32 row
+            const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_D + col);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ET_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        if (m0 + r < p.M) {
+            if (p.y16) *reinterpret_cast<us8*>(p.y16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(Yt + r * ET_LD + col);
+            if (p.ypos16) *reinterpret_cast<us8*>(p.ypos16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(At + r * ET_LD + col);
+        }
+    }
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* ln1_g,
+                                         const float* ln1_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                         const float* ln2_g, const float* ln2_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                         void* ypos_bf16, int M, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(attn && src && wo && bo && ln1_g && ln1_b && w1 && b1 && w2 && b2 && ln2_g && ln2_b && M > 0, "encoder_tail: null pointer");
+    NPS_CHECK_ARG(y || y_bf16 || ypos_bf16, "encoder_tail: no output requested");
+    NPS_CHECK_ARG(!ypos_bf16 || (pos && pos_rows > 0), "encoder_tail: ypos needs pos");
+    const void* ptrs[] = {attn, src, wo, bo, ln1_g, ln1_b, w1, b1, w2, b2, ln2_g, ln2_b, pos, y, y_bf16, ypos_bf16};
+    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "encoder_tail: pointers must be 16-byte aligned");
+    EncTailArgs a;
+    a.attn = (const bf16_t*)attn; a.src = src; a.wo = (const bf16_t*)wo; a.bo = bo; a.g1 = ln1_g; a.be1 = ln1_b;
+    a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = ln2_g; a.be2 = ln2_b;
+    a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)enc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ET_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    NPS_LAUNCH_RET();
+}

@@ -54,6 +54,7 @@ class PlaneTRHead(ParamModule):
                 if k.startswith("sem_seg_head.")}
         super().__init__(spec)
         self._pos_cache = {}
+        self.fused_encoder_tail = True
 
     # ---------------------------------------------------------------- packing
     def _mha(self, prefix: str, fuse_qk: bool):
@@ -168,6 +169,16 @@ class PlaneTRHead(ParamModule):
         mark("ph.decoder")
         return self._heads(features, hs, memory, B, hc, wc, nq, want_logits, mark)
 
+    def _enc_tail_weights(self, i: int) -> dict:
+        cache = self.__dict__.setdefault("_enc_tail_w", {})
+        if i not in cache:
+            p, W = f"context_SA.layers.{i}", self.packed[f"context_SA.layers.{i}"]
+            f = lambda k: self.raw(p + k).float().contiguous()
+            cache[i] = {"wo": W["attn"]["o"].wfrag(torch.bfloat16), "bo": W["attn"]["o"].bias, "w1": W["l1"].wfrag(torch.bfloat16),
+                        "b1": W["l1"].bias, "w2": W["l2"].wfrag(torch.bfloat16), "b2": W["l2"].bias,
+                        "g1": f(".norm1.weight"), "be1": f(".norm1.bias"), "g2": f(".norm2.weight"), "be2": f(".norm2.bias")}
+        return cache[i]
+
     def _transformer_bf16(self, src, pos, B, L, nq, nh, scale, mark):
         """bf16-mode encoder/decoder.  Same arithmetic as the fp32-activation path above run in mixed mode - every GEMM / attention
         operand was rounded to bf16 when staged there - but the tensors that only feed GEMMs or attention (q|k, v, attention
@@ -188,6 +199,10 @@ class PlaneTRHead(ParamModule):
             qk = lin(q_in16, W["attn"]["qk"].w2d(bf), W["attn"]["qk"].bias, out_dtype=bf)
             v = lin(src16, W["attn"]["v"].w2d(bf), W["attn"]["v"].bias, out_dtype=bf)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale, mfma_bf16=True)
+            if self.fused_encoder_tail:      # out-proj + LN1 + FFN + LN2 in one launch (csrc/enc_tail.hip)
+                r = ops.encoder_tail(o, src, self._enc_tail_weights(i), pos=pos)
+                src, src16, q_in16 = r["y"], r["y16"], r["ypos16"]
+                continue
             s = lin(o, W["attn"]["o"].w2d(bf), W["attn"]["o"].bias, residual=src, out_dtype=f32)
             r = ln(s, p + ".norm1", want=("y", "y16"))
             src, src16 = r["y"], r["y16"]

@@ -477,3 +477,19 @@ def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out:
                                      _p(W["g1"]), _p(W["b1"]), _p(W["g2"]), _p(W["b2"]), _stream())
     _lib.check(rc, "nopesac_gnn_layer_bf16")
     return out
+
+
+def encoder_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, pos=None, want=("y", "y16", "ypos16")) -> dict:
+    """Fused out-proj + residual + LN1 + FFN + residual + LN2 of a post-norm encoder layer (csrc/enc_tail.hip).
+    attn bf16 [M,256], src f32 [M,256]; W: fragment-major bf16 "wo", "w1", "w2" + f32 "bo", "g1", "be1", "b1", "b2", "g2", "be2"."""
+    _chk(attn, torch.bfloat16); _chk(src, torch.float32)
+    M = src.shape[0]
+    assert attn.shape == (M, 256) and src.shape == (M, 256)
+    out = {k: torch.empty(M, 256, device=src.device, dtype=torch.float32 if k == "y" else torch.bfloat16) for k in want}
+    if pos is not None:
+        _chk(pos, torch.float32)
+    rc = _L().nopesac_encoder_tail_bf16(_p(attn), _p(src), _p(W["wo"]), _p(W["bo"]), _p(W["g1"]), _p(W["be1"]), _p(W["w1"]), _p(W["b1"]),
+                                        _p(W["w2"]), _p(W["b2"]), _p(W["g2"]), _p(W["be2"]), _p(pos), 0 if pos is None else pos.shape[0],
+                                        _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")), M, _stream())
+    _lib.check(rc, "nopesac_encoder_tail_bf16")
+    return out

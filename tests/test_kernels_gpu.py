@@ -316,3 +316,27 @@ def test_layernorm_ex_and_attention_bf16io(device):
     o16 = ops.attention(q, k, v, B, Lq, Lk, H, 0.25, mfma_bf16=True)           # scale 2^-2: the q scaling is exact in bf16
     o32 = ops.attention(q.float(), k.float().contiguous(), v.float().contiguous(), B, Lq, Lk, H, 0.25, mfma_bf16=True)
     assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.bfloat16())
+
+
+@pytest.mark.parametrize("M", [19200 // 8, 333])
+def test_encoder_tail(device, M):
+    """Fused out-proj + LN1 + FFN + LN2 (csrc/enc_tail.hip) vs the same chain through the per-op bf16-mode kernels
+    (differences: LayerNorm summation order, hence an occasional 1-ulp flip of a bf16 intermediate)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    attn, src, pos = rn(M, 256).bfloat16(), rn(M, 256), rn(300, 256)
+    wo, w1, w2 = rn(256, 256, k=1 / 16).bfloat16(), rn(1024, 256, k=1 / 16).bfloat16(), rn(256, 1024, k=1 / 32).bfloat16()
+    bo, b1, b2 = rn(256, k=0.1), rn(1024, k=0.1), rn(256, k=0.1)
+    g1, be1, g2, be2 = 1 + rn(256, k=0.1), rn(256, k=0.1), 1 + rn(256, k=0.1), rn(256, k=0.1)
+    W = {"wo": ops.mfma_fragment_major(wo), "w1": ops.mfma_fragment_major(w1), "w2": ops.mfma_fragment_major(w2),
+         "bo": bo, "b1": b1, "b2": b2, "g1": g1, "be1": be1, "g2": g2, "be2": be2}
+    out = ops.encoder_tail(attn, src, W, pos=pos)
+    s = ops.linear(attn, wo, bo, residual=src, out_dtype=torch.float32)
+    r = ops.layernorm_ex(s, g1, be1, want=("y", "y16"))
+    h = ops.linear(r["y16"], w1, b1, act=ops.ACT_RELU, out_dtype=torch.bfloat16)
+    s2 = ops.linear(h, w2, b2, residual=r["y"], out_dtype=torch.float32)
+    ref = ops.layernorm_ex(s2, g2, be2, addend=pos, want=("y", "y16", "y2_16"))
+    assert _rel(out["y"], ref["y"]) < 5e-3
+    assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2
+    assert float((out["y"] - ref["y"]).abs().mean()) < 2e-4 * float(ref["y"].abs().mean() + 1)
