@@ -99,7 +99,8 @@ int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, co
  * The three weight matrices w3 [C4][C], wsc [C4][C2], w1 [CN][C4] are passed FRAGMENT-MAJOR: a [N][K] matrix is stored as
  * [N/32][K/16][2][32][8], i.e. element (n, k) at ((((n/32)*(K/16) + k/16)*2 + (k%16)/8)*32 + n%32)*8 + k%8 - the order in which
  * the 64 lanes of a wave consume it as MFMA operands, so every weight load is 1 KB contiguous (nopesac_amd.ops.mfma_fragment_major).
- * Supported (C, C4, CN, C2): (64,256,{0,64,128},0), (64,256,{0,64},64), (128,512,{0,128,256},0), (128,512,{0,128},256);
+ * Supported (C, C4, CN, C2): (64,256,{0,64,128},0), (64,256,{0,64},64), (128,512,{0,128,256},0), (128,512,{0,128},256),
+ * (256,1024,{0,256,512},0), (256,1024,{0,256},512);
  * anything else returns an error (the caller then uses
  * nopesac_conv2d_nhwc per layer). */
 int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,

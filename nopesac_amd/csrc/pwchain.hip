@@ -262,6 +262,216 @@ __global__ __launch_bounds__(256, (PwLds<C, C4, CN, C2, BM>::WAVES_PER_SIMD)) vo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Wide variant (res4: C = 256, C4 = 1024): 32 pixels per workgroup, EIGHT waves, the whole 32 x C4 y tile in LDS (66 KB) and
+// the weight fragments streamed through a two-deep register ring that is refilled one step (= one 32-channel column tile x
+// 256 input channels = 16 fragment loads) ahead, across column tiles and across the two phases (enc_tail.hip / gnn_layer.hip).
+// Wave w owns column tiles w*NT1 .. of y and w*NT2 .. of a'.
+template <int C, int C4, int CN, int C2>
+struct PwWide {
+    static constexpr int BM = 32;
+    static constexpr int A_LD = C + 8, A2_LD = C2 + 8, Y_LD = C4 + 8, O_LD = CN + 8;
+    static constexpr int OPER = BM * A_LD + (C2 ? BM * A2_LD : 0), OUT = CN ? BM * O_LD : 0;
+    static constexpr int R0 = OPER > OUT ? OPER : OUT;
+    static constexpr size_t BYTES = 2 * (size_t)(R0 + BM * Y_LD);
+    static constexpr int KS1 = C / 256, KS1S = C2 / 256, PER1 = KS1 + KS1S;     // ring steps per column tile (expand, shortcut)
+    static constexpr int NT1 = C4 / 256, S1 = NT1 * PER1;                       // column tiles per wave, steps of phase 1
+    static constexpr int KS2 = C4 / 256, NT2 = CN / 256, S2 = NT2 * KS2;
+    static_assert(C % 256 == 0 && C4 % 256 == 0 && CN % 256 == 0 && C2 % 256 == 0, "wide tail: multiples of 256 channels");
+};
+
+struct PwRing {
+    bf16x8 f[2][16];
+};
+
+template <int C, int C4, int CN, int C2>
+__device__ __forceinline__ void pww_issue(PwRing& ring, const PwArgs& p, int s, int wave, int lane) {
+    typedef PwWide<C, C4, CN, C2> W;
+    const bf16_t* w;
+    int kf_total, kf_off, nt;
+    if (s < W::S1) {
+        const int j = s / W::PER1, t = s % W::PER1;
+        nt = wave * W::NT1 + j;
+        if (t < W::KS1) { w = p.w3; kf_total = C / 16; kf_off = 16 * t; }
+        else { w = p.wsc; kf_total = C2 / 16; kf_off = 16 * (t - W::KS1); }
+    } else if (s < W::S1 + W::S2) {
+        const int s2 = s - W::S1, j = s2 / W::KS2, t = s2 % W::KS2;
+        nt = wave * W::NT2 + j;
+        w = p.w1; kf_total = C4 / 16; kf_off = 16 * t;
+    } else {
+        return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        ring.f[s & 1][kk] = *reinterpret_cast<const bf16x8*>(w + ((long long)(nt * kf_total + kf_off + kk) * 64 + lane) * 8);
+}
+__device__ __forceinline__ void pww_gemm(const PwRing& ring, int buf, const bf16_t* A, int lda, f32x16& acc, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + l31 * lda + kk * 16 + half * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[buf][kk], af, acc, 0, 0, 0);
+    }
+}
+template <int ROWS, int K, int LD>
+__device__ __forceinline__ void pww_copy_rows(const bf16_t* __restrict__ src, long long row0, long long M, bf16_t* T, int tid) {
+    constexpr int CPR = K / 8;
+    static_assert(ROWS * CPR % 512 == 0, "tile chunking");
+    us8 reg[ROWS * CPR / 512];
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / 512; ++i) {
+        const int c = tid + i * 512, row = c / CPR, col = c % CPR;
+        reg[i] = us8{};
+        if (row0 + row < M) reg[i] = *reinterpret_cast<const us8*>(src + (row0 + row) * K + col * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / 512; ++i) {
+        const int c = tid + i * 512, row = c / CPR, col = c % CPR;
+        *reinterpret_cast<us8*>(T + row * LD + col * 8) = reg[i];
+    }
+}
+
+template <int C, int C4, int CN, int C2>
+__global__ __launch_bounds__(512, 2) void pw_chain_wide_kernel(const PwArgs p) {
+    typedef PwWide<C, C4, CN, C2> W;
+    constexpr int BM = W::BM, A_LD = W::A_LD, A2_LD = W::A2_LD, Y_LD = W::Y_LD, O_LD = W::O_LD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* A2 = A1 + BM * A_LD;
+    bf16_t* O = A1;
+    bf16_t* Y = A1 + W::R0;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+    const bool has_res = p.res != nullptr;
+    PwRing ring;
+    pww_issue<C, C4, CN, C2>(ring, p, 0, wave, lane);
+    pww_copy_rows<BM, C, A_LD>(p.a1, m0, p.M, A1, tid);
+    if (has_res) pww_copy_rows<BM, C4, Y_LD>(p.res, m0, p.M, Y, tid);
+    if constexpr (C2 > 0) {
+        constexpr int CPR = C2 / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 512; ++i) {
+            const int c = tid + i * 512, row = c / CPR, col = c % CPR;
+            us8 v = us8{};
+            const long long m = m0 + row;
+            if (m < p.M) {
+                long long pix = m;
+                if (p.a2_stride != 1 || p.a2_H != p.OH || p.a2_W != p.OW) {
+                    const int per = p.OH * p.OW;
+                    const int b = (int)(m / per), rem = (int)(m % per), oy = rem / p.OW, ox = rem % p.OW;
+                    pix = ((long long)b * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
+                }
+                v = *reinterpret_cast<const us8*>(p.a2 + pix * C2 + col * 8);
+            }
+            *reinterpret_cast<us8*>(A2 + row * A2_LD + col * 8) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < W::NT1; ++j) {
+        f32x16 acc, accs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < W::PER1; ++t) {
+            pww_issue<C, C4, CN, C2>(ring, p, s + 1, wave, lane);
+            if (t < W::KS1) pww_gemm(ring, s & 1, A1 + 256 * t, A_LD, acc, lane);
+            else pww_gemm(ring, s & 1, A2 + 256 * (t - W::KS1), A2_LD, accs, lane);
+            ++s;
+        }
+        const int n0 = (wave * W::NT1 + j) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + 8 * q + 4 * half;
+            const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + n), b3 = *reinterpret_cast<const f32x4*>(p.b3 + n);
+            f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(p.ssc + n); bs = *reinterpret_cast<const f32x4*>(p.bsc + n); }
+            bf16_t* yp = Y + l31 * Y_LD + n;
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_res) {
+                const us4 r4 = *reinterpret_cast<const us4*>(yp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = bf16_to_f32(r4[e]);
+            }
+            us4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[4 * q + e] * s3[e];
+                v += b3[e];
+                if constexpr (C2 > 0) {
+                    float sc = accs[4 * q + e] * ss[e];
+                    sc += bs[e];
+                    rv[e] = sc;
+                }
+                v += rv[e];
+                o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+            }
+            *reinterpret_cast<us4*>(yp) = o4;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = C4 / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 512; ++i) {
+            const int c = tid + i * 512, row = c / CPR, col = c % CPR;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.y + (m0 + row) * C4 + col * 8) = *reinterpret_cast<const us8*>(Y + row * Y_LD + col * 8);
+        }
+    }
+    if constexpr (CN > 0) {
+        // ---- phase 2: a' = relu(bn1(y W1'^T)), K = C4 in KS2 ring steps per column tile
+#pragma unroll
+        for (int j = 0; j < W::NT2; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < W::KS2; ++t) {
+                pww_issue<C, C4, CN, C2>(ring, p, s + 1, wave, lane);
+                pww_gemm(ring, s & 1, Y + 256 * t, Y_LD, acc, lane);
+                ++s;
+            }
+            const int n0 = (wave * W::NT2 + j) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 8 * q + 4 * half;
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+                us4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[4 * q + e] * s1[e];
+                    v += b1[e];
+                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(O + l31 * O_LD + n) = o4;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = CN / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 512; ++i) {
+            const int c = tid + i * 512, row = c / CPR, col = c % CPR;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+        }
+    }
+}
+
+template <int C, int C4, int CN, int C2>
+static int pw_launch_wide(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwWide<C, C4, CN, C2>::BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pw_chain_wide_kernel<C, C4, CN, C2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pw_chain_wide_kernel<C, C4, CN, C2>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), lds, stream, a);
+    return 0;
+}
+
 template <int C, int C4, int CN, int C2, int BM>
 static int pw_launch(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
@@ -303,6 +513,9 @@ extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const
     PW_CASE(64, 256, 64, 0, 64) PW_CASE(64, 256, 128, 0, 64) PW_CASE(64, 256, 64, 64, 64) PW_CASE(64, 256, 0, 0, 64) PW_CASE(64, 256, 0, 64, 64)
     PW_CASE(128, 512, 128, 0, 32) PW_CASE(128, 512, 256, 0, 32) PW_CASE(128, 512, 128, 256, 32) PW_CASE(128, 512, 0, 0, 32) PW_CASE(128, 512, 0, 256, 32)
 #undef PW_CASE
+#define PW_WIDE(c, c4, cn, cc2) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch_wide<c, c4, cn, cc2>(a, st); NPS_LAUNCH_RET(); }
+    PW_WIDE(256, 1024, 256, 0) PW_WIDE(256, 1024, 512, 0) PW_WIDE(256, 1024, 256, 512) PW_WIDE(256, 1024, 0, 0) PW_WIDE(256, 1024, 0, 512)
+#undef PW_WIDE
     set_error("bottleneck_tail: unsupported channel configuration C=%d C4=%d CN=%d C2=%d", C, C4, CN, c2);
     return NPS_E_ARG;
 }

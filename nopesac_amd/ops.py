@@ -177,7 +177,8 @@ def stem_fused(x: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor, bias: t
 
 
 BOTTLENECK_TAIL_CONFIGS = {(64, 256, 0, 0), (64, 256, 64, 0), (64, 256, 128, 0), (64, 256, 0, 64), (64, 256, 64, 64),          # (C, C4, CN, C2)
-                           (128, 512, 0, 0), (128, 512, 128, 0), (128, 512, 256, 0), (128, 512, 0, 256), (128, 512, 128, 256)}
+                           (128, 512, 0, 0), (128, 512, 128, 0), (128, 512, 256, 0), (128, 512, 0, 256), (128, 512, 128, 256),
+                           (256, 1024, 0, 0), (256, 1024, 256, 0), (256, 1024, 512, 0), (256, 1024, 0, 512), (256, 1024, 256, 512)}
 
 
 def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:

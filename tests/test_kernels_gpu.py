@@ -239,7 +239,8 @@ def test_rle_from_winner_map(device, V, H, W, nq, seed):
 
 @pytest.mark.parametrize("C,proj,CN,stride,M_odd", [
     (64, False, 64, 1, False), (64, False, 128, 1, True), (64, True, 64, 1, False), (64, False, 0, 1, False), (64, True, 0, 1, True),
-    (128, False, 128, 1, True), (128, False, 256, 1, False), (128, True, 128, 2, True), (128, True, 0, 2, False), (128, False, 0, 1, False)])
+    (128, False, 128, 1, True), (128, False, 256, 1, False), (128, True, 128, 2, True), (128, True, 0, 2, False), (128, False, 0, 1, False),
+    (256, False, 256, 1, True), (256, False, 512, 1, False), (256, True, 256, 2, True), (256, True, 0, 2, False), (256, False, 0, 1, True)])
 def test_bottleneck_tail(device, C, proj, CN, stride, M_odd):
     """Fused conv3 + shortcut + ReLU (+ next conv1) vs the per-layer bf16 kernels: identity blocks bit-exact, projection
     blocks within bf16 rounding (the fused kernel does not round the shortcut to bf16 in between)."""
