@@ -472,6 +472,192 @@ static int pw_launch_wide(const PwArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Streaming variant for identity blocks with a very wide y (res4: C4 = 1024).  Streaming weights per 32
+// pixels (above) makes the L2 -> CU weight traffic the limiter (1 MB per 32 pixels in res4).  Here a workgroup owns BM = 64
+// pixels - every weight fragment feeds two MFMAs - and y is produced in 256-channel CHUNKS: chunk c is computed into a
+// [BM][256] LDS tile (over its residual, which was prefetched into registers during chunk c-1), leaves for HBM as 512-byte row
+// segments, and is immediately consumed as K-slice c of the next block's conv1, whose accumulators stay in registers across
+// the chunks.  LDS = b tile + one y chunk; three barriers per chunk.
+template <int C, int C4, int CN, int BM>
+struct PwStream {
+    static constexpr int RT = BM / 32, A_LD = C + 8, Y_LD = 256 + 8, O_LD = CN + 8;
+    static constexpr int NCH = C4 / 256, KS1 = C / 256, NT2 = CN / 256;          // chunks; ring steps per chunk: KS1 + NT2
+    static constexpr int OPER = BM * A_LD + BM * Y_LD, OUT = CN ? BM * O_LD : 0;
+    static constexpr int ELEMS = OPER > OUT ? OPER : OUT;
+    static constexpr size_t BYTES = 2 * (size_t)ELEMS;
+    static constexpr int PER = KS1 + NT2, STEPS = NCH * PER;
+    static_assert(C % 256 == 0 && C4 % 256 == 0 && CN % 256 == 0 && BM % 32 == 0, "streaming tail: shapes");
+};
+
+// Rolling weight ring: 16 fragment registers; fragment kk of step s+1 is loaded into slot kk right after the MFMAs of step s
+// have consumed it, so a full step (16 KB per wave) is always in flight with half the registers of a double buffer.
+struct PwRoll {
+    bf16x8 f[16];
+};
+template <int C, int C4, int CN, int BM>
+__device__ __forceinline__ const bf16_t* pws_step_ptr(const PwArgs& p, int s, int wave, int lane) {
+    typedef PwStream<C, C4, CN, BM> S;
+    if (s >= S::STEPS) return nullptr;
+    const int c = s / S::PER, t = s % S::PER;
+    const bf16_t* w;
+    int kf_total, kf_off, nt;
+    if (t < S::KS1) { w = p.w3; kf_total = C / 16; kf_off = 16 * t; nt = c * 8 + wave; }             // y channels c*256 + wave*32
+    else { w = p.w1; kf_total = C4 / 16; kf_off = 16 * c; nt = wave * S::NT2 + (t - S::KS1); }      // conv1 tile, K-slice c
+    return w + ((long long)(nt * kf_total + kf_off) * 64 + lane) * 8;
+}
+template <int RT>
+__device__ __forceinline__ void pws_gemm(PwRoll& ring, const bf16_t* __restrict__ next, const bf16_t* A, int lda, f32x16 (&acc)[RT], int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + (r * 32 + l31) * lda + kk * 16 + half * 8);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[kk], af, acc[r], 0, 0, 0);
+        }
+        if (next) ring.f[kk] = *reinterpret_cast<const bf16x8*>(next + kk * 512);
+        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting all 16 k-steps' LDS reads (spills)
+    }
+}
+
+template <int C, int C4, int CN, int BM>
+__global__ __launch_bounds__(512, 2) void pw_chain_stream_kernel(const PwArgs p) {
+    typedef PwStream<C, C4, CN, BM> S;
+    constexpr int RT = S::RT, A_LD = S::A_LD, Y_LD = S::Y_LD, O_LD = S::O_LD;
+    constexpr int RCH = BM * 32 / 512;                       // 16-byte chunks per thread of one [BM][256] tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* Y = A1 + BM * A_LD;
+    bf16_t* O = A1;                                          // aliases both tiles once the last chunk has been consumed
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+    PwRoll ring;
+    {
+        const bf16_t* w0 = pws_step_ptr<C, C4, CN, BM>(p, 0, wave, lane);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) ring.f[kk] = *reinterpret_cast<const bf16x8*>(w0 + kk * 512);
+    }
+    us8 rres[RCH];
+    auto fetch_res = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int ch = tid + i * 512, row = ch >> 5, col = (ch & 31) * 8;
+            rres[i] = us8{};
+            if (m0 + row < p.M) rres[i] = *reinterpret_cast<const us8*>(p.res + (m0 + row) * C4 + c * 256 + col);
+        }
+    };
+    auto park_res = [&]() {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int ch = tid + i * 512, row = ch >> 5, col = (ch & 31) * 8;
+            *reinterpret_cast<us8*>(Y + row * Y_LD + col) = rres[i];
+        }
+    };
+    fetch_res(0);
+    pww_copy_rows<BM, C, A_LD>(p.a1, m0, p.M, A1, tid);
+    park_res();
+    __syncthreads();
+
+    f32x16 acc2[CN ? S::NT2 : 1][RT];
+#pragma unroll
+    for (int j = 0; j < (CN ? S::NT2 : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[j][r][e] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < S::NCH; ++c) {
+        if (c + 1 < S::NCH) fetch_res(c + 1);
+        // ---- y chunk c: wave owns channels c*256 + wave*32 .. +32, all RT row tiles
+        f32x16 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < S::KS1; ++t)
+            pws_gemm<RT>(ring, pws_step_ptr<C, C4, CN, BM>(p, c * S::PER + t + 1, wave, lane), A1 + 256 * t, A_LD, acc, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = wave * 32 + 8 * q + 4 * half, n = c * 256 + nl;
+            const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + n), b3 = *reinterpret_cast<const f32x4*>(p.b3 + n);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                bf16_t* yp = Y + (r * 32 + l31) * Y_LD + nl;
+                const us4 r4 = *reinterpret_cast<const us4*>(yp);
+                us4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][4 * q + e] * s3[e];
+                    v += b3[e];
+                    v += bf16_to_f32(r4[e]);
+                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(yp) = o4;
+            }
+        }
+        __syncthreads();                                     // y chunk complete
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int ch = tid + i * 512, row = ch >> 5, col = (ch & 31) * 8;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.y + (m0 + row) * C4 + c * 256 + col) = *reinterpret_cast<const us8*>(Y + row * Y_LD + col);
+        }
+        if constexpr (CN > 0) {
+#pragma unroll
+            for (int j = 0; j < S::NT2; ++j)
+                pws_gemm<RT>(ring, pws_step_ptr<C, C4, CN, BM>(p, c * S::PER + S::KS1 + j + 1, wave, lane), Y, Y_LD, acc2[j], lane);
+        }
+        __syncthreads();                                     // every wave is done with chunk c
+        if (c + 1 < S::NCH) {
+            park_res();
+            __syncthreads();
+        }
+    }
+    if constexpr (CN > 0) {
+#pragma unroll
+        for (int j = 0; j < S::NT2; ++j) {
+            const int n0 = (wave * S::NT2 + j) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 8 * q + 4 * half;
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    us4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[j][r][4 * q + e] * s1[e];
+                        v += b1[e];
+                        o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                    *reinterpret_cast<us4*>(O + (r * 32 + l31) * O_LD + n) = o4;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = CN / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 512; ++i) {
+            const int ch = tid + i * 512, row = ch / CPR, col = ch % CPR;
+            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+        }
+    }
+}
+
+template <int C, int C4, int CN, int BM>
+static int pw_launch_stream(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwStream<C, C4, CN, BM>::BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pw_chain_stream_kernel<C, C4, CN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pw_chain_stream_kernel<C, C4, CN, BM>), dim3((unsigned)((a.M + BM - 1) / BM)), dim3(512), lds, stream, a);
+    return 0;
+}
+
 template <int C, int C4, int CN, int C2, int BM>
 static int pw_launch(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
@@ -513,6 +699,12 @@ extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const
     PW_CASE(64, 256, 64, 0, 64) PW_CASE(64, 256, 128, 0, 64) PW_CASE(64, 256, 64, 64, 64) PW_CASE(64, 256, 0, 0, 64) PW_CASE(64, 256, 0, 64, 64)
     PW_CASE(128, 512, 128, 0, 32) PW_CASE(128, 512, 256, 0, 32) PW_CASE(128, 512, 128, 256, 32) PW_CASE(128, 512, 0, 0, 32) PW_CASE(128, 512, 0, 256, 32)
 #undef PW_CASE
+    // identity blocks of res4 / res5: chunk-streaming kernel (weights shared by 128 / 64 pixels)
+    if (!x2 && !getenv("NOPESAC_TAIL_NO_STREAM")) {
+        if (C == 256 && C4 == 1024 && CN == 256) { pw_launch_stream<256, 1024, 256, 64>(a, st); NPS_LAUNCH_RET(); }
+        if (C == 256 && C4 == 1024 && CN == 0) { pw_launch_stream<256, 1024, 0, 64>(a, st); NPS_LAUNCH_RET(); }
+        // (res5, C4 = 2048, was measured too: 0.185 ms fused vs 0.158 ms per-layer at 15x20 - only 300 workgroups - so it stays per-layer)
+    }
 #define PW_WIDE(c, c4, cn, cc2) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch_wide<c, c4, cn, cc2>(a, st); NPS_LAUNCH_RET(); }
     PW_WIDE(256, 1024, 256, 0) PW_WIDE(256, 1024, 512, 0) PW_WIDE(256, 1024, 256, 512) PW_WIDE(256, 1024, 0, 0) PW_WIDE(256, 1024, 0, 512)
 #undef PW_WIDE
