@@ -146,9 +146,10 @@ class ConvTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for dt, fl, e0, e1, _, _ in self.records:
-            d = out.setdefault(dt, {"flops": 0.0, "ms": 0.0, "launches": 0})
+        for dt, fl, e0, e1, nb, _ in self.records:
+            d = out.setdefault(dt, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
             d["flops"] += fl
+            d["bytes"] += nb
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
         return out
@@ -346,9 +347,20 @@ def main():
     dom = conv.get(key, {"flops": 0.0, "ms": 1.0, "launches": 0})
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bfloat16" else 157.3
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    # HBM traffic of the same kernel family from the PMC counters (cannot be collected from inside this process: measured by
+    # scripts/pmc_bench.sh on this benchmark command and committed as profiles/*pmc_traffic.json)
+    traffic, traffic_src = None, None
+    if args.dtype == "bfloat16":
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
+            fam = json.load(open(path))["bf16_conv_family"]
+            traffic = round((fam["read_bytes_per_step"] + fam["write_bytes_per_step"]) / max(fam["launches_per_step"], 1))
+            traffic_src = os.path.relpath(path, ROOT)
     roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16>" if args.dtype == "bfloat16" else "conv_igemm_kernel<f32>",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (family average)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1)),
+                "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
                 "step_share": round(dom["ms"] / ms_per_step, 3),
                 "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
