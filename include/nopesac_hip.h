@@ -290,6 +290,10 @@ int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo
                               const float* ln2_g, const float* ln2_b, const float* pos, int pos_rows, float* y, void* y_bf16,
                               void* ypos_bf16, int M, void* stream);
 
+/* cv2.resize(img, (OW, OH)) with the default INTER_LINEAR on uint8 HWC images (the ScanNet input path,
+ * data/planercnn_transforms.py:314): OpenCV's 11-bit fixed-point algorithm (csrc/resize.hip). src [H][W][C], dst [OH][OW][C]. */
+int nopesac_resize_bilinear_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int OH, int OW, void* stream);
+
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
  * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)

@@ -1,0 +1,99 @@
+"""Inference-side counterpart of the reference's dataset plumbing:
+
+  * `SPLITS` / `load_pairs_json`   ~ data/datasets/builtin.py:15-51, data/datasets/mp3d.py:18-45 (the json's "data" list)
+  * `PairMapper`                   ~ data/planercnn_transforms.py:205-398 restricted to what inference reads: the two images of
+    a pair as float32 [3,H,W] tensors in cfg.INPUT.FORMAT channel order with values 0..255, file names / ids, `rel_pose`.
+    Matterport3D images are used as stored (:210-227); ScanNet images are resized to 640 x 480 (:312-314, cv2.resize =
+    8-bit INTER_LINEAR) - here on the GPU by `nopesac_resize_bilinear_u8` (csrc/resize.hip).
+Decoding is PIL on the host (the image has no GPU JPEG/PNG decoder; detectron2's `utils.read_image` is PIL too).  Ground-truth
+masks / depth / k-means pose classes are not read: nothing on the inference path consumes them.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+SPLITS = {   # builtin.py:15-21: name -> (root folder under ./datasets, annotation json)
+    "mp3d_val": ("mp3d_dataset", "mp3d_planercnn_json/cached_set_val.json"),
+    "mp3d_test": ("mp3d_dataset", "mp3d_planercnn_json/cached_set_test.json"),
+    "mp3d_train": ("mp3d_dataset", "mp3d_planercnn_json/cached_set_train.json"),
+    "scannet_train": ("scannet_dataset", "scannet_json/cached_set_trainV2.json"),
+    "scannet_test": ("scannet_dataset", "scannet_json/cached_set_testV2.json"),
+}
+MP3D_ORIGINAL_ROOT = "/Pool1/users/jinlinyi/dataset/mp3d_rpnet_v4_sep20/"   # prefix stored in the json (planercnn_transforms.py:213-214)
+
+
+def dataset_json(name: str, datasets_dir: str = "./datasets") -> str:
+    if name not in SPLITS:
+        raise KeyError(f"unknown dataset {name!r}; known: {sorted(SPLITS)}")
+    root, rel = SPLITS[name]
+    return os.path.join(datasets_dir, root, rel)
+
+
+def load_pairs_json(json_file: str) -> List[dict]:
+    """The reference's `load_mp3d_json`: the json's "data" list (one dict per image pair, no pixels)."""
+    with open(json_file, "r") as f:
+        summary = json.load(f)
+    if "data" not in summary:
+        raise ValueError(f"{json_file}: not a NopeSAC pair file (no 'data' list)")
+    return summary["data"]
+
+
+def read_image(path: str, fmt: str = "BGR") -> np.ndarray:
+    """detectron2 `utils.read_image`: uint8 [H,W,3] in `fmt` order (PIL decode, EXIF orientation ignored like d2 v0.4)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        arr = np.asarray(im.convert("RGB"))
+    if fmt == "BGR":
+        arr = arr[:, :, ::-1]
+    elif fmt != "RGB":
+        raise ValueError(f"unsupported INPUT.FORMAT {fmt!r}")
+    return np.ascontiguousarray(arr)
+
+
+class PairMapper:
+    """dataset dict -> model input dict (the `image` tensors stay on the host unless `device` is given, exactly like the
+    reference mapper's output; ScanNet images pass through the GPU resize kernel)."""
+
+    def __init__(self, cfg, dataset_name: str = "", device=None):
+        self.img_format = cfg.INPUT.FORMAT
+        self.root_dir = cfg.DATASETS.ROOT_DIR
+        name = dataset_name or (cfg.DATASETS.TEST[0] if len(cfg.DATASETS.TEST) else "")
+        self.scannet = "scannet" in name
+        self.device = device
+
+    def _image(self, path: str) -> torch.Tensor:
+        img = read_image(path, self.img_format)
+        if self.scannet and img.shape[:2] != (480, 640):
+            from . import ops
+            dev = self.device or torch.device("cuda", torch.cuda.current_device())
+            img_t = ops.resize_bilinear_u8(torch.from_numpy(img.copy()).to(dev), 480, 640)
+            t = img_t.permute(2, 0, 1).float()
+            return t if self.device is not None else t.cpu()
+        t = torch.as_tensor(img.transpose(2, 0, 1).astype("float32"))
+        return t.to(self.device) if self.device is not None else t
+
+    def __call__(self, dataset_dict: dict) -> dict:
+        d = copy.deepcopy(dataset_dict)
+        for v in "01":
+            if not self.scannet and self.root_dir:
+                d[v]["file_name"] = d[v]["file_name"].replace(MP3D_ORIGINAL_ROOT, self.root_dir)
+            d[v]["image"] = self._image(d[v]["file_name"])
+            h, w = d[v]["image"].shape[-2:]
+            if "height" in d[v] and (d[v]["height"], d[v]["width"]) != (h, w) and not self.scannet:
+                raise ValueError(f"{d[v]['file_name']}: image is {h}x{w}, annotation says {d[v]['height']}x{d[v]['width']}")
+            d[v]["height"], d[v]["width"] = h, w
+        return d
+
+
+def build_inference_pairs(cfg, dataset_name: str, datasets_dir: str = "./datasets", limit: int = 0, device=None) -> List[dict]:
+    pairs = load_pairs_json(dataset_json(dataset_name, datasets_dir))
+    if limit:
+        pairs = pairs[:limit]
+    mapper = PairMapper(cfg, dataset_name, device)
+    return [mapper(p) for p in pairs]

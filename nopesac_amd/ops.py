@@ -494,3 +494,12 @@ def encoder_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, pos=None, want=
                                         _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")), M, _stream())
     _lib.check(rc, "nopesac_encoder_tail_bf16")
     return out
+
+
+def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [H,W,C] (device) -> uint8 [out_h,out_w,C], cv2 INTER_LINEAR fixed-point semantics."""
+    _chk(img, torch.uint8)
+    H, W, C = img.shape
+    out = torch.empty((out_h, out_w, C), device=img.device, dtype=torch.uint8)
+    _lib.check(_L().nopesac_resize_bilinear_u8(_p(img), H, W, C, _p(out), out_h, out_w, _stream()), "nopesac_resize_bilinear_u8")
+    return out

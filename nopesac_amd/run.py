@@ -37,6 +37,10 @@ def default_argument_parser():
     ap.add_argument("--num-gpus", type=int, default=1)
     ap.add_argument("--pairs-per-batch", type=int, default=8)
     ap.add_argument("--pairs-file", default="", help="torch-saved list of input dicts (reference mapper format)")
+    ap.add_argument("--dataset", default="", help="registered split name (mp3d_test, scannet_test, ...): read <datasets-dir>/<split json> "
+                    "through the PairMapper (nopesac_amd/data.py); default = cfg.DATASETS.TEST[0] when its json exists")
+    ap.add_argument("--datasets-dir", default="./datasets")
+    ap.add_argument("--limit", type=int, default=0, help="use only the first N pairs of the dataset")
     ap.add_argument("--synthetic-pairs", type=int, default=0)
     ap.add_argument("--structured", action="store_true", help="structured synthetic images instead of noise")
     ap.add_argument("--synthetic-weights", action="store_true", help="name-seeded checkpoint instead of cfg.MODEL.WEIGHTS")
@@ -67,9 +71,14 @@ def load_checkpoint(model, cfg, synthetic: bool):
     return path
 
 
-def load_pairs(args):
+def load_pairs(args, cfg=None):
     if args.pairs_file:
         return torch.load(args.pairs_file)
+    name = args.dataset or (cfg.DATASETS.TEST[0] if cfg is not None and len(cfg.DATASETS.TEST) and not args.synthetic_pairs else "")
+    if name:
+        from . import data
+        if args.dataset or os.path.exists(data.dataset_json(name, args.datasets_dir)):
+            return data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit)
     n = args.synthetic_pairs or 8
     pairs = []
     for i in range(n):
@@ -108,7 +117,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
     model = build_model(cfg)
     src = load_checkpoint(model, cfg, args.synthetic_weights)
-    pairs = load_pairs(args)
+    pairs = load_pairs(args, cfg)
     lo, hi = runner.shard_range(len(pairs), rank, world)
     logger.info("rank %d/%d: weights=%s pairs [%d,%d) of %d", rank, world, src, lo, hi, len(pairs))
     evaluator = PoseEvaluator(keep_predictions=bool(args.dump_dir))

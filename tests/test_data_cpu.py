@@ -1,0 +1,86 @@
+"""Dataset plumbing on the host (no GPU): pair json loading, the Matterport3D mapper path (PIL decode, channel order, root
+replacement), and the invariants of the cv2-INTER_LINEAR restatement used for the ScanNet path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT
+
+
+def _cfg(extra=()):
+    from nopesac_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
+    cfg.merge_from_list(list(extra))
+    return cfg
+
+
+def _write_pair(tmp_path, shape=(480, 640)):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    files = []
+    for i in range(2):
+        arr = rng.integers(0, 256, (*shape, 3), dtype=np.uint8)
+        f = tmp_path / f"img{i}.png"
+        Image.fromarray(arr).save(f)
+        files.append((str(f), arr))
+    entry = {"0": {"file_name": files[0][0], "image_id": "house_0_1", "height": shape[0], "width": shape[1]},
+             "1": {"file_name": files[1][0], "image_id": "house_0_2", "height": shape[0], "width": shape[1]},
+             "rel_pose": {"position": [0.1, 0.2, 0.3], "rotation": [1.0, 0.0, 0.0, 0.0]}}
+    jf = tmp_path / "cached_set_test.json"
+    json.dump({"categories": [{"id": 1, "name": "plane"}], "data": [entry]}, open(jf, "w"))
+    return str(jf), files
+
+
+def test_splits_and_json(tmp_path):
+    from nopesac_amd import data
+    assert data.dataset_json("mp3d_test").endswith("mp3d_dataset/mp3d_planercnn_json/cached_set_test.json")
+    assert data.dataset_json("scannet_test", "/d").startswith("/d/scannet_dataset/scannet_json/")
+    with pytest.raises(KeyError):
+        data.dataset_json("coco")
+    jf, _ = _write_pair(tmp_path)
+    pairs = data.load_pairs_json(jf)
+    assert len(pairs) == 1 and pairs[0]["rel_pose"]["rotation"][0] == 1.0
+    bad = tmp_path / "bad.json"
+    json.dump({"images": []}, open(bad, "w"))
+    with pytest.raises(ValueError):
+        data.load_pairs_json(str(bad))
+
+
+def test_mp3d_mapper(tmp_path):
+    from nopesac_amd import data
+    jf, files = _write_pair(tmp_path)
+    entry = data.load_pairs_json(jf)[0]
+    out = data.PairMapper(_cfg(), "mp3d_test")(entry)                       # configs/Base.yaml: INPUT.FORMAT = RGB
+    for v in "01":
+        img = out[v]["image"]
+        assert img.dtype == torch.float32 and img.shape == (3, 480, 640) and not img.is_cuda
+        assert torch.equal(img, torch.from_numpy(files[int(v)][1].transpose(2, 0, 1).astype("float32")))
+    assert "image" not in entry["0"] and out["rel_pose"] == entry["rel_pose"]            # deep copy, pose passed through
+    bgr = data.PairMapper(_cfg(["INPUT.FORMAT", "BGR"]), "mp3d_test")(entry)
+    assert torch.equal(bgr["0"]["image"], out["0"]["image"].flip(0))
+    moved = dict(entry, **{"0": dict(entry["0"], file_name=data.MP3D_ORIGINAL_ROOT + "x.png")})
+    with pytest.raises(FileNotFoundError):
+        data.PairMapper(_cfg(["DATASETS.ROOT_DIR", str(tmp_path) + "/"]), "mp3d_test")(moved)   # prefix replaced -> tmp_path/x.png
+    wrong = dict(entry, **{"0": dict(entry["0"], height=100)})
+    with pytest.raises(ValueError):
+        data.PairMapper(_cfg(), "mp3d_test")(wrong)
+
+
+def test_resize_oracle_invariants():
+    from oracle.resize_oracle import resize_bilinear_u8
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (31, 45, 3), dtype=np.uint8)
+    assert np.array_equal(resize_bilinear_u8(img, 31, 45), img)                          # same size: identity
+    const = np.full((20, 30, 3), 137, np.uint8)
+    assert np.array_equal(resize_bilinear_u8(const, 48, 64), const[:1, :1].repeat(48, 0).repeat(64, 1))
+    up = resize_bilinear_u8(img, 62, 90)                                                 # exact 2x: each output is a 1/4-3/4 blend
+    assert up.shape == (62, 90, 3) and int(up.min()) >= int(img.min()) and int(up.max()) <= int(img.max())
+    ramp = np.tile(np.arange(0, 200, 4, dtype=np.uint8)[None, :, None], (8, 1, 3))       # horizontal ramp, 50 px -> 100 px
+    r2 = resize_bilinear_u8(ramp, 8, 100).astype(int)
+    assert np.all(np.diff(r2[0, :, 0]) >= 0) and abs(int(r2[0, 50, 0]) - 99) <= 2        # monotone, midpoint preserved
+    half = resize_bilinear_u8(np.array([[[0], [100]], [[200], [60]]], np.uint8).repeat(1, 2), 1, 1)
+    assert int(half[0, 0, 0]) == 90                                                      # 2x2 -> 1x1: the mean of the four

@@ -1,6 +1,8 @@
 """HIP kernels (through the C ABI) vs plain PyTorch fp32 CPU references of the same op."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 from torch.nn import functional as F
@@ -341,3 +343,37 @@ def test_encoder_tail(device, M):
     assert _rel(out["y"], ref["y"]) < 5e-3
     assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2
     assert float((out["y"] - ref["y"]).abs().mean()) < 2e-4 * float(ref["y"].abs().mean() + 1)
+
+
+@pytest.mark.parametrize("H,W,OH,OW", [(968, 1296, 480, 640), (480, 640, 480, 640), (37, 53, 48, 64), (1000, 700, 480, 640)])
+def test_resize_bilinear_u8(device, H, W, OH, OW):
+    """ScanNet input resize (cv2 INTER_LINEAR, 8-bit fixed point) vs the numpy restatement: bit-exact."""
+    from nopesac_amd import ops
+    from oracle.resize_oracle import resize_bilinear_u8
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    out = ops.resize_bilinear_u8(torch.from_numpy(img).to(device), OH, OW).cpu().numpy()
+    assert np.array_equal(out, resize_bilinear_u8(img, OH, OW))
+
+
+def test_scannet_mapper_resizes_on_gpu(device, tmp_path):
+    from PIL import Image
+    from nopesac_amd import data
+    from nopesac_amd.config import get_cfg
+    from oracle.resize_oracle import resize_bilinear_u8
+    from tests.util import ROOT
+    import os
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_scannet.yaml"))
+    rng = np.random.default_rng(3)
+    entry = {}
+    arrs = []
+    for v in "01":
+        arr = rng.integers(0, 256, (968, 1296, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(tmp_path / f"{v}.png")
+        arrs.append(arr)
+        entry[v] = {"file_name": str(tmp_path / f"{v}.png"), "image_id": f"0-{v}"}
+    out = data.PairMapper(cfg, "scannet_test")(entry)
+    for v in "01":
+        ref = resize_bilinear_u8(arrs[int(v)], 480, 640).transpose(2, 0, 1).astype("float32")
+        assert out[v]["image"].shape == (3, 480, 640) and np.array_equal(out[v]["image"].numpy(), ref)
