@@ -26,6 +26,8 @@ CAM_MODES = {"soft": 0, "avg-all": 1, "min-cost": 2, "max-score": 3}
 
 @CAMERA_HEAD_REGISTRY.register()
 class PlaneCameraHead(ParamModule):
+    CORR_PAD = 304      # 15 x 20 = 300 correlation channels at 480 x 640, padded to a multiple of 8
+
     def __init__(self, cfg, input_shape=None):
         C = cfg.MODEL.CAMERA_HEAD
         self.num_queries = cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES
@@ -51,7 +53,9 @@ class PlaneCameraHead(ParamModule):
             P[f"cb{i}"] = conv_bn(self, f"convs_backbone.{i}.0.weight", f"convs_backbone.{i}.1", 1e-3)
         for br in ("convs_trans", "convs_rots"):
             for i in range(6):
-                P[f"{br}.{i}"] = conv_bn(self, f"{br}.{i}.0.weight", f"{br}.{i}.1", 1e-3)
+                # the first conv reads the 300-channel correlation volume: pad Cin to 304 (zeros) so its im2col rows are
+                # 8-element aligned and the vector / MFMA-friendly staging path applies
+                P[f"{br}.{i}"] = conv_bn(self, f"{br}.{i}.0.weight", f"{br}.{i}.1", 1e-3, cin_pad=self.CORR_PAD if i == 0 else 0)
         for nm in ("fc_trans", "fc_rots"):
             # the reference flattens NCHW (128,2,3) -> index c*6+hw; our activations are NHWC -> hw*128+c
             w = self.raw(nm + ".weight").float().view(256, 128, 6).permute(0, 2, 1).reshape(256, 768)
@@ -96,6 +100,10 @@ class PlaneCameraHead(ParamModule):
         x2t = ops.transpose_hw_rows(x2.reshape(B, h * w, 256), h, w)
         corr = ops.conv2d(x1, x2t.view(B, h * w, 1, 1, 256), batched_weights=True)          # [B,h,w,h*w]
         aff = ops.softmax_rows(corr)
+        if (h * w) % 8:                                  # zero-padded channels (see pack): 300 -> 304
+            aff_p = torch.zeros(B, h, w, self.CORR_PAD, device=aff.device, dtype=aff.dtype)
+            aff_p[..., :h * w] = aff
+            aff = aff_p
 
         def branch(name, fc):
             t = aff
