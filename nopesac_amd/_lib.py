@@ -72,6 +72,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -m nopesac_amd.build` "
             "(needs hipcc for gfx950).  nopesac_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; whichever copy is loaded first serves the whole process.  Import torch first so
+    # that this library (linked against the same SONAME) shares torch's runtime, streams and device context - loading the
+    # system copy first leaves the kernels of this library without a device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -120,3 +120,14 @@ def test_e2e_more_queries(device, nq):
     res = model(inp)
     ref = O.inference(synth_state_dict(nq), inp, O.OracleConfig(num_queries=nq))
     _check_pair(res[0], ref[0])
+
+
+def test_graft_entry_build_then_smoke_in_one_process():
+    """build() loads the C-ABI library before anything touched torch.cuda; smoke() must still find the device (the library
+    has to share PyTorch's bundled HIP runtime, see nopesac_amd/_lib.py::load)."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('SMOKE-OK')"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SMOKE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
