@@ -281,6 +281,15 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
                            const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
                            const float* ln2_g, const float* ln2_b, void* stream);
 
+/* Finest top-down level + mask head of the PlaneTR head in one launch (planeTR_head.py:148-162, 241-252), bf16:
+ *   p1 = relu(scale * (w_lateral . c1) + bias) + relu(bilinear_2x(t1));   prob = [sigmoid](mask_w[b] . p1 + mask_b[b])
+ * c1 [B,H,W,256], t1 [B,H/2,W/2,256] bf16; w_lateral [256][256] and mask_w [B][64][256] (rows >= nq zero) bf16 in MFMA
+ * fragment-major order; mask_b f32 [B][64]; prob f32 [B,H,W,nq] (nq even, <= 64); p1_out optional bf16 [B,H,W,256].
+ * H*W must be a multiple of 128. */
+int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
+                           const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
+                           int apply_sigmoid, void* stream);
+
 /* Tail of one post-norm transformer encoder layer (transformer/transformer.py:183-199) for M tokens of width 256, FFN 1024:
  *   y1 = LN1(src + attn . wo^T + bo);  y2 = LN2(y1 + relu(y1 . w1^T + b1) . w2^T + b2)
  * attn bf16 [M][256] (attention output), src f32 [M][256]; wo [256][256], w1 [1024][256], w2 [256][1024] bf16 in MFMA

@@ -27,6 +27,7 @@ SIGNATURES = {
     "nopesac_gnn_layer_bf16": [P, I, P, I, P, I, I, I, P, P] + [P] * 10 + [P],
     "nopesac_encoder_tail_bf16": [P] * 13 + [I] + [P] * 3 + [I, P],
     "nopesac_resize_bilinear_u8": [P, I, I, I, P, I, I, P],
+    "nopesac_mask_head_bf16": [P] * 9 + [I] * 5 + [P],
     "nopesac_rle_labels": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_rle_transitions": [P, P, P, P, P, I, I, I, P],
     "nopesac_rle_compress_host": [P, I, I, I, P, I, P],

@@ -1,0 +1,178 @@
+// Finest level of the PlaneTR top-down path and the per-plane mask head in ONE launch (bf16 mode;
+// planeTR_net/planeTR_head.py:148-162 mask einsum, :241-252 top_down):
+//
+//     p1[px]   = relu(bn(W_c1 . c1[px])) + relu(bilinear_2x(t1)[px])       c1 = res2 map (120x160x256), t1 = up_conv1 output (60x80)
+//     mask[px] = sigmoid(M_b . p1[px] + m_b)                               M_b = per-image 50x256 mask weights (pixel-embedding conv
+//                                                                          already folded in, see modeling/plane_head.py)
+// Un-fused: lateral conv (629 MB in, 629 MB out), bilinear add (629 + 629 MB), mask GEMM (629 MB in): 3.4 GB per step for a
+// tensor nobody else reads.  Here a workgroup (8 waves) owns 128 consecutive pixels of one image: the c1 rows are parked in
+// LDS, the lateral GEMM streams W_c1 fragment-major from L2 (pwchain.hip), the up-sampling term is added cooperatively
+// (16-byte channel chunks, 4 taps from the L2-resident low-resolution map), p1 stays in LDS as the A operand of the mask GEMM,
+// and the 128 x 50 probabilities leave as one contiguous 25 KB run.  HBM: 629 MB in + 246 MB out.
+#include "common.h"
+
+namespace nps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+
+constexpr int MH_C = 256, MH_LD = MH_C + 8, MH_BM = 128, MH_RT = MH_BM / 32, MH_NQP = 64;
+constexpr size_t MH_LDS_BYTES = 2 * (size_t)(2 * MH_BM * MH_LD);
+static_assert((size_t)MH_BM * MH_NQP * 4 <= 2 * (size_t)MH_BM * MH_LD, "output staging must fit the A tile");
+
+struct MaskHeadArgs {
+    const bf16_t* c1; const bf16_t* t1;          // [B][H][W][256], [B][H/2][W/2][256]
+    const bf16_t* wc; const float* sc; const float* bc;   // lateral conv (fragment-major) + folded BN
+    const bf16_t* mw; const float* mb;           // [B][64][256] fragment-major per image (rows >= nq zero), [B][64]
+    float* prob; bf16_t* p1;                     // [B][H][W][nq] f32; optional [B][H][W][256] bf16
+    int B, H, W, nq, apply_sigmoid;
+};
+
+__global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mh_smem[];
+    bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem);         // c1 rows; later the f32 output staging
+    bf16_t* Pt = At + MH_BM * MH_LD;                         // lateral -> p1
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = p.H * p.W;
+    const long long m0 = (long long)blockIdx.x * MH_BM;      // per % 128 == 0: a workgroup never straddles two images
+    const int b = (int)(m0 / per), pix0 = (int)(m0 % per);
+
+    // weight fragments: lateral tile `wave` (16 k-steps) and this wave's mask tile (tile wave&1 of image b)
+    bf16x8 wl[16], wm[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) wl[kk] = *reinterpret_cast<const bf16x8*>(p.wc + ((long long)(wave * 16 + kk) * 64 + lane) * 8);
+    // c1 rows -> LDS
+#pragma unroll
+    for (int i = 0; i < MH_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        *reinterpret_cast<us8*>(At + r * MH_LD + col) = *reinterpret_cast<const us8*>(p.c1 + (m0 + r) * MH_C + col);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        wm[kk] = *reinterpret_cast<const bf16x8*>(p.mw + (((long long)b * 2 + (wave & 1)) * 16 + kk) * 512 + lane * 8);
+    __syncthreads();
+
+    // ---- lateral = relu(bn(W_c1 c1)): wave owns channels wave*32 .. +32 of all four 32-pixel row tiles
+    {
+        f32x16 acc[MH_RT];
+#pragma unroll
+        for (int r = 0; r < MH_RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int r = 0; r < MH_RT; ++r) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kk], af, acc[r], 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = wave * 32 + 8 * q + 4 * half;
+            const f32x4 s = *reinterpret_cast<const f32x4*>(p.sc + n), bb = *reinterpret_cast<const f32x4*>(p.bc + n);
+#pragma unroll
+            for (int r = 0; r < MH_RT; ++r) {
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][4 * q + e] * s[e];
+                    v += bb[e];
+                    o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(Pt + (r * 32 + l31) * MH_LD + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- p1 = lateral + relu(bilinear_2x(t1)): thread = (pixel, 8-channel chunk); F.interpolate align_corners=False
+    {
+        const int H2 = p.H >> 1, W2 = p.W >> 1;
+        const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
+#pragma unroll 2
+        for (int i = 0; i < MH_BM * 32 / 512; ++i) {
+            const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+            const int pix = pix0 + r, oh = pix / p.W, ow = pix % p.W;
+            const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H2 - 1), x1 = min(x0 + 1, W2 - 1);
+            const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+            const us8 v00 = *reinterpret_cast<const us8*>(tb + ((long long)y0 * W2 + x0) * MH_C + col);
+            const us8 v01 = *reinterpret_cast<const us8*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
+            const us8 v10 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
+            const us8 v11 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
+            us8 l8 = *reinterpret_cast<const us8*>(Pt + r * MH_LD + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float u = hy * (hx * bf16_to_f32(v00[e]) + lx * bf16_to_f32(v01[e])) + ly * (hx * bf16_to_f32(v10[e]) + lx * bf16_to_f32(v11[e]));
+                u = u > 0.f ? u : 0.f;
+                l8[e] = f32_to_bf16(u + bf16_to_f32(l8[e]));
+            }
+            *reinterpret_cast<us8*>(Pt + r * MH_LD + col) = l8;
+            if (p.p1) *reinterpret_cast<us8*>(p.p1 + (m0 + r) * MH_C + col) = l8;
+        }
+    }
+    __syncthreads();
+
+    // ---- mask logits: 64 (padded) planes = 2 column tiles x 4 row tiles = 8 (tile, rows) pairs, one per wave
+    {
+        const int nt = wave & 1, r = wave >> 1;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Pt + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kk], af, acc, 0, 0, 0);
+        }
+        float* St = reinterpret_cast<float*>(At);            // [128][nq] f32 (the c1 tile is dead: all waves passed two barriers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = nt * 32 + 8 * q + 4 * half;
+            const f32x4 mbv = *reinterpret_cast<const f32x4*>(p.mb + (long long)b * MH_NQP + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < p.nq) {
+                    float v = acc[4 * q + e] + mbv[e];
+                    if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+                    St[(r * 32 + l31) * p.nq + n + e] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float* St = reinterpret_cast<const float*>(At);
+        float* og = p.prob + m0 * p.nq;                       // 128 * nq floats, contiguous; 16-byte aligned when nq % 2 == 0 (m0 % 128 == 0)
+        const int total4 = MH_BM * p.nq / 4;
+        for (int i = tid; i < total4; i += 512) *reinterpret_cast<f32x4*>(og + 4 * i) = *reinterpret_cast<const f32x4*>(St + 4 * i);
+    }
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
+                                      const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
+                                      int apply_sigmoid, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(c1 && t1 && w_lateral && scale && bias && mask_w && mask_b && prob, "mask_head: null pointer");
+    NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && (H * W) % MH_BM == 0, "mask_head: H*W must be a multiple of 128, H and W even");
+    NPS_CHECK_ARG(nq > 0 && nq <= MH_NQP && nq % 2 == 0, "mask_head: nq must be even and <= 64");
+    const void* ptrs[] = {c1, t1, w_lateral, scale, bias, mask_w, mask_b, prob, p1_out};
+    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "mask_head: pointers must be 16-byte aligned");
+    MaskHeadArgs a;
+    a.c1 = (const bf16_t*)c1; a.t1 = (const bf16_t*)t1; a.wc = (const bf16_t*)w_lateral; a.sc = scale; a.bc = bias;
+    a.mw = (const bf16_t*)mask_w; a.mb = mask_b; a.prob = prob; a.p1 = (bf16_t*)p1_out;
+    a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mask_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MH_LDS_BYTES);
+        attr_set = true;
+    }
+    const long long blocks = (long long)B * H * W / MH_BM;
+    hipLaunchKernelGGL(mask_head_kernel, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+    NPS_LAUNCH_RET();
+}

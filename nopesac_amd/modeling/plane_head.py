@@ -55,6 +55,7 @@ class PlaneTRHead(ParamModule):
         super().__init__(spec)
         self._pos_cache = {}
         self.fused_encoder_tail = True
+        self.fused_mask_head = True
 
     # ---------------------------------------------------------------- packing
     def _mha(self, prefix: str, fuse_qk: bool):
@@ -259,19 +260,30 @@ class PlaneTRHead(ParamModule):
 
         p3 = up_stage(p4, "up_conv3", cbr(c3, "c3_conv"))
         p2 = up_stage(p3, "up_conv2", cbr(c2, "c2_conv"))
-        p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
-        mark("ph.top_down")
-        # ---- instance heads
         emb = run_mlp(hs, P["plane_embedding"], gd=gd)                                    # [B*nq, 256]
         fold = ops.linear(emb, P["pe_fold"].w2d(gd))                                      # [B*nq, 264]: mask weights | bias | pad
-        mw = fold[:, :256].to(cd).contiguous().view(B, nq, 1, 1, 256)
-        mb = fold[:, 256].contiguous().view(B, nq)
-        out = {
+        heads = {
             "pred_logits": ops.linear(hs, P["plane_prob"].w2d(gd), P["plane_prob"].bias).view(B, nq, 2),
             "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
             "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
-            "mask_prob": ops.conv2d(p1, mw, None, mb, batched_weights=True, act=ops.ACT_SIGMOID, out_dtype=torch.float32),
         }
+        h1, w1 = c1.shape[1], c1.shape[2]
+        if (self.fused_mask_head and cd == torch.bfloat16 and not want_logits and nq <= 64 and nq % 2 == 0 and (h1 * w1) % 128 == 0):
+            # finest lateral conv + bilinear add + mask GEMM in one launch: p1 never goes to HBM (csrc/mask_head.hip)
+            c = P["up_conv1"]
+            t1 = ops.conv2d(p2, c.w(cd), c.scale, c.bias, act=ops.ACT_NONE)
+            l = P["c1_conv"]
+            mark("ph.top_down")
+            heads["mask_prob"] = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, fold[:, :256].view(B, nq, 256),
+                                               fold[:, 256].contiguous().view(B, nq))
+            return heads, hs.view(B, nq, 256)
+        p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
+        mark("ph.top_down")
+        # ---- instance heads
+        mw = fold[:, :256].to(cd).contiguous().view(B, nq, 1, 1, 256)
+        mb = fold[:, 256].contiguous().view(B, nq)
+        out = dict(heads)
+        out["mask_prob"] = ops.conv2d(p1, mw, None, mb, batched_weights=True, act=ops.ACT_SIGMOID, out_dtype=torch.float32)
         if want_logits:
             out["pred_mask_logits"] = ops.conv2d(p1, mw, None, mb, batched_weights=True, out_dtype=torch.float32)
             pc = P["pixel_plane_center"]

@@ -503,3 +503,24 @@ def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tenso
     out = torch.empty((out_h, out_w, C), device=img.device, dtype=torch.uint8)
     _lib.check(_L().nopesac_resize_bilinear_u8(_p(img), H, W, C, _p(out), out_h, out_w, _stream()), "nopesac_resize_bilinear_u8")
     return out
+
+
+def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scale, bias, mask_w: torch.Tensor, mask_b: torch.Tensor,
+              sigmoid: bool = True, want_p1: bool = False):
+    """Fused lateral conv + bilinear add + per-image mask GEMM (csrc/mask_head.hip).  c1 [B,H,W,256] / t1 [B,H/2,W/2,256] bf16;
+    mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] (and p1 bf16 if asked)."""
+    _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
+    B, H, W, C = c1.shape
+    nq = mask_w.shape[1]
+    assert C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0
+    mw = torch.zeros(B, 64, 256, device=c1.device, dtype=torch.bfloat16)
+    mw[:, :nq] = mask_w
+    mw = mw.view(B, 2, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()          # per-image MFMA fragment-major
+    mb = torch.zeros(B, 64, device=c1.device, dtype=torch.float32)
+    mb[:, :nq] = mask_b
+    prob = torch.empty(B, H, W, nq, device=c1.device, dtype=torch.float32)
+    p1 = torch.empty(B, H, W, 256, device=c1.device, dtype=torch.bfloat16) if want_p1 else None
+    rc = _L().nopesac_mask_head_bf16(_p(c1), _p(t1), _p(w_lat_frag), _p(scale), _p(bias), _p(mw), _p(mb), _p(prob), _p(p1), B, H, W, nq,
+                                     int(sigmoid), _stream())
+    _lib.check(rc, "nopesac_mask_head_bf16")
+    return (prob, p1) if want_p1 else prob

@@ -249,3 +249,21 @@ def test_fused_gnn_layers_match_per_launch_bf16_path(device):
             assert rel_err(d[b, :n], r[b, :n]) < 6e-2
     assert worst_fused < 1.25 * worst_plain + 5e-3, (worst_fused, worst_plain)
     assert torch.isfinite(d0).all() and torch.isfinite(d1).all()
+
+
+def test_fused_mask_head_matches_per_layer_bf16_path(device):
+    """bf16 mode: lateral conv + bilinear add + mask GEMM in one launch (csrc/mask_head.hip) vs the per-layer kernels."""
+    model = make_model(device, dtype="bfloat16")
+    head = model.sem_seg_head
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    feats = {"res2": torch.randn(B, 120, 160, 256, generator=g), "res3": torch.randn(B, 60, 80, 512, generator=g),
+             "res4": torch.randn(B, 30, 40, 1024, generator=g), "res5": torch.randn(B, 15, 20, 2048, generator=g)}
+    feats = {k: (0.5 * v).to(device, torch.bfloat16) for k, v in feats.items()}
+    head.fused_mask_head = True
+    a, qa = head(feats)
+    head.fused_mask_head = False
+    b, qb = head(feats)
+    head.fused_mask_head = True
+    assert torch.equal(qa, qb) and a["mask_prob"].shape == (B, 120, 160, 50)
+    assert float((a["mask_prob"] - b["mask_prob"]).abs().max()) < 2e-3
