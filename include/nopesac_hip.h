@@ -84,6 +84,15 @@ int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, con
                            int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int64_t w_bstride,
                            int act, int in_dt, int out_dt, int kernel_cfg, void* stream);
 
+/* bf16 conv with the weights in MFMA FRAGMENT-MAJOR order ([Cout][KH*KW*Cin] re-ordered as in nopesac_bottleneck_tail_bf16):
+ * activations go through a 3-deep LDS-DMA ring (variant 3: K-tile 64, 3 workgroups/CU; variant 32: K-tile 32, 4 workgroups/CU),
+ * every wave streams the weight fragments of its own 32 output channels from L2 (csrc/conv_igemm.hip, conv_igemm_bfrag_kernel).  Same semantics as nopesac_conv2d_nhwc for x / w bf16;
+ * needs Cin % 64 == 0, Cout % 128 == 0; act may carry NPS_ACT_RES_AFTER. */
+int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,
+                              void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                              int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
+                              void* stream);
+
 /* Fused bf16 ResNet stem: y = maxpool3x3/s2/p1( relu( bn( conv7x7/s2/p3(x) ) ) ) in one kernel (d2 BasicStem).
  *   x bf16 NHWC [B,H,W,4] (RGB + zero pad channel); w bf16 [64][7][8][4] (kw padded 7 -> 8 with zeros, i.e. 224 per
  *   output channel); scale/bias f32[64] (folded FrozenBN); y bf16 NHWC [B,PH,PW,64]. */

@@ -45,11 +45,11 @@ template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<float, 1> { typedef float type; };
 
 // Shared epilogue (see the comment inside): acc -> LDS (f32) -> 8-channel chunks -> scale/shift/residual/act -> store.
-template <int BM, int BN, int TM, int TN, int WAVES_M = 2>
+template <int BM, int BN, int TM, int TN, int WAVES_M = 2, int WAVES_N = 2>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi, int lds_bytes, const ConvParams& p, int m0, int n0,
                                               int bz, int wm, int wn, int lane, int tid) {
-    constexpr int WM = BM / WAVES_M, WN = BN / 2;
-    constexpr int NTHREADS = WAVES_M * 2 * 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
     // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
     // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
     // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
@@ -491,6 +491,147 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? (BKT
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// "A through LDS, B from L2" variant (bf16, Cin % 64 == 0, N % 128 == 0).  PMC on the kernel above shows the waves parked 40 %
+// of the time at the barrier that waits for the next K-tile's DMAs: with 128x128 tiles and both operands in LDS, only ONE tile
+// of prefetch fits at 2 workgroups/CU, and one tile of MFMA work (512 cycles per wave) does not cover the ~2 us DMA latency.
+// Here only the activation tile goes through LDS (16 KB per stage -> a 3-deep ring at 3 workgroups per CU; a 4-deep ring at 2
+// workgroups per CU measured slower; K-tile 32 at 4 workgroups per CU wins on the bandwidth-leaning 1x1 layers); the weights are
+// pre-permuted to MFMA fragment-major order and each wave streams the fragments of ITS OWN 32 output channels straight from
+// L2 into a two-deep register ring (wave tile = 128 pixels x 32 channels: no weight fragment is fetched twice in a workgroup,
+// every load is 1 KB contiguous).  vmcnt is counted (DMAs and fragment loads retire in issue order): at the top of K-tile j
+// only "everything up to B(j)" has to be back, A(j+1..) and B(j+1) stay in flight across the barrier.
+template <int NSTAGE, int BKT = 64>
+__global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void conv_igemm_bfrag_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef bf16_t T;
+    constexpr int BM = 128, BN = 128, BK = BKT, ROWB = BK * 2, CPR = BK / 8, RPD = 64 / CPR, SWSH = BK == 64 ? 1 : 2;
+    constexpr int KF = BK / 16;                                 // weight fragments (k16 steps) per K-tile
+    constexpr int A_BYTES = BM * ROWB;                          // 16 (8) KB per stage
+    constexpr int TM = 4, A_DMA = BM / RPD / 4;                 // 4 (2) DMAs per wave per K-tile
+    constexpr int EPI_BYTES = BM * (64 + 4) * 4;
+    constexpr int LDS_BYTES = NSTAGE * A_BYTES > EPI_BYTES ? NSTAGE * A_BYTES : EPI_BYTES;
+    constexpr int DA = NSTAGE - 1;                              // A tiles issued ahead of the one being consumed
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, within = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int slot = lane % CPR, rsub = lane / CPR;
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const long long padb = ((long long)p.pad * p.W + p.pad) * p.x_cs * 2;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.x - padb), 0, (int)(((long long)p.B * p.H * p.W * p.x_cs) * 2 + padb), 0x00020000);
+    unsigned a_voff[A_DMA], a_mask[A_DMA];
+#pragma unroll
+    for (int j = 0; j < A_DMA; ++j) {
+        const int pr = (wave * A_DMA + j) * RPD + rsub;
+        const int m = m0 + pr;
+        const int coff = (slot ^ ((pr >> SWSH) & (CPR - 1))) * 8;
+        a_voff[j] = OOB; a_mask[j] = 0u;
+        if (m < p.M) {
+            const int b = m / p.rows_per_b, rem = m % p.rows_per_b;
+            const int oh = rem / p.OW, ow = rem % p.OW;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            a_voff[j] = (unsigned)((((long long)b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + coff) * 2u;
+            unsigned mk = 0u;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= 1u << (kh * p.KW + kw);
+            a_mask[j] = mk;
+        }
+    }
+    int cur_tap = 0, cur_kw = 0, cur_c0 = 0;
+    unsigned cur_tapoff = 0u;
+    auto issue_a = [&](int stage) {
+        unsigned char* sbase = lds + stage * A_BYTES;
+        const unsigned a_soff = cur_tapoff + (unsigned)cur_c0 * 2u;
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) {
+            const unsigned vo = ((a_mask[j] >> cur_tap) & 1u) ? a_voff[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)(sbase + (wave * A_DMA + j) * 1024), 16, vo, a_soff, 0, 0);
+        }
+        cur_c0 += BK;
+        if (cur_c0 >= p.Cin) {
+            cur_c0 = 0; ++cur_tap; ++cur_kw;
+            cur_tapoff += (unsigned)p.x_cs * 2u;
+            if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * 2u; }
+        }
+    };
+    // this wave's weight fragments: column tile n0/32 + wave, fragment-major [N/32][K/16][64][8]
+    const int nk = p.K / BK, kf_total = p.K / 16;
+    const T* wfr = (const T*)p.w + ((long long)(n0 / 32 + wave) * kf_total * 64 + lane) * 8;
+    bf16x8 bring[2][KF];
+    auto load_b = [&](int kt, int buf, int kk) { bring[buf][kk] = *(const bf16x8*)(wfr + (long long)(kt * KF + kk) * 512); };
+
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int sw = (lane >> SWSH) & (CPR - 1);
+    const int a_row_off = (lane & 31) * ROWB;
+
+    // prologue: B(0), A(0..DA-1), B(1)
+#pragma unroll
+    for (int kk = 0; kk < KF; ++kk) load_b(0, 0, kk);
+    for (int t = 0; t < DA; ++t)
+        if (t < nk) issue_a(t);
+    if (nk > 1) {
+#pragma unroll
+        for (int kk = 0; kk < KF; ++kk) load_b(1, 1, kk);
+    }
+    // steady state per K-tile j (buf = j & 1): newer than B(j) are A(j+DA-1)?.. see the counts below
+    auto step = [&](int j, int buf, int stage_j) {
+        // outstanding-op budget when tile j is needed: B(j+1) (4 ops) + the A tiles issued after B(j)
+        //   issue order: ... B(j) | A(j+DA-1)* | B(j+1) | A(j+DA) ...   (* issued at the top of iteration j-1, after its barrier)
+        // => ops newer than B(j): A_DMA (A(j+DA-1)) + KF (B(j+1)), fewer near the tail.
+        const int rem = nk - 1 - j;                          // tiles after j
+        if (rem >= 1 && j + DA - 1 < nk && j >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_DMA + KF) : "memory");
+        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KF) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave's piece of A(j) landed; everyone left tile j-1's stage
+        asm volatile("" ::: "memory");
+        if (j + DA < nk) {
+            int st = stage_j + DA;
+            if (st >= NSTAGE) st -= NSTAGE;
+            issue_a(st);                                     // A(j+DA) into the stage tile j-1 just vacated
+        }
+        const unsigned char* sb = lds + stage_j * A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KF; ++kk) {
+            const int so = ((kk * 2 + (lane >> 5)) ^ sw) * 16;
+            bf16x8 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * ROWB + so);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bring[buf][kk], af[i], acc[i][0], 0, 0, 0);
+            if (j + 2 < nk) load_b(j + 2, buf, kk);          // refill the slot that was just consumed
+        }
+    };
+    {
+        int stage = 0, j = 0;
+        for (; j + 1 < nk; j += 2) {
+            step(j, 0, stage);
+            if (++stage == NSTAGE) stage = 0;
+            step(j + 1, 1, stage);
+            if (++stage == NSTAGE) stage = 0;
+        }
+        if (j < nk) step(j, 0, stage);
+        __syncthreads();
+    }
+    conv_epilogue<BM, BN, TM, 1, 1, 4>(acc, reinterpret_cast<float*>(lds), LDS_BYTES, p, m0, n0, 0, 0, wave, lane, tid);
+#endif
+}
+
 template <typename TA, typename T, int BM, int BN>
 static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
     ConvParams p = p0;
@@ -639,5 +780,51 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
     if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t, bf16_t>(p, (hipStream_t)stream);
     else if (in_dt == NPS_DT_F32_BF16W) launch_dtype<float, bf16_t>(p, (hipStream_t)stream);
     else launch_dtype<float, float>(p, (hipStream_t)stream);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,
+                                         void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                         int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int nstage,
+                                         void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && w_frag && y, "conv2d_bfrag: null pointer");
+    NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_bfrag: bad dims");
+    NPS_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 128 == 0, "conv2d_bfrag: needs Cin %% 64 == 0 and Cout %% 128 == 0");
+    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d_bfrag: bad out_dt %d", out_dt);
+    NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (3-stage ring, K-tile 32)");
+    NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % 8 == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_frag % 16 == 0),
+                  "conv2d_bfrag: strides / alignment");
+    NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d_bfrag: residual stride");
+    const int res_after = (act & NPS_ACT_RES_AFTER) ? 1 : 0;
+    NPS_CHECK_ARG((act & ~(0xff | NPS_ACT_RES_AFTER)) == 0, "conv2d_bfrag: unsupported act flags");
+    act &= 0xff;
+    NPS_CHECK_ARG(act >= 0 && act <= 3, "conv2d_bfrag: bad act %d", act);
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w_frag; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.OH = (H + 2 * pad - KH) / stride + 1;
+    p.OW = (W + 2 * pad - KW) / stride + 1;
+    NPS_CHECK_ARG(p.OH > 0 && p.OW > 0, "conv2d_bfrag: empty output");
+    p.x_cs = x_cstride; p.y_cs = y_cstride; p.r_cs = r_cstride; p.w_bs = 0;
+    p.rows_per_b = p.OH * p.OW;
+    p.batched = 0;
+    p.M = B * p.rows_per_b; p.N = Cout; p.K = KH * KW * Cin;
+    p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    NPS_CHECK_ARG((long long)B * H * W * x_cstride * 2 + ((long long)pad * W + pad) * x_cstride * 2 < (1ll << 31), "conv2d_bfrag: input larger than 2 GB");
+    {
+        const int al = out_dt == NPS_DT_F32 ? 4 : 8;
+        bool ok = (y_cstride % al == 0) && ((uintptr_t)y % 16 == 0);
+        if (residual) ok = ok && (r_cstride % al == 0) && ((uintptr_t)residual % 16 == 0);
+        if (scale) ok = ok && ((uintptr_t)scale % 16 == 0);
+        if (bias) ok = ok && ((uintptr_t)bias % 16 == 0);
+        p.epi_vec = ok ? 1 : 0;
+    }
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = p.N / 128;
+    const dim3 grid(p.tiles_m * p.tiles_n);
+    if (nstage == 3) hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
     NPS_LAUNCH_RET();
 }

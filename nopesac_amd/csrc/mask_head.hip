@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
     {
         const int H2 = p.H >> 1, W2 = p.W >> 1;
         const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < MH_BM * 32 / 512; ++i) {
             const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
             const int pix = pix0 + r, oh = pix / p.W, ow = pix % p.W;

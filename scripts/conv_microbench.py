@@ -45,18 +45,35 @@ def main():
         os.environ["NOPESAC_CONV_FORCE"] = "t128"
         ref = ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU).float()
         for m in modes:
-            if m:
-                os.environ["NOPESAC_CONV_FORCE"] = m
+            if m.startswith("bfrag"):
+                if Cin % 64 or Cout % 128:
+                    line += "n/a".rjust(26)
+                    continue
+                from nopesac_amd import _lib
+                wf = ops._frag_weights(w)
+                st = torch.cuda.current_stream().cuda_stream
+
+                def call():
+                    rc = _lib.load().nopesac_conv2d_nhwc_bfrag(x.data_ptr(), wf.data_ptr(), sc.data_ptr(), bi.data_ptr(), r.data_ptr() if res else None,
+                                                                y.data_ptr(), B, H, W, Cin, Cout, k, k, s, k // 2, Cin, Cout, Cout if res else 0,
+                                                                ops.ACT_RELU, 1, int(m[5:]), st)
+                    assert rc == 0
             else:
-                os.environ.pop("NOPESAC_CONV_FORCE", None)
+                if m:
+                    os.environ["NOPESAC_CONV_FORCE"] = m
+                else:
+                    os.environ.pop("NOPESAC_CONV_FORCE", None)
+
+                def call():
+                    ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU, out=y)
             for _ in range(3):
-                ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU, out=y)
+                call()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             n = 20
             for _ in range(n):
-                ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU, out=y)
+                call()
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n

@@ -377,3 +377,30 @@ def test_scannet_mapper_resizes_on_gpu(device, tmp_path):
     for v in "01":
         ref = resize_bilinear_u8(arrs[int(v)], 480, 640).transpose(2, 0, 1).astype("float32")
         assert out[v]["image"].shape == (3, 480, 640) and np.array_equal(out[v]["image"].numpy(), ref)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1), (3, 31, 29, 128, 128, 3, 2, 1), (2, 24, 32, 512, 256, 1, 1, 0),
+                                  (1, 15, 20, 64, 384, 3, 1, 1), (2, 9, 7, 64, 128, 1, 1, 0)])
+@pytest.mark.parametrize("nstage", [3, 32])
+def test_conv2d_bfrag(device, case, nstage):
+    """'A through LDS, B from L2' conv kernel (fragment-major weights) vs F.conv2d on bf16-rounded operands: M tails, stride 2,
+    1x1 and 3x3, several output-channel tiles, K loops shorter than the ring."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case) + nstage)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g).bfloat16().float()
+    ref = F.relu(ref + res)
+    xd, rd = _nhwc(x).to(device, torch.bfloat16), _nhwc(res).to(device, torch.bfloat16)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    y = torch.empty(B, ref.shape[2], ref.shape[3], Cout, device=device, dtype=torch.bfloat16)
+    sd, bd = scale.to(device), bias.to(device)                     # keep the device copies alive across the raw-pointer call
+    rc = _lib.load().nopesac_conv2d_nhwc_bfrag(xd.data_ptr(), ops._frag_weights(wd).data_ptr(), sd.data_ptr(),
+                                                bd.data_ptr(), rd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, k, k, s, p,
+                                                Cin, Cout, Cout, ops.ACT_RELU, 1, nstage, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1.5e-2
