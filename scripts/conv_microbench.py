@@ -46,7 +46,7 @@ def main():
         ref = ops.conv2d(x, w, sc, bi, r, stride=s, pad=k // 2, act=ops.ACT_RELU).float()
         for m in modes:
             if m.startswith("bfrag"):
-                if Cin % 64 or Cout % 128:
+                if Cin % 64 or Cout % 128 or (m == 'bfrag256' and Cout % 256):
                     line += "n/a".rjust(26)
                     continue
                 from nopesac_amd import _lib
