@@ -85,7 +85,7 @@ int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, con
                            int act, int in_dt, int out_dt, int kernel_cfg, void* stream);
 
 /* bf16 conv with the weights in MFMA FRAGMENT-MAJOR order ([Cout][KH*KW*Cin] re-ordered as in nopesac_bottleneck_tail_bf16):
- * activations go through a 3-deep LDS-DMA ring (variant 3: K-tile 64, 3 workgroups/CU; variant 32: K-tile 32, 4 workgroups/CU),
+ * activations go through a 3-deep LDS-DMA ring (variant 3: K-tile 64, 3 workgroups/CU; variant 32: K-tile 32, 4-deep ring, 4 workgroups/CU),
  * every wave streams the weight fragments of its own 32 output channels from L2 (csrc/conv_igemm.hip, conv_igemm_bfrag_kernel).  Same semantics as nopesac_conv2d_nhwc for x / w bf16;
  * needs Cin % 64 == 0, Cout % 128 == 0; act may carry NPS_ACT_RES_AFTER. */
 int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,

@@ -792,7 +792,7 @@ extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, cons
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_bfrag: bad dims");
     NPS_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 128 == 0, "conv2d_bfrag: needs Cin %% 64 == 0 and Cout %% 128 == 0");
     NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d_bfrag: bad out_dt %d", out_dt);
-    NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (3-stage ring, K-tile 32)");
+    NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (4-stage ring, K-tile 32)");
     NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % 8 == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_frag % 16 == 0),
                   "conv2d_bfrag: strides / alignment");
     NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d_bfrag: residual stride");
@@ -825,6 +825,6 @@ extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, cons
     p.tiles_n = p.N / 128;
     const dim3 grid(p.tiles_m * p.tiles_n);
     if (nstage == 3) hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
     NPS_LAUNCH_RET();
 }

@@ -9,7 +9,7 @@ from nopesac_amd import ops  # noqa: E402
 
 B, H, W, Cin, Cout, k, s = [int(v) for v in sys.argv[1:8]]
 mode = sys.argv[8] if len(sys.argv) > 8 else ""
-if mode and mode != "auto":
+if mode and mode != "auto" and not mode.startswith("bfrag"):
     os.environ["NOPESAC_CONV_FORCE"] = mode
 dev = torch.device("cuda:0")
 x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
@@ -19,6 +19,20 @@ res = None
 if len(sys.argv) > 9 and sys.argv[9] == "res":
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     res = torch.randn(B, Ho, Wo, Cout, device=dev).bfloat16()
+if mode.startswith("bfrag"):
+    from nopesac_amd import _lib
+    wf = ops._frag_weights(w)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    yb = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
+    _conv2d = ops.conv2d
+
+    def _bfrag(x, w, sc, bi, res, stride=1, pad=0, act=0):
+        rc = _lib.load().nopesac_conv2d_nhwc_bfrag(x.data_ptr(), wf.data_ptr(), sc.data_ptr(), bi.data_ptr(), res.data_ptr() if res is not None else None,
+                                                    yb.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, Cin, Cout, Cout if res is not None else 0,
+                                                    act, 1, int(mode[5:]), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return yb
+    ops.conv2d = _bfrag
 for _ in range(5):
     y = ops.conv2d(x, w, sc, bi, res, stride=s, pad=k // 2, act=ops.ACT_RELU)
 torch.cuda.synchronize()
