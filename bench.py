@@ -185,8 +185,8 @@ def cpu_baseline(budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--k", type=int, default=32, help="hypotheses (matched planes) per pair")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])

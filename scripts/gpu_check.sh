@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 if [ "${2:-}" != "skip-tests" ]; then
   python -m pytest tests -x -q -m gpu 2>&1 | tail -15
 fi
-python bench.py --steps 10 --warmup 3 --stages --layers gpurun_out/layers_${TAG}.tsv 2>&1 | tail -1 > gpurun_out/bench_${TAG}.json
+python bench.py --stages --layers gpurun_out/layers_${TAG}.tsv 2>&1 | tail -1 > gpurun_out/bench_${TAG}.json
 cat gpurun_out/bench_${TAG}.json
 export TMPDIR=/tmp
 cd /tmp
