@@ -85,11 +85,16 @@ CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv
 
 def _frag_weights(w: torch.Tensor) -> torch.Tensor:
     """Fragment-major copy of a conv weight [Cout,KH,KW,Cin], made once and kept ON the weight tensor object (packed weights
-    are static and long-lived; an address-keyed cache would hand out stale fragments when a freed weight's memory is reused)."""
-    f = getattr(w, "_nps_frag", None)
+    are static and long-lived; an address-keyed cache would hand out stale fragments when a freed weight's memory is reused).
+    `linear()` passes a fresh 4-D view of the packed matrix on every call: the copy then lives on the view's base tensor."""
+    holder = w
+    base = w._base
+    if base is not None and base.numel() == w.numel() and base.storage_offset() == w.storage_offset() and base.is_contiguous():
+        holder = base
+    f = getattr(holder, "_nps_frag", None)
     if f is None:
         f = mfma_fragment_major(w.reshape(w.shape[0], -1))
-        w._nps_frag = f
+        holder._nps_frag = f
     return f
 
 
