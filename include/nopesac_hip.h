@@ -312,6 +312,15 @@ int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo
  * data/planercnn_transforms.py:314): OpenCV's 11-bit fixed-point algorithm (csrc/resize.hip). src [H][W][C], dst [OH][OW][C]. */
 int nopesac_resize_bilinear_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int OH, int OW, void* stream);
 
+/* Pre-norm counterpart for the decoder layers (transformer/transformer.py:293-322, after the cross-attention), same kernel:
+ *   s = tgt + attn . wo^T + bo;  u = s + relu(LN3(s) . w1^T + b1) . w2^T + b2;  n = LN_next(u)
+ * y = u (f32 residual stream), y_bf16 = bf16(n), ypos_bf16 = bf16(n + pos[row % pos_rows]), yn = n in f32 (each nullable);
+ * LN_next = the next layer's norm1, or the decoder's final norm after the last layer. */
+int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, const void* wo, const float* bo, const float* ln3_g,
+                              const float* ln3_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                              const float* lnn_g, const float* lnn_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                              void* ypos_bf16, float* yn, int M, void* stream);
+
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
  * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)

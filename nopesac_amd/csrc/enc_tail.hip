@@ -25,7 +25,7 @@ constexpr int ET_D = 256, ET_FF = 1024, ET_BM = 32;
 constexpr int ET_LD = ET_D + 8, ET_HLD = ET_FF + 8;
 constexpr int ET_A = ET_BM * ET_LD;                      // elements of one [32][264] bf16 tile
 constexpr size_t ET_LDS_BYTES = 2 * (size_t)(2 * ET_A + ET_BM * ET_HLD) + 2 * 8 * 32 * sizeof(float);
-static_assert((size_t)ET_BM * ET_D * 4 <= 2 * (size_t)ET_BM * ET_HLD, "f32 staging tile must fit the hidden tile");
+static_assert(2 * (size_t)ET_BM * ET_D * 4 <= 2 * (size_t)ET_BM * ET_HLD, "two f32 staging tiles must fit the hidden tile");
 
 struct EncTailArgs {
     const bf16_t* attn; const float* src;                 // [M][256]
@@ -33,7 +33,8 @@ struct EncTailArgs {
     const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2; const float* g2; const float* be2;
     const float* pos; int pos_rows;                       // [pos_rows][256], row index = token % pos_rows (may be null)
     float* y; bf16_t* y16; bf16_t* ypos16;                // outputs [M][256] (each nullable)
-    int M;
+    float* yn;                                            // pre-norm only: f32 copy of the normalised result (nullable)
+    int M, pre_norm;
 };
 
 struct EtRing {
@@ -126,7 +127,11 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y1[4 * q + e] = (y1[4 * q + e] + b[e]) + s[e];
     }
+    // post-norm (encoder): the normalised y1 is both the FFN input and the second residual;
+    // pre-norm (decoder): the FFN reads LN(s) while the residual stays s
+    f32x16 resid = y1;
     et_layernorm(y1, p.g1, p.be1, red, wave, lane);
+    if (!p.pre_norm) resid = y1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         us4 o;
@@ -174,17 +179,25 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
         const int n = wave * 32 + 8 * q + 4 * half;
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y2[4 * q + e] = (y2[4 * q + e] + b[e]) + y1[4 * q + e];
+        for (int e = 0; e < 4; ++e) y2[4 * q + e] = (y2[4 * q + e] + b[e]) + resid[4 * q + e];
     }
+    const f32x16 u = y2;                                      // pre-norm: the residual stream leaves un-normalised
     et_layernorm(y2, p.g2, p.be2, red, wave, lane);           // its barriers also retire every read of Ht / Yt
 
-    // ---- outputs through LDS so that they leave as whole rows: f32 tile in the hidden region, bf16 tiles in At / Yt
-    float* Yf = reinterpret_cast<float*>(Ht);                 // [32][256] f32
+    // ---- outputs through LDS so that they leave as whole rows: f32 tile(s) in the hidden region, bf16 tiles in At / Yt
+    float* Yf = reinterpret_cast<float*>(Ht);                 // [32][256] f32: the residual-stream output
+    float* Yn = Yf + ET_BM * ET_D;                            // [32][256] f32: normalised copy (pre-norm, optional)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = wave * 32 + 8 * q + 4 * half;
         f32x4 v = {y2[4 * q], y2[4 * q + 1], y2[4 * q + 2], y2[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = v;
+        if (p.pre_norm) {
+            const f32x4 uv = {u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = uv;
+            *reinterpret_cast<f32x4*>(Yn + l31 * ET_D + n) = v;
+        } else {
+            *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = v;
+        }
         us4 o, op;
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
         if (p.pos && row_ok) pv = *reinterpret_cast<const f32x4*>(p.pos + (row % p.pos_rows) * ET_D + n);
@@ -199,6 +212,13 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
         for (int i = 0; i < ET_BM * 64 / 512; ++i) {          // 64 16-byte chunks per f32 row
             const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
             if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_D + col);
+        }
+    }
+    if (p.yn && p.pre_norm) {
+#pragma unroll
+        for (int i = 0; i < ET_BM * 64 / 512; ++i) {
+            const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.yn + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yn + r * ET_D + col);
         }
     }
 #pragma unroll
@@ -227,6 +247,35 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.attn = (const bf16_t*)attn; a.src = src; a.wo = (const bf16_t*)wo; a.bo = bo; a.g1 = ln1_g; a.be1 = ln1_b;
     a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = ln2_g; a.be2 = ln2_b;
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
+    a.yn = nullptr; a.pre_norm = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)enc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ET_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    NPS_LAUNCH_RET();
+}
+
+// Pre-norm counterpart for the decoder (transformer/transformer.py:293-322 forward_pre, after the cross-attention):
+//     s = tgt + out_proj(attn);  u = s + linear2(relu(linear1(LN3(s))));  n = LN_next(u)
+// y = u (f32 residual stream); y_bf16 = bf16(n), ypos_bf16 = bf16(n + pos) feed the next layer's projections; yn = n in f32
+// (the decoder's final norm).  Same kernel as the encoder tail (pre_norm = 1).
+extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, const void* wo, const float* bo, const float* ln3_g,
+                                         const float* ln3_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                         const float* lnn_g, const float* lnn_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                         void* ypos_bf16, float* yn, int M, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(attn && tgt && wo && bo && ln3_g && ln3_b && w1 && b1 && w2 && b2 && lnn_g && lnn_b && M > 0, "decoder_tail: null pointer");
+    NPS_CHECK_ARG(y || y_bf16 || ypos_bf16 || yn, "decoder_tail: no output requested");
+    NPS_CHECK_ARG(!ypos_bf16 || (pos && pos_rows > 0), "decoder_tail: ypos needs pos");
+    const void* ptrs[] = {attn, tgt, wo, bo, ln3_g, ln3_b, w1, b1, w2, b2, lnn_g, lnn_b, pos, y, y_bf16, ypos_bf16, yn};
+    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "decoder_tail: pointers must be 16-byte aligned");
+    EncTailArgs a;
+    a.attn = (const bf16_t*)attn; a.src = tgt; a.wo = (const bf16_t*)wo; a.bo = bo; a.g1 = ln3_g; a.be1 = ln3_b;
+    a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = lnn_g; a.be2 = lnn_b;
+    a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
+    a.yn = yn; a.pre_norm = 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)enc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ET_LDS_BYTES);

@@ -56,6 +56,7 @@ class PlaneTRHead(ParamModule):
         self._pos_cache = {}
         self.fused_encoder_tail = True
         self.fused_mask_head = True
+        self.fused_decoder_tail = True
 
     # ---------------------------------------------------------------- packing
     def _mha(self, prefix: str, fuse_qk: bool):
@@ -218,23 +219,48 @@ class PlaneTRHead(ParamModule):
         v_all = lin(mem16, P["cross_v_all"].w2d(bf), P["cross_v_all"].bias, out_dtype=bf)
         qpos = self.raw("query_embed.weight")
         tgt = torch.zeros(B * nq, 256, device=src.device, dtype=f32)
+        nin = ln(tgt, "context2plane_decoder.layers.0.norm1", addend=qpos, want=("y16", "y2_16"))
+        n16, npos16, hs = nin["y16"], nin["y2_16"], None
         for i in range(6):
             p = f"context2plane_decoder.layers.{i}"
             W = P[p]
-            r = ln(tgt, p + ".norm1", addend=qpos, want=("y16", "y2_16"))
-            qk = lin(r["y2_16"], W["self"]["qk"].w2d(bf), W["self"]["qk"].bias, out_dtype=bf)
-            v = lin(r["y16"], W["self"]["v"].w2d(bf), W["self"]["v"].bias, out_dtype=bf)
+            qk = lin(npos16, W["self"]["qk"].w2d(bf), W["self"]["qk"].bias, out_dtype=bf)
+            v = lin(n16, W["self"]["v"].w2d(bf), W["self"]["v"].bias, out_dtype=bf)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale, mfma_bf16=True)
             tgt = lin(o, W["self"]["o"].w2d(bf), W["self"]["o"].bias, residual=tgt, out_dtype=f32)
             r = ln(tgt, p + ".norm2", addend=qpos, want=("y2_16",))
             q = lin(r["y2_16"], W["cross"]["q"].w2d(bf), W["cross"]["q"].bias, out_dtype=bf)
             o = ops.attention(q, k_all[:, 256 * i:256 * (i + 1)], v_all[:, 256 * i:256 * (i + 1)], B, nq, L, nh, scale, mfma_bf16=True)
+            nxt = f"context2plane_decoder.layers.{i + 1}.norm1" if i < 5 else "context2plane_decoder.norm"
+            if self.fused_decoder_tail:      # cross out-proj + LN3 + FFN + the next norm in one launch (csrc/enc_tail.hip)
+                r = ops.decoder_tail(o, tgt, self._dec_tail_weights(i, nxt), pos=qpos,
+                                     want=("y", "y16", "ypos16") if i < 5 else ("yn",))
+                if i < 5:
+                    tgt, n16, npos16 = r["y"], r["y16"], r["ypos16"]
+                else:
+                    hs = r["yn"]
+                continue
             tgt = lin(o, W["cross"]["o"].w2d(bf), W["cross"]["o"].bias, residual=tgt, out_dtype=f32)
             r = ln(tgt, p + ".norm3", want=("y16",))
             hdn = lin(r["y16"], W["l1"].w2d(bf), W["l1"].bias, act=ops.ACT_RELU, out_dtype=bf)
             tgt = lin(hdn, W["l2"].w2d(bf), W["l2"].bias, residual=tgt, out_dtype=f32)
-        hs = self._ln(tgt, "context2plane_decoder.norm")
+            if i < 5:
+                nin = ln(tgt, nxt, addend=qpos, want=("y16", "y2_16"))
+                n16, npos16 = nin["y16"], nin["y2_16"]
+        if hs is None:
+            hs = self._ln(tgt, "context2plane_decoder.norm")
         return hs, memory
+
+    def _dec_tail_weights(self, i: int, next_norm: str) -> dict:
+        cache = self.__dict__.setdefault("_dec_tail_w", {})
+        if i not in cache:
+            p, W = f"context2plane_decoder.layers.{i}", self.packed[f"context2plane_decoder.layers.{i}"]
+            f = lambda k: self.raw(k).float().contiguous()
+            cache[i] = {"wo": W["cross"]["o"].wfrag(torch.bfloat16), "bo": W["cross"]["o"].bias, "w1": W["l1"].wfrag(torch.bfloat16),
+                        "b1": W["l1"].bias, "w2": W["l2"].wfrag(torch.bfloat16), "b2": W["l2"].bias,
+                        "g3": f(p + ".norm3.weight"), "be3": f(p + ".norm3.bias"),
+                        "gn": f(next_norm + ".weight"), "ben": f(next_norm + ".bias")}
+        return cache[i]
 
     def _heads(self, features, hs, memory, B, hc, wc, nq, want_logits, mark):
         P, gd = self.packed, self.gemm_dtype

@@ -555,3 +555,20 @@ def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scal
                                      int(sigmoid), _stream())
     _lib.check(rc, "nopesac_mask_head_bf16")
     return (prob, p1) if want_p1 else prob
+
+
+def decoder_tail(attn: torch.Tensor, tgt: torch.Tensor, W: dict, pos=None, want=("y", "y16", "ypos16")) -> dict:
+    """Pre-norm decoder tail (csrc/enc_tail.hip, pre_norm = 1): out-proj + residual, LN3, FFN + residual, next norm.
+    W: fragment-major bf16 "wo", "w1", "w2"; f32 "bo", "b1", "b2", "g3", "be3" (norm3), "gn", "ben" (next norm).
+    want: "y" (f32 residual stream), "y16" / "ypos16" (bf16 of the normalised result / + pos), "yn" (f32 normalised)."""
+    _chk(attn, torch.bfloat16); _chk(tgt, torch.float32)
+    M = tgt.shape[0]
+    assert attn.shape == (M, 256) and tgt.shape == (M, 256)
+    out = {k: torch.empty(M, 256, device=tgt.device, dtype=torch.float32 if k in ("y", "yn") else torch.bfloat16) for k in want}
+    if pos is not None:
+        _chk(pos, torch.float32)
+    rc = _L().nopesac_decoder_tail_bf16(_p(attn), _p(tgt), _p(W["wo"]), _p(W["bo"]), _p(W["g3"]), _p(W["be3"]), _p(W["w1"]), _p(W["b1"]),
+                                        _p(W["w2"]), _p(W["b2"]), _p(W["gn"]), _p(W["ben"]), _p(pos), 0 if pos is None else pos.shape[0],
+                                        _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")), _p(out.get("yn")), M, _stream())
+    _lib.check(rc, "nopesac_decoder_tail_bf16")
+    return out

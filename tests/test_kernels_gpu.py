@@ -404,3 +404,28 @@ def test_conv2d_bfrag(device, case, nstage):
     torch.cuda.synchronize()
     assert rc == 0
     assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,last", [(3200, False), (3200, True), (77, False)])
+def test_decoder_tail(device, M, last):
+    """Pre-norm decoder tail (enc_tail kernel, pre_norm = 1) vs the same chain through the per-op bf16-mode kernels."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(M + last)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    attn, tgt, qpos = rn(M, 256).bfloat16(), rn(M, 256), rn(50, 256)
+    wo, w1, w2 = rn(256, 256, k=1 / 16).bfloat16(), rn(1024, 256, k=1 / 16).bfloat16(), rn(256, 1024, k=1 / 32).bfloat16()
+    bo, b1, b2 = rn(256, k=0.1), rn(1024, k=0.1), rn(256, k=0.1)
+    g3, be3, gn, ben = 1 + rn(256, k=0.1), rn(256, k=0.1), 1 + rn(256, k=0.1), rn(256, k=0.1)
+    W = {"wo": ops.mfma_fragment_major(wo), "w1": ops.mfma_fragment_major(w1), "w2": ops.mfma_fragment_major(w2),
+         "bo": bo, "b1": b1, "b2": b2, "g3": g3, "be3": be3, "gn": gn, "ben": ben}
+    out = ops.decoder_tail(attn, tgt, W, pos=qpos, want=("yn",) if last else ("y", "y16", "ypos16"))
+    s = ops.linear(attn, wo, bo, residual=tgt, out_dtype=torch.float32)
+    t16 = ops.layernorm_ex(s, g3, be3, want=("y16",))["y16"]
+    h = ops.linear(t16, w1, b1, act=ops.ACT_RELU, out_dtype=torch.bfloat16)
+    u = ops.linear(h, w2, b2, residual=s, out_dtype=torch.float32)
+    ref = ops.layernorm_ex(u, gn, ben, addend=qpos, want=("y", "y16", "y2_16"))
+    if last:
+        assert set(out) == {"yn"} and _rel(out["yn"], ref["y"]) < 5e-3
+    else:
+        assert _rel(out["y"], u) < 5e-3
+        assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2

@@ -267,3 +267,22 @@ def test_fused_mask_head_matches_per_layer_bf16_path(device):
     head.fused_mask_head = True
     assert torch.equal(qa, qb) and a["mask_prob"].shape == (B, 120, 160, 50)
     assert float((a["mask_prob"] - b["mask_prob"]).abs().max()) < 2e-3
+
+
+def test_fused_decoder_tail_matches_per_layer_bf16_path(device):
+    """bf16 mode: decoder layers with the fused pre-norm tail (out-proj + LN3 + FFN + next norm in one launch) vs per-op launches."""
+    model = make_model(device, dtype="bfloat16")
+    head = model.sem_seg_head
+    g = torch.Generator().manual_seed(4)
+    B = 2
+    feats = {"res2": torch.randn(B, 120, 160, 256, generator=g), "res3": torch.randn(B, 60, 80, 512, generator=g),
+             "res4": torch.randn(B, 30, 40, 1024, generator=g), "res5": torch.randn(B, 15, 20, 2048, generator=g)}
+    f16 = {k: (0.5 * v).to(device, torch.bfloat16) for k, v in feats.items()}
+    head.fused_decoder_tail = True
+    a, qa = head(f16)
+    head.fused_decoder_tail = False
+    b, qb = head(f16)
+    head.fused_decoder_tail = True
+    # six chained random-weight layers amplify 1-ulp bf16 differences (the bf16 path itself is ~0.5 away from fp32 on these
+    # inputs): this is a wiring check; the kernel itself is checked tightly in test_kernels_gpu.py::test_decoder_tail
+    assert rel_err(qa, qb) < 0.15 and torch.isfinite(qa).all()
