@@ -93,6 +93,12 @@ int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* sc
                               int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
                               void* stream);
 
+/* bf16 3x3 / stride 1 / pad 1 conv with 64 -> 64 channels + folded BN + activation (conv2 of the res2 bottlenecks): 16x16 pixel
+ * tiles computed out of an 18x18 halo kept in LDS (csrc/conv3x3_c64.hip).  x, y bf16 NHWC [B,H,W,64]; w_frag = the
+ * [64][3*3*64] weight matrix in MFMA fragment-major order. */
+int nopesac_conv3x3_c64_bf16(const void* x, const void* w_frag, const float* scale, const float* bias, void* y, int B, int H, int W,
+                             int act, void* stream);
+
 /* Fused bf16 ResNet stem: y = maxpool3x3/s2/p1( relu( bn( conv7x7/s2/p3(x) ) ) ) in one kernel (d2 BasicStem).
  *   x bf16 NHWC [B,H,W,4] (RGB + zero pad channel); w bf16 [64][7][8][4] (kw padded 7 -> 8 with zeros, i.e. 224 per
  *   output channel); scale/bias f32[64] (folded FrozenBN); y bf16 NHWC [B,PH,PW,64]. */

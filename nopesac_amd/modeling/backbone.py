@@ -6,6 +6,8 @@ epilogue, so a bottleneck is 3 (4 with projection shortcut) kernel launches and 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
@@ -35,6 +37,7 @@ class HipResNet50(ParamModule):
             self.out_features = ["res2", "res3", "res4", "res5"]
         self.fused_stem = True
         self.fused_tail = True
+        self.halo_conv2 = not os.environ.get("NOPESAC_NO_HALO_CONV2")
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -80,7 +83,11 @@ class HipResNet50(ParamModule):
             stride = 2 if (i == 0 and name != "res2") else 1
             proj = cin != cout
             y = a_pre if a_pre is not None else cv(x, p + ".conv1")
-            y = cv(y, p + ".conv2", stride, 1)
+            if fuse and cmid == 64 and stride == 1 and self.halo_conv2:
+                c2 = P[p + ".conv2"]           # res2: 3x3 out of an LDS halo tile (csrc/conv3x3_c64.hip)
+                y = ops.conv3x3_c64(y, c2.w(dt), c2.scale, c2.bias)
+            else:
+                y = cv(y, p + ".conv2", stride, 1)
             a_pre = None
             nxt = None
             if bi + 1 < len(blocks):

@@ -572,3 +572,14 @@ def decoder_tail(attn: torch.Tensor, tgt: torch.Tensor, W: dict, pos=None, want=
                                         _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")), _p(out.get("yn")), M, _stream())
     _lib.check(rc, "nopesac_decoder_tail_bf16")
     return out
+
+
+def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, act: int = ACT_RELU) -> torch.Tensor:
+    """bf16 3x3/s1/p1 conv 64 -> 64 + BN + act from an LDS halo tile (csrc/conv3x3_c64.hip).  x [B,H,W,64], w [64,3,3,64]."""
+    _chk(x, torch.bfloat16); _chk(w, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
+    B, H, W, C = x.shape
+    assert C == 64 and tuple(w.shape) == (64, 3, 3, 64)
+    y = torch.empty_like(x)
+    _lib.check(_L().nopesac_conv3x3_c64_bf16(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(y), B, H, W, act, _stream()),
+               "nopesac_conv3x3_c64_bf16")
+    return y

@@ -429,3 +429,19 @@ def test_decoder_tail(device, M, last):
     else:
         assert _rel(out["y"], u) < 5e-3
         assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 120, 160), (3, 37, 45), (1, 16, 16), (1, 5, 70)])
+def test_conv3x3_c64(device, B, H, W):
+    """Halo-tile 3x3 64 -> 64 conv vs the generic bf16 conv kernel (same MFMA K order: bit-exact) and F.conv2d."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, 64, H, W, generator=g).bfloat16()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).bfloat16()
+    scale, bias = (1 + 0.1 * torch.randn(64, generator=g)).to(device), (0.1 * torch.randn(64, generator=g)).to(device)
+    xd, wd = _nhwc(x.float()).to(device, torch.bfloat16), w.float().permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    y = ops.conv3x3_c64(xd, wd, scale, bias)
+    ref = ops.conv2d(xd, wd, scale, bias, stride=1, pad=1, act=ops.ACT_RELU)
+    assert torch.equal(y, ref)
+    ref32 = F.relu(F.conv2d(x.float(), w.float(), None, 1, 1) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1))
+    assert _rel(y.float().permute(0, 3, 1, 2).cpu(), ref32) < 1.5e-2
