@@ -236,7 +236,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, int HW, int C, int G, float eps, int act) {
+    // per-channel affine of this image, once per workgroup: y = x * a[c] + d[c]  (a = rstd_g * gamma_c, d = beta_c - mean_g * a)
     __shared__ float s_mean[256], s_rstd[256];
+    __shared__ float s_a[2048], s_d[2048];
     const int b = blockIdx.y;
     const int cpg = C / G;
     for (int g = threadIdx.x; g < G; g += 256) {
@@ -251,20 +253,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         s_mean[g] = mean; s_rstd[g] = rsqrtf(var + eps);
     }
     __syncthreads();
-    const int cv = C / 8;
-    const long long total = (long long)HW * cv;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * gamma[c];
+        s_a[c] = a;
+        s_d[c] = beta[c] - s_mean[g] * a;
+    }
+    __syncthreads();
+    const int cv = C / 8;                                  // 256 % cv == 0: a thread keeps its 8-channel chunk across iterations
+    const int c = (int)(threadIdx.x % cv) * 8;
+    float a8[8], d8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a8[e] = s_a[c + e]; d8[e] = s_d[c + e]; }
+    const int rows_per_iter = 256 / cv;
     const T* xb = x + (long long)b * HW * C;
     T* yb = y + (long long)b * HW * C;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * 8;
+    for (long long p = (long long)blockIdx.x * rows_per_iter + threadIdx.x / cv; p < HW; p += (long long)gridDim.x * rows_per_iter) {
         float v[8];
-        load_vec<T, 8>(xb + (i / cv) * C + c, v);
+        load_vec<T, 8>(xb + p * C + c, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / cpg;
-            v[e] = apply_act((v[e] - s_mean[g]) * s_rstd[g] * gamma[c + e] + beta[c + e], act);
-        }
-        store_vec<T, 8>(yb + (i / cv) * C + c, v);
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * a8[e] + d8[e], act);
+        store_vec<T, 8>(yb + p * C + c, v);
     }
 }
 
@@ -455,7 +464,8 @@ extern "C" int nopesac_groupnorm_nhwc(const void* x, const float* gamma, const f
     const int cpg = C / G;
     if (workspace && C % 8 == 0 && 256 % (C / 8) == 0 && C <= 2048 && G <= 256 && vec_aligned(x, y)) {
         hipStream_t st = (hipStream_t)stream;
-        dim3 g1(GN_SPLITS, B), g2((unsigned)std::min<long long>(((long long)HW * (C / 8) + 255) / 256, 1024), B);
+        // apply: few, fat workgroups (each pays the statistics prologue once)
+        dim3 g1(GN_SPLITS, B), g2((unsigned)std::max<long long>(1, std::min<long long>(((long long)HW * (C / 8) + 1023) / 1024, 48)), B);
         if (dt == NPS_DT_BF16) {
             hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, workspace, HW, C, G);
             hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g2, dim3(256), 0, st, (const bf16_t*)x, workspace, gamma, beta, (bf16_t*)y, HW, C, G, eps, act);

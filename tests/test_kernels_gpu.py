@@ -445,3 +445,16 @@ def test_conv3x3_c64(device, B, H, W):
     assert torch.equal(y, ref)
     ref32 = F.relu(F.conv2d(x.float(), w.float(), None, 1, 1) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1))
     assert _rel(y.float().permute(0, 3, 1, 2).cpu(), ref32) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype,B,H,W,C", [(torch.float32, 3, 60, 80, 128), (torch.bfloat16, 2, 30, 40, 128), (torch.bfloat16, 1, 7, 9, 256)])
+def test_groupnorm_split_path(device, dtype, B, H, W, C):
+    """GroupNorm (split statistics + per-channel affine apply) vs F.group_norm, incl. a mean far from zero."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 5
+    ga, be = 1 + 0.2 * torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xd = _nhwc(x).to(device, dtype)
+    y = ops.groupnorm(xd, ga.to(device), be.to(device), 32, 1e-5, act=ops.ACT_NONE)
+    ref = F.group_norm(xd.float().cpu().permute(0, 3, 1, 2), 32, ga, be, 1e-5)
+    assert y.dtype == dtype and _rel(y.float().cpu().permute(0, 3, 1, 2), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
