@@ -99,6 +99,12 @@ int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* sc
 int nopesac_conv3x3_c64_bf16(const void* x, const void* w_frag, const float* scale, const float* bias, void* y, int B, int H, int W,
                              int act, void* stream);
 
+/* bf16 3x3 / stride 1 / pad 1 conv, Cin % 64 == 0, Cout % 128 == 0, + folded BN + activation, computed from LDS halo tiles
+ * (csrc/conv3x3_halo.hip): tile 0 = 16x16 pixels, 1 = 16 rows x 8 columns per workgroup.  x [B,H,W,Cin], y [B,H,W,Cout] bf16
+ * (pixel-dense), w_frag = the [Cout][3*3*Cin] weights in MFMA fragment-major order. */
+int nopesac_conv3x3_halo_bf16(const void* x, const void* w_frag, const float* scale, const float* bias, void* y, int B, int H, int W,
+                              int Cin, int Cout, int act, int tile, void* stream);
+
 /* Fused bf16 ResNet stem: y = maxpool3x3/s2/p1( relu( bn( conv7x7/s2/p3(x) ) ) ) in one kernel (d2 BasicStem).
  *   x bf16 NHWC [B,H,W,4] (RGB + zero pad channel); w bf16 [64][7][8][4] (kw padded 7 -> 8 with zeros, i.e. 224 per
  *   output channel); scale/bias f32[64] (folded FrozenBN); y bf16 NHWC [B,PH,PW,64]. */

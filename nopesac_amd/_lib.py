@@ -31,6 +31,7 @@ SIGNATURES = {
     "nopesac_mask_head_bf16": [P] * 9 + [I] * 5 + [P],
     "nopesac_decoder_tail_bf16": [P] * 13 + [I] + [P] * 4 + [I, P],
     "nopesac_conv3x3_c64_bf16": [P, P, P, P, P, I, I, I, I, P],
+    "nopesac_conv3x3_halo_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "nopesac_rle_labels": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_rle_transitions": [P, P, P, P, P, I, I, I, P],
     "nopesac_rle_compress_host": [P, I, I, I, P, I, P],

@@ -81,6 +81,7 @@ class ConvTuner:
 
 TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
+CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 
 
 def _frag_weights(w: torch.Tensor) -> torch.Tensor:
@@ -142,7 +143,15 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
                 and x_cs % 8 == 0 and KH * KW <= 32 and (act & ~(0xff | ACT_RES_AFTER)) == 0
                 and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31)
 
+    halo_ok = (bfrag_ok and KH == 3 and KW == 3 and stride == 1 and pad == 1 and residual is None and x_cs == Cin and y_cs == Cout
+               and out_dtype == torch.bfloat16 and scale is not None and bias is not None and (act & ~0xff) == 0)
+
     def launch(cfg):
+        if cfg in (CFG_HALO16, CFG_HALO8):
+            rc = _L().nopesac_conv3x3_halo_bf16(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(out), B, H, W, Cin, Cout, act,
+                                                0 if cfg == CFG_HALO16 else 1, _stream())
+            _lib.check(rc, "nopesac_conv3x3_halo_bf16")
+            return
         if cfg in (CFG_BFRAG3, CFG_BFRAG32):
             rc = _L().nopesac_conv2d_nhwc_bfrag(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout,
                                                 KH, KW, stride, pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], 3 if cfg == CFG_BFRAG3 else 32,
@@ -157,7 +166,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     cfg = 0
     if TUNER.measuring or TUNER.best:
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0)
-        cfg = TUNER.choose(key, launch, (CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ())
+        cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ()))
     launch(cfg)
     return out
 

@@ -458,3 +458,27 @@ def test_groupnorm_split_path(device, dtype, B, H, W, C):
     y = ops.groupnorm(xd, ga.to(device), be.to(device), 32, 1e-5, act=ops.ACT_NONE)
     ref = F.group_norm(xd.float().cpu().permute(0, 3, 1, 2), 32, ga, be, 1e-5)
     assert y.dtype == dtype and _rel(y.float().cpu().permute(0, 3, 1, 2), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 40, 256, 256), (1, 60, 80, 128, 128), (2, 17, 21, 64, 128), (1, 16, 16, 512, 384)])
+@pytest.mark.parametrize("tile", [0, 1])
+def test_conv3x3_halo(device, case, tile):
+    """Halo-tile 3x3 conv (input channels walked in chunks of 64, all nine taps read from the LDS halo) vs the generic bf16 kernel
+    and F.conv2d; partial tiles at the image border, several output-channel blocks."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + tile)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).bfloat16()
+    scale, bias = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    xd, wd = _nhwc(x.float()).to(device, torch.bfloat16), w.float().permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    y = torch.empty(B, H, W, Cout, device=device, dtype=torch.bfloat16)
+    wf = ops._frag_weights(wd)
+    rc = _lib.load().nopesac_conv3x3_halo_bf16(xd.data_ptr(), wf.data_ptr(), scale.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout,
+                                                ops.ACT_LEAKY, tile, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    ref = ops.conv2d(xd, wd, scale, bias, stride=1, pad=1, act=ops.ACT_LEAKY)
+    assert _rel(y.float(), ref.float()) < 1e-2
+    ref32 = F.leaky_relu(F.conv2d(x.float(), w.float(), None, 1, 1) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1), 0.01)
+    assert _rel(y.float().permute(0, 3, 1, 2).cpu(), ref32) < 1.5e-2
