@@ -99,6 +99,54 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
     int tg = 64;
     while (tg > 1 && (256 / tg) < big) tg >>= 1;       // largest pow2 group with enough groups; may still need >1 pass
     const int ngroups = 256 / tg, grp = tid / tg, gl = tid % tg;
+    constexpr int ZREG = 16;                                    // coupling entries a lane can keep in registers per phase
+    if (ngroups >= big && (big + tg - 1) / tg <= ZREG) {
+        // Every lane group owns exactly one row (row phase) and one column (column phase): the lane's slice of both is
+        // loop invariant, so it is read from LDS ONCE and the 200 iterations run out of registers (same partition, same
+        // reduction order and therefore the same results as the LDS loop below; only u / v travel through LDS).
+        float zr[ZREG], zc[ZREG];
+        const bool rok = grp < R1, cok = grp < C1;
+#pragma unroll
+        for (int k = 0; k < ZREG; ++k) {
+            const int j = gl + tg * k;
+            zr[k] = (rok && j < C1) ? Z[grp * LD + j] : 0.f;
+            zc[k] = (cok && j < R1) ? Z[j * LD + grp] : 0.f;
+        }
+        for (int it = 0; it < iters; ++it) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < ZREG; ++k) {
+                const int j = gl + tg * k;
+                if (rok && j < C1) m = fmaxf(m, zr[k] + v[j]);
+            }
+            m = group_max(m, tg);
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < ZREG; ++k) {
+                const int j = gl + tg * k;
+                if (rok && j < C1) sm += expf(zr[k] + v[j] - m);
+            }
+            sm = group_sum(sm, tg);
+            if (rok && gl == 0) u[grp] = lmu[grp] - (m + logf(sm));
+            __syncthreads();
+            m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < ZREG; ++k) {
+                const int i = gl + tg * k;
+                if (cok && i < R1) m = fmaxf(m, zc[k] + u[i]);
+            }
+            m = group_max(m, tg);
+            sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < ZREG; ++k) {
+                const int i = gl + tg * k;
+                if (cok && i < R1) sm += expf(zc[k] + u[i] - m);
+            }
+            sm = group_sum(sm, tg);
+            if (cok && gl == 0) v[grp] = lnu[grp] - (m + logf(sm));
+            __syncthreads();
+        }
+    } else
     for (int it = 0; it < iters; ++it) {
         for (int i = grp; i < ((R1 + ngroups - 1) / ngroups) * ngroups; i += ngroups) {
             const bool ok = i < R1;
