@@ -574,9 +574,11 @@ def ransac_refine(sd, init_trans_feat, init_rot_feat, geo_global, geo_local, sig
             "l2_dist": d_l2[:m + 1, :m], "normal_dist": ang[:m + 1, :m], "offset_dist": d_off[:m + 1, :m]}
 
 
-def camera_head(sd, feats1, feats2, planes1, planes2, app1, app2, cfg: OracleConfig):
+def camera_head(sd, feats1, feats2, planes1, planes2, app1, app2, cfg: OracleConfig, forced_assignment=None):
     """PlaneCameraHead.inference_Joint for ONE pair (camera_head.py:400-640).
-    feats: dict res2..res5 [1,C,H,W]; planes [n,3]; app [n,256].  Returns (cameras, assignments, aux)."""
+    feats: dict res2..res5 [1,C,H,W]; planes [n,3]; app [n,256].  Returns (cameras, assignments, aux).
+    `forced_assignment` ([n1,n2] 0/1, benchmark K control only): the matcher still runs, its
+    assignment is replaced."""
     p = "camera_head_list.0"
     trans0, rot0, tf0, rf0, _ = pixel_pose_net(sd, feats1, feats2, p)
     if rot0[0, 0] < 0:                                                      # :436-437
@@ -587,6 +589,8 @@ def camera_head(sd, feats1, feats2, planes1, planes2, app1, app2, cfg: OracleCon
     cam7 = torch.cat([rec_t[0], rec_r[0]])
     log_scores = matcher(sd, app1, app2, cam7, planes1, planes2, cfg)       # :493-497
     A0 = assignment_matrix(log_scores, cfg.matching_score_threshold)         # :501
+    if forced_assignment is not None:
+        A0 = forced_assignment.to(A0.dtype)
     nq = cfg.num_queries
     geo_local, m = geo_sequence(planes1, planes2, A0, nq)
     geo_global, _ = geo_sequence(planes1, planes2, A0, nq, rec_r[0], rec_t[0])
@@ -616,19 +620,37 @@ def inference_single(sd, image: Tensor, cfg: OracleConfig):
     out, qf = plane_head(sd, feats, cfg)
     sel = post_select(out["pred_logits"][0], out["pred_params"][0], out["pred_mask_logits"][0], qf[0], cfg,
                       image.shape[-2], image.shape[-1])
+    out = dict(out, _query_feat=qf)
     return feats, out, sel
 
 
-def inference(sd, batched_inputs: List[dict], cfg: Optional[OracleConfig] = None) -> List[dict]:
+def force_k(out1: dict, qf1: Tensor, forced: dict, b: int):
+    """Benchmark K control of SURVEY.md §8d for pair `b` (the CPU twin of PlaneTR_NopeSAC._force_k in the build): the K
+    highest-scoring queries of view 1, view-2 appearance = permuted view-1 appearance + noise, planes / matches from `forced`
+    ({"K", "planes" [2B,nq,3], "assignment" [B,nq,nq], "perm" [B,K], "noise" [B,K,256]})."""
+    K = forced["K"]
+    B = forced["perm"].shape[0]
+    score = out1["pred_logits"][0, :, 0] - out1["pred_logits"][0, :, 1]
+    idx = torch.topk(score, K).indices.sort().values
+    f1 = qf1[0][idx]
+    f2 = f1[forced["perm"][b]] + forced["noise"][b]
+    return (forced["planes"][b, :K], forced["planes"][B + b, :K], f1, f2, forced["assignment"][b, :K, :K])
+
+
+def inference(sd, batched_inputs: List[dict], cfg: Optional[OracleConfig] = None, forced: Optional[dict] = None) -> List[dict]:
     """Per pair (the reference asserts batch 1; we simply loop).  Output dict keys as SURVEY §8 a1."""
     cfg = cfg or OracleConfig()
     results = []
     with torch.no_grad():
-        for item in batched_inputs:
-            f1, _, s1 = inference_single(sd, item["0"]["image"], cfg)
+        for b, item in enumerate(batched_inputs):
+            f1, o1, s1 = inference_single(sd, item["0"]["image"], cfg)
             f2, _, s2 = inference_single(sd, item["1"]["image"], cfg)
-            cams, assign, aux = camera_head(sd, f1, f2, s1["pred_plane"], s2["pred_plane"],
-                                            s1["pred_plane_feats"][0], s2["pred_plane_feats"][0], cfg)
+            if forced is not None:
+                p1, p2, a1, a2, A = force_k(o1, o1["_query_feat"], forced, b)
+                cams, assign, aux = camera_head(sd, f1, f2, p1, p2, a1, a2, cfg, forced_assignment=A)
+            else:
+                cams, assign, aux = camera_head(sd, f1, f2, s1["pred_plane"], s2["pred_plane"],
+                                                s1["pred_plane_feats"][0], s2["pred_plane_feats"][0], cfg)
             res = {"0": s1, "1": s2, "pred_aff": None, "depth": {"0": None, "1": None}}
             for k, (t, r) in cams.items():
                 res[k] = {"tran": t.numpy(), "rot": r.numpy()}

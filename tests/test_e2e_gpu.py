@@ -82,6 +82,31 @@ def test_e2e_loose_structured_batch(device, sd50):
     assert torch.equal(solo["pred_assignment"], res[1]["pred_assignment"])
 
 
+@pytest.mark.parametrize("K,nq", [(32, 50), (64, 64)])
+def test_bench_workload_forced_k_matches_oracle(device, K, nq):
+    """The bench workload (SURVEY.md §8d K control: K planes per view, K matches) on the fp32 HIP path against the oracle
+    driven through the same K control - the configuration bench.py times is itself parity-checked, K = 32 (config 2)
+    and K = 64 / nq = 64 (config 3)."""
+    import bench
+    from nopesac_amd.synth import synth_pair, synth_state_dict
+    from oracle import nopesac_oracle as O
+    B = 2
+    model = make_model(device, nq=nq)
+    inp = [synth_pair(20 + i) for i in range(B)]
+    forced = bench.make_forced(B, K, nq, device, 5)
+    with torch.no_grad():
+        d = model.forward_tensors(model.preprocess_image(inp), B, 480, 640, forced=forced)
+    cam = d["cam"]
+    cpu_forced = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in forced.items()}
+    ref = O.inference(synth_state_dict(nq), inp, O.OracleConfig(num_queries=nq), forced=cpu_forced)
+    assert cam["m"].tolist() == [K] * B and [r["_aux"]["matched_num"] for r in ref] == [K] * B
+    for key in ("camera_init", "camera_initRec", "camera_avgRef0", "camera"):
+        t, r = cam["cameras"][key]
+        for b in range(B):
+            assert rel_err(t[b].cpu().numpy(), ref[b][key]["tran"]) < 5 * TOL, (key, b)
+            assert rel_err(r[b].cpu().numpy(), ref[b][key]["rot"]) < 5 * TOL, (key, b)
+
+
 def test_bf16_backbone_pose_error(device):
     """bf16 dense convs: judged by pose error against the fp32 HIP path (discrete decisions may flip,
     SURVEY.md §7 'hard parts'), not by the 1e-4 gate."""
