@@ -130,6 +130,21 @@ class ConvTimer:
             return y, o
 
         ops.stem_fused, ops.bottleneck_tail = timed_stem, timed_tail
+        orig_fp8 = ops.conv2d_fp8
+
+        def timed_fp8(x, w8, scale, bias, **k):
+            if not timer.enabled:
+                return orig_fp8(x, w8, scale, bias, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_fp8(x, w8, scale, bias, **k)
+            e1.record()
+            flops = 2.0 * (y.numel() // y.shape[-1]) * w8.shape[0] * w8.shape[1]
+            nbytes = x.numel() + w8.numel() + y.numel() * y.element_size()
+            timer.records.append(("torch.float8_e4m3fn", flops, e0, e1, nbytes, "fp8 x%s w%s s%d" % (tuple(x.shape), tuple(w8.shape), k.get("stride", 1))))
+            return y
+
+        ops.conv2d_fp8 = timed_fp8
         # modules imported `ops` as a module and call ops.conv2d / ops.linear, so the patch is seen everywhere
         return self
 
@@ -192,6 +207,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step")
     ap.add_argument("--k", type=int, default=32, help="hypotheses (matched planes) per pair")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 (NOT the headline line): the backbone's 3x3 convs on the fp8 "
+                    "(e4m3fn) MFMA, static activation scales calibrated on the synthetic pairs; the JSON line says dtype fp8+bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
@@ -215,7 +232,8 @@ def main():
     device = torch.device("cuda", local)
     B, K = args.pairs, args.k
     nq = 50 if K <= 50 else K
-    model = build_model(device, nq, args.dtype)
+    assert not args.fp8 or args.dtype == "bfloat16"
+    model = build_model(device, nq, args.dtype, ["MODEL.AMD.BACKBONE_FP8", True] if args.fp8 else ())
     if args.single_stream:
         model.two_streams = False
     # synthetic inputs resident in HBM: uint8-valued fp32 RGB, seeds 1000+pair
@@ -223,6 +241,10 @@ def main():
     raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float().to(device)
     forced = make_forced(B, K, nq, device, 7 + rank)
     from nopesac_amd import ops
+    if args.fp8:                                          # static activation scales from 4 of the synthetic images
+        with torch.no_grad():
+            model.backbone.calibrate_fp8(ops.preprocess(raw[:4], model.pixel_mean, model.pixel_std, model.backbone.STEM_CIN_PAD,
+                                                        model.compute_dtype))
     tuned = model.autotune(B) if args.autotune else 0     # load-time kernel selection, outside the timed region
 
     # Two batches in flight: step i runs on HIP stream i % 2, so the launch-latency-bound head stages of one batch
@@ -379,7 +401,7 @@ def main():
     out = {"metric": "image-pairs/sec (480x640, K=%d hyp)" % K, "value": round(pairs_per_s, 3), "unit": "pairs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+           "dtype": ("fp8(backbone 3x3 convs)+bf16" if args.fp8 else "bf16") if args.dtype == "bfloat16" else "f32", "data": "synthetic",
            "config": {"workload": "configs/inference_mp3d.yaml, %d synthetic 480x640 pairs/GPU/step, ResNet-50 + pyramids in %s, "
                                   "heads fp32, K=%d matched planes forced (m mean %.1f), nq=%d" % (B, args.dtype, K, m_mean, nq),
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
@@ -430,7 +452,9 @@ def accuracy_vs_fp32(model16, device, nq, n_pairs=4):
     m32 = build_model(device, nq, "float32")
     res = {"default": compare(m32, model16, [synth_pair(i) for i in range(n_pairs)])}
     del m32
-    m32, m16 = build_model(device, nq, "float32", LOOSE), build_model(device, nq, "bfloat16", LOOSE)
+    fp8 = bool(getattr(model16.backbone, "fp8_conv2", False))
+    m32, m16 = build_model(device, nq, "float32", LOOSE), build_model(device, nq, "bfloat16", LOOSE + (["MODEL.AMD.BACKBONE_FP8", True] if fp8 else []))
+    m16.backbone.act_scale = dict(model16.backbone.act_scale)
     res["loose_structured"] = compare(m32, m16, [synth_pair(i, structured=True) for i in range(n_pairs)])
     del m32, m16
     torch.cuda.empty_cache()

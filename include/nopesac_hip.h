@@ -31,6 +31,8 @@ extern "C" {
 #define NPS_DT_F32 0
 #define NPS_DT_BF16 1
 #define NPS_DT_F32_BF16W 2 /* conv in_dt only: x is f32 in memory, w is bf16; x is rounded to bf16 while staged */
+#define NPS_DT_FP8 3       /* OCP e4m3fn bytes (gfx950's fp8).  As out_dt: the epilogue result is saturated to +-448 and rounded to
+                            * nearest even; only with a channel count / stride that is a multiple of 8 and no residual */
 
 #define NPS_ACT_NONE 0
 #define NPS_ACT_RELU 1
@@ -87,11 +89,24 @@ int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float* scale, con
 /* bf16 conv with the weights in MFMA FRAGMENT-MAJOR order ([Cout][KH*KW*Cin] re-ordered as in nopesac_bottleneck_tail_bf16):
  * activations go through a 3-deep LDS-DMA ring (variant 3: K-tile 64, 3 workgroups/CU; variant 32: K-tile 32, 4-deep ring, 4 workgroups/CU),
  * every wave streams the weight fragments of its own 32 output channels from L2 (csrc/conv_igemm.hip, conv_igemm_bfrag_kernel).  Same semantics as nopesac_conv2d_nhwc for x / w bf16;
- * needs Cin % 64 == 0, Cout % 128 == 0; act may carry NPS_ACT_RES_AFTER. */
+ * needs Cin % 64 == 0, Cout % 128 == 0; act may carry NPS_ACT_RES_AFTER; out_dt may also be NPS_DT_FP8 (no residual). */
 int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,
                               void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                               int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
                               void* stream);
+
+/* fp8 (OCP e4m3fn) conv on the gfx950 K=64 fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4, unit block scales; 2x the bf16 MFMA rate): x is
+ * fp8 NHWC, w_frag8 the fp8 [Cout][KH*KW*Cin] matrix in the fp8 fragment-major order
+ *   [Cout/32][K/64][2][64][16]:  byte j of piece h of lane l = w[nt*32 + (l & 31)][kf*64 + 32*(l >> 5) + 16*h + j]
+ * (ops.mfma_fragment_major_fp8).  Accumulation is f32; `scale` must already contain the de-quantisation factors
+ * (bn_scale[n] * w_scale[n] * x_scale) - the kernel is otherwise nopesac_conv2d_nhwc_bfrag (same structure: activations through an
+ * LDS-DMA ring - half the bytes per K step -, weights streamed from L2).  out_dt: F32, BF16 or FP8.  residual (if any) has out_dt's
+ * type (not allowed with FP8).  Needs Cin % 64 == 0, Cout % 128 == 0, x_cstride % 16 == 0.  variant 3: K-tile 128 (Cin % 128 == 0),
+ * variant 32: K-tile 64.  Replaces: the reference has no reduced-precision path; BASELINE config 5 ("fp8 MFMA backbone weights"). */
+int nopesac_conv2d_nhwc_fp8(const void* x, const void* w_frag8, const float* scale, const float* bias, const void* residual,
+                            void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
+                            void* stream);
 
 /* bf16 3x3 / stride 1 / pad 1 conv with 64 -> 64 channels + folded BN + activation (conv2 of the res2 bottlenecks): 16x16 pixel
  * tiles computed out of an 18x18 halo kept in LDS (csrc/conv3x3_c64.hip).  x, y bf16 NHWC [B,H,W,64]; w_frag = the
@@ -128,6 +143,12 @@ int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const float* sca
                                  const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH, int OW,
                                  int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
                                  const float* scale1, const float* bias1, int CN, void* o, void* stream);
+/* Same; o_dt = NPS_DT_BF16, or NPS_DT_FP8: o is written as OCP e4m3fn bytes (the next block's 3x3 conv then runs on
+ * nopesac_conv2d_nhwc_fp8; scale1 / bias1 must already contain the 1 / x_scale of that conv's input quantisation). */
+int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,
+                                    const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH, int OW,
+                                    int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
+                                    const float* scale1, const float* bias1, int CN, void* o, int o_dt, void* stream);
 
 /* (x - mean[c]) / std[c], NCHW f32 -> NHWC (C padded with zeros to Cpad), out_dt f32/bf16.
  * siamese_planeTR.py:85-89,534-542. */

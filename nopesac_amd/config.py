@@ -253,6 +253,9 @@ def add_amd_defaults(cfg: CfgNode) -> CfgNode:
         OUTPUT_RLE=True,              # COCO RLE "segmentation" + "bbox" in every `instances` entry (siamese_planeTR.py:703-720)
         USE_HIP_GRAPH=False,          # capture the static-shape forward in a hipGraph
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
+        BACKBONE_FP8=False,           # BASELINE config 5: the 3x3 convs of the res3-res5 bottlenecks (44 % of the backbone FLOPs, its
+                                      # MFMA-bound layers) on the fp8 (e4m3fn) K = 64 MFMA: per-output-channel weight scales, static
+                                      # per-layer activation scales (PlaneTR_NopeSAC.calibrate_fp8); needs COMPUTE_DTYPE bfloat16
     ))
     return cfg
 

@@ -18,6 +18,19 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// OCP e4m3fn (gfx950's fp8): 8 floats -> 8 bytes, round to nearest even, saturating at +-448 (no NaN from overflow).
+__device__ __forceinline__ uint2 f32x8_to_fp8(const float* v) {
+    float c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = fminf(fmaxf(v[e], -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }

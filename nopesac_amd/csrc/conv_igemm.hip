@@ -21,6 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 struct ConvParams {
     const void* x; const void* w; const float* scale; const float* bias; const void* res; void* y;
@@ -113,6 +115,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                     float* yp = (float*)p.y + pix * p.y_cs + n;
                     *(f32x4*)(yp) = *(const f32x4*)(v);
                     *(f32x4*)(yp + 4) = *(const f32x4*)(v + 4);
+                } else if (p.out_dt == NPS_DT_FP8) {
+                    *(uint2*)((unsigned char*)p.y + pix * p.y_cs + n) = f32x8_to_fp8(v);
                 } else {
                     us8 o;
 #pragma unroll
@@ -501,12 +505,16 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? (BKT
 // L2 into a two-deep register ring (wave tile = 128 pixels x 32 channels: no weight fragment is fetched twice in a workgroup,
 // every load is 1 KB contiguous).  vmcnt is counted (DMAs and fragment loads retire in issue order): at the top of K-tile j
 // only "everything up to B(j)" has to be back, A(j+1..) and B(j+1) stay in flight across the barrier.
-template <int NSTAGE, int BKT = 64>
+// FP8 = true: x and the weights are OCP e4m3fn bytes, a K-tile row is still BKT * 2 bytes (= BKT * 2 channels), the MFMA is the
+// K = 64 v_mfma_f32_32x32x64_f8f6f4 with unit block scales (32 bytes per lane and operand = two 16-byte pieces; the weight pieces
+// are stored [K/64][2][64 lanes][16 B] so that every load is still 1 KB contiguous per wave and counts as one vmcnt op).
+template <int NSTAGE, int BKT = 64, bool FP8 = false>
 __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void conv_igemm_bfrag_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
-    constexpr int BM = 128, BN = 128, BK = BKT, ROWB = BK * 2, CPR = BK / 8, RPD = 64 / CPR, SWSH = BK == 64 ? 1 : 2;
-    constexpr int KF = BK / 16;                                 // weight fragments (k16 steps) per K-tile
+    constexpr int EB = FP8 ? 1 : 2;                             // bytes per element
+    constexpr int BM = 128, BN = 128, BK = BKT * 2 / EB, ROWB = BKT * 2, CPR = BKT / 8, RPD = 64 / CPR, SWSH = BKT == 64 ? 1 : 2;
+    constexpr int KF = BKT / 16;                                // 16-byte-per-lane weight pieces per K-tile (bf16: one per k16 step)
     constexpr int A_BYTES = BM * ROWB;                          // 16 (8) KB per stage
     constexpr int TM = 4, A_DMA = BM / RPD / 4;                 // 4 (2) DMAs per wave per K-tile
     constexpr int EPI_BYTES = BM * (64 + 4) * 4;
@@ -527,21 +535,21 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
 
     const int slot = lane % CPR, rsub = lane / CPR;
     constexpr unsigned OOB = 0xFFFFFF00u;
-    const long long padb = ((long long)p.pad * p.W + p.pad) * p.x_cs * 2;
+    const long long padb = ((long long)p.pad * p.W + p.pad) * p.x_cs * EB;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.x - padb), 0, (int)(((long long)p.B * p.H * p.W * p.x_cs) * 2 + padb), 0x00020000);
+        (void*)((const char*)p.x - padb), 0, (int)(((long long)p.B * p.H * p.W * p.x_cs) * EB + padb), 0x00020000);
     unsigned a_voff[A_DMA], a_mask[A_DMA];
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
         const int pr = (wave * A_DMA + j) * RPD + rsub;
         const int m = m0 + pr;
-        const int coff = (slot ^ ((pr >> SWSH) & (CPR - 1))) * 8;
+        const int coff = (slot ^ ((pr >> SWSH) & (CPR - 1))) * (16 / EB);
         a_voff[j] = OOB; a_mask[j] = 0u;
         if (m < p.M) {
             const int b = m / p.rows_per_b, rem = m % p.rows_per_b;
             const int oh = rem / p.OW, ow = rem % p.OW;
             const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-            a_voff[j] = (unsigned)((((long long)b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + coff) * 2u;
+            a_voff[j] = (unsigned)((((long long)b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.x_cs + coff) * (unsigned)EB;
             unsigned mk = 0u;
             for (int kh = 0; kh < p.KH; ++kh)
                 for (int kw = 0; kw < p.KW; ++kw)
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
     unsigned cur_tapoff = 0u;
     auto issue_a = [&](int stage) {
         unsigned char* sbase = lds + stage * A_BYTES;
-        const unsigned a_soff = cur_tapoff + (unsigned)cur_c0 * 2u;
+        const unsigned a_soff = cur_tapoff + (unsigned)cur_c0 * (unsigned)EB;
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
             const unsigned vo = ((a_mask[j] >> cur_tap) & 1u) ? a_voff[j] : OOB;
@@ -562,12 +570,12 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
         cur_c0 += BK;
         if (cur_c0 >= p.Cin) {
             cur_c0 = 0; ++cur_tap; ++cur_kw;
-            cur_tapoff += (unsigned)p.x_cs * 2u;
-            if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * 2u; }
+            cur_tapoff += (unsigned)p.x_cs * (unsigned)EB;
+            if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * (unsigned)EB; }
         }
     };
-    // this wave's weight fragments: column tile n0/32 + wave, fragment-major [N/32][K/16][64][8]
-    const int nk = p.K / BK, kf_total = p.K / 16;
+    // this wave's weight fragments: column tile n0/32 + wave, fragment-major [N/32][K*EB/32 pieces][64][16 B]
+    const int nk = p.K / BK, kf_total = p.K * EB / 32;
     const T* wfr = (const T*)p.w + ((long long)(n0 / 32 + wave) * kf_total * 64 + lane) * 8;
     bf16x8 bring[2][KF];
     auto load_b = [&](int kt, int buf, int kk) { bring[buf][kk] = *(const bf16x8*)(wfr + (long long)(kt * KF + kk) * 512); };
@@ -606,15 +614,36 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
             issue_a(st);                                     // A(j+DA) into the stage tile j-1 just vacated
         }
         const unsigned char* sb = lds + stage_j * A_BYTES;
+        if constexpr (FP8) {
 #pragma unroll
-        for (int kk = 0; kk < KF; ++kk) {
-            const int so = ((kk * 2 + (lane >> 5)) ^ sw) * 16;
-            bf16x8 af[TM];
+            for (int f = 0; f < KF / 2; ++f) {                   // one K = 64 MFMA step: lane needs bytes 32*(lane>>5) .. +31 of the 64
+                const int so0 = ((f * 4 + (lane >> 5) * 2) ^ sw) * 16, so1 = ((f * 4 + (lane >> 5) * 2 + 1) ^ sw) * 16;
+                i32x4 a0[TM], a1[TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * ROWB + so);
+                for (int i = 0; i < TM; ++i) {
+                    a0[i] = *(const i32x4*)(sb + a_row_off + i * 32 * ROWB + so0);
+                    a1[i] = *(const i32x4*)(sb + a_row_off + i * 32 * ROWB + so1);
+                }
+                const i32x4 b0 = __builtin_bit_cast(i32x4, bring[buf][2 * f]), b1 = __builtin_bit_cast(i32x4, bring[buf][2 * f + 1]);
+                const i32x8 bw = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bring[buf][kk], af[i], acc[i][0], 0, 0, 0);
-            if (j + 2 < nk) load_b(j + 2, buf, kk);          // refill the slot that was just consumed
+                for (int i = 0; i < TM; ++i) {
+                    const i32x8 aw = {a0[i][0], a0[i][1], a0[i][2], a0[i][3], a1[i][0], a1[i][1], a1[i][2], a1[i][3]};
+                    acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, aw, acc[i][0], 0, 0, 0, 0, 0, 0);
+                }
+                if (j + 2 < nk) { load_b(j + 2, buf, 2 * f); load_b(j + 2, buf, 2 * f + 1); }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KF; ++kk) {
+                const int so = ((kk * 2 + (lane >> 5)) ^ sw) * 16;
+                bf16x8 af[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * ROWB + so);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bring[buf][kk], af[i], acc[i][0], 0, 0, 0);
+                if (j + 2 < nk) load_b(j + 2, buf, kk);          // refill the slot that was just consumed
+            }
         }
     };
     {
@@ -727,7 +756,8 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                   "conv2d: bad dims B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d", B, H, W, Cin, Cout, KH, KW, stride, pad);
     NPS_CHECK_ARG(in_dt == NPS_DT_F32 || in_dt == NPS_DT_BF16 || in_dt == NPS_DT_F32_BF16W, "conv2d: bad in_dt %d", in_dt);
-    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d: bad out_dt %d", out_dt);
+    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16 || (out_dt == NPS_DT_FP8 && in_dt == NPS_DT_BF16 && !residual),
+                  "conv2d: bad out_dt %d (fp8 output: bf16 conv without residual only)", out_dt);
     NPS_CHECK_ARG(x_cstride >= Cin && y_cstride >= Cout, "conv2d: channel stride smaller than channel count");
     NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d: residual stride");
     const int res_after = (act & NPS_ACT_RES_AFTER) ? 1 : 0;
@@ -776,6 +806,7 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
         if (bias) ok = ok && ((uintptr_t)bias % 16 == 0) && (!bias_batched || Cout % 4 == 0);
         (void)osz;
         p.epi_vec = ok ? 1 : 0;
+        NPS_CHECK_ARG(out_dt != NPS_DT_FP8 || (ok && Cout % 8 == 0), "conv2d: fp8 output needs Cout %% 8 == 0 and 8-channel-aligned y / scale / bias");
     }
     if (in_dt == NPS_DT_BF16) launch_dtype<bf16_t, bf16_t>(p, (hipStream_t)stream);
     else if (in_dt == NPS_DT_F32_BF16W) launch_dtype<float, bf16_t>(p, (hipStream_t)stream);
@@ -783,19 +814,20 @@ extern "C" int nopesac_conv2d_nhwc_ex(const void* x, const void* w, const float*
     NPS_LAUNCH_RET();
 }
 
-extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,
-                                         void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                                         int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int nstage,
-                                         void* stream) {
+static int bfrag_launch(bool fp8, const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual, void* y,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride,
+                        int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int nstage, void* stream) {
     using namespace nps;
+    const int eb = fp8 ? 1 : 2;
     NPS_CHECK_ARG(x && w_frag && y, "conv2d_bfrag: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_bfrag: bad dims");
     NPS_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 128 == 0, "conv2d_bfrag: needs Cin %% 64 == 0 and Cout %% 128 == 0");
-    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "conv2d_bfrag: bad out_dt %d", out_dt);
+    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16 || out_dt == NPS_DT_FP8, "conv2d_bfrag: bad out_dt %d", out_dt);
     NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (4-stage ring, K-tile 32)");
-    NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % 8 == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_frag % 16 == 0),
+    NPS_CHECK_ARG(!(fp8 && nstage == 3) || Cin % 128 == 0, "conv2d_fp8: variant 3 (K-tile 128) needs Cin %% 128 == 0");
+    NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % (16 / eb) == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_frag % 16 == 0),
                   "conv2d_bfrag: strides / alignment");
-    NPS_CHECK_ARG(!residual || r_cstride >= Cout, "conv2d_bfrag: residual stride");
+    NPS_CHECK_ARG(!residual || (r_cstride >= Cout && out_dt != NPS_DT_FP8), "conv2d_bfrag: residual stride / residual with fp8 output");
     const int res_after = (act & NPS_ACT_RES_AFTER) ? 1 : 0;
     NPS_CHECK_ARG((act & ~(0xff | NPS_ACT_RES_AFTER)) == 0, "conv2d_bfrag: unsupported act flags");
     act &= 0xff;
@@ -812,7 +844,7 @@ extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, cons
     p.batched = 0;
     p.M = B * p.rows_per_b; p.N = Cout; p.K = KH * KW * Cin;
     p.act = act; p.out_dt = out_dt; p.res_after = res_after;
-    NPS_CHECK_ARG((long long)B * H * W * x_cstride * 2 + ((long long)pad * W + pad) * x_cstride * 2 < (1ll << 31), "conv2d_bfrag: input larger than 2 GB");
+    NPS_CHECK_ARG((long long)B * H * W * x_cstride * eb + ((long long)pad * W + pad) * x_cstride * eb < (1ll << 31), "conv2d_bfrag: input larger than 2 GB");
     {
         const int al = out_dt == NPS_DT_F32 ? 4 : 8;
         bool ok = (y_cstride % al == 0) && ((uintptr_t)y % 16 == 0);
@@ -820,11 +852,33 @@ extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, cons
         if (scale) ok = ok && ((uintptr_t)scale % 16 == 0);
         if (bias) ok = ok && ((uintptr_t)bias % 16 == 0);
         p.epi_vec = ok ? 1 : 0;
+        NPS_CHECK_ARG(ok || out_dt != NPS_DT_FP8, "conv2d_fp8: fp8 output needs 8-channel-aligned y / scale / bias");
     }
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = p.N / 128;
     const dim3 grid(p.tiles_m * p.tiles_n);
-    if (nstage == 3) hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (fp8) {
+        if (nstage == 3) hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<4, 32, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (nstage == 3) hipLaunchKernelGGL((conv_igemm_bfrag_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_igemm_bfrag_kernel<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* scale, const float* bias, const void* residual,
+                                         void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                         int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int nstage,
+                                         void* stream) {
+    return bfrag_launch(false, x, w_frag, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, r_cstride,
+                        act, out_dt, nstage, stream);
+}
+
+extern "C" int nopesac_conv2d_nhwc_fp8(const void* x, const void* w_frag8, const float* scale, const float* bias, const void* residual,
+                                       void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                       int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
+                                       void* stream) {
+    return bfrag_launch(true, x, w_frag8, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, r_cstride,
+                        act, out_dt, variant, stream);
 }

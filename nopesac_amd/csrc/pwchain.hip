@@ -36,7 +36,21 @@ struct PwArgs {
     bf16_t* y;                                                                 // [M][C4]
     const bf16_t* w1; const float* s1; const float* b1; bf16_t* o;             // next conv1: w1 [CN][C4], o [M][CN]
     long long M;
+    int o_fp8;                                                                 // 1: o is OCP e4m3fn bytes (fp8 conv2 follows)
 };
+
+// 8 channels of the next block's conv1 output (bf16 in LDS) -> o, as bf16 or (o_fp8) saturated / rounded to e4m3fn
+template <int CN>
+__device__ __forceinline__ void pw_store_o(const PwArgs& p, long long m, int col, us8 v) {
+    if (p.o_fp8) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p.o) + m * CN + col * 8) = f32x8_to_fp8(f);
+    } else {
+        *reinterpret_cast<us8*>(p.o + m * CN + col * 8) = v;
+    }
+}
 
 template <int BM, int K>
 __device__ __forceinline__ void pw_load_tile(const bf16_t* __restrict__ src, long long row0, long long M, int tid, us8 (&reg)[BM * K / 8 / 256]) {
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256, (PwLds<C, C4, CN, C2, BM>::WAVES_PER_SIMD)) vo
 #pragma unroll
         for (int i = 0; i < BM * CPR / 256; ++i) {
             const int c = tid + i * 256, row = c / CPR, col = c % CPR;
-            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+            if (m0 + row < p.M) pw_store_o<CN>(p, m0 + row, col, *reinterpret_cast<const us8*>(O + row * O_LD + col * 8));
         }
     }
 }
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void pw_chain_wide_kernel(const PwArgs p) {
 #pragma unroll
         for (int i = 0; i < BM * CPR / 512; ++i) {
             const int c = tid + i * 512, row = c / CPR, col = c % CPR;
-            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+            if (m0 + row < p.M) pw_store_o<CN>(p, m0 + row, col, *reinterpret_cast<const us8*>(O + row * O_LD + col * 8));
         }
     }
 }
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void pw_chain_stream_kernel(const PwArgs p)
 #pragma unroll
         for (int i = 0; i < BM * CPR / 512; ++i) {
             const int ch = tid + i * 512, row = ch / CPR, col = ch % CPR;
-            if (m0 + row < p.M) *reinterpret_cast<us8*>(p.o + (m0 + row) * CN + col * 8) = *reinterpret_cast<const us8*>(O + row * O_LD + col * 8);
+            if (m0 + row < p.M) pw_store_o<CN>(p, m0 + row, col, *reinterpret_cast<const us8*>(O + row * O_LD + col * 8));
         }
     }
 }
@@ -678,7 +692,16 @@ extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const
                                             const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH,
                                             int OW, int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
                                             const float* scale1, const float* bias1, int CN, void* o, void* stream) {
+    return nopesac_bottleneck_tail_bf16_ex(b, w3, scale3, bias3, residual, x2, wsc, scale_sc, bias_sc, B, OH, OW, x2_H, x2_W, x2_stride, C, C4,
+                                           C2, y, w1, scale1, bias1, CN, o, NPS_DT_BF16, stream);
+}
+
+extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,
+                                               const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH,
+                                               int OW, int x2_H, int x2_W, int x2_stride, int C, int C4, int C2, void* y, const void* w1,
+                                               const float* scale1, const float* bias1, int CN, void* o, int o_dt, void* stream) {
     using namespace nps;
+    NPS_CHECK_ARG(o_dt == NPS_DT_BF16 || o_dt == NPS_DT_FP8, "bottleneck_tail: o_dt must be NPS_DT_BF16 or NPS_DT_FP8");
     NPS_CHECK_ARG(b && w3 && scale3 && bias3 && y && B > 0 && OH > 0 && OW > 0, "bottleneck_tail: bad args");
     NPS_CHECK_ARG((residual != nullptr) != (x2 != nullptr), "bottleneck_tail: exactly one of residual / x2 (projection shortcut)");
     NPS_CHECK_ARG(!x2 || (wsc && scale_sc && bias_sc && C2 > 0 && x2_stride >= 1 && (OH - 1) * x2_stride < x2_H && (OW - 1) * x2_stride < x2_W),
@@ -693,6 +716,7 @@ extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const
     a.a2_H = x2_H; a.a2_W = x2_W; a.a2_stride = x2_stride; a.OH = OH; a.OW = OW;
     a.y = (bf16_t*)y; a.w1 = (const bf16_t*)w1; a.s1 = scale1; a.b1 = bias1; a.o = (bf16_t*)o;
     a.M = (long long)B * OH * OW;
+    a.o_fp8 = o_dt == NPS_DT_FP8 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int c2 = x2 ? C2 : 0;
 #define PW_CASE(c, c4, cn, cc2, bm) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch<c, c4, cn, cc2, bm>(a, st); NPS_LAUNCH_RET(); }

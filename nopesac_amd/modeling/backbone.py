@@ -38,6 +38,12 @@ class HipResNet50(ParamModule):
         self.fused_stem = True
         self.fused_tail = True
         self.halo_conv2 = not os.environ.get("NOPESAC_NO_HALO_CONV2")
+        # fp8 mode (MODEL.AMD.BACKBONE_FP8): the 3x3 conv of every res3 / res4 / res5 bottleneck runs on the fp8 MFMA; its input (the block's conv1 output)
+        # is written as e4m3fn by the producing kernel.  act_scale[block] = static scale of that input (x ~= x8 * scale).
+        self.fp8_conv2 = bool(cfg.MODEL.AMD.get("BACKBONE_FP8", False)) if cfg is not None else False
+        self.act_scale: dict = {}
+        self._calib: dict | None = None
+        self._q8: dict = {}
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -60,9 +66,45 @@ class HipResNet50(ParamModule):
                 cin = cout
         return P
 
+    def _apply(self, fn, *a, **k):
+        self._q8 = {}
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._q8 = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    def calibrate_fp8(self, x: torch.Tensor, headroom: float = 2.0) -> dict:
+        """One bf16 forward over representative (normalised NHWC) inputs that records the largest magnitude of every 3x3 conv's
+        input and fixes the static activation scales of the fp8 mode so that this maximum maps to 448 / headroom."""
+        was, self.fp8_conv2, self._calib = self.fp8_conv2, False, {}
+        try:
+            with torch.no_grad():
+                self.forward(x)
+            amax = {k: float(v) for k, v in self._calib.items()}
+        finally:
+            self.fp8_conv2, self._calib = was, None
+        self.act_scale = {k: max(v, 1e-6) * headroom / ops.FP8_MAX for k, v in amax.items()}
+        self._q8 = {}
+        return dict(self.act_scale)
+
+    def _quant(self, p: str) -> dict:
+        """fp8 operands of block p: fragment-major e4m3fn 3x3 weights, the de-quantising epilogue scale of conv2, and the conv1
+        scale / shift with 1 / act_scale folded in (ReLU commutes with a positive factor)."""
+        q = self._q8.get(p)
+        if q is None:
+            P = self.packed
+            c1, c2 = P[p + ".conv1"], P[p + ".conv2"]
+            xs = float(self.act_scale.get(p, 1.0))
+            w8, wsc = ops.quantize_weights_fp8(c2.w(torch.float32))
+            q = {"w8": w8, "s2": (c2.scale * wsc * xs).contiguous(), "s1": (c1.scale / xs).contiguous(), "b1": (c1.bias / xs).contiguous()}
+            self._q8[p] = q
+        return q
+
     def forward(self, x: torch.Tensor) -> dict:
         """x: NHWC [B,H,W,4] (normalised, channel-padded) in the compute dtype -> {res2..res5} NHWC."""
         P, dt = self.packed, x.dtype
+        assert not self.fp8_conv2 or (dt == torch.bfloat16 and self.fused_tail), "MODEL.AMD.BACKBONE_FP8 needs MODEL.AMD.COMPUTE_DTYPE bfloat16"
 
         def cv(t, key, stride=1, pad=0, act=ops.ACT_RELU, residual=None):
             c = P[key]
@@ -82,8 +124,21 @@ class HipResNet50(ParamModule):
             p = f"{name}.{i}"
             stride = 2 if (i == 0 and name != "res2") else 1
             proj = cin != cout
-            y = a_pre if a_pre is not None else cv(x, p + ".conv1")
-            if fuse and cmid == 64 and stride == 1 and self.halo_conv2:
+            fp8 = self.fp8_conv2 and cmid % 128 == 0           # res3-res5 (the fp8 kernel's tiles are 128 output channels wide)
+            if fp8:
+                q = self._quant(p)
+                if a_pre is None:
+                    y = ops.conv2d(x, P[p + ".conv1"].w(dt), q["s1"], q["b1"], act=ops.ACT_RELU, out_dtype=torch.float8_e4m3fn)
+                else:
+                    y = a_pre
+            else:
+                y = a_pre if a_pre is not None else cv(x, p + ".conv1")
+            if self._calib is not None:
+                self._calib[p] = torch.maximum(self._calib.get(p, y.new_zeros((), dtype=torch.float32)), y.float().abs().amax())
+            if fp8:
+                c2 = P[p + ".conv2"]
+                y = ops.conv2d_fp8(y, q["w8"], q["s2"], c2.bias, ksize=3, stride=stride, pad=1, act=ops.ACT_RELU)
+            elif fuse and cmid == 64 and stride == 1 and self.halo_conv2:
                 c2 = P[p + ".conv2"]           # res2: 3x3 out of an LDS halo tile (csrc/conv3x3_c64.hip)
                 y = ops.conv3x3_c64(y, c2.w(dt), c2.scale, c2.bias)
             else:
@@ -105,7 +160,10 @@ class HipResNet50(ParamModule):
                     kw.update(x2=x, wsc=sc.wfrag(dt), ssc=sc.scale, bsc=sc.bias, stride=stride)
                 else:
                     kw.update(residual=x)
-                if use_next:
+                if use_next and self.fp8_conv2 and blocks[bi + 1][3] % 128 == 0:
+                    qn = self._quant(f"{blocks[bi + 1][0]}.{blocks[bi + 1][1]}")
+                    kw.update(w1=nxt.wfrag(dt), s1=qn["s1"], b1=qn["b1"], o_fp8=True)
+                elif use_next:
                     kw.update(w1=nxt.wfrag(dt), s1=nxt.scale, b1=nxt.bias)
                 x, a_pre = ops.bottleneck_tail(y, c3.wfrag(dt), c3.scale, c3.bias, **kw)
             else:

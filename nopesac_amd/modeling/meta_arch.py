@@ -131,6 +131,11 @@ class PlaneTR_NopeSAC(nn.Module):
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
 
+    def calibrate_fp8(self, batched_inputs: List[dict]) -> dict:
+        """Static activation scales of the fp8 backbone mode (MODEL.AMD.BACKBONE_FP8) from representative pairs; returns them."""
+        with torch.no_grad():
+            return self.backbone.calibrate_fp8(self.preprocess_image(batched_inputs))
+
     def autotune(self, pairs: int, height: int = 480, width: int = 640) -> int:
         """One dedicated single-stream forward on zeros that lets ops.TUNER pick, per conv/GEMM shape of this
         (batch, resolution), the fastest of the library's equivalent kernel configurations.  Returns the number of

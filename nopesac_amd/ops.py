@@ -15,7 +15,8 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACT_RES_AFTER = 0x100      # OR-able: residual is added after the activation
 ACT_BIAS_BATCHED = 0x200   # OR-able (set by conv2d): with batched weights, bias is [B, Cout]
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+FP8 = 3                    # NPS_DT_FP8: OCP e4m3fn bytes
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
 
 def _L():
@@ -229,10 +230,54 @@ def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:
     return w2d.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
-def bottleneck_tail(b, w3, s3, b3, *, residual=None, x2=None, wsc=None, ssc=None, bsc=None, stride=1, w1=None, s1=None, b1=None):
+def mfma_fragment_major_fp8(w2d: torch.Tensor) -> torch.Tensor:
+    """[N,K] one-byte elements (N % 32 == 0, K % 64 == 0) -> same shape, re-ordered [N/32][K/64][2][64][16]: the two 16-byte
+    pieces h = 0, 1 that lane l = 32*half + n%32 feeds to v_mfma_f32_32x32x64_f8f6f4 hold k = kf*64 + 32*half + 16*h + 0..15."""
+    N, K = w2d.shape
+    assert N % 32 == 0 and K % 64 == 0 and w2d.element_size() == 1
+    return w2d.view(N // 32, 32, K // 64, 2, 2, 16).permute(0, 2, 4, 3, 1, 5).contiguous().view(N, K)
+
+
+FP8_MAX = 448.0            # largest finite e4m3fn
+
+
+def quantize_weights_fp8(w: torch.Tensor):
+    """Conv weight [Cout,KH,KW,Cin] (any float dtype) -> (fp8 fragment-major matrix [Cout, KH*KW*Cin], per-output-channel
+    scale f32[Cout]) with w ~= w8 * scale[:, None]; symmetric, amax -> 448 per output channel."""
+    w2 = w.reshape(w.shape[0], -1).float()
+    sc = w2.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX
+    w8 = (w2 / sc[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return mfma_fragment_major_fp8(w8), sc.contiguous()
+
+
+def conv2d_fp8(x: torch.Tensor, w8frag: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, *, ksize: int, stride=1, pad=0,
+               act=ACT_NONE, out_dtype=torch.bfloat16, residual=None, variant: int = 0) -> torch.Tensor:
+    """fp8 (e4m3fn) NHWC conv on the K = 64 fp8 MFMA.  x [B,H,W,Cin] float8_e4m3fn, w8frag from `quantize_weights_fp8`
+    ([Cout, k*k*Cin]); `scale` carries the de-quantisation (bn_scale * w_scale * x_scale).  variant 0 = by Cin."""
+    assert x.dtype == torch.float8_e4m3fn and w8frag.dtype == torch.float8_e4m3fn and x.is_contiguous() and w8frag.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w8frag.shape[0]
+    assert w8frag.shape[1] == ksize * ksize * Cin
+    _chk(scale, torch.float32); _chk(bias, torch.float32)
+    OH = (H + 2 * pad - ksize) // stride + 1
+    OW = (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=out_dtype)
+    if residual is not None:
+        _chk(residual, out_dtype)
+        assert residual.shape == out.shape
+    if not variant:
+        variant = 3 if Cin % 128 == 0 else 32
+    rc = _L().nopesac_conv2d_nhwc_fp8(_p(x), _p(w8frag), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, ksize, ksize,
+                                      stride, pad, Cin, Cout, Cout if residual is not None else 0, act, _DT[out_dtype], variant, _stream())
+    _lib.check(rc, "nopesac_conv2d_nhwc_fp8")
+    return out
+
+
+def bottleneck_tail(b, w3, s3, b3, *, residual=None, x2=None, wsc=None, ssc=None, bsc=None, stride=1, w1=None, s1=None, b1=None,
+                    o_fp8: bool = False):
     """Fused conv3 + shortcut + ReLU (+ the next block's conv1) of a bf16 bottleneck; returns (y, o or None).
     b [B,OH,OW,C]; residual [B,OH,OW,C4] or projection source x2 [B,H2,W2,C2] with wsc [C4,C2]; w1 [CN,C4].
-    The weight matrices are expected in `mfma_fragment_major` order."""
+    The weight matrices are expected in `mfma_fragment_major` order.  o_fp8: o is written as float8_e4m3fn."""
     _chk(b, torch.bfloat16); _chk(w3, torch.bfloat16)
     B, OH, OW, C = b.shape
     C4 = w3.shape[0]
@@ -240,16 +285,17 @@ def bottleneck_tail(b, w3, s3, b3, *, residual=None, x2=None, wsc=None, ssc=None
     C2 = 0 if x2 is None else x2.shape[3]
     assert (C, C4, CN, C2) in BOTTLENECK_TAIL_CONFIGS, (C, C4, CN, C2)
     y = torch.empty((B, OH, OW, C4), device=b.device, dtype=torch.bfloat16)
-    o = torch.empty((B, OH, OW, CN), device=b.device, dtype=torch.bfloat16) if CN else None
+    o = torch.empty((B, OH, OW, CN), device=b.device, dtype=torch.float8_e4m3fn if o_fp8 else torch.bfloat16) if CN else None
     if residual is not None:
         _chk(residual, torch.bfloat16)
         assert residual.shape == y.shape
     if x2 is not None:
         _chk(x2, torch.bfloat16); _chk(wsc, torch.bfloat16)
     H2, W2 = (x2.shape[1], x2.shape[2]) if x2 is not None else (0, 0)
-    rc = _L().nopesac_bottleneck_tail_bf16(_p(b), _p(w3), _p(s3), _p(b3), _p(residual), _p(x2), _p(wsc), _p(ssc), _p(bsc), B, OH, OW,
-                                           H2, W2, stride, C, C4, C2, _p(y), _p(w1), _p(s1), _p(b1), CN, _p(o), _stream())
-    _lib.check(rc, "nopesac_bottleneck_tail_bf16")
+    rc = _L().nopesac_bottleneck_tail_bf16_ex(_p(b), _p(w3), _p(s3), _p(b3), _p(residual), _p(x2), _p(wsc), _p(ssc), _p(bsc), B, OH, OW,
+                                              H2, W2, stride, C, C4, C2, _p(y), _p(w1), _p(s1), _p(b1), CN, _p(o),
+                                              FP8 if o_fp8 else BF16, _stream())
+    _lib.check(rc, "nopesac_bottleneck_tail_bf16_ex")
     return y, o
 
 

@@ -482,3 +482,64 @@ def test_conv3x3_halo(device, case, tile):
     assert _rel(y.float(), ref.float()) < 1e-2
     ref32 = F.leaky_relu(F.conv2d(x.float(), w.float(), None, 1, 1) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1), 0.01)
     assert _rel(y.float().permute(0, 3, 1, 2).cpu(), ref32) < 1.5e-2
+
+
+def _q8(t):
+    """float -> e4m3fn with the kernels' saturating round-to-nearest-even."""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1), (3, 31, 29, 128, 128, 3, 2, 1), (2, 24, 32, 512, 256, 1, 1, 0),
+                                  (1, 15, 20, 64, 384, 3, 1, 1), (2, 9, 7, 64, 128, 1, 1, 0), (2, 15, 20, 512, 512, 3, 2, 1)])
+@pytest.mark.parametrize("out_dt", ["bf16", "f32", "fp8"])
+def test_conv2d_fp8(device, case, out_dt):
+    """fp8 (e4m3fn) conv on the K = 64 fp8 MFMA vs F.conv2d on the de-quantised operands (the products of two e4m3 values are exact
+    in f32, so only the accumulation order differs): operand layouts, M tails, stride 2, both K-tile variants, all output types."""
+    from nopesac_amd import ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x8 = _q8(torch.randn(B, Cin, H, W, generator=g) * 2)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k) * (1 + torch.arange(Cout).view(-1, 1, 1, 1) % 5)
+    w8f, wsc = ops.quantize_weights_fp8(w.permute(0, 2, 3, 1).contiguous())
+    wdq = (w / wsc.view(-1, 1, 1, 1)).clamp(-448, 448).to(torch.float8_e4m3fn).float() * wsc.view(-1, 1, 1, 1)
+    assert _rel(wdq, w) < 0.07                                        # 3 mantissa bits
+    bn_s, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x8.float(), wdq, None, s, p) * bn_s.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.float8_e4m3fn}[out_dt]
+    for variant in ([3, 32] if Cin % 128 == 0 else [32]):
+        y = ops.conv2d_fp8(_nhwc(x8.view(torch.uint8)).view(torch.float8_e4m3fn).to(device), w8f.to(device), (bn_s * wsc).to(device),
+                           bias.to(device), ksize=k, stride=s, pad=p, act=ops.ACT_RELU, out_dtype=dt, variant=variant)
+        torch.cuda.synchronize()
+        got = y.float().permute(0, 3, 1, 2).cpu()
+        if out_dt == "fp8":                                           # same rounding as torch's cast; allow one-ulp flips at ties
+            want = _q8(ref).float()
+            assert (got != want).float().mean() < 2e-3 and _rel(got, want) < 0.07
+        else:
+            assert _rel(got, ref) < (1e-2 if out_dt == "bf16" else 1e-4), variant
+
+
+def test_conv2d_generic_and_tail_fp8_outputs(device):
+    """The producers of the fp8 conv inputs: nopesac_conv2d_nhwc with out_dt = FP8, and the bottleneck tail's next-conv1 output
+    written as fp8 - both must equal the bf16 result rounded to e4m3fn."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 20, 24, 64, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(64, 1, 1, 64, generator=g) / 8).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(64, generator=g)).to(device) * 150, torch.randn(64, generator=g).to(device)
+    y16 = ops.conv2d(x, w, sc, bi, act=ops.ACT_RELU)
+    y8 = ops.conv2d(x, w, sc, bi, act=ops.ACT_RELU, out_dtype=torch.float8_e4m3fn)
+    # the kernel rounds the f32 result, the reference the bf16-rounded one: identical except for rare double-rounding flips
+    want = _q8(y16)
+    assert y8.dtype == torch.float8_e4m3fn and (y8.float() != want.float()).float().mean() < 0.02
+    assert _rel(y8.float(), want.float().to(device)) < 0.08 and float(y8.float().max()) <= 448.0 and float(y16.float().max()) > 448.0   # saturates
+    # tail: C=64, C4=256, CN=64 identity block
+    b = torch.randn(2, 20, 24, 64, generator=g).to(device, torch.bfloat16)
+    res = torch.randn(2, 20, 24, 256, generator=g).to(device, torch.bfloat16)
+    w3 = ops.mfma_fragment_major((torch.randn(256, 64, generator=g) / 8).to(device, torch.bfloat16))
+    w1 = ops.mfma_fragment_major((torch.randn(64, 256, generator=g) / 16).to(device, torch.bfloat16))
+    s3, b3 = torch.ones(256, device=device), torch.zeros(256, device=device)
+    s1, b1 = torch.full((64,), 30.0, device=device), torch.zeros(64, device=device)
+    ya, oa = ops.bottleneck_tail(b, w3, s3, b3, residual=res, w1=w1, s1=s1, b1=b1)
+    yb, ob = ops.bottleneck_tail(b, w3, s3, b3, residual=res, w1=w1, s1=s1, b1=b1, o_fp8=True)
+    assert torch.equal(ya, yb) and ob.dtype == torch.float8_e4m3fn
+    assert torch.equal(ob.float(), _q8(oa).float().to(device))         # converted from the same bf16 staging values: bit-identical

@@ -286,3 +286,31 @@ def test_fused_decoder_tail_matches_per_layer_bf16_path(device):
     # six chained random-weight layers amplify 1-ulp bf16 differences (the bf16 path itself is ~0.5 away from fp32 on these
     # inputs): this is a wiring check; the kernel itself is checked tightly in test_kernels_gpu.py::test_decoder_tail
     assert rel_err(qa, qb) < 0.15 and torch.isfinite(qa).all()
+
+
+def test_backbone_fp8_conv2_mode(device):
+    """MODEL.AMD.BACKBONE_FP8 (BASELINE config 5): the bottlenecks' 3x3 convs on the fp8 MFMA with calibrated static activation
+    scales.  Judged against the bf16 backbone (same weights): feature maps within fp8 quantisation noise, and the end-to-end
+    initial pose close to the fp32 path's."""
+    import numpy as np
+    from nopesac_amd.synth import synth_pair
+    m8 = make_model(device, ("MODEL.AMD.BACKBONE_FP8", True), dtype="bfloat16")
+    m16, m32 = make_model(device, dtype="bfloat16"), make_model(device)
+    inp = [synth_pair(i) for i in range(2)]
+    scales = m8.calibrate_fp8(inp)
+    assert len(scales) == 16 and all(0 < v < 1e3 for v in scales.values())
+    x = m8.preprocess_image(inp)
+    with torch.no_grad():
+        f8, f16 = m8.backbone(x), m16.backbone(x)
+    for k in ("res2", "res3", "res4", "res5"):
+        a, b = f8[k].float(), f16[k].float()
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        rms = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+        assert rms < 0.08, (k, rms)                      # e4m3 operands: ~2-3 % per conv, accumulated over the stage's blocks
+    with torch.no_grad():
+        r8, r32 = m8(inp), m32(inp)
+    for a, b in zip(r8, r32):
+        t_err = float(np.linalg.norm(a["camera_init"]["tran"] - b["camera_init"]["tran"]))
+        q = abs(float(np.dot(a["camera_init"]["rot"], b["camera_init"]["rot"])))
+        assert t_err < 0.1 * (1 + np.linalg.norm(b["camera_init"]["tran"])) and 2 * np.degrees(np.arccos(min(q, 1.0))) < 15.0
+        assert np.isfinite(a["camera"]["tran"]).all() and np.isfinite(a["camera"]["rot"]).all()
