@@ -239,6 +239,15 @@ int nopesac_postselect_planes(const float* cls_logits, const float* mask_prob, c
                               int32_t* n_kept, int32_t* kept_idx, float* planes, float* feats, float* scores,
                               int32_t* areas, float* centers, uint8_t* winner, int32_t* flags, int32_t* work,
                               void* stream);
+/* Same; prob_planar = 1: mask_prob is laid out [B,nq,h,w] (what nopesac_mask_head_bf16 writes with flag bit 1): only the planes
+ * of the queries that pass the score test are read. */
+int nopesac_postselect_planes_ex(const float* cls_logits, const float* mask_prob, const float* params,
+                                 const float* query_feat,
+                                 int B, int nq, int D, int h, int w, int H, int W,
+                                 float score_thr, float mask_thr, float overlap_thr,
+                                 int32_t* n_kept, int32_t* kept_idx, float* planes, float* feats, float* scores,
+                                 int32_t* areas, float* centers, uint8_t* winner, int32_t* flags, int32_t* work,
+                                 int prob_planar, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Matching head tail: geometric priors + log-space Sinkhorn with dustbin + mutual-NN assignment,
@@ -327,7 +336,7 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
  *   p1 = relu(scale * (w_lateral . c1) + bias) + relu(bilinear_2x(t1));   prob = [sigmoid](mask_w[b] . p1 + mask_b[b])
  * c1 [B,H,W,256], t1 [B,H/2,W/2,256] bf16; w_lateral [256][256] and mask_w [B][64][256] (rows >= nq zero) bf16 in MFMA
  * fragment-major order; mask_b f32 [B][64]; prob f32 [B,H,W,nq] (nq even, <= 64); p1_out optional bf16 [B,H,W,256].
- * H*W must be a multiple of 128. */
+ * H*W must be a multiple of 128.  apply_sigmoid: bit 0 = apply the sigmoid, bit 1 = write prob planar, [B,nq,H,W]. */
 int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                            const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
                            int apply_sigmoid, void* stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "nopesac_attention_small_bf16io": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_transpose_hw_rows": [P, P, I, I, I, I, P],
     "nopesac_postselect_planes": [P, P, P, P, I, I, I, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P, P, P, P],
+    "nopesac_postselect_planes_ex": [P, P, P, P, I, I, I, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P, P, P, I, P],
     "nopesac_matcher_sinkhorn": [P, P, P, P, P, P, P, F, F, I, F, I, I, P, P, P],
     "nopesac_geo_sequence": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "nopesac_ransac_score_maps": [P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P],

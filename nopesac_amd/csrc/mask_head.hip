@@ -20,7 +20,8 @@ typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 
 constexpr int MH_C = 256, MH_LD = MH_C + 8, MH_BM = 128, MH_RT = MH_BM / 32, MH_NQP = 64;
-constexpr size_t MH_LDS_BYTES = 2 * (size_t)(2 * MH_BM * MH_LD);
+constexpr size_t MH_LDS_BYTES = (size_t)(2 * MH_BM * MH_LD);      // ONE 128 x 264 bf16 tile (67.6 KB): c1 rows -> p1 -> f32 output staging
+constexpr int MH_RING = 8;                                          // weight fragments in flight per wave (rolling ring)
 static_assert((size_t)MH_BM * MH_NQP * 4 <= 2 * (size_t)MH_BM * MH_LD, "output staging must fit the A tile");
 
 struct MaskHeadArgs {
@@ -28,32 +29,32 @@ struct MaskHeadArgs {
     const bf16_t* wc; const float* sc; const float* bc;   // lateral conv (fragment-major) + folded BN
     const bf16_t* mw; const float* mb;           // [B][64][256] fragment-major per image (rows >= nq zero), [B][64]
     float* prob; bf16_t* p1;                     // [B][H][W][nq] f32; optional [B][H][W][256] bf16
-    int B, H, W, nq, apply_sigmoid;
+    int B, H, W, nq, apply_sigmoid, planar;      // planar: prob is [B][nq][H][W] (one 512-byte run per plane and workgroup)
 };
 
-__global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p) {
+// Two workgroups per CU (67.6 KB LDS, <= 128 registers): while one is in its load / bilinear / store phase the other one's MFMAs
+// run.  The weights stream through an 8-slot rolling register ring (16 k-steps per GEMM), the single LDS tile is reused in
+// place: c1 rows (A of the lateral GEMM) -> p1 (A of the mask GEMM) -> f32 probabilities.
+__global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mh_smem[];
-    bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem);         // c1 rows; later the f32 output staging
-    bf16_t* Pt = At + MH_BM * MH_LD;                         // lateral -> p1
+    bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = p.H * p.W;
     const long long m0 = (long long)blockIdx.x * MH_BM;      // per % 128 == 0: a workgroup never straddles two images
     const int b = (int)(m0 / per), pix0 = (int)(m0 % per);
 
-    // weight fragments: lateral tile `wave` (16 k-steps) and this wave's mask tile (tile wave&1 of image b)
-    bf16x8 wl[16], wm[16];
+    bf16x8 ring[MH_RING];
+    const bf16_t* wlp = p.wc + ((long long)wave * 16 * 64 + lane) * 8;                              // lateral column tile `wave`
+    const bf16_t* wmp = p.mw + (((long long)b * 2 + (wave & 1)) * 16) * 512 + lane * 8;            // mask column tile wave & 1 of image b
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) wl[kk] = *reinterpret_cast<const bf16x8*>(p.wc + ((long long)(wave * 16 + kk) * 64 + lane) * 8);
+    for (int s = 0; s < MH_RING; ++s) ring[s] = *reinterpret_cast<const bf16x8*>(wlp + s * 512);
     // c1 rows -> LDS
 #pragma unroll
     for (int i = 0; i < MH_BM * 32 / 512; ++i) {
         const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
         *reinterpret_cast<us8*>(At + r * MH_LD + col) = *reinterpret_cast<const us8*>(p.c1 + (m0 + r) * MH_C + col);
     }
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-        wm[kk] = *reinterpret_cast<const bf16x8*>(p.mw + (((long long)b * 2 + (wave & 1)) * 16 + kk) * 512 + lane * 8);
     __syncthreads();
 
     // ---- lateral = relu(bn(W_c1 c1)): wave owns channels wave*32 .. +32 of all four 32-pixel row tiles
@@ -64,12 +65,17 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
+        for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
             for (int r = 0; r < MH_RT; ++r) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[kk], af, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc[r], 0, 0, 0);
             }
+            if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wlp + (kk + MH_RING) * 512);
+            else ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING - 16) * 512);     // mask GEMM k-steps 0..7
+            if ((kk & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                      // every wave is done reading the c1 rows
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = wave * 32 + 8 * q + 4 * half;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
                     v += bb[e];
                     o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
                 }
-                *reinterpret_cast<us4*>(Pt + (r * 32 + l31) * MH_LD + n) = o;
+                *reinterpret_cast<us4*>(At + (r * 32 + l31) * MH_LD + n) = o;
             }
         }
     }
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
     {
         const int H2 = p.H >> 1, W2 = p.W >> 1;
         const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
-#pragma unroll 4
+#pragma unroll 2
         for (int i = 0; i < MH_BM * 32 / 512; ++i) {
             const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
             const int pix = pix0 + r, oh = pix / p.W, ow = pix % p.W;
@@ -104,14 +110,14 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
             const us8 v01 = *reinterpret_cast<const us8*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
             const us8 v10 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
             const us8 v11 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
-            us8 l8 = *reinterpret_cast<const us8*>(Pt + r * MH_LD + col);
+            us8 l8 = *reinterpret_cast<const us8*>(At + r * MH_LD + col);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float u = hy * (hx * bf16_to_f32(v00[e]) + lx * bf16_to_f32(v01[e])) + ly * (hx * bf16_to_f32(v10[e]) + lx * bf16_to_f32(v11[e]));
                 u = u > 0.f ? u : 0.f;
                 l8[e] = f32_to_bf16(u + bf16_to_f32(l8[e]));
             }
-            *reinterpret_cast<us8*>(Pt + r * MH_LD + col) = l8;
+            *reinterpret_cast<us8*>(At + r * MH_LD + col) = l8;
             if (p.p1) *reinterpret_cast<us8*>(p.p1 + (m0 + r) * MH_C + col) = l8;
         }
     }
@@ -125,10 +131,12 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Pt + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[kk], af, acc, 0, 0, 0);
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc, 0, 0, 0);
+            if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING) * 512);
         }
-        float* St = reinterpret_cast<float*>(At);            // [128][nq] f32 (the c1 tile is dead: all waves passed two barriers)
+        __syncthreads();                                      // p1 is dead: the tile becomes the [128][nq] f32 staging buffer
+        float* St = reinterpret_cast<float*>(At);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nt * 32 + 8 * q + 4 * half;
@@ -138,7 +146,8 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
                 if (n + e < p.nq) {
                     float v = acc[4 * q + e] + mbv[e];
                     if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
-                    St[(r * 32 + l31) * p.nq + n + e] = v;
+                    if (p.planar) St[(n + e) * MH_BM + r * 32 + l31] = v;
+                    else St[(r * 32 + l31) * p.nq + n + e] = v;
                 }
             }
         }
@@ -148,7 +157,13 @@ __global__ __launch_bounds__(512, 2) void mask_head_kernel(const MaskHeadArgs p)
         const float* St = reinterpret_cast<const float*>(At);
         float* og = p.prob + m0 * p.nq;                       // 128 * nq floats, contiguous; 16-byte aligned when nq % 2 == 0 (m0 % 128 == 0)
         const int total4 = MH_BM * p.nq / 4;
-        for (int i = tid; i < total4; i += 512) *reinterpret_cast<f32x4*>(og + 4 * i) = *reinterpret_cast<const f32x4*>(St + 4 * i);
+        if (p.planar) {
+            float* ob = p.prob + (long long)b * p.nq * per + pix0;
+            for (int i = tid; i < total4; i += 512)
+                *reinterpret_cast<f32x4*>(ob + (long long)(i >> 5) * per + (i & 31) * 4) = *reinterpret_cast<const f32x4*>(St + 4 * i);
+        } else {
+            for (int i = tid; i < total4; i += 512) *reinterpret_cast<f32x4*>(og + 4 * i) = *reinterpret_cast<const f32x4*>(St + 4 * i);
+        }
     }
 }
 
@@ -166,7 +181,7 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
     MaskHeadArgs a;
     a.c1 = (const bf16_t*)c1; a.t1 = (const bf16_t*)t1; a.wc = (const bf16_t*)w_lateral; a.sc = scale; a.bc = bias;
     a.mw = (const bf16_t*)mask_w; a.mb = mask_b; a.prob = prob; a.p1 = (bf16_t*)p1_out;
-    a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid;
+    a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid & 1; a.planar = (apply_sigmoid >> 1) & 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mask_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MH_LDS_BYTES);

@@ -60,35 +60,97 @@ __device__ __forceinline__ int wave_isum(int v) {
     return v;
 }
 
-// One workgroup = one TW x TH tile of output pixels.  The (few) source rows x columns of the 1/4-resolution
-// probability map that the tile's bilinear taps touch are first copied into LDS with coalesced loads ([row][col][q],
-// q contiguous as in memory); the per-pixel loop over the valid queries then reads LDS only (bank = (nq*x + q) % 32:
-// distinct for the 16 source columns a wave touches).  Area / centroid sums are aggregated per wave, then per
-// workgroup in LDS, then flushed with a few integer global atomics.
-constexpr int PS_TW = 64, PS_TH = 8;
+// One workgroup = one TW x TH tile of output pixels (a wave = one 64-pixel row segment).  The (few) source rows x columns of
+// the 1/4-resolution probability map that the tile's bilinear taps touch are first copied into LDS with coalesced loads
+// ([row][col][q], q contiguous as in memory; wave w copies rows w, w+4, ..: all loads of a row are issued before its stores);
+// the per-pixel loop then runs over a COMPACT list of the valid queries and reads LDS only.  The kernel is issue-bound (38k
+// small workgroups per 64 images), so the bookkeeping is scalar: area / centroid sums come from wave ballots (sum of the set
+// lanes' X = X0 * popcount + sum of set bit positions) and are aggregated per workgroup in LDS, then flushed with a few
+// integer global atomics (order independent => deterministic).
+constexpr int PS_TW = 64;                     // tile height `th` (multiple of 4) is chosen by the host
+__host__ __device__ inline int ps_head_words(int nq) { return 11 * nq + 4; }     // 9 nq work mirror, 2 nq valid list (q, score), count
+
+__device__ __forceinline__ int mask_lane_sum(unsigned long long m) {              // sum of the indices of the set bits
+    return __popcll(m & 0xAAAAAAAAAAAAAAAAull) + 2 * __popcll(m & 0xCCCCCCCCCCCCCCCCull) + 4 * __popcll(m & 0xF0F0F0F0F0F0F0F0ull) +
+           8 * __popcll(m & 0xFF00FF00FF00FF00ull) + 16 * __popcll(m & 0xFFFF0000FFFF0000ull) + 32 * __popcll(m & 0xFFFFFFFF00000000ull);
+}
 
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
                                                         int W, float mask_thr, int src_rows, int src_cols,
-                                                        int* __restrict__ work, uint8_t* __restrict__ winner) {
-    extern __shared__ int sh[];   // [0,nq) valid, [nq,2nq) score, 7*nq accumulators, then the f32 source tile
-    float* tile = reinterpret_cast<float*>(sh + 9 * nq);
-    const int b = blockIdx.z;
+                                                        int* __restrict__ work, uint8_t* __restrict__ winner, int planar, int th) {
+    extern __shared__ int sh[];   // [2nq,9nq) accumulators, [9nq,11nq) valid list, [11nq] its length, then the f32 source tile
+    int* vlist = sh + 9 * nq;
+    float* tile = reinterpret_cast<float*>(sh + ps_head_words(nq));
+    const int b = blockIdx.z, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int* wk = work + (long long)b * work_words(nq);
-    for (int i = threadIdx.x; i < 9 * nq; i += 256) sh[i] = i < 2 * nq ? wk[i] : 0;
     const float sch = (float)h / (float)H, scw = (float)w / (float)W;
-    const int X0 = blockIdx.x * PS_TW, Y0 = blockIdx.y * PS_TH;
+    const int X0 = blockIdx.x * PS_TW, Y0 = blockIdx.y * th;
     const int ry0 = min((int)fmaxf(sch * (Y0 + 0.5f) - 0.5f, 0.f), h - 1);
     const int cx0 = min((int)fmaxf(scw * (X0 + 0.5f) - 0.5f, 0.f), w - 1);
     const int nrows = min(src_rows, h - ry0), ncols = min(src_cols, w - cx0);
     const float* pb = prob + (long long)b * h * w * nq;
-    for (int r = 0; r < nrows; ++r) {
-        const float* srow = pb + ((long long)(ry0 + r) * w + cx0) * nq;
-        for (int i = threadIdx.x; i < ncols * nq; i += 256) tile[r * src_cols * nq + i] = srow[i];
+    // ---- accumulators + compact list of the valid queries (ascending q, with their scores)
+    for (int i = threadIdx.x; i < 9 * nq; i += 256) sh[i] = 0;
+    if (wave == 0) {
+        int off = 0;
+        for (int base = 0; base < nq; base += 64) {
+            const int q = base + lane;
+            const int v = q < nq ? wk[q] : 0;
+            const unsigned long long m = __ballot(v != 0);
+            if (v) {
+                const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+                vlist[2 * pos] = q;
+                vlist[2 * pos + 1] = wk[nq + q];
+            }
+            off += __popcll(m);
+        }
+        if (lane == 0) sh[11 * nq] = off;
     }
     __syncthreads();
-    for (int it = 0; it < PS_TW * PS_TH / 256; ++it) {
-        const int lp = it * 256 + threadIdx.x;
-        const int X = X0 + (lp % PS_TW), Y = Y0 + (lp / PS_TW);
+    const int nv = sh[11 * nq];
+    if (planar) {
+        // prob is [B][nq][h][w]: only the planes of the VALID queries are fetched; tile layout [k][row][col] (k = position in the list).
+        // One half-wave per (k, row) segment of ncols (<= 32 + ..) floats.
+        const int nseg = nv * nrows, l32 = threadIdx.x & 31;
+        for (int sg = threadIdx.x >> 5; sg < nseg; sg += 8) {
+            const int k = sg / nrows, r = sg - k * nrows;
+            const float* srow = prob + (((long long)b * nq + vlist[2 * k]) * h + ry0 + r) * w + cx0;
+            float* trow = tile + (k * src_rows + r) * src_cols;
+            for (int c = l32; c < ncols; c += 32) trow[c] = srow[c];
+        }
+    } else {
+        // ---- source tile: wave -> rows wave, wave + 4, ...
+        {
+            const int per_row = ncols * nq;
+            constexpr int PS_NL = 8;
+            for (int r = wave; r < nrows; r += 4) {
+                const float* srow = pb + ((long long)(ry0 + r) * w + cx0) * nq;
+                float* trow = tile + r * src_cols * nq;
+                if ((nq & 1) == 0) {                                  // rows start 8-byte aligned: float2 pieces
+                    const int n2 = per_row >> 1;
+                    for (int base = 0; base < n2; base += PS_NL * 64) {
+                        float2 v[PS_NL];
+    #pragma unroll
+                        for (int j = 0; j < PS_NL; ++j) {
+                            const int i = base + j * 64 + lane;
+                            v[j] = i < n2 ? reinterpret_cast<const float2*>(srow)[i] : make_float2(0.f, 0.f);
+                        }
+    #pragma unroll
+                        for (int j = 0; j < PS_NL; ++j) {
+                            const int i = base + j * 64 + lane;
+                            if (i < n2) reinterpret_cast<float2*>(trow)[i] = v[j];
+                        }
+                    }
+                } else {
+                    for (int i = lane; i < per_row; i += 64) trow[i] = srow[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < th / 4; ++it) {
+        const int X = X0 + lane, Y = Y0 + it * 4 + wave;
         const bool in = X < W && Y < H;
         const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
         const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
@@ -97,44 +159,38 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
         // clamp the local indices so that out-of-image lanes still read inside the tile
         const int r0 = min(max(y0 - ry0, 0), nrows - 1), r1 = min(max(y1 - ry0, 0), nrows - 1);
         const int c0 = min(max(x0 - cx0, 0), ncols - 1), c1 = min(max(x1 - cx0, 0), ncols - 1);
-        const float* p00 = tile + (r0 * src_cols + c0) * nq;
-        const float* p01 = tile + (r0 * src_cols + c1) * nq;
-        const float* p10 = tile + (r1 * src_cols + c0) * nq;
-        const float* p11 = tile + (r1 * src_cols + c1) * nq;
+        // tap (r, c) of query q (list position k): NHWC-q tile [r][c][q], planar tile [k][r][c]
+        const int qs = planar ? src_rows * src_cols : 1, es = planar ? 1 : nq;
+        const float* p00 = tile + (r0 * src_cols + c0) * es;
+        const float* p01 = tile + (r0 * src_cols + c1) * es;
+        const float* p10 = tile + (r1 * src_cols + c0) * es;
+        const float* p11 = tile + (r1 * src_cols + c1) * es;
         float best = -INFINITY;
         int win = -1;
-        for (int q = 0; q < nq; ++q) {
-            if (!sh[q]) continue;   // block-uniform
+        for (int k = 0; k < nv; ++k) {
+            const int q = vlist[2 * k];                          // wave-uniform (LDS broadcast)
+            const int o = (planar ? k : q) * qs;
             float p = 0.f;
-            if (in) p = hy * (hx * p00[q] + lx * p01[q]) + ly * (hx * p10[q] + lx * p11[q]);
-            const float wgt = __int_as_float(sh[nq + q]) * p;
+            if (in) p = hy * (hx * p00[o] + lx * p01[o]) + ly * (hx * p10[o] + lx * p11[o]);
+            const float wgt = __int_as_float(vlist[2 * k + 1]) * p;
             if (in && wgt > best) { best = wgt; win = q; }
             const unsigned long long bal = __ballot(in && p >= mask_thr);
-            if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
+            if (lane == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
         }
-        const int pass = in && win >= 0 && best > mask_thr;
-        if (in && win >= 0) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win | (pass ? 0x80 : 0));
-        // wave-level aggregation: in the common case every lane of the wave has the same winner
-        const int w0 = __builtin_amdgcn_readfirstlane(win);
-        if (__all(win == w0 || !in)) {
-            if (w0 >= 0) {
-                const int ok = in && win >= 0;
-                const int cnt = wave_isum(ok), sxs = wave_isum(ok ? X : 0), sys = wave_isum(ok ? Y : 0);
-                const int cp = wave_isum(pass), sxp = wave_isum(pass ? X : 0), syp = wave_isum(pass ? Y : 0);
-                if ((threadIdx.x & 63) == 0) {
-                    atomicAdd(&sh[6 * nq + w0], cnt); atomicAdd(&sh[7 * nq + w0], sxs); atomicAdd(&sh[8 * nq + w0], sys);
-                    if (cp) { atomicAdd(&sh[3 * nq + w0], cp); atomicAdd(&sh[4 * nq + w0], sxp); atomicAdd(&sh[5 * nq + w0], syp); }
-                }
+        const bool ok = in && win >= 0;
+        const bool pass = ok && best > mask_thr;
+        if (ok) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win | (pass ? 0x80 : 0));
+        // per distinct winner of the wave (usually one): counts and coordinate sums from the ballots
+        unsigned long long rem = __ballot(ok);
+        while (rem) {
+            const int w0 = __builtin_amdgcn_readlane(win, __ffsll((long long)rem) - 1);
+            const unsigned long long m = __ballot(ok && win == w0), mp = __ballot(pass && win == w0);
+            if (lane == 0) {
+                const int cnt = __popcll(m), cp = __popcll(mp);
+                atomicAdd(&sh[6 * nq + w0], cnt); atomicAdd(&sh[7 * nq + w0], X0 * cnt + mask_lane_sum(m)); atomicAdd(&sh[8 * nq + w0], Y * cnt);
+                if (cp) { atomicAdd(&sh[3 * nq + w0], cp); atomicAdd(&sh[4 * nq + w0], X0 * cp + mask_lane_sum(mp)); atomicAdd(&sh[5 * nq + w0], Y * cp); }
             }
-        } else if (in && win >= 0) {
-            atomicAdd(&sh[6 * nq + win], 1);
-            atomicAdd(&sh[7 * nq + win], X);
-            atomicAdd(&sh[8 * nq + win], Y);
-            if (pass) {
-                atomicAdd(&sh[3 * nq + win], 1);
-                atomicAdd(&sh[4 * nq + win], X);
-                atomicAdd(&sh[5 * nq + win], Y);
-            }
+            rem &= ~m;
         }
     }
     __syncthreads();
@@ -228,7 +284,18 @@ extern "C" int nopesac_postselect_planes(const float* cls_logits, const float* m
                                          int32_t* kept_idx, float* planes, float* feats, float* scores,
                                          int32_t* areas, float* centers, uint8_t* winner, int32_t* flags,
                                          int32_t* work, void* stream) {
+    return nopesac_postselect_planes_ex(cls_logits, mask_prob, params, query_feat, B, nq, D, h, w, H, W, score_thr, mask_thr, overlap_thr,
+                                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags, work, 0, stream);
+}
+
+extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float* mask_prob, const float* params,
+                                            const float* query_feat, int B, int nq, int D, int h, int w, int H, int W,
+                                            float score_thr, float mask_thr, float overlap_thr, int32_t* n_kept,
+                                            int32_t* kept_idx, float* planes, float* feats, float* scores,
+                                            int32_t* areas, float* centers, uint8_t* winner, int32_t* flags,
+                                            int32_t* work, int prob_planar, void* stream) {
     using namespace nps;
+    NPS_CHECK_ARG(prob_planar == 0 || prob_planar == 1, "postselect: prob_planar must be 0 ([B,h,w,nq]) or 1 ([B,nq,h,w])");
     NPS_CHECK_ARG(cls_logits && mask_prob && params && query_feat && n_kept && kept_idx && planes && feats && scores &&
                       areas && centers && winner && flags && work, "postselect: null pointer");
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && D > 0 && h > 0 && w > 0 && H > 0 && W > 0, "postselect: bad dims (nq<=128)");
@@ -236,13 +303,21 @@ extern "C" int nopesac_postselect_planes(const float* cls_logits, const float* m
     hipError_t e = hipMemsetAsync(work, 0, (size_t)B * work_words(nq) * sizeof(int), st);
     if (e != hipSuccess) { set_error("postselect: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(ps_classify_kernel, dim3(B), dim3(64), 0, st, cls_logits, nq, score_thr, work);
-    // source extent touched by one PS_TW x PS_TH output tile (+2 for the second tap and the start rounding)
-    const int src_rows = (int)(((long long)PS_TH * h + H - 1) / H) + 2, src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
-    const size_t lds = (size_t)9 * nq * sizeof(int) + (size_t)src_rows * src_cols * nq * sizeof(float);
+    // source extent touched by one PS_TW x th output tile (+2 for the second tap and the start rounding).  th = 8 rows measured
+    // best at 480x640 x 64 images with ~nq valid queries (437 us; 16 rows 560 us, 32 rows 675 us: the kernel is bound by the
+    // per-(pixel, valid query) instruction stream, and small workgroups balance it better); halved until the source tile fits
+    int th = 8, src_rows = 0;
+    const int src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
+    size_t lds = 0;
+    for (;; th >>= 1) {
+        src_rows = (int)(((long long)th * h + H - 1) / H) + 2;
+        lds = (size_t)ps_head_words(nq) * sizeof(int) + (size_t)src_rows * src_cols * nq * sizeof(float);
+        if (lds <= 64 * 1024 || th == 4) break;
+    }
     NPS_CHECK_ARG(lds <= 64 * 1024, "postselect: up-sampling ratio too small for the LDS tile (%zu bytes)", lds);
-    dim3 grid((W + PS_TW - 1) / PS_TW, (H + PS_TH - 1) / PS_TH, B);
+    dim3 grid((W + PS_TW - 1) / PS_TW, (H + th - 1) / th, B);
     hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols,
-                       work, winner);
+                       work, winner, prob_planar, th);
     hipLaunchKernelGGL(ps_finalize_kernel, dim3(B), dim3(64), 0, st, params, query_feat, nq, D, H, W, overlap_thr, work,
                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags);
     NPS_LAUNCH_RET();

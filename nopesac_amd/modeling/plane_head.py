@@ -300,6 +300,8 @@ class PlaneTRHead(ParamModule):
             t1 = ops.conv2d(p2, c.w(cd), c.scale, c.bias, act=ops.ACT_NONE)
             l = P["c1_conv"]
             mark("ph.top_down")
+            # (a planar [B,nq,h,w] output + valid-planes-only fetch in the post-selection is implemented and tested, but measured
+            # slower - 581 vs 437 us: that kernel is bound by its per-(pixel, valid query) instruction stream, not by bytes)
             heads["mask_prob"] = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, fold[:, :256].view(B, nq, 256),
                                                fold[:, 256].contiguous().view(B, nq))
             return heads, hs.view(B, nq, 256)
@@ -326,4 +328,4 @@ def post_select(head_out: dict, query_feat: torch.Tensor, height: int, width: in
     cfg.TEST (config/config.py:92-94).  Everything stays on the device (no per-plane host sync)."""
     return ops.postselect_planes(head_out["pred_logits"], head_out["mask_prob"], head_out["pred_params"], query_feat,
                                  height, width, float(cfg.TEST.PLANE_SCORE_THRESHOLD), float(cfg.TEST.MASK_PROB_THRESHOLD),
-                                 float(cfg.TEST.OVERLAP_THRESHOLD))
+                                 float(cfg.TEST.OVERLAP_THRESHOLD), planar=bool(head_out.get("mask_prob_planar", False)))

@@ -423,10 +423,14 @@ def normalize_rows(x: torch.Tensor, canonical_sign: bool = False) -> torch.Tenso
     return y
 
 
-def postselect_planes(cls_logits, mask_prob, params, query_feat, H, W, score_thr, mask_thr, overlap_thr) -> dict:
+def postselect_planes(cls_logits, mask_prob, params, query_feat, H, W, score_thr, mask_thr, overlap_thr, planar: bool = False) -> dict:
+    """mask_prob: [B,h,w,nq], or [B,nq,h,w] when `planar`."""
     _chk(cls_logits, torch.float32); _chk(mask_prob, torch.float32); _chk(params, torch.float32); _chk(query_feat, torch.float32)
     B, nq, _ = cls_logits.shape
-    _, h, w, nq2 = mask_prob.shape
+    if planar:
+        _, nq2, h, w = mask_prob.shape
+    else:
+        _, h, w, nq2 = mask_prob.shape
     assert nq2 == nq
     D = query_feat.shape[-1]
     dev = cls_logits.device
@@ -439,11 +443,11 @@ def postselect_planes(cls_logits, mask_prob, params, query_feat, H, W, score_thr
         "flags": torch.empty(B, **i32),
     }
     work = torch.empty(B, 9 * nq + 8, **i32)
-    rc = _L().nopesac_postselect_planes(_p(cls_logits), _p(mask_prob), _p(params), _p(query_feat), B, nq, D, h, w, H, W,
-                                        score_thr, mask_thr, overlap_thr, _p(out["n_kept"]), _p(out["kept_idx"]),
-                                        _p(out["planes"]), _p(out["feats"]), _p(out["scores"]), _p(out["areas"]),
-                                        _p(out["centers"]), _p(out["winner"]), _p(out["flags"]), _p(work), _stream())
-    _lib.check(rc, "nopesac_postselect_planes")
+    rc = _L().nopesac_postselect_planes_ex(_p(cls_logits), _p(mask_prob), _p(params), _p(query_feat), B, nq, D, h, w, H, W,
+                                           score_thr, mask_thr, overlap_thr, _p(out["n_kept"]), _p(out["kept_idx"]),
+                                           _p(out["planes"]), _p(out["feats"]), _p(out["scores"]), _p(out["areas"]),
+                                           _p(out["centers"]), _p(out["winner"]), _p(out["flags"]), _p(work), int(planar), _stream())
+    _lib.check(rc, "nopesac_postselect_planes_ex")
     return out
 
 
@@ -592,9 +596,9 @@ def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tenso
 
 
 def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scale, bias, mask_w: torch.Tensor, mask_b: torch.Tensor,
-              sigmoid: bool = True, want_p1: bool = False):
+              sigmoid: bool = True, want_p1: bool = False, planar: bool = False):
     """Fused lateral conv + bilinear add + per-image mask GEMM (csrc/mask_head.hip).  c1 [B,H,W,256] / t1 [B,H/2,W/2,256] bf16;
-    mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] (and p1 bf16 if asked)."""
+    mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] ([B,nq,H,W] when `planar`) (and p1 bf16 if asked)."""
     _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
     B, H, W, C = c1.shape
     nq = mask_w.shape[1]
@@ -604,10 +608,10 @@ def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scal
     mw = mw.view(B, 2, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()          # per-image MFMA fragment-major
     mb = torch.zeros(B, 64, device=c1.device, dtype=torch.float32)
     mb[:, :nq] = mask_b
-    prob = torch.empty(B, H, W, nq, device=c1.device, dtype=torch.float32)
+    prob = torch.empty((B, nq, H, W) if planar else (B, H, W, nq), device=c1.device, dtype=torch.float32)
     p1 = torch.empty(B, H, W, 256, device=c1.device, dtype=torch.bfloat16) if want_p1 else None
     rc = _L().nopesac_mask_head_bf16(_p(c1), _p(t1), _p(w_lat_frag), _p(scale), _p(bias), _p(mw), _p(mb), _p(prob), _p(p1), B, H, W, nq,
-                                     int(sigmoid), _stream())
+                                     int(sigmoid) | (2 if planar else 0), _stream())
     _lib.check(rc, "nopesac_mask_head_bf16")
     return (prob, p1) if want_p1 else prob
 

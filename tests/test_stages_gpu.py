@@ -51,8 +51,9 @@ def test_plane_head(device, model, O, sd50):
     assert rel_err(out["pixel_centers"].permute(0, 3, 1, 2), ref["pixel_centers"]) < 1e-4
 
 
+@pytest.mark.parametrize("planar", [False, True])
 @pytest.mark.parametrize("kind,seed", [("multi", 31), ("none_pass", 32), ("all_overlap_rejected", 33), ("full", 34)])
-def test_postselect(device, O, kind, seed):
+def test_postselect(device, O, kind, seed, planar):
     from nopesac_amd import ops
     from nopesac_amd.modeling import decode_masks
     logits, params, mask, feat = GI.postselect_case(kind, seed)
@@ -60,9 +61,12 @@ def test_postselect(device, O, kind, seed):
     ref = O.post_select(logits, params, mask, feat, cfg)
     prob = torch.sigmoid(mask).permute(1, 2, 0).contiguous()[None]          # [1,h,w,nq]
     # two images in one launch: the designed case and a copy with the "on" planes' scores flipped
-    out = ops.postselect_planes(torch.stack([logits, logits]).to(device), torch.cat([prob, prob]).to(device),
+    prob2 = torch.cat([prob, prob])
+    if planar:                                                               # [B,nq,h,w]: the fused mask head's layout
+        prob2 = prob2.permute(0, 3, 1, 2).contiguous()
+    out = ops.postselect_planes(torch.stack([logits, logits]).to(device), prob2.to(device),
                                 torch.stack([params, params]).to(device), torch.stack([feat, feat]).to(device), 480, 640,
-                                cfg.plane_score_threshold, cfg.mask_prob_threshold, cfg.overlap_threshold)
+                                cfg.plane_score_threshold, cfg.mask_prob_threshold, cfg.overlap_threshold, planar=planar)
     g = gold(f"C_postselect_{kind}")
     for b in range(2):
         n = int(out["n_kept"][b])
@@ -267,6 +271,17 @@ def test_fused_mask_head_matches_per_layer_bf16_path(device):
     head.fused_mask_head = True
     assert torch.equal(qa, qb) and a["mask_prob"].shape == (B, 120, 160, 50)
     assert float((a["mask_prob"] - b["mask_prob"]).abs().max()) < 2e-3
+    # planar output variant of the kernel ([B,nq,h,w], accepted by the post-selection): same numbers, transposed
+    P, cd = head.packed, torch.bfloat16
+    g2 = torch.Generator().manual_seed(10)
+    c1 = (0.5 * torch.randn(B, 120, 160, 256, generator=g2)).to(device, cd)
+    t1 = (0.5 * torch.randn(B, 60, 80, 256, generator=g2)).to(device, cd)
+    mw, mb = (torch.randn(B, 50, 256, generator=g2) / 16).to(device), torch.randn(B, 50, generator=g2).to(device)
+    l = P["c1_conv"]
+    from nopesac_amd import ops
+    pa = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, mw, mb)
+    pb = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, mw, mb, planar=True)
+    assert pb.shape == (B, 50, 120, 160) and torch.equal(pa, pb.permute(0, 2, 3, 1))
 
 
 def test_fused_decoder_tail_matches_per_layer_bf16_path(device):
