@@ -29,10 +29,10 @@ constexpr int ST_K = 224, ST_WLD = 232;              // weight row: 224 + 8 pad 
 constexpr int ST_CLD = 72;                           // conv tile row: 64 + 8 pad elements (144 bytes)
 constexpr int ST_PATCH_BYTES = ST_IH * ST_IW * 8 + 64;          // + slack for the padded kw = 7 tap
 constexpr int ST_W_BYTES = 64 * ST_WLD * 2;
-constexpr int ST_CONV_BYTES = 384 * ST_CLD * 2;
+constexpr int ST_CONV_BYTES = ST_M * ST_CLD * 2;     // 53,136 B: three workgroups per CU (the 384-row version allowed two)
 constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH_BYTES + ST_W_BYTES) : ST_CONV_BYTES;
 
-__global__ __launch_bounds__(256) void stem_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const bf16_t* __restric
                     const float v = fmaxf(acc[t][j][4 * q + e] * scale[n + e] + bias[n + e], 0.f);
                     o[e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
                 }
-                if (p < 384) *reinterpret_cast<us4*>(ctile + p * ST_CLD + n) = o;
+                if (p < ST_M) *reinterpret_cast<us4*>(ctile + p * ST_CLD + n) = o;
             }
     }
     __syncthreads();
