@@ -168,8 +168,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
         for (int ks = 0; ks < 2; ++ks) {
             float t[8];
             att_load8<TIO>(qp + ks * 16 + half * 8, t);
-            u32x4 pk = {pack_bf16x2(t[0] * scale, t[1] * scale), pack_bf16x2(t[2] * scale, t[3] * scale),
-                        pack_bf16x2(t[4] * scale, t[5] * scale), pack_bf16x2(t[6] * scale, t[7] * scale)};
+            // scores are kept in the log2 domain (scale * log2(e) folded into q): the soft-max then needs bare v_exp_f32's
+            const float sc2 = scale * 1.4426950408889634f;
+            u32x4 pk = {pack_bf16x2(t[0] * sc2, t[1] * sc2), pack_bf16x2(t[2] * sc2, t[3] * sc2),
+                        pack_bf16x2(t[4] * sc2, t[5] * sc2), pack_bf16x2(t[6] * sc2, t[7] * sc2)};
             qf[ks] = __builtin_bit_cast(bf16x8, pk);
         }
     }
@@ -197,10 +199,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ps += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ps += s[r]; }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
