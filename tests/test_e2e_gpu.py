@@ -82,11 +82,11 @@ def test_e2e_loose_structured_batch(device, sd50):
     assert torch.equal(solo["pred_assignment"], res[1]["pred_assignment"])
 
 
-@pytest.mark.parametrize("K,nq", [(32, 50), (64, 64)])
+@pytest.mark.parametrize("K,nq", [(32, 50), (64, 64), (128, 128)])
 def test_bench_workload_forced_k_matches_oracle(device, K, nq):
     """The bench workload (SURVEY.md §8d K control: K planes per view, K matches) on the fp32 HIP path against the oracle
     driven through the same K control - the configuration bench.py times is itself parity-checked, K = 32 (config 2)
-    and K = 64 / nq = 64 (config 3)."""
+    K = 64 / nq = 64 (config 3) and K = 128 / nq = 128 (the K of config 5)."""
     import bench
     from nopesac_amd.synth import synth_pair, synth_state_dict
     from oracle import nopesac_oracle as O
@@ -156,3 +156,29 @@ def test_graft_entry_build_then_smoke_in_one_process():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('SMOKE-OK')"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SMOKE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_config5_fp8_backbone_k128(device):
+    """BASELINE config 5 on one GPU: fp8 3x3 backbone convs (MODEL.AMD.BACKBONE_FP8) + K = 128 forced hypotheses, nq = 128,
+    against the fp32 HIP path on the same inputs and K control: all 128 hypotheses take part, the initial pose stays close
+    (the refined pose goes through discrete decisions that reduced precision may flip: finite + unit quaternion only)."""
+    import bench
+    from nopesac_amd.synth import synth_pair
+    B, K, nq = 2, 128, 128
+    m8 = make_model(device, ("MODEL.AMD.BACKBONE_FP8", True), nq=nq, dtype="bfloat16")
+    m32 = make_model(device, nq=nq)
+    inp = [synth_pair(40 + i) for i in range(B)]
+    m8.calibrate_fp8(inp)
+    forced = bench.make_forced(B, K, nq, device, 9)
+    with torch.no_grad():
+        a = m8.forward_tensors(m8.preprocess_image(inp), B, 480, 640, forced=forced)["cam"]
+        b = m32.forward_tensors(m32.preprocess_image(inp), B, 480, 640, forced=forced)["cam"]
+    assert a["m"].tolist() == [K] * B == b["m"].tolist()
+    t8, q8 = a["cameras"]["camera_init"]
+    t32, q32 = b["cameras"]["camera_init"]
+    for i in range(B):
+        t_err = float((t8[i] - t32[i]).norm())
+        dot = abs(float((q8[i] * q32[i]).sum()))
+        assert t_err < 0.1 * (1 + float(t32[i].norm())) and 2 * np.degrees(np.arccos(min(dot, 1.0))) < 15.0, (t_err, dot)
+    t, q = a["cameras"]["camera"]
+    assert torch.isfinite(t).all() and torch.isfinite(q).all() and float((q.norm(dim=-1) - 1).abs().max()) < 1e-3
