@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (HIP streams) per GPU")
+    ap.add_argument("--inflight", type=int, default=4, help="batches in flight (HIP streams) per GPU")
     ap.add_argument("--no-autotune", dest="autotune", action="store_false", help="skip the load-time conv kernel autotuning")
     ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward in a hipGraph and replay it")
     ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
@@ -247,7 +247,7 @@ def main():
                                                         model.compute_dtype))
     tuned = model.autotune(B) if args.autotune else 0     # load-time kernel selection, outside the timed region
 
-    # Two batches in flight: step i runs on HIP stream i % 2, so the launch-latency-bound head stages of one batch
+    # Several batches in flight (default 4; 3 -> 4 measured +1.1 %): step i runs on HIP stream i % n, so the launch-latency-bound head stages of one batch
     # (transformer, GNN, Sinkhorn, RANSAC) overlap with the HBM/MFMA-bound backbone of the next.  Each stream owns its
     # input buffer and a pinned host buffer for the per-pair result rows; a step's results are complete when its
     # stream's event has fired (checked before the slot is reused and at the end of the timed region).
