@@ -131,9 +131,13 @@ __global__ __launch_bounds__(256, (PwLds<C, C4, CN, C2, BM>::WAVES_PER_SIMD)) vo
     // weight fragments of this wave's first column tile (L2 resident)
     bf16x8 wf[2][KF1];
     bf16x8 wsf[2][C2 ? KF1S : 1];
+    // every workgroup walks its waves' column tiles in a ROTATED order (start = blockIdx % NT1): the resident workgroups then pull
+    // different weight lines from L2 at any one time instead of all queueing on the same channel (results are unaffected: the
+    // column tiles are independent)
+    const int rot = NT1 > 1 ? (int)(blockIdx.x % NT1) : 0;
     auto load_w1frags = [&](int j, int buf) {
         // fragment-major weights (see the header): one load instruction = 1 KB contiguous = 8 whole cache lines
-        const int nt = wave * NT1 + j;
+        const int nt = wave * NT1 + (j + rot) % NT1;
 #pragma unroll
         for (int kk = 0; kk < KF1; ++kk) wf[buf][kk] = *reinterpret_cast<const bf16x8*>(p.w3 + ((long long)(nt * KF1 + kk) * 64 + lane) * 8);
         if constexpr (C2 > 0) {
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, (PwLds<C, C4, CN, C2, BM>::WAVES_PER_SIMD)) vo
     for (int j = 0; j < NT1; ++j) {
         const int buf = j & 1;
         if (j + 1 < NT1) load_w1frags(j + 1, buf ^ 1);
-        const int n0 = (wave * NT1 + j) * 32;
+        const int n0 = (wave * NT1 + (j + rot) % NT1) * 32;
         // one 32-pixel row tile at a time (the weight fragments stay in registers, the accumulators are re-used)
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
