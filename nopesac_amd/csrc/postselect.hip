@@ -54,21 +54,19 @@ __global__ __launch_bounds__(64) void ps_classify_kernel(const float* __restrict
     if (lane == 0) wk[9 * nq] = any ? 0 : 1;
 }
 
-__device__ __forceinline__ int wave_isum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// One workgroup = one TW x TH tile of output pixels (a wave = one 64-pixel row segment).  The (few) source rows x columns of
-// the 1/4-resolution probability map that the tile's bilinear taps touch are first copied into LDS with coalesced loads
-// ([row][col][q], q contiguous as in memory; wave w copies rows w, w+4, ..: all loads of a row are issued before its stores);
-// the per-pixel loop then runs over a COMPACT list of the valid queries and reads LDS only.  The kernel is issue-bound (38k
-// small workgroups per 64 images), so the bookkeeping is scalar: area / centroid sums come from wave ballots (sum of the set
-// lanes' X = X0 * popcount + sum of set bit positions) and are aggregated per workgroup in LDS, then flushed with a few
-// integer global atomics (order independent => deterministic).
+// One workgroup = one TW x th tile of output pixels (a wave = one 64-pixel row segment).  Only the VALID queries (score test
+// passed; a compact ascending list built per workgroup) take part: the (few) source rows x columns of the 1/4-resolution
+// probability map that the tile's bilinear taps touch are gathered into LDS as [row][col][k] with k = position in the list,
+// padded to a multiple of 4 - so the per-pixel loop handles FOUR queries per step with 16-byte LDS reads (4 taps) and two
+// broadcast reads (ids, scores).  The kernel is issue-bound (38k small workgroups per 64 images, ~23 valid queries on the
+// benchmark inputs), so the bookkeeping is scalar or per-lane: the per-query pixel counts live in lane k of a register
+// (flushed once per wave), area / centroid sums come from wave ballots (sum of the set lanes' X = X0 * popcount + sum of set
+// bit positions) and are aggregated per workgroup in LDS, then flushed with a few integer global atomics (order independent
+// => deterministic).
 constexpr int PS_TW = 64;                     // tile height `th` (multiple of 4) is chosen by the host
-__host__ __device__ inline int ps_head_words(int nq) { return 11 * nq + 4; }     // 9 nq work mirror, 2 nq valid list (q, score), count
+// LDS head (int32 words): [0,9nq) mirror of the work accumulators, [9nq,9nq+nqp) valid ids, [..+nqp) their scores, then the count
+__host__ __device__ inline int ps_pad4(int nq) { return (nq + 3) & ~3; }
+__host__ __device__ inline int ps_head_words(int nq) { return ((9 * nq + 3) & ~3) + 2 * ps_pad4(nq) + 4; }
 
 __device__ __forceinline__ int mask_lane_sum(unsigned long long m) {              // sum of the indices of the set bits
     return __popcll(m & 0xAAAAAAAAAAAAAAAAull) + 2 * __popcll(m & 0xCCCCCCCCCCCCCCCCull) + 4 * __popcll(m & 0xF0F0F0F0F0F0F0F0ull) +
@@ -78,8 +76,11 @@ __device__ __forceinline__ int mask_lane_sum(unsigned long long m) {            
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
                                                         int W, float mask_thr, int src_rows, int src_cols,
                                                         int* __restrict__ work, uint8_t* __restrict__ winner, int planar, int th) {
-    extern __shared__ int sh[];   // [2nq,9nq) accumulators, [9nq,11nq) valid list, [11nq] its length, then the f32 source tile
-    int* vlist = sh + 9 * nq;
+    extern __shared__ __attribute__((aligned(16))) int sh[];
+    const int nqp = ps_pad4(nq), acc_words = (9 * nq + 3) & ~3;
+    int* vq = sh + acc_words;                                   // valid query ids (16-byte aligned), padded with the last id
+    float* vs = reinterpret_cast<float*>(vq + nqp);             // their scores, padded with -1 (a pad can never win)
+    int* nvp = vq + 2 * nqp;
     float* tile = reinterpret_cast<float*>(sh + ps_head_words(nq));
     const int b = blockIdx.z, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,7 +90,6 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
     const int ry0 = min((int)fmaxf(sch * (Y0 + 0.5f) - 0.5f, 0.f), h - 1);
     const int cx0 = min((int)fmaxf(scw * (X0 + 0.5f) - 0.5f, 0.f), w - 1);
     const int nrows = min(src_rows, h - ry0), ncols = min(src_cols, w - cx0);
-    const float* pb = prob + (long long)b * h * w * nq;
     // ---- accumulators + compact list of the valid queries (ascending q, with their scores)
     for (int i = threadIdx.x; i < 9 * nq; i += 256) sh[i] = 0;
     if (wave == 0) {
@@ -100,55 +100,41 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
             const unsigned long long m = __ballot(v != 0);
             if (v) {
                 const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-                vlist[2 * pos] = q;
-                vlist[2 * pos + 1] = wk[nq + q];
+                vq[pos] = q;
+                vs[pos] = __int_as_float(wk[nq + q]);
             }
             off += __popcll(m);
         }
-        if (lane == 0) sh[11 * nq] = off;
+        if (lane == 0) *nvp = off;
     }
     __syncthreads();
-    const int nv = sh[11 * nq];
-    if (planar) {
-        // prob is [B][nq][h][w]: only the planes of the VALID queries are fetched; tile layout [k][row][col] (k = position in the list).
-        // One half-wave per (k, row) segment of ncols (<= 32 + ..) floats.
-        const int nseg = nv * nrows, l32 = threadIdx.x & 31;
-        for (int sg = threadIdx.x >> 5; sg < nseg; sg += 8) {
-            const int k = sg / nrows, r = sg - k * nrows;
-            const float* srow = prob + (((long long)b * nq + vlist[2 * k]) * h + ry0 + r) * w + cx0;
-            float* trow = tile + (k * src_rows + r) * src_cols;
-            for (int c = l32; c < ncols; c += 32) trow[c] = srow[c];
-        }
-    } else {
-        // ---- source tile: wave -> rows wave, wave + 4, ...
-        {
-            const int per_row = ncols * nq;
-            constexpr int PS_NL = 8;
-            for (int r = wave; r < nrows; r += 4) {
-                const float* srow = pb + ((long long)(ry0 + r) * w + cx0) * nq;
-                float* trow = tile + r * src_cols * nq;
-                if ((nq & 1) == 0) {                                  // rows start 8-byte aligned: float2 pieces
-                    const int n2 = per_row >> 1;
-                    for (int base = 0; base < n2; base += PS_NL * 64) {
-                        float2 v[PS_NL];
-    #pragma unroll
-                        for (int j = 0; j < PS_NL; ++j) {
-                            const int i = base + j * 64 + lane;
-                            v[j] = i < n2 ? reinterpret_cast<const float2*>(srow)[i] : make_float2(0.f, 0.f);
-                        }
-    #pragma unroll
-                        for (int j = 0; j < PS_NL; ++j) {
-                            const int i = base + j * 64 + lane;
-                            if (i < n2) reinterpret_cast<float2*>(trow)[i] = v[j];
-                        }
-                    }
-                } else {
-                    for (int i = lane; i < per_row; i += 64) trow[i] = srow[i];
-                }
+    const int nv = *nvp, kp = ps_pad4(nv), nk4 = kp >> 2;
+    if (nv == 0) return;                                         // nothing can win: winner map and accumulators stay zero
+    if (threadIdx.x < kp - nv) { vq[nv + threadIdx.x] = vq[nv - 1]; vs[nv + threadIdx.x] = -1.f; }
+    __syncthreads();
+    // ---- gather the source tile: item = (source pixel rc, group of 4 list entries); it / nk4 by multiplication (it < 2^15, nk4 <= 32)
+    {
+        const unsigned inv = ((1u << 20) + nk4 - 1) / nk4;
+        const int items = nrows * ncols * nk4;
+        const long long plane = (long long)h * w;
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int rc = (int)(((unsigned)it * inv) >> 20), k4 = it - rc * nk4;
+            const int r = rc / ncols, c = rc - r * ncols;
+            const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);
+            const long long pix = (long long)(ry0 + r) * w + cx0 + c;
+            float4 v;
+            if (planar) {
+                const float* pb = prob + (long long)b * nq * plane + pix;
+                v = make_float4(pb[q4.x * plane], pb[q4.y * plane], pb[q4.z * plane], pb[q4.w * plane]);
+            } else {
+                const float* pb = prob + ((long long)b * plane + pix) * nq;
+                v = make_float4(pb[q4.x], pb[q4.y], pb[q4.z], pb[q4.w]);
             }
+            *reinterpret_cast<float4*>(tile + ((r * src_cols + c) * kp + 4 * k4)) = v;
         }
     }
     __syncthreads();
+    int cnt_lo = 0, cnt_hi = 0;                                  // lane k: pixels of this wave with p >= thr for list entry k (k + 64)
     for (int it = 0; it < th / 4; ++it) {
         const int X = X0 + lane, Y = Y0 + it * 4 + wave;
         const bool in = X < W && Y < H;
@@ -159,23 +145,30 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
         // clamp the local indices so that out-of-image lanes still read inside the tile
         const int r0 = min(max(y0 - ry0, 0), nrows - 1), r1 = min(max(y1 - ry0, 0), nrows - 1);
         const int c0 = min(max(x0 - cx0, 0), ncols - 1), c1 = min(max(x1 - cx0, 0), ncols - 1);
-        // tap (r, c) of query q (list position k): NHWC-q tile [r][c][q], planar tile [k][r][c]
-        const int qs = planar ? src_rows * src_cols : 1, es = planar ? 1 : nq;
-        const float* p00 = tile + (r0 * src_cols + c0) * es;
-        const float* p01 = tile + (r0 * src_cols + c1) * es;
-        const float* p10 = tile + (r1 * src_cols + c0) * es;
-        const float* p11 = tile + (r1 * src_cols + c1) * es;
+        const float* p00 = tile + (r0 * src_cols + c0) * kp;
+        const float* p01 = tile + (r0 * src_cols + c1) * kp;
+        const float* p10 = tile + (r1 * src_cols + c0) * kp;
+        const float* p11 = tile + (r1 * src_cols + c1) * kp;
         float best = -INFINITY;
         int win = -1;
-        for (int k = 0; k < nv; ++k) {
-            const int q = vlist[2 * k];                          // wave-uniform (LDS broadcast)
-            const int o = (planar ? k : q) * qs;
-            float p = 0.f;
-            if (in) p = hy * (hx * p00[o] + lx * p01[o]) + ly * (hx * p10[o] + lx * p11[o]);
-            const float wgt = __int_as_float(vlist[2 * k + 1]) * p;
-            if (in && wgt > best) { best = wgt; win = q; }
-            const unsigned long long bal = __ballot(in && p >= mask_thr);
-            if (lane == 0 && bal) atomicAdd(&sh[2 * nq + q], __popcll(bal));
+        for (int k4 = 0; k4 < nk4; ++k4) {
+            const float4 a = *reinterpret_cast<const float4*>(p00 + 4 * k4), bq = *reinterpret_cast<const float4*>(p01 + 4 * k4);
+            const float4 c = *reinterpret_cast<const float4*>(p10 + 4 * k4), d = *reinterpret_cast<const float4*>(p11 + 4 * k4);
+            const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);          // wave-uniform (LDS broadcast)
+            const float4 s4 = *reinterpret_cast<const float4*>(vs + 4 * k4);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
+            const int qv[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = hy * (hx * av[e] + lx * bv[e]) + ly * (hx * cv[e] + lx * dv[e]);
+                const float wgt = sv[e] * p;
+                if (wgt > best) { best = wgt; win = qv[e]; }
+                const int np = __popcll(__ballot(in && p >= mask_thr && sv[e] >= 0.f));
+                const int k = 4 * k4 + e;
+                if (k < 64) cnt_lo += (lane == k) ? np : 0;
+                else cnt_hi += (lane == k - 64) ? np : 0;
+            }
         }
         const bool ok = in && win >= 0;
         const bool pass = ok && best > mask_thr;
@@ -193,6 +186,8 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
             rem &= ~m;
         }
     }
+    if (lane < nv && cnt_lo) atomicAdd(&sh[2 * nq + vq[lane]], cnt_lo);
+    if (lane + 64 < nv && cnt_hi) atomicAdd(&sh[2 * nq + vq[lane + 64]], cnt_hi);
     __syncthreads();
     for (int i = 2 * nq + threadIdx.x; i < 9 * nq; i += 256)
         if (sh[i]) atomicAdd(&wk[i], sh[i]);
@@ -307,11 +302,12 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
     // best at 480x640 x 64 images with ~nq valid queries (437 us; 16 rows 560 us, 32 rows 675 us: the kernel is bound by the
     // per-(pixel, valid query) instruction stream, and small workgroups balance it better); halved until the source tile fits
     int th = 8, src_rows = 0;
+    if (const char* e = getenv("NOPESAC_PS_TH")) th = atoi(e) >= 4 ? (atoi(e) & ~3) : 8;   // tuning aid
     const int src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
     size_t lds = 0;
     for (;; th >>= 1) {
         src_rows = (int)(((long long)th * h + H - 1) / H) + 2;
-        lds = (size_t)ps_head_words(nq) * sizeof(int) + (size_t)src_rows * src_cols * nq * sizeof(float);
+        lds = (size_t)ps_head_words(nq) * sizeof(int) + (size_t)src_rows * src_cols * ps_pad4(nq) * sizeof(float);
         if (lds <= 64 * 1024 || th == 4) break;
     }
     NPS_CHECK_ARG(lds <= 64 * 1024, "postselect: up-sampling ratio too small for the LDS tile (%zu bytes)", lds);
