@@ -92,3 +92,20 @@ def test_synth_is_deterministic():
     p = synth_pair(3)
     assert p["0"]["image"].shape == (3, 480, 640) and float(p["0"]["image"].max()) <= 255
     assert torch.equal(structured_image(5), structured_image(5))
+
+
+def test_fp8_weight_packing_cpu():
+    """Host side of the fp8 conv (no GPU): per-output-channel e4m3fn quantisation and the fragment-major byte order
+    [N/32][K/64][2][64][16] that nopesac_conv2d_nhwc_fp8 documents in include/nopesac_hip.h."""
+    import torch
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 3, 3, 64, generator=g) * (1 + torch.arange(64).view(-1, 1, 1, 1))
+    w8f, sc = ops.quantize_weights_fp8(w)
+    assert w8f.dtype == torch.float8_e4m3fn and w8f.shape == (64, 576) and sc.shape == (64,)
+    w8 = (w.reshape(64, -1) / sc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert float(w8.float().abs().amax(dim=1).min()) == 448.0                     # every row uses the full e4m3 range
+    assert float(((w8.float() * sc[:, None]) - w.reshape(64, -1)).abs().max() / w.abs().max()) < 0.04
+    raw, frag = w8.view(torch.uint8), w8f.view(torch.uint8).view(2, 9, 2, 64, 16)
+    for nt, kf, h, lane, j in [(0, 0, 0, 0, 0), (1, 8, 1, 63, 15), (0, 3, 1, 37, 5), (1, 5, 0, 32, 9)]:
+        assert int(frag[nt, kf, h, lane, j]) == int(raw[nt * 32 + (lane & 31), kf * 64 + 32 * (lane >> 5) + 16 * h + j])
