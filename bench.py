@@ -87,7 +87,8 @@ class ConvTimer:
             nbytes = x.numel() * x.element_size() + y.numel() * y.element_size() + w.numel() * w.element_size()
             if k.get("residual") is not None or (len(a) > 2 and a[2] is not None):
                 nbytes += y.numel() * y.element_size()
-            desc = "x%s w%s s%d" % (tuple(x.shape), tuple(w.shape), k.get("stride", 1))
+            kern = ops.CONV_CFG_KERNEL.get(ops.LAST_CONV_CFG[0], "heuristic")
+            desc = "x%s w%s s%d [%s]" % (tuple(x.shape), tuple(w.shape), k.get("stride", 1), kern)
             timer.records.append((str(x.dtype), flops, e0, e1, nbytes, desc))
             return y
 
@@ -157,6 +158,21 @@ class ConvTimer:
                 ms = e0.elapsed_time(e1)
                 f.write("%s\t%.4f\t%.1f\t%.0f\t%.2f\t%.1f\t%s\n" % (dt.replace("torch.", ""), ms, fl / ms / 1e9, nb / ms / 1e6,
                                                                    fl / 1e9, nb / 1e6, desc))
+
+    def by_kernel(self, dtype="torch.bfloat16"):
+        """Launches of conv2d grouped by the kernel the autotuner routed them to (the name in [..] of the description)."""
+        torch.cuda.synchronize()
+        out = {}
+        for dt, fl, e0, e1, nb, desc in self.records:
+            if dt != dtype or not desc.endswith("]") or "[" not in desc:
+                continue
+            k = desc[desc.rindex("[") + 1:-1]
+            d = out.setdefault(k, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
+            d["flops"] += fl
+            d["bytes"] += nb
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
@@ -362,31 +378,50 @@ def main():
     timer = ConvTimer().install()
     _timer_box["t"] = timer
     timer.enabled = True
+    two, model.two_streams = model.two_streams, False      # pose net on the main stream: every timed launch has the chip to itself
     step()
+    model.two_streams = two
     timer.enabled = False
     conv = timer.summary()
     if args.layers and rank == 0:
         timer.dump(args.layers)
     key = "torch.bfloat16" if args.dtype == "bfloat16" else "torch.float32"
-    dom = conv.get(key, {"flops": 0.0, "ms": 1.0, "launches": 0})
+    fam = conv.get(key, {"flops": 0.0, "ms": 1.0, "launches": 0})
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bfloat16" else 157.3
+    # the DOMINANT KERNEL: the conv kernel with the largest share of the step (per-launch HIP-event times of the instrumented step,
+    # grouped by the kernel the load-time autotuner routed each layer to); the whole conv / GEMM family is reported next to it
+    per_kernel = {k: v for k, v in timer.by_kernel(key).items() if k != "heuristic"}
+    dom_name, dom = (max(per_kernel.items(), key=lambda kv: kv[1]["ms"]) if per_kernel else
+                     ("conv_igemm_kernel<bf16>" if args.dtype == "bfloat16" else "conv_igemm_kernel<f32>", fam))
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    # HBM traffic of the same kernel family from the PMC counters (cannot be collected from inside this process: measured by
+    fam_achieved = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
+    # HBM traffic of the same kernel from the PMC counters (cannot be collected from inside this process: measured by
     # scripts/pmc_bench.sh on this benchmark command and committed as profiles/*pmc_traffic.json)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, fam_traffic = None, None, None
     if args.dtype == "bfloat16":
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
-            fam = json.load(open(path))["bf16_conv_family"]
-            traffic = round((fam["read_bytes_per_step"] + fam["write_bytes_per_step"]) / max(fam["launches_per_step"], 1))
+            pm = json.load(open(path))
+            f2 = pm["bf16_conv_family"]
+            fam_traffic = round((f2["read_bytes_per_step"] + f2["write_bytes_per_step"]) / max(f2["launches_per_step"], 1))
+            for kname, kv in pm.get("kernels", {}).items():
+                if dom_name.replace(" ", "") in kname.replace(" ", "") and kv.get("launches_per_step"):
+                    traffic = round((kv["read_bytes_per_step"] + kv["write_bytes_per_step"]) / kv["launches_per_step"])
             traffic_src = os.path.relpath(path, ROOT)
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16>" if args.dtype == "bfloat16" else "conv_igemm_kernel<f32>",
+    roofline = {"bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (family average)", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (PMC)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
                 "step_share": round(dom["ms"] / ms_per_step, 3),
+                "conv_family": {"note": "every bf16 conv / fused-conv launch of the step (MFMA- and HBM-bound layers together)",
+                                "TFLOP/s": round(fam_achieved, 2), "frac_of_mfma_peak": round(fam_achieved / peak, 4), "launches_per_step": fam["launches"],
+                                "flops_per_step": fam["flops"], "ms": round(fam["ms"], 3), "step_share": round(fam["ms"] / ms_per_step, 3),
+                                "algorithmic_bytes_per_launch": round(fam.get("bytes", 0.0) / max(fam["launches"], 1)),
+                                "traffic_bytes_per_launch": fam_traffic},
+                "other_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 3), "launches": v["launches"]}
+                                  for k, v in per_kernel.items() if k != dom_name},
                 "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
                                           "launches": v["launches"]} for k, v in conv.items() if k != key}}
 

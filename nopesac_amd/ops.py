@@ -83,6 +83,10 @@ class ConvTuner:
 TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
+LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
+CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
+                   7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
+                   10: "conv3x3_halo_kernel<16, 8>"}
 
 
 def _frag_weights(w: torch.Tensor) -> torch.Tensor:
@@ -169,6 +173,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ()))
     launch(cfg)
+    LAST_CONV_CFG[0] = cfg             # read by bench.py's per-launch timer to attribute the launch to a kernel
     return out
 
 
