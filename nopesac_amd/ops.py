@@ -62,15 +62,15 @@ class ConvTuner:
         cands = tuple(self.CANDIDATES) + tuple(extra)
         for c in cands:
             launch(c)                                     # warm (first-touch, icache)
-        for rnd in range(2):                              # two interleaved rounds, keep each candidate's best: robust to
+        for rnd in range(3):                              # three interleaved rounds, keep each candidate's best: robust to
             for c in cands:                               # a noisy neighbour / clock ramp during one candidate's window
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(4):
+                for _ in range(6):
                     launch(c)
                 e1.record()
                 e1.synchronize()
-                t = e0.elapsed_time(e1) / 4
+                t = e0.elapsed_time(e1) / 6
                 times[c] = min(times.get(c, t), t)
         cfg = min(times, key=times.get)
         if times[cfg] > 0.97 * times[0]:      # keep the heuristic unless a candidate is clearly faster
