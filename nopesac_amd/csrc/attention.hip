@@ -101,7 +101,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+    return f32x2_to_bf16x2(lo, hi);
 }
 
 constexpr int ATT_KSTRIDE = 40;   // bf16 elements per K row in LDS (32 + 8 pad = 80 bytes: conflict-free b128 reads)

@@ -12,10 +12,14 @@ namespace nps {
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
-    return (bf16_t)(u >> 16);
+// f32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction);
+// the integer sequence it replaces (add 0x7fff + lsb, shift) cost 4-5 VALU operations per value in every epilogue.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // OCP e4m3fn (gfx950's fp8): 8 floats -> 8 bytes, round to nearest even, saturating at +-448 (no NaN from overflow).
