@@ -106,11 +106,13 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
     // ---- p1 = lateral + relu(bilinear_2x(t1)): thread = (pixel, 8-channel chunk); F.interpolate align_corners=False
     {
         const int H2 = p.H >> 1, W2 = p.W >> 1;
+        const int oh0 = pix0 / p.W, ow0 = pix0 - oh0 * p.W;       // workgroup-uniform
         const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
 #pragma unroll 2
         for (int i = 0; i < MH_BM * 32 / 512; ++i) {
             const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
-            const int pix = pix0 + r, oh = pix / p.W, ow = pix % p.W;
+            int oh = oh0, ow = ow0 + r;                      // (pix0 + r) / W, % W without a per-item division
+            while (ow >= p.W) { ow -= p.W; ++oh; }
             const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
             const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H2 - 1), x1 = min(x0 + 1, W2 - 1);
             const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
