@@ -95,6 +95,8 @@ class PlaneCameraHead(ParamModule):
         x = ops.maxpool(x, 2, 2, 0)
         x = cv(cv(x, "cb6", 1, act=ops.ACT_LEAKY), "cb7", 1, act=ops.ACT_LEAKY, out_dtype=torch.float32)   # [2B,h,w,256] f32
         _, h, w, _ = x.shape
+        assert h * w == 300, \
+            f"the correlation stack of the pixel pose net has 300 = 15*20 input channels: inputs must be 480x640 (got a {h}x{w} 1/32 map)"
         x1, x2 = x[:B], x[B:]
         # correlation volume (:1117-1133): channel = view-2 position in (w,h) order, softmax over channels
         x2t = ops.transpose_hw_rows(x2.reshape(B, h * w, 256), h, w)

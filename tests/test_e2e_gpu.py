@@ -182,3 +182,12 @@ def test_config5_fp8_backbone_k128(device):
         assert t_err < 0.1 * (1 + float(t32[i].norm())) and 2 * np.degrees(np.arccos(min(dot, 1.0))) < 15.0, (t_err, dot)
     t, q = a["cameras"]["camera"]
     assert torch.isfinite(t).all() and torch.isfinite(q).all() and float((q.norm(dim=-1) - 1).abs().max()) < 1e-3
+
+
+def test_other_resolutions_are_rejected_like_the_reference(device):
+    """The pixel pose net's correlation stack has 15*20 = 300 input channels (camera_modules.py: convs_trans.0 / convs_rots.0), so the
+    reference architecture only runs on 480x640 inputs; any other size must fail with a clear message, not a kernel error."""
+    from nopesac_amd.synth import synth_pair
+    model = make_model(device)
+    with pytest.raises(AssertionError, match="480x640"):
+        model([synth_pair(60, 256, 384)])
