@@ -116,17 +116,27 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
             const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H2 - 1), x1 = min(x0 + 1, W2 - 1);
             const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-            const us8 v00 = *reinterpret_cast<const us8*>(tb + ((long long)y0 * W2 + x0) * MH_C + col);
-            const us8 v01 = *reinterpret_cast<const us8*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
-            const us8 v10 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
-            const us8 v11 = *reinterpret_cast<const us8*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
-            us8 l8 = *reinterpret_cast<const us8*>(At + r * MH_LD + col);
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const u32x4_t v00 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x0) * MH_C + col);
+            const u32x4_t v01 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
+            const u32x4_t v10 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
+            const u32x4_t v11 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
+            const u32x4_t lw = *reinterpret_cast<const u32x4_t*>(At + r * MH_LD + col);
+            u32x4_t ow4;
+            // two channels per step on float2 (v_pk_mul_f32 / v_pk_add_f32); a bf16 pair unpacks with one shift and one mask
+            auto unpack = [](unsigned int wd) { return f32x2_t{__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)}; };
+            const f32x2_t hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float u = hy * (hx * bf16_to_f32(v00[e]) + lx * bf16_to_f32(v01[e])) + ly * (hx * bf16_to_f32(v10[e]) + lx * bf16_to_f32(v11[e]));
-                u = u > 0.f ? u : 0.f;
-                l8[e] = f32_to_bf16(u + bf16_to_f32(l8[e]));
+            for (int e = 0; e < 4; ++e) {
+                const f32x2_t top = hx2 * unpack(v00[e]) + lx2 * unpack(v01[e]), bot = hx2 * unpack(v10[e]) + lx2 * unpack(v11[e]);
+                f32x2_t u = hy2 * top + ly2 * bot;
+                u.x = u.x > 0.f ? u.x : 0.f;
+                u.y = u.y > 0.f ? u.y : 0.f;
+                u = u + unpack(lw[e]);
+                ow4[e] = f32x2_to_bf16x2(u.x, u.y);
             }
+            const us8 l8 = __builtin_bit_cast(us8, ow4);
             *reinterpret_cast<us8*>(At + r * MH_LD + col) = l8;
             if (p.p1) *reinterpret_cast<us8*>(p.p1 + (m0 + r) * MH_C + col) = l8;
         }
