@@ -406,7 +406,14 @@ def main():
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bfloat16" else 157.3
     # the DOMINANT KERNEL: the conv kernel with the largest share of the step (per-launch HIP-event times of the instrumented step,
     # grouped by the kernel the load-time autotuner routed each layer to); the whole conv / GEMM family is reported next to it
-    per_kernel = {k: v for k, v in timer.by_kernel(key).items() if k != "heuristic"}
+    inst = {k: v for k, v in timer.by_kernel(key).items() if k != "heuristic"}
+    # instantiations of one kernel template (same source, different K-tile / ring-depth constants) count as ONE kernel: which of
+    # conv_igemm_bfrag_kernel<3, 64> / <4, 32> gets a layer is a per-run autotuner decision, the template's total is stable
+    per_kernel = {}
+    for k, v in inst.items():
+        d = per_kernel.setdefault(k.split("<")[0], {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
+        for f in d:
+            d[f] += v[f]
     dom_name, dom = (max(per_kernel.items(), key=lambda kv: kv[1]["ms"]) if per_kernel else
                      ("conv_igemm_kernel<bf16>" if args.dtype == "bfloat16" else "conv_igemm_kernel<f32>", fam))
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -420,9 +427,9 @@ def main():
             pm = json.load(open(path))
             f2 = pm["bf16_conv_family"]
             fam_traffic = round((f2["read_bytes_per_step"] + f2["write_bytes_per_step"]) / max(f2["launches_per_step"], 1))
-            for kname, kv in pm.get("kernels", {}).items():
-                if dom_name.replace(" ", "") in kname.replace(" ", "") and kv.get("launches_per_step"):
-                    traffic = round((kv["read_bytes_per_step"] + kv["write_bytes_per_step"]) / kv["launches_per_step"])
+            hit = [kv for kname, kv in pm.get("kernels", {}).items() if dom_name in kname and kv.get("launches_per_step")]
+            if hit:
+                traffic = round(sum(kv["read_bytes_per_step"] + kv["write_bytes_per_step"] for kv in hit) / sum(kv["launches_per_step"] for kv in hit))
             traffic_src = os.path.relpath(path, ROOT)
     roofline = {"bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -431,13 +438,15 @@ def main():
                 "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
                 "step_share": round(dom["ms"] / ms_per_step, 3),
+                "instantiations": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"],
+                                       "avg_launch_us": round(1e3 * v["ms"] / max(v["launches"], 1), 2)} for k, v in inst.items() if k.split("<")[0] == dom_name},
                 "conv_family": {"note": "every bf16 conv / fused-conv launch of the step (MFMA- and HBM-bound layers together)",
                                 "TFLOP/s": round(fam_achieved, 2), "frac_of_mfma_peak": round(fam_achieved / peak, 4), "launches_per_step": fam["launches"],
                                 "flops_per_step": fam["flops"], "ms": round(fam["ms"], 3), "step_share": round(fam["ms"] / ms_per_step, 3),
                                 "algorithmic_bytes_per_launch": round(fam.get("bytes", 0.0) / max(fam["launches"], 1)),
                                 "traffic_bytes_per_launch": fam_traffic},
                 "other_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 3), "launches": v["launches"]}
-                                  for k, v in per_kernel.items() if k != dom_name},
+                                  for k, v in inst.items() if k.split("<")[0] != dom_name},
                 "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
                                           "launches": v["launches"]} for k, v in conv.items() if k != key}}
 
