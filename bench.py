@@ -131,6 +131,21 @@ class ConvTimer:
             return y, o
 
         ops.stem_fused, ops.bottleneck_tail = timed_stem, timed_tail
+        orig_raw = ops.stem_fused_raw
+
+        def timed_stem_raw(images, mean, std, w224, scale, bias):
+            if not timer.enabled:
+                return orig_raw(images, mean, std, w224, scale, bias)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_raw(images, mean, std, w224, scale, bias)
+            e1.record()
+            B, _, H, W = images.shape
+            flops = 2.0 * B * (H // 2) * (W // 2) * 64 * 147
+            timer.records.append(("torch.bfloat16", flops, e0, e1, images.numel() * 4 + y.numel() * 2, "stem_fused_raw x%s" % (tuple(images.shape),)))
+            return y
+
+        ops.stem_fused_raw = timed_stem_raw
         orig_fp8 = ops.conv2d_fp8
 
         def timed_fp8(x, w8, scale, bias, **k):
@@ -298,7 +313,14 @@ def main():
 
     zero_rows = torch.zeros(B, runner.METRIC_WIDTH, device=device)
 
+    raw_stem = args.dtype == "bfloat16" and model.backbone.fused_stem and not args.ablate
+
     def device_step(slot):
+        if raw_stem:       # bf16: the fused stem normalises the f32 NCHW images while it loads them (no preprocess launch)
+            d = model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=raws[slot])
+            cam = d["cam"]
+            rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B)
+            return d, rows
         x = ops.preprocess(raws[slot], model.pixel_mean, model.pixel_std, model.backbone.STEM_CIN_PAD, model.compute_dtype)
         if args.ablate:
             from nopesac_amd.modeling.plane_head import post_select

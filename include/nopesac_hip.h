@@ -125,6 +125,11 @@ int nopesac_conv3x3_halo_bf16(const void* x, const void* w_frag, const float* sc
  *   output channel); scale/bias f32[64] (folded FrozenBN); y bf16 NHWC [B,PH,PW,64]. */
 int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, const float* bias, void* y,
                             int B, int H, int W, void* stream);
+/* Same, fed directly with the f32 NCHW images [B,3,H,W] of preprocess_image (siamese_planeTR.py:534-542): the normalisation
+ * (v - mean[c]) / std[c] and the rounding to bf16 happen while the input patch is staged, bit-identical to
+ * nopesac_preprocess_nchw_to_nhwc followed by nopesac_stem_fused_bf16. */
+int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mean, const float* std, const void* w, const float* scale,
+                                const float* bias, void* y, int B, int H, int W, void* stream);
 
 /* Fused tail of a bf16 ResNet bottleneck (d2 BottleneckBlock.forward: conv3 + shortcut + ReLU) plus, optionally, the NEXT
  * block's 1x1 reduce conv, in one launch (all tensors bf16 NHWC, pixel-dense; FrozenBN as f32 scale/bias):

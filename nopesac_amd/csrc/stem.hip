@@ -32,7 +32,13 @@ constexpr int ST_W_BYTES = 64 * ST_WLD * 2;
 constexpr int ST_CONV_BYTES = ST_M * ST_CLD * 2;     // 53,136 B: three workgroups per CU (the 384-row version allowed two)
 constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH_BYTES + ST_W_BYTES) : ST_CONV_BYTES;
 
-__global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+// RAW = true: x is not read; the patch comes straight from the f32 NCHW images `xraw` [B,3,H,W], normalised per channel
+// ((v - mean[c]) / std[c], then rounded to bf16 - exactly what nopesac_preprocess_nchw_to_nhwc writes) while it is staged:
+// the 157 MB bf16 NHWC copy of the batch is never written or read.
+template <bool RAW>
+__global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ xraw,
+                                                         const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                         const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
@@ -46,14 +52,30 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- stage the input patch (zero outside the image) and the weights
-    const bf16_t* xb = x + (long long)b * H * W * 4;
-    for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
-        const int r = i / ST_IW, c = i % ST_IW;
-        const int iy = iy0 + r, ix = ix0 + c;
-        uint2 v = make_uint2(0u, 0u);
-        if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = *reinterpret_cast<const uint2*>(xb + ((long long)iy * W + ix) * 4);
-        *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
+    if constexpr (RAW) {
+        const float* xr = xraw + (long long)b * 3 * H * W;
+        const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+        for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
+            const int r = i / ST_IW, c = i % ST_IW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            uint2 v = make_uint2(0u, 0u);
+            if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const long long o = (long long)iy * W + ix, hw = (long long)H * W;
+                v.x = f32x2_to_bf16x2((xr[o] - m0) / s0, (xr[hw + o] - m1) / s1);
+                v.y = f32x2_to_bf16x2((xr[2 * hw + o] - m2) / s2, 0.f);
+            }
+            *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
+        }
+    } else {
+        const bf16_t* xb = x + (long long)b * H * W * 4;
+        for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
+            const int r = i / ST_IW, c = i % ST_IW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            uint2 v = make_uint2(0u, 0u);
+            if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const uint2*>(xb + ((long long)iy * W + ix) * 4);
+            *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
+        }
     }
     for (int i = tid; i < 64 * (ST_K / 8); i += 256) {
         const int n = i / (ST_K / 8), c = i % (ST_K / 8);
@@ -149,7 +171,20 @@ extern "C" int nopesac_stem_fused_bf16(const void* x, const void* w, const float
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    hipLaunchKernelGGL(stem_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, scale, bias,
-                       (bf16_t*)y, H, W, CH, CW, PH, PW);
+    hipLaunchKernelGGL(stem_fused_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mean, const float* stdv, const void* w, const float* scale,
+                                           const float* bias, void* y, int B, int H, int W, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x_nchw && mean && stdv && w && scale && bias && y && B > 0 && H >= 7 && W >= 7, "stem_fused_raw: bad args");
+    NPS_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "stem_fused_raw: alignment");
+    const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
+    const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
+    dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
+    hipLaunchKernelGGL(stem_fused_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, mean, stdv,
+                       (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
     NPS_LAUNCH_RET();
 }

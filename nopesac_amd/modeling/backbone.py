@@ -101,16 +101,22 @@ class HipResNet50(ParamModule):
             self._q8[p] = q
         return q
 
-    def forward(self, x: torch.Tensor) -> dict:
-        """x: NHWC [B,H,W,4] (normalised, channel-padded) in the compute dtype -> {res2..res5} NHWC."""
-        P, dt = self.packed, x.dtype
+    def forward(self, x: torch.Tensor, raw=None) -> dict:
+        """x: NHWC [B,H,W,4] (normalised, channel-padded) in the compute dtype -> {res2..res5} NHWC.
+        bf16 mode only: `raw` = (images f32 NCHW [B,3,H,W], mean f32[3], std f32[3]) may be given INSTEAD of x - the fused stem then
+        normalises while it stages its input patches (no NHWC copy of the batch is made)."""
+        P = self.packed
+        dt = x.dtype if x is not None else torch.bfloat16
+        assert x is not None or (raw is not None and self.fused_stem), "backbone: raw images need the fused bf16 stem"
         assert not self.fp8_conv2 or (dt == torch.bfloat16 and self.fused_tail), "MODEL.AMD.BACKBONE_FP8 needs MODEL.AMD.COMPUTE_DTYPE bfloat16"
 
         def cv(t, key, stride=1, pad=0, act=ops.ACT_RELU, residual=None):
             c = P[key]
             return ops.conv2d(t, c.w(dt), c.scale, c.bias, residual, stride=stride, pad=pad, act=act)
 
-        if dt == torch.bfloat16 and self.fused_stem:
+        if x is None:
+            x = ops.stem_fused_raw(raw[0], raw[1], raw[2], P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
+        elif dt == torch.bfloat16 and self.fused_stem:
             x = ops.stem_fused(x, P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         else:
             x = cv(x, "stem", 2, 3)

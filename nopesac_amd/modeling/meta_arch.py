@@ -86,29 +86,42 @@ class PlaneTR_NopeSAC(nn.Module):
         x = torch.stack([i.to(self.device, torch.float32, non_blocking=True) for i in imgs], 0).contiguous()
         return ops.preprocess(x, self.pixel_mean, self.pixel_std, self.backbone.STEM_CIN_PAD, self.compute_dtype)
 
+    def stack_images(self, batched_inputs: List[dict]) -> torch.Tensor:
+        """The 2B raw images as one f32 NCHW tensor on the device (all view-"0" images first): the bf16 path hands this to the
+        fused stem, which normalises while it loads (`forward_tensors(None, ..., raw_images=...)`)."""
+        imgs = [x["0"]["image"] for x in batched_inputs] + [x["1"]["image"] for x in batched_inputs]
+        sizes = {tuple(i.shape) for i in imgs}
+        assert len(sizes) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
+        return torch.stack([i.to(self.device, torch.float32, non_blocking=True) for i in imgs], 0).contiguous()
+
     def forward_device(self, batched_inputs: List[dict], diagnostics: bool = False) -> dict:
         """All device work for B pairs; returns device tensors only (no synchronisation)."""
         B = len(batched_inputs)
         H, W = batched_inputs[0]["0"]["image"].shape[-2:]
+        if self.compute_dtype == torch.bfloat16 and self.backbone.fused_stem:
+            return self.forward_tensors(None, B, H, W, diagnostics, raw_images=self.stack_images(batched_inputs))
         x = self.preprocess_image(batched_inputs)
         return self.forward_tensors(x, B, H, W, diagnostics)
 
     def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False,
-                        forced: dict = None) -> dict:
+                        forced: dict = None, raw_images: torch.Tensor = None) -> dict:
+        """x_nhwc: the preprocessed batch (NHWC, channel-padded) - or None with `raw_images` (f32 NCHW [2B,3,H,W], bf16 mode)."""
         mark = self._mark
         mark("start")
-        feats = self.backbone(x_nhwc)
+        is_cuda = (x_nhwc if x_nhwc is not None else raw_images).is_cuda
+        dev = (x_nhwc if x_nhwc is not None else raw_images).device
+        feats = self.backbone(x_nhwc, raw=None if raw_images is None else (raw_images, self.pixel_mean, self.pixel_std))
         mark("backbone")
         head = self.camera_head_list[0]
         pose = None
-        if self.two_streams and x_nhwc.is_cuda:
+        if self.two_streams and is_cuda:
             # the pixel pose net depends only on the backbone maps: run it on a side HIP stream, concurrently
             # with the (launch-latency-bound) transformer of the plane head
             main = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = {}
             if main.cuda_stream not in self._side_stream:      # one side stream per caller stream (batches may be pipelined)
-                self._side_stream[main.cuda_stream] = torch.cuda.Stream(device=x_nhwc.device)
+                self._side_stream[main.cuda_stream] = torch.cuda.Stream(device=dev)
             side = self._side_stream[main.cuda_stream]
             side.wait_stream(main)
             with torch.cuda.stream(side):

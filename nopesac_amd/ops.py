@@ -222,6 +222,21 @@ def stem_fused(x: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor, bias: t
     return y
 
 
+def stem_fused_raw(images: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor,
+                   bias: torch.Tensor) -> torch.Tensor:
+    """`preprocess` + `stem_fused` in one kernel: images f32 NCHW [B,3,H,W] (0-255), per-channel mean / std f32[3]."""
+    _chk(images, torch.float32); _chk(mean, torch.float32); _chk(std, torch.float32)
+    _chk(w224, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
+    B, C, H, W = images.shape
+    assert C == 3 and mean.numel() == 3 and std.numel() == 3 and w224.shape == (64, 224)
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    y = torch.empty((B, PH, PW, 64), device=images.device, dtype=torch.bfloat16)
+    _lib.check(_L().nopesac_stem_fused_raw_bf16(_p(images), _p(mean), _p(std), _p(w224), _p(scale), _p(bias), _p(y), B, H, W, _stream()),
+               "nopesac_stem_fused_raw_bf16")
+    return y
+
+
 BOTTLENECK_TAIL_CONFIGS = {(64, 256, 0, 0), (64, 256, 64, 0), (64, 256, 128, 0), (64, 256, 0, 64), (64, 256, 64, 64),          # (C, C4, CN, C2)
                            (128, 512, 0, 0), (128, 512, 128, 0), (128, 512, 256, 0), (128, 512, 0, 256), (128, 512, 128, 256),
                            (256, 1024, 0, 0), (256, 1024, 256, 0), (256, 1024, 512, 0), (256, 1024, 0, 512), (256, 1024, 256, 512)}

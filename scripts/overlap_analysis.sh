@@ -8,9 +8,9 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/prof_ovl/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
-# the last 25 preprocess launches = 24 timed steps + the instrumented one; analyse timed steps 6 .. 20
-a, b = starts[-25 + 6], starts[-25 + 20]
+starts = [i for i, r in enumerate(rows) if ("stem_fused_kernel<true>" in r["Kernel_Name"] or "preprocess" in r["Kernel_Name"])]
+# the last 27 step starts = 24 timed steps + 3 instrumented ones; analyse timed steps 6 .. 20
+a, b = starts[-27 + 6], starts[-27 + 20]
 sel = rows[a:b]
 t0 = int(sel[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in sel)
 def wgs(r):

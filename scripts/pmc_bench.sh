@@ -11,16 +11,16 @@ import csv, glob, collections, json
 tot=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
 for f in glob.glob("gpurun_out/pmc_bench/*/*counter_collection.csv"):
     rows=sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
-    # only the 4 real forward passes at the end (each starts with the preprocess kernel): the load-time autotuner's trial
+    # only the 6 real forward passes at the end (each starts with the preprocess kernel): the load-time autotuner's trial
     # launches before them are not part of a step
-    starts=[int(r["Dispatch_Id"]) for r in rows if "preprocess" in r["Kernel_Name"] and r["Counter_Name"]==rows[0]["Counter_Name"]]
-    first=sorted(set(starts))[-4]
+    starts=[int(r["Dispatch_Id"]) for r in rows if ("stem_fused_kernel<true>" in r["Kernel_Name"] or "preprocess" in r["Kernel_Name"]) and r["Counter_Name"]==rows[0]["Counter_Name"]]
+    first=sorted(set(starts))[-6]          # warmup 1 + 2 timed + 3 instrumented forward passes
     for r in rows:
         if int(r["Dispatch_Id"]) < first: continue
         k=r["Kernel_Name"].split("(")[0].replace("void ","").strip()[-80:]
         tot[k][r["Counter_Name"]]+=float(r["Counter_Value"])
         if r["Counter_Name"]=="FETCH_SIZE": calls[k]+=1
-steps=4   # warmup 1 + 2 timed + 1 instrumented forward passes
+steps=6   # warmup 1 + 2 timed + 3 instrumented forward passes
 rows=[]
 for k,v in tot.items():
     # FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md)
@@ -31,7 +31,7 @@ print("per step: kernel, launches, HBM read GB (2x FETCH_SIZE), write GB")
 for t,k,rd,wr,n in rows[:16]:
     print("%-80s %6.1f  %7.3f  %7.3f"%(k,n,rd/1e9,wr/1e9))
 fam=[r for r in rows if any(s in r[1] for s in ("conv_igemm", "pw_chain", "stem_fused", "conv3x3_halo")) and "float" not in r[1]]
-out={"note": "HBM bytes per forward pass of 32 pairs (bench.py --inflight 1, autotuned kernel routing, the 4 forward passes after the tuning), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+out={"note": "HBM bytes per forward pass of 32 pairs (bench.py --inflight 1, autotuned kernel routing, the 6 forward passes after the tuning), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
              "read = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md), write = WRITE_SIZE x 1024",
      "bf16_conv_family": {"launches_per_step": sum(r[4] for r in fam), "read_bytes_per_step": sum(r[2] for r in fam), "write_bytes_per_step": sum(r[3] for r in fam)},
      "kernels": {r[1]: {"launches_per_step": r[4], "read_bytes_per_step": r[2], "write_bytes_per_step": r[3]} for r in rows[:40]}}

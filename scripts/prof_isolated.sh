@@ -12,10 +12,10 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/prof_${TAG}/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the timed region = the last $STEPS + 1 steps; find step boundaries via the preprocess kernel (first kernel of a step)
-starts = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+# step boundaries = the first kernel of a step (raw-input stem, or preprocess); the run ends with 3 instrumented steps
+starts = [i for i, r in enumerate(rows) if ("stem_fused_kernel<true>" in r["Kernel_Name"] or "preprocess" in r["Kernel_Name"])]
 n = $STEPS
-sel = rows[starts[-(n + 1)]:starts[-1]]           # n full steps (skips the instrumented last step)
+sel = rows[starts[-(n + 3)]:starts[-3]]           # n full timed steps (skips the 3 instrumented ones)
 tot = collections.defaultdict(lambda: [0, 0.0])
 for r in sel:
     k = r["Kernel_Name"].split("(")[0].replace("void nps::", "").replace("nps::", "")[:90]

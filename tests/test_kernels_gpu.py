@@ -543,3 +543,18 @@ def test_conv2d_generic_and_tail_fp8_outputs(device):
     yb, ob = ops.bottleneck_tail(b, w3, s3, b3, residual=res, w1=w1, s1=s1, b1=b1, o_fp8=True)
     assert torch.equal(ya, yb) and ob.dtype == torch.float8_e4m3fn
     assert torch.equal(ob.float(), _q8(oa).float().to(device))         # converted from the same bf16 staging values: bit-identical
+
+
+def test_stem_fused_raw_equals_preprocess_plus_stem(device):
+    """The raw-input stem (f32 NCHW images, normalisation while staging) is bit-identical to preprocess + fused stem, including
+    image borders and a height / width that are not multiples of the tile."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(21)
+    img = torch.randint(0, 256, (3, 3, 100, 172), generator=g).float().to(device)
+    mean = torch.tensor([123.675, 116.28, 103.53], device=device)
+    std = torch.tensor([58.395, 57.12, 57.375], device=device)
+    w = (torch.randn(64, 224, generator=g) / 12).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(64, generator=g)).to(device), (0.1 * torch.randn(64, generator=g)).to(device)
+    a = ops.stem_fused(ops.preprocess(img, mean, std, 4, torch.bfloat16), w, sc, bi)
+    b = ops.stem_fused_raw(img, mean, std, w, sc, bi)
+    assert a.shape == b.shape and torch.equal(a, b)
