@@ -245,9 +245,23 @@ def add_nopesac_defaults(cfg: CfgNode) -> CfgNode:
     return cfg
 
 
-def add_amd_defaults(cfg: CfgNode) -> CfgNode:
-    """Keys that only this implementation has (the reference ignores them)."""
-    cfg.MODEL.AMD = CN(dict(
+def amd_options(cfg) -> CfgNode:
+    """cfg.MODEL.AMD with every missing key filled from the defaults, as a detached node: the model reads its own options
+    through this, so that a FOREIGN config (detectron2's CfgNode + the reference's get_sparseplane_cfg_defaults, which has
+    no MODEL.AMD, possibly frozen) builds the model in its default configuration instead of failing."""
+    out = add_amd_defaults(CN({"MODEL": {}})).MODEL.AMD
+    model = cfg["MODEL"] if isinstance(cfg, dict) else cfg.MODEL
+    given = model.get("AMD") if isinstance(model, dict) else getattr(model, "AMD", None)
+    if given is not None:
+        for k, v in (given.items() if isinstance(given, dict) else vars(given).items()):
+            out[k] = v
+    return out
+
+
+def add_amd_defaults(cfg) -> CfgNode:
+    """Keys that only this implementation has (the reference ignores them).  Works on any yacs-style node: call it on
+    detectron2's cfg before merge_from_file / merge_from_list if MODEL.AMD.* overrides are wanted there."""
+    cfg.MODEL.AMD = type(cfg.MODEL)(dict(
         COMPUTE_DTYPE="float32",      # "float32" (parity path) or "bfloat16" (dense convs on bf16 MFMA)
         OUTPUT_MASKS=True,            # decode pred_plane_masks [n,H,W] from the winner map for every image
         OUTPUT_RLE=True,              # COCO RLE "segmentation" + "bbox" in every `instances` entry (siamese_planeTR.py:703-720)

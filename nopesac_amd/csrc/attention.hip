@@ -279,11 +279,7 @@ static int launch_attention_mfma(const TIO* q, int64_t q_stride, const TIO* k, i
                   "attention_bf16: rows must be 16-byte aligned");
     const int Lk_pad = ((Lk + 31) / 32) * 32;
     const size_t lds = (size_t)Lk_pad * ATT_KSTRIDE * 2 + (size_t)32 * (Lk_pad + 8) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<TIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS(96 * 1024, attention_mfma_kernel<TIO>);
     dim3 grid((Lq + 127) / 128, heads, B);
     hipLaunchKernelGGL(attention_mfma_kernel<TIO>, grid, dim3(256), lds, (hipStream_t)stream, q, (long long)q_stride, k,
                        (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad, scale, qlen, klen);

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/nopesac_hip.h"
 
 namespace nps {
@@ -107,6 +109,21 @@ void set_error(const char* fmt, ...);
             nps::set_error(__VA_ARGS__);       \
             return NPS_E_ARG;                  \
         }                                      \
+    } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set it once per (call site, device), not once per
+// process (a process that drives several GPUs would otherwise fail to launch on the second one).  Usage:
+// NPS_ENSURE_LDS(bytes, kernel<template, args>);
+#define NPS_ENSURE_LDS(bytes, ...)                                                                                     \
+    do {                                                                                                               \
+        static std::atomic<unsigned long long> done__{0ull};                                                           \
+        int dev__ = 0;                                                                                                 \
+        (void)hipGetDevice(&dev__);                                                                                    \
+        const unsigned long long bit__ = 1ull << (dev__ & 63);                                                         \
+        if (!(done__.load(std::memory_order_relaxed) & bit__)) {                                                       \
+            (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            done__.fetch_or(bit__, std::memory_order_relaxed);                                                         \
+        }                                                                                                              \
     } while (0)
 
 #define NPS_LAUNCH_RET()                                                   \

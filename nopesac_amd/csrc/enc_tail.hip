@@ -248,11 +248,7 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = ln2_g; a.be2 = ln2_b;
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = nullptr; a.pre_norm = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)enc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ET_LDS_BYTES);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
     hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
 }
@@ -276,11 +272,7 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
     a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = lnn_g; a.be2 = lnn_b;
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = yn; a.pre_norm = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)enc_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ET_LDS_BYTES);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
     hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
 }

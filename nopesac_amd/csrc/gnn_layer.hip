@@ -339,11 +339,7 @@ extern "C" int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* sr
     a.qlen = qlen; a.klen = klen;
     a.wq = (const bf16_t*)wq; a.wk = (const bf16_t*)wk; a.wv = (const bf16_t*)wv; a.wm = (const bf16_t*)wmerge;
     a.w0 = (const bf16_t*)w0; a.w2 = (const bf16_t*)w2; a.g1 = ln1_g; a.b1 = ln1_b; a.g2 = ln2_g; a.b2 = ln2_b;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gnn_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GN_LDS_BYTES);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)GN_LDS_BYTES, gnn_layer_kernel);
     hipLaunchKernelGGL(gnn_layer_kernel, dim3(n_sets), dim3(512), GN_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
 }

@@ -202,11 +202,7 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
     a.c1 = (const bf16_t*)c1; a.t1 = (const bf16_t*)t1; a.wc = (const bf16_t*)w_lateral; a.sc = scale; a.bc = bias;
     a.mw = (const bf16_t*)mask_w; a.mb = mask_b; a.prob = prob; a.p1 = (bf16_t*)p1_out;
     a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid & 1; a.planar = (apply_sigmoid >> 1) & 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mask_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MH_LDS_BYTES);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel);
     const long long blocks = (long long)B * H * W / MH_BM;
     hipLaunchKernelGGL(mask_head_kernel, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();

@@ -264,11 +264,7 @@ extern "C" int nopesac_matcher_sinkhorn(const float* desc_dot, const float* plan
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && iters >= 0, "sinkhorn: bad dims (nq<=128)");
     const int R = nq + 1, LD = (R & 1) ? R : R + 1;
     const size_t lds = sizeof(float) * ((size_t)R * LD + 4 * R + 11 * nq + R + 2 * R);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)matcher_sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, matcher_sinkhorn_kernel);   // per device, only when it is needed
     hipLaunchKernelGGL(matcher_sinkhorn_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
                        cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
     NPS_LAUNCH_RET();

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void ps_finalize_kernel(const float* __restrict
     const int zero_flag = wk[9 * nq];
     if (lane == 0) {
         int n = 0, fb = 0;
-        float max_overlap = 0.f;
+        double max_overlap = 0.0;   // kept as a double like the Python float (:693-698)
         int max_overlap_q = -1, first_valid = -1;
         for (int q = 0; q < nq; ++q) {
             if (!wk[q]) continue;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void ps_finalize_kernel(const float* __restrict
                 if (area < 1 || orig < 1) continue;
                 // Python float division, compared in double like the reference (:693-698)
                 const double overlap = (double)area / (double)orig;
-                if (overlap > (double)max_overlap) { max_overlap = (float)overlap; max_overlap_q = q; }
+                if (overlap > max_overlap) { max_overlap = overlap; max_overlap_q = q; }
                 if (overlap < (double)overlap_thr) continue;
             }
             s_keep[n++] = q;

@@ -481,11 +481,7 @@ __global__ __launch_bounds__(512, 2) void pw_chain_wide_kernel(const PwArgs p) {
 template <int C, int C4, int CN, int C2>
 static int pw_launch_wide(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwWide<C, C4, CN, C2>::BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pw_chain_wide_kernel<C, C4, CN, C2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)lds, pw_chain_wide_kernel<C, C4, CN, C2>);
     hipLaunchKernelGGL((pw_chain_wide_kernel<C, C4, CN, C2>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), lds, stream, a);
     return 0;
 }
@@ -667,11 +663,7 @@ __global__ __launch_bounds__(512, 2) void pw_chain_stream_kernel(const PwArgs p)
 template <int C, int C4, int CN, int BM>
 static int pw_launch_stream(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwStream<C, C4, CN, BM>::BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pw_chain_stream_kernel<C, C4, CN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)lds, pw_chain_stream_kernel<C, C4, CN, BM>);
     hipLaunchKernelGGL((pw_chain_stream_kernel<C, C4, CN, BM>), dim3((unsigned)((a.M + BM - 1) / BM)), dim3(512), lds, stream, a);
     return 0;
 }
@@ -679,12 +671,7 @@ static int pw_launch_stream(const PwArgs& a, hipStream_t stream) {
 template <int C, int C4, int CN, int C2, int BM>
 static int pw_launch(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)pw_chain_kernel<C, C4, CN, C2, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    NPS_ENSURE_LDS((int)lds, pw_chain_kernel<C, C4, CN, C2, BM>);
     const unsigned blocks = (unsigned)((a.M + BM - 1) / BM);
     hipLaunchKernelGGL((pw_chain_kernel<C, C4, CN, C2, BM>), dim3(blocks), dim3(256), lds, stream, a);
     return 0;

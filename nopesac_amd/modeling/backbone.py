@@ -11,6 +11,7 @@ import os
 import torch
 
 from .. import ops
+from ..config import amd_options
 from ..registry import BACKBONE_REGISTRY
 from ..synth import RES_STAGES, state_dict_spec
 from .params import ParamModule, conv_bn
@@ -40,7 +41,7 @@ class HipResNet50(ParamModule):
         self.halo_conv2 = not os.environ.get("NOPESAC_NO_HALO_CONV2")
         # fp8 mode (MODEL.AMD.BACKBONE_FP8): the 3x3 conv of every res3 / res4 / res5 bottleneck runs on the fp8 MFMA; its input (the block's conv1 output)
         # is written as e4m3fn by the producing kernel.  act_scale[block] = static scale of that input (x ~= x8 * scale).
-        self.fp8_conv2 = bool(cfg.MODEL.AMD.get("BACKBONE_FP8", False)) if cfg is not None else False
+        self.fp8_conv2 = bool(amd_options(cfg).BACKBONE_FP8) if cfg is not None else False
         self.act_scale: dict = {}
         self._calib: dict | None = None
         self._q8: dict = {}

@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from .. import ops, rle
+from ..config import amd_options
 from ..registry import META_ARCH_REGISTRY, configurable
 from .backbone import build_backbone
 from .camera_head import build_camera_head
@@ -42,13 +43,14 @@ class PlaneTR_NopeSAC(nn.Module):
         self.num_queries = num_queries
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32), False)
-        self.compute_dtype = _DTYPES[cfg.MODEL.AMD.COMPUTE_DTYPE]
-        self.output_masks = bool(cfg.MODEL.AMD.OUTPUT_MASKS)
-        self.output_rle = bool(cfg.MODEL.AMD.get("OUTPUT_RLE", True))
+        amd = amd_options(cfg)            # MODEL.AMD.* with defaults filled in (a detectron2 cfg has no such node)
+        self.compute_dtype = _DTYPES[amd.COMPUTE_DTYPE]
+        self.output_masks = bool(amd.OUTPUT_MASKS)
+        self.output_rle = bool(amd.OUTPUT_RLE)
         for mod in (self.sem_seg_head, self.matching_head, self.camera_head_list[0]):
             mod.gemm_dtype = self.compute_dtype     # bf16 => head GEMMs run f32-activation x bf16-weight MFMA
         self.infer_iter = 0
-        self.two_streams = bool(cfg.MODEL.AMD.TWO_STREAMS)
+        self.two_streams = bool(amd.TWO_STREAMS)
         self._side_stream = None
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 

@@ -56,17 +56,25 @@ class ParamModule(nn.Module):
         except AttributeError:
             return False
 
-    # packed-weight cache invalidation
-    def _apply(self, fn, *a, **k):
+    # packed-weight cache invalidation: `_packed` and every derived-weight cache a subclass keeps in its __dict__
+    # (fragment-major bf16 copies for the fused kernels) are dropped whenever the raw tensors can have changed
+    _DERIVED_CACHES = ("_fused_w", "_enc_tail_w", "_dec_tail_w", "_mlp_chain_w")
+
+    def _drop_derived(self):
         self._packed = None
+        for name in self._DERIVED_CACHES:
+            self.__dict__.pop(name, None)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_derived()
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._packed = None
+        self._drop_derived()
         return super()._load_from_state_dict(*a, **k)
 
     def invalidate(self):
-        self._packed = None
+        self._drop_derived()
         for m in self.children():
             if isinstance(m, ParamModule):
                 m.invalidate()

@@ -56,10 +56,10 @@ class ConvTuner:
 
     def choose(self, key, launch, extra=()):
         cfg = self.best.get(key)
-        if cfg is not None or not self.measuring:
-            return cfg or 0
-        times = {}
         cands = tuple(self.CANDIDATES) + tuple(extra)
+        if cfg is not None or not self.measuring:
+            return cfg if (cfg is not None and cfg in cands) else 0     # a remembered cfg this call is not eligible for -> heuristic
+        times = {}
         for c in cands:
             launch(c)                                     # warm (first-touch, icache)
         for rnd in range(3):                              # three interleaved rounds, keep each candidate's best: robust to
@@ -170,7 +170,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
 
     cfg = 0
     if TUNER.measuring or TUNER.best:
-        key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0)
+        # everything that decides which kernel configurations are eligible (bfrag_ok / halo_ok) is part of the key
+        key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0,
+               scale is not None, bias is not None, act, bfrag_ok, halo_ok)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ()))
     launch(cfg)
     LAST_CONV_CFG[0] = cfg             # read by bench.py's per-launch timer to attribute the launch to a kernel

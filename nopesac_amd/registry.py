@@ -6,8 +6,10 @@
     MATCHING_HEAD_REGISTRY["MatchingHead"]       (matching_net/matching_head.py:15-24)
     CAMERA_HEAD_REGISTRY["PlaneCameraHead"]      (camera_net/camera_head.py:21-35)
 
-If detectron2 is importable the meta-arch is ALSO registered into detectron2's own META_ARCH_REGISTRY
-(see INTEGRATION.md), so `MODEL.META_ARCHITECTURE: "PlaneTR_NopeSAC"` resolves to this implementation.
+`register_into_detectron2()` (called once when `nopesac_amd.modeling` is imported; a no-op without detectron2) puts the
+meta-arch into detectron2's own META_ARCH_REGISTRY too, so that detectron2's
+`build_model(cfg)` with `MODEL.META_ARCHITECTURE: "PlaneTR_NopeSAC"` resolves to this implementation.  `configurable`
+accepts any yacs / detectron2-style config node (duck-typed), not only this package's CfgNode.
 """
 from __future__ import annotations
 
@@ -49,20 +51,55 @@ MATCHING_HEAD_REGISTRY = Registry("MATCHING_HEAD")
 CAMERA_HEAD_REGISTRY = Registry("CAMERA_HEAD")
 
 
+def is_config_node(a) -> bool:
+    """A yacs / fvcore / detectron2 / nopesac_amd config node, duck-typed: a mapping (or attribute bag) whose `MODEL` child
+    names the META_ARCHITECTURE.  detectron2's own test is isinstance(yacs CfgNode | omegaconf DictConfig) - both qualify."""
+    try:
+        model = a["MODEL"] if isinstance(a, dict) else getattr(a, "MODEL", None)
+        if model is None:
+            return False
+        return ("META_ARCHITECTURE" in model) if isinstance(model, dict) else hasattr(model, "META_ARCHITECTURE")
+    except Exception:
+        return False
+
+
 def configurable(init_func):
-    """`cls(cfg, *args)` -> `cls(**cls.from_config(cfg, *args))`; explicit kwargs pass straight through."""
-    from .config import CfgNode
+    """detectron2.config.configurable for `__init__`: `cls(cfg, *args)` / `cls(cfg=cfg)` -> `cls(**cls.from_config(cfg, *args))`;
+    a call with explicit keyword arguments (e.g. `cls(num_queries=..., cfg=cfg, ...)`) passes straight through
+    (meta_arch/siamese_planeTR.py:38,133: the reference is built as `cls(cfg)` by detectron2's build_model)."""
 
     @functools.wraps(init_func)
     def wrapped(self, *args, **kwargs):
-        if (args and isinstance(args[0], CfgNode)) or isinstance(kwargs.get("cfg"), CfgNode) and not args:
+        via_cfg = (bool(args) and is_config_node(args[0])) or (not args and set(kwargs) == {"cfg"} and is_config_node(kwargs["cfg"]))
+        if via_cfg:
             from_config = type(self).from_config
-            assert inspect.ismethod(from_config), "from_config must be a classmethod"
+            if not inspect.ismethod(from_config):
+                raise TypeError("from_config must be a classmethod")
             init_func(self, **from_config(*args, **kwargs))
         else:
             init_func(self, *args, **kwargs)
 
     return wrapped
+
+
+def register_into_detectron2(override: bool = True) -> bool:
+    """Put this package's classes into detectron2's registries under the reference's names.  Returns False when
+    detectron2 is not importable.  With `override` an existing entry of the same name (the reference's own class, if
+    NopeSAC_Net was imported first) is replaced - that IS the drop-in; without it an existing entry is left alone."""
+    try:
+        from detectron2.modeling import META_ARCH_REGISTRY as D2_META
+    except Exception:
+        return False
+    from . import modeling  # noqa: F401  (fills the local registries)
+    cls = META_ARCH_REGISTRY.get("PlaneTR_NopeSAC")
+    existing = getattr(D2_META, "_obj_map", None)
+    if existing is not None and "PlaneTR_NopeSAC" in existing:
+        if not override or existing["PlaneTR_NopeSAC"] is cls:
+            return existing["PlaneTR_NopeSAC"] is cls
+        existing["PlaneTR_NopeSAC"] = cls
+        return True
+    D2_META.register(cls)
+    return True
 
 
 def build_model(cfg):

@@ -109,7 +109,14 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int):
 
 
 def main(argv=None):
+    """Entry point (test_NopeSAC.py:207-216): `--num-gpus N` outside a torchrun environment starts N ranks itself."""
     args = default_argument_parser().parse_args(argv)
+    if args.num_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return runner.launch(_main_rank, args.num_gpus, (args,))
+    return _main_rank(args)
+
+
+def _main_rank(args):
     logging.basicConfig(level=logging.INFO, format="[%(asctime)s %(name)s]: %(message)s")
     rank, world, local = runner.init_distributed()
     cfg = setup(args)

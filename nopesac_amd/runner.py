@@ -33,6 +33,35 @@ def init_distributed(backend: Optional[str] = None):
     return rank, world, local
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch_worker(local_rank: int, world: int, port: int, main_func, args):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    main_func(*args)
+
+
+def launch(main_func, num_gpus_per_machine: int, args=()):
+    """detectron2.engine.launch for ONE machine (test_NopeSAC.py:209-216): with num_gpus > 1 and no torchrun environment,
+    spawn one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for `init_distributed`) and run
+    `main_func(*args)` in each; otherwise (1 GPU, or already under torchrun) call it in this process.
+    Returns main_func's value in the single-process case, None after a multi-process run (rank 0 writes the results)."""
+    if num_gpus_per_machine <= 1 or "WORLD_SIZE" in os.environ:
+        return main_func(*args)
+    import torch.multiprocessing as mp
+    mp.start_processes(_launch_worker, args=(num_gpus_per_machine, _free_port(), main_func, tuple(args)),
+                       nprocs=num_gpus_per_machine, join=True, start_method="spawn")
+    return None
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of rank `rank` (InferenceSampler semantics: ceil(N/W) per rank)."""
     per = int(math.ceil(n_items / world))

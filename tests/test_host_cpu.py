@@ -109,3 +109,118 @@ def test_fp8_weight_packing_cpu():
     raw, frag = w8.view(torch.uint8), w8f.view(torch.uint8).view(2, 9, 2, 64, 16)
     for nt, kf, h, lane, j in [(0, 0, 0, 0, 0), (1, 8, 1, 63, 15), (0, 3, 1, 37, 5), (1, 5, 0, 32, 9)]:
         assert int(frag[nt, kf, h, lane, j]) == int(raw[nt * 32 + (lane & 31), kf * 64 + 32 * (lane >> 5) + 16 * h + j])
+
+
+# ---- plugin boundary under a FOREIGN config node (meta_arch/siamese_planeTR.py:33-38,133: detectron2 builds `cls(cfg)`) ----
+class _ForeignCfg(dict):
+    """Stand-in for yacs / detectron2's CfgNode: a different dict subclass with attribute access and NO MODEL.AMD node."""
+
+    def __init__(self, init=None):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = _ForeignCfg(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _foreign_cfg():
+    from nopesac_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    plain = _ForeignCfg(cfg)
+    del plain["MODEL"]["AMD"]                       # what detectron2 + get_sparseplane_cfg_defaults would hand over
+    return plain
+
+
+def test_configurable_accepts_foreign_cfg_node(sd50):
+    from nopesac_amd.registry import META_ARCH_REGISTRY, is_config_node
+    cfg = _foreign_cfg()
+    assert is_config_node(cfg) and not is_config_node({"MODEL": 3}) and not is_config_node(7)
+    cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    for model in (cls(cfg), cls(cfg=cfg)):                              # d2's build_model calls cls(cfg)
+        assert model.num_queries == 50 and model.compute_dtype == torch.float32 and model.output_rle and model.two_streams
+        assert set(model.state_dict()) == set(sd50)
+    # explicit keyword construction passes straight through, cfg among the kwargs included
+    m = cls(num_queries=50, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, device="cpu", cfg=cfg)
+    assert m.num_queries == 50
+    with pytest.raises(TypeError):
+        cls(3)
+
+
+def test_amd_options_overlay():
+    from nopesac_amd.config import add_amd_defaults, amd_options
+    cfg = _foreign_cfg()
+    assert amd_options(cfg).COMPUTE_DTYPE == "float32" and "AMD" not in cfg.MODEL          # the foreign node is not touched
+    add_amd_defaults(cfg)                                                                   # d2-side opt-in (INTEGRATION.md)
+    assert type(cfg.MODEL.AMD) is _ForeignCfg
+    cfg.MODEL.AMD.COMPUTE_DTYPE = "bfloat16"
+    o = amd_options(cfg)
+    assert o.COMPUTE_DTYPE == "bfloat16" and o.TWO_STREAMS is True
+
+
+def test_registers_into_detectron2_when_importable(monkeypatch):
+    """A stub `detectron2.modeling` with an fvcore-style registry: the drop-in must appear under the reference's name,
+    replace a previously registered class of that name, and build through a d2-style build_model."""
+    import sys
+    import types
+    from nopesac_amd import registry
+
+    d2reg = registry.Registry("META_ARCH")                   # same protocol as fvcore.common.registry.Registry
+    d2 = types.ModuleType("detectron2")
+    d2m = types.ModuleType("detectron2.modeling")
+    d2m.META_ARCH_REGISTRY = d2reg
+    d2.modeling = d2m
+    monkeypatch.setitem(sys.modules, "detectron2", d2)
+    monkeypatch.setitem(sys.modules, "detectron2.modeling", d2m)
+
+    class PlaneTR_NopeSAC:                                   # "the reference's class was registered first"
+        pass
+
+    d2reg.register(PlaneTR_NopeSAC)
+    assert registry.register_into_detectron2(override=False) is False
+    assert registry.register_into_detectron2() is True
+    ours = registry.META_ARCH_REGISTRY.get("PlaneTR_NopeSAC")
+    assert d2reg.get("PlaneTR_NopeSAC") is ours
+    assert registry.register_into_detectron2() is True       # idempotent
+    cfg = _foreign_cfg()
+    model = d2reg.get(cfg.MODEL.META_ARCHITECTURE)(cfg)      # detectron2.modeling.build_model's two lines
+    assert type(model) is ours
+
+
+def test_register_into_detectron2_is_a_noop_without_it():
+    import importlib.util
+    from nopesac_amd import registry
+    if importlib.util.find_spec("detectron2") is None:
+        assert registry.register_into_detectron2() is False
+
+
+def test_derived_weight_caches_are_dropped_on_reload():
+    """fragment-major copies for the fused kernels must not survive load_state_dict / .to()."""
+    from nopesac_amd.modeling.params import ParamModule
+    pm = ParamModule({"a.weight": (4, 4)})
+    for name in ParamModule._DERIVED_CACHES:
+        pm.__dict__[name] = {0: "stale"}
+    pm._packed = {"x": 1}
+    pm.load_state_dict({"a.weight": torch.ones(4, 4)})
+    assert pm._packed is None and not any(n in pm.__dict__ for n in ParamModule._DERIVED_CACHES)
+    pm.__dict__["_fused_w"] = {0: "stale"}
+    pm.to(torch.float32)
+    assert "_fused_w" not in pm.__dict__
+
+
+def test_tuner_key_and_eligibility_fallback():
+    """a remembered kernel configuration that this call is not eligible for falls back to the heuristic."""
+    from nopesac_amd import ops
+    t = ops.ConvTuner()
+    t.best["k"] = ops.CFG_HALO16
+    assert t.choose("k", None, (ops.CFG_BFRAG3, ops.CFG_HALO16)) == ops.CFG_HALO16
+    assert t.choose("k", None, (ops.CFG_BFRAG3,)) == 0
+    assert t.choose("unknown", None, ()) == 0

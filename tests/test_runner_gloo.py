@@ -69,3 +69,29 @@ def test_pose_error_formulas():
     assert np.allclose(runner.rotation_error_deg(q[:1], q[1:]), np.degrees(0.5), atol=1e-4)
     assert np.allclose(runner.rotation_error_deg(q[:1], -q[1:]), np.degrees(0.5), atol=1e-4)   # sign invariant
     assert np.allclose(runner.translation_error(np.array([[3.0, 4, 0]]), np.zeros((1, 3))), 5.0)
+
+
+def _launched_main(n_pairs, out_dir):
+    """What run.py's per-rank main does, minus the GPU model: join the group, take the shard, gather the rows."""
+    from nopesac_amd import runner
+    r, w, local = runner.init_distributed("gloo")
+    lo, hi = runner.shard_range(n_pairs, r, w)
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    B = hi - lo
+    rows = runner.metric_rows(idx.view(-1, 1).repeat(1, 3), torch.ones(B, 4) / 2, torch.ones(B), torch.ones(B), torch.zeros(B), lo)
+    allrows = runner.gather_metrics(rows)
+    np.save(os.path.join(out_dir, f"rows_{r}.npy"), allrows.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
+    """`run.py --num-gpus N` without torchrun: runner.launch starts the ranks itself (detectron2 `launch`,
+    test_NopeSAC.py:209-216)."""
+    from nopesac_amd import runner
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert runner.launch(lambda a: a + 1, 1, (1,)) == 2                    # single GPU: plain call
+    runner.launch(_launched_main, 2, (6, str(tmp_path)))
+    a, b = np.load(tmp_path / "rows_0.npy"), np.load(tmp_path / "rows_1.npy")
+    assert a.shape == (6, 16) and a[:, 12].tolist() == list(range(6))
+    np.testing.assert_array_equal(a, b)
