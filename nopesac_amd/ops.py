@@ -51,11 +51,16 @@ class ConvTuner:
 
     def __init__(self):
         self.best = {}
+        self.loaded = {}          # key_str -> cfg from a routing file (ConvTuner.load)
         self.measuring = False
         self.log = []
 
     def choose(self, key, launch, extra=()):
         cfg = self.best.get(key)
+        if cfg is None and self.loaded:
+            cfg = self.loaded.get(self.key_str(key))
+            if cfg is not None:
+                self.best[key] = cfg
         cands = tuple(self.CANDIDATES) + tuple(extra)
         if cfg is not None or not self.measuring:
             return cfg if (cfg is not None and cfg in cands) else 0     # a remembered cfg this call is not eligible for -> heuristic
@@ -78,6 +83,29 @@ class ConvTuner:
         self.best[key] = cfg
         self.log.append((key, cfg, times))
         return cfg
+
+    # ---- persistent routing: the decisions of one tuning pass as a JSON file, so that the benchmark, the PMC / rocprofv3 scripts
+    # and the driver's runs all launch IDENTICAL kernels (profiles/routing_*.json; `bench.py --routing`)
+    @staticmethod
+    def key_str(key) -> str:
+        return "|".join(str(v).replace("torch.", "") for v in key)
+
+    def save(self, path: str, meta: dict = None):
+        import json
+        rows = {self.key_str(k): int(v) for k, v in self.best.items()}
+        with open(path, "w") as f:
+            json.dump({"format": "nopesac_amd.ConvTuner/1", "meta": meta or {}, "kernels": {str(k): v for k, v in CONV_CFG_KERNEL.items()},
+                       "routing": dict(sorted(rows.items()))}, f, indent=1)
+
+    def load(self, path: str) -> int:
+        """Install a saved routing: shapes it lists are never re-measured (shapes it does not list fall back to the built-in
+        heuristic unless `measuring` is switched on again).  Returns the number of entries."""
+        import json
+        with open(path) as f:
+            doc = json.load(f)
+        assert doc.get("format") == "nopesac_amd.ConvTuner/1", "not a ConvTuner routing file"
+        self.loaded = {k: int(v) for k, v in doc["routing"].items()}
+        return len(self.loaded)
 
 
 TUNER = ConvTuner()
@@ -169,7 +197,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         _lib.check(rc, "nopesac_conv2d_nhwc_ex")
 
     cfg = 0
-    if TUNER.measuring or TUNER.best:
+    if TUNER.measuring or TUNER.best or TUNER.loaded:
         # everything that decides which kernel configurations are eligible (bfrag_ok / halo_ok) is part of the key
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0,
                scale is not None, bias is not None, act, bfrag_ok, halo_ok)

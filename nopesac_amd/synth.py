@@ -231,3 +231,71 @@ def synth_pair(pair_idx: int, h: int = 480, w: int = 640, structured: bool = Fal
         out[v] = {"image": gen(base + pair_idx, h, w), "image_id": f"p{pair_idx}_v{v}",
                   "file_name": f"synthetic/p{pair_idx}_v{v}.png", "height": h, "width": w}
     return out
+
+
+# ---- seeded plane-pair generators (shared by bench.py's K control and the designed stage inputs of tests/golden_inputs.py)
+from torch.nn import functional as F  # noqa: E402
+
+
+def _g(seed: int) -> torch.Generator:
+    return torch.Generator().manual_seed(seed)
+
+
+def rand_unit_quat(g, w_nonneg=True) -> torch.Tensor:
+    q = F.normalize(torch.randn(4, generator=g), dim=0)
+    return -q if (w_nonneg and q[0] < 0) else q
+
+
+def rand_planes(n: int, g) -> torch.Tensor:
+    """n*d plane vectors [n,3], offsets in [0.5, 4]."""
+    nrm = F.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    d = 0.5 + 3.5 * torch.rand(n, 1, generator=g)
+    return nrm * d
+
+
+def quat_to_rotmat(q):
+    w, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+                         [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                         [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def consistent_planes(n1: int, n2: int, n_common: int, g, noise=0.02):
+    """Two plane sets related by a ground-truth pose on the first `n_common` (permuted) planes:
+    warp(view-1 plane) ~= flip(view-2 plane), so geometric matching terms are informative.
+    Returns planes1 [n1,3], planes2 [n2,3], perm (view-2 index of view-1 plane i, -1 if none), (t,q)."""
+    q = rand_unit_quat(g)
+    t = 0.4 * torch.randn(3, generator=g)
+    R = quat_to_rotmat(q)
+    flip = torch.tensor([1.0, -1.0, -1.0])
+    planes1 = rand_planes(n1, g)
+    planes2 = rand_planes(n2, g)
+    perm2 = torch.randperm(n2, generator=g)[:n_common]
+    idx1 = torch.randperm(n1, generator=g)[:n_common]
+    perm = torch.full((n1,), -1, dtype=torch.long)
+    for i1, i2 in zip(idx1.tolist(), perm2.tolist()):
+        p = planes1[i1] * flip
+        nrm = R @ (p / p.norm())
+        d = p.norm() + (t * nrm).sum()
+        glob = nrm * d + noise * torch.randn(3, generator=g)
+        planes2[i2] = glob * flip
+        perm[i1] = i2
+    return planes1, planes2, perm, (t, q)
+
+
+def make_forced(B: int, K: int, nq: int, device, seed: int) -> dict:
+    """Device-resident K control tensors of the benchmark workload (K planes per view, K matches): consistent
+    plane pairs under a random pose and a K-permutation, consumed by PlaneTR_NopeSAC._force_k and the oracle's `forced=`."""
+    g = torch.Generator().manual_seed(seed)
+    planes = torch.zeros(2 * B, nq, 3)
+    A = torch.zeros(B, nq, nq)
+    perm = torch.zeros(B, K, dtype=torch.long)
+    for b in range(B):
+        p1, p2, pm, _ = consistent_planes(K, K, K, g, noise=0.02)
+        planes[b, :K], planes[B + b, :K] = p1, p2
+        inv = torch.empty(K, dtype=torch.long)
+        inv[pm] = torch.arange(K)            # view-2 row j shows view-1 plane inv[j]
+        perm[b] = inv
+        A[b, torch.arange(K), pm] = 1.0
+    noise = 0.01 * torch.randn(B, K, 256, generator=g)
+    return {"K": K, "planes": planes.to(device), "assignment": A.to(device), "perm": perm.to(device), "noise": noise.to(device)}

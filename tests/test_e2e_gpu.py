@@ -5,11 +5,13 @@ import pytest
 import torch
 
 from oracle import rle_oracle as R
-from tests.util import LOOSE, gold, loose_oracle_cfg, make_model, rel_err
+from tests.util import LOOSE, abs_err, gold, loose_oracle_cfg, make_model, quat_abs_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4   # north_star: outputs within 1e-4 of the reference fp32 path (relative to the output scale)
+TOL = 1e-4   # north_star: outputs within 1e-4 of the reference fp32 path
+# camera.tran, camera.rot (up to the quaternion sign) and pred_plane are gated on the ABSOLUTE difference;
+# everything else (feature vectors, centres, scores) relative to the output's scale.
 
 
 def _check_pair(res, ref, g=None, soft_masks=False):
@@ -19,7 +21,7 @@ def _check_pair(res, ref, g=None, soft_masks=False):
     c_tol, px_tol = (5e-3, 3000) if soft_masks else (1e-3, 200)
     for v in "01":
         assert res[v]["pred_plane_oriIdxs"] == ref[v]["pred_plane_oriIdxs"].tolist()
-        assert rel_err(res[v]["pred_plane"], ref[v]["pred_plane"]) < TOL
+        assert abs_err(res[v]["pred_plane"], ref[v]["pred_plane"]) < TOL
         assert rel_err(res[v]["pred_plane_feats"], ref[v]["pred_plane_feats"]) < 5e-4
         assert rel_err(res[v]["pred_plane_ins_center"], ref[v]["pred_plane_ins_center"]) < c_tol
         mism = int((res[v]["pred_plane_masks"].cpu() != ref[v]["pred_plane_masks"]).sum())
@@ -35,15 +37,15 @@ def _check_pair(res, ref, g=None, soft_masks=False):
                 assert ins["segmentation"] == rins["segmentation"] and ins["bbox"] == rins["bbox"]
         if g is not None:
             assert res[v]["pred_plane_oriIdxs"] == g[f"v{v}_idx"].tolist()
-            assert rel_err(res[v]["pred_plane"], g[f"v{v}_planes"]) < TOL
+            assert abs_err(res[v]["pred_plane"], g[f"v{v}_planes"]) < TOL
             assert (res[v]["pred_plane_areas"].long() - g[f"v{v}_areas"].long()).abs().max() <= px_tol
     for k in ref:
         if "camera" in k:
             assert k in res, k
-            assert rel_err(res[k]["tran"], ref[k]["tran"]) < TOL, k
-            assert rel_err(res[k]["rot"], ref[k]["rot"]) < TOL, k
+            assert abs_err(res[k]["tran"], ref[k]["tran"]) < TOL, k
+            assert quat_abs_err(res[k]["rot"], ref[k]["rot"]) < TOL, k
             if g is not None:
-                assert rel_err(res[k]["tran"], g[k + "_tran"]) < TOL and rel_err(res[k]["rot"], g[k + "_rot"]) < TOL, k
+                assert abs_err(res[k]["tran"], g[k + "_tran"]) < TOL and quat_abs_err(res[k]["rot"], g[k + "_rot"]) < TOL, k
         if "assignment" in k:
             assert torch.equal(res[k], ref[k]), k
     assert set(k for k in res if "camera" in k) == set(k for k in ref if "camera" in k)
@@ -103,8 +105,51 @@ def test_bench_workload_forced_k_matches_oracle(device, K, nq):
     for key in ("camera_init", "camera_initRec", "camera_avgRef0", "camera"):
         t, r = cam["cameras"][key]
         for b in range(B):
-            assert rel_err(t[b].cpu().numpy(), ref[b][key]["tran"]) < 5 * TOL, (key, b)
-            assert rel_err(r[b].cpu().numpy(), ref[b][key]["rot"]) < 5 * TOL, (key, b)
+            assert abs_err(t[b].cpu().numpy(), ref[b][key]["tran"]) < TOL, (key, b)          # absolute 1e-4 (|tran| is ~10 here)
+            assert quat_abs_err(r[b].cpu().numpy(), ref[b][key]["rot"]) < TOL, (key, b)
+
+
+def test_bench_configuration_bf16_forced_k32_b32(device):
+    """EXACTLY what the driver times (bench.py defaults: bf16, 32 pairs per step, K = 32 forced, raw-image fused stem) against the
+    fp32 HIP path (the 1e-4-parity path, test above) under the SAME forced control: every pair keeps m = 32 hypotheses, the
+    quaternions are unit, everything is finite, and the pose error stays inside the bounds bench.py prints as
+    `pose_err_vs_fp32_path.bench_workload` (measured on MI355X: camera T 0.04 of |t| = 11, R 0.25 deg mean / 0.45 max;
+    camera_init T 0.003 / R 0.8 deg mean, 2.9 max)."""
+    import bench
+    B, K, nq = 32, 32, 50
+    m16, m32 = bench.build_model(device, nq, "bfloat16"), bench.build_model(device, nq, "float32")
+    err = bench.bench_workload_pose_error(m16, m32, device, B, K, nq)
+    assert err["m_bf16"] == [K] * B and err["m_fp32"] == [K] * B
+    assert err["finite"] and err["max_quat_norm_dev"] < 1e-3
+    cam, ini = err["camera"], err["camera_init"]
+    assert cam["R_err_deg_max"] < 2.0 and cam["T_err_max"] < 0.02 * cam["mean_abs_t"], cam
+    assert ini["R_err_deg_max"] < 8.0 and ini["T_err_max"] < 0.03, ini
+
+
+def test_e2e_scannet_config_nq64(device):
+    """BASELINE configs[2]: configs/inference_scannet.yaml through the model with NUM_OBJECT_QUERIES = 64 (K = 64 needs nq = 64,
+    SURVEY.md fact 4): end-to-end parity with the oracle, and the K = 64 forced workload of `bench.py --config scannet --k 64`."""
+    import bench
+    from nopesac_amd.synth import synth_pair, synth_state_dict
+    from oracle import nopesac_oracle as O
+    nq, K, B = 64, 64, 2
+    model = make_model(device, nq=nq, config="inference_scannet.yaml")
+    assert model.cfg.DATASETS.TEST == ("scannet_test",) and model.num_queries == nq
+    inp = [synth_pair(11), synth_pair(12)]
+    res = model(inp)
+    ref = O.inference(synth_state_dict(nq), inp, O.OracleConfig(num_queries=nq))
+    for a, b in zip(res, ref):
+        _check_pair(a, b)
+    forced = bench.make_forced(B, K, nq, device, 3)
+    with torch.no_grad():
+        cam = model.forward_tensors(model.preprocess_image(inp), B, 480, 640, forced=forced)["cam"]
+    cpu_forced = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in forced.items()}
+    ref = O.inference(synth_state_dict(nq), inp, O.OracleConfig(num_queries=nq), forced=cpu_forced)
+    assert cam["m"].tolist() == [K] * B
+    for key in ("camera_init", "camera"):
+        t, r = cam["cameras"][key]
+        for b in range(B):
+            assert abs_err(t[b].cpu().numpy(), ref[b][key]["tran"]) < TOL and quat_abs_err(r[b].cpu().numpy(), ref[b][key]["rot"]) < TOL, (key, b)
 
 
 def test_bf16_backbone_pose_error(device):

@@ -20,6 +20,18 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+def abs_err(a, b):
+    """max |a - b| - the ABSOLUTE gate SURVEY.md Appendix D / north_star ask for on camera.tran, camera.rot and pred_plane."""
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def quat_abs_err(a, b):
+    """abs_err up to the quaternion sign (q and -q are the same rotation; BASELINE.md: 'camera.rot up to sign')."""
+    return min(abs_err(a, b), abs_err(a, -torch.as_tensor(b)))
+
+
 def loose_oracle_cfg(nq=50):
     from oracle.nopesac_oracle import OracleConfig
     return OracleConfig(num_queries=nq, overlap_threshold=0.0, plane_score_threshold=0.5, matching_score_threshold=0.0,
@@ -29,15 +41,15 @@ def loose_oracle_cfg(nq=50):
 _MODELS = {}
 
 
-def make_model(device, overrides=(), nq=50, dtype="float32"):
+def make_model(device, overrides=(), nq=50, dtype="float32", config="inference_mp3d.yaml"):
     """PlaneTR_NopeSAC (HIP) with the name-seeded synthetic checkpoint, cached per configuration."""
-    key = (str(device), tuple(overrides), nq, dtype)
+    key = (str(device), tuple(overrides), nq, dtype, config)
     if key not in _MODELS:
         from nopesac_amd.config import get_cfg
         from nopesac_amd.registry import build_model
         from nopesac_amd.synth import synth_state_dict
         cfg = get_cfg()
-        cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
+        cfg.merge_from_file(os.path.join(ROOT, "configs", config))
         cfg.merge_from_list(["MODEL.DEVICE", str(device), "MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES", nq,
                              "MODEL.AMD.COMPUTE_DTYPE", dtype] + list(overrides))
         cfg.freeze()
