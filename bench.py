@@ -299,7 +299,7 @@ def main():
             merged.update({ops.TUNER.key_str(k): int(v) for k, v in ops.TUNER.best.items()})
             ops.TUNER.loaded = merged
             saved_best, ops.TUNER.best = ops.TUNER.best, {}
-            doc_meta = {"written_by": "bench.py", "note": "key = dtype|w dtype|out dtype|B|H|W|Cin|Cout|KH|KW|stride|pad|residual|x_cs|y_cs|batched|scale|bias|act|bfrag_ok|halo_ok"}
+            doc_meta = {"written_by": "bench.py", "note": "key = dtype|w dtype|out dtype|B|H|W|Cin|Cout|KH|KW|stride|pad|residual|x_cs|y_cs|batched|scale|bias|act|bfrag_ok|halo_ok|p8_ok"}
             import json as _json
             with open(args.routing, "w") as f:
                 _json.dump({"format": "nopesac_amd.ConvTuner/1", "meta": doc_meta, "kernels": {str(k): v for k, v in ops.CONV_CFG_KERNEL.items()},

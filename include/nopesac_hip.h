@@ -95,6 +95,17 @@ int nopesac_conv2d_nhwc_bfrag(const void* x, const void* w_frag, const float* sc
                               int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
                               void* stream);
 
+/* bf16 conv on 256 x 256 x 64 workgroup tiles (csrc/conv_p8.hip, conv_igemm_p8_kernel): 8 waves, both operands through LDS-DMA,
+ * the two waves of a SIMD alternate LDS-read / MFMA phases, counted vmcnt across barriers.  For the MFMA-bound layers: twice the
+ * FLOPs per byte pulled from L2 of the 128 x 128 kernels.  x / w as for nopesac_conv2d_nhwc with in_dt BF16 (w = plain
+ * [Cout][KH][KW][Cin] rows, NOT fragment-major); needs Cin % 64 == 0, Cout % 256 == 0, x_cstride % 8 == 0; act may carry
+ * NPS_ACT_RES_AFTER; out_dt F32 / BF16 / FP8 (FP8: no residual).  variant: 0 = static wave priority for the lagging half (default),
+ * 1 = priority raised around every MFMA cluster, 2 = no priority hints (tuning aid; results are identical).
+ * Replaces: the same reference convolutions as nopesac_conv2d_nhwc (detectron2 Conv2d + FrozenBN + ReLU; camera_modules.py conv stacks). */
+int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                           int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* stream);
+
 /* fp8 (OCP e4m3fn) conv on the gfx950 K=64 fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4, unit block scales; 2x the bf16 MFMA rate): x is
  * fp8 NHWC, w_frag8 the fp8 [Cout][KH*KW*Cin] matrix in the fp8 fragment-major order
  *   [Cout/32][K/64][2][64][16]:  byte j of piece h of lane l = w[nt*32 + (l & 31)][kf*64 + 32*(l >> 5) + 16*h + j]

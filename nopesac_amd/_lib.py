@@ -22,6 +22,7 @@ SIGNATURES = {
     "nopesac_last_error": [],
     "nopesac_conv2d_nhwc": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, P],
     "nopesac_conv2d_nhwc_bfrag": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],
+    "nopesac_conv2d_nhwc_p8": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],
     "nopesac_conv2d_nhwc_ex": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, I, P],
     "nopesac_stem_fused_bf16": [P, P, P, P, P, I, I, I, P],
     "nopesac_stem_fused_raw_bf16": [P, P, P, P, P, P, P, I, I, I, P],

@@ -53,6 +53,31 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// The epilogue form: 8 values at a time, ONE wave-uniform decision per vector instead of a switch per element (a per-element
+// switch inside unrolled epilogue loops compiled to thousands of scalar branches: the 256x256 conv tile's epilogue was 20 k
+// lines of ISA, larger than the instruction cache, 43 k cycles per tile).  Same operations in the same order as
+//   res_after ? apply_act(v, act) + r : apply_act(v + r, act)
+__device__ __forceinline__ void act_residual8(float (&v)[8], const float (&r)[8], int act, int res_after) {
+    if (!res_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (act == NPS_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (act == NPS_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+    } else if (act == NPS_ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+    }
+    if (res_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -12,133 +12,9 @@
 // A rows.
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace nps {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short us8 __attribute__((ext_vector_type(8)));
-typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-
-struct ConvParams {
-    const void* x; const void* w; const float* scale; const float* bias; const void* res; void* y;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
-    long long x_cs, y_cs, r_cs, w_bs;
-    int M, N, K;       // M = rows per grid.y slice
-    int rows_per_b;    // OH*OW
-    int batched;       // 1: grid.y = batch index, per-batch weights
-    int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1, bias_bs;
-    int tiles_m, tiles_n;
-};
-
-template <typename T> struct Cfg;
-template <> struct Cfg<bf16_t> { static constexpr int BK = 32; static constexpr int VECW = 8; };
-template <> struct Cfg<float> { static constexpr int BK = 16; static constexpr int VECW = 4; };
-
-template <typename T, int V> struct VecT;
-template <> struct VecT<bf16_t, 8> { typedef us8 type; };
-template <> struct VecT<bf16_t, 4> { typedef us4 type; };
-template <> struct VecT<bf16_t, 1> { typedef unsigned short type; };
-template <> struct VecT<float, 4> { typedef f32x4 type; };
-template <> struct VecT<float, 1> { typedef float type; };
-
-// Shared epilogue (see the comment inside): acc -> LDS (f32) -> 8-channel chunks -> scale/shift/residual/act -> store.
-template <int BM, int BN, int TM, int TN, int WAVES_M = 2, int WAVES_N = 2>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi, int lds_bytes, const ConvParams& p, int m0, int n0,
-                                              int bz, int wm, int wn, int lane, int tid) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int NTHREADS = WAVES_M * WAVES_N * 64;
-    // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as the row operand), so lane l
-    // holds, for pixel (l&31), 4 runs of 4 consecutive channels per 32x32 tile.  The f32 tile is staged through
-    // LDS (EN = 64 columns per pass, rows padded by 4 floats -> conflict-free ds_write_b128) and re-read as
-    // 8-channel row chunks, so scale/shift, residual and the output are 16/32-byte accesses that cover whole
-    // 128/256-byte channel runs per row (the layers with small K are HBM-bound: this is what has to stream).
-    constexpr int EN = BN > 64 ? 64 : BN;
-    constexpr int ELD = EN + 4;
-    constexpr int NPASS = BN / EN;
-    const bool vec_ok = p.epi_vec;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int c_wave = wn * WN - pass * EN;          // first column of this wave inside the pass window
-        if (c_wave >= 0 && c_wave < EN) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = wm * WM + i * 32 + (lane & 31);
-                        const int c = c_wave + j * 32 + 8 * q + 4 * (lane >> 5);
-                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        *(f32x4*)(epi + row * ELD + c) = v;
-                    }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < BM * (EN / 8); idx += NTHREADS) {
-            const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
-            const int m = m0 + row, n = n0 + pass * EN + ch;
-            if (m >= p.M || n >= p.N) continue;
-            const long long pix = (long long)m + (long long)bz * p.rows_per_b;
-            float v[8];
-            *(f32x4*)(v) = *(const f32x4*)(epi + row * ELD + ch);
-            *(f32x4*)(v + 4) = *(const f32x4*)(epi + row * ELD + ch + 4);
-            if (vec_ok && n + 8 <= p.N) {
-                if (p.scale) {
-                    const f32x4 s0 = *(const f32x4*)(p.scale + n), s1 = *(const f32x4*)(p.scale + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
-                }
-                if (p.bias) {
-                    const float* bp = p.bias + (long long)bz * p.bias_bs + n;
-                    const f32x4 b0 = *(const f32x4*)(bp), b1 = *(const f32x4*)(bp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (p.res) {
-                    if (p.out_dt == NPS_DT_F32) {
-                        *(f32x4*)(rv) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n);
-                        *(f32x4*)(rv + 4) = *(const f32x4*)((const float*)p.res + pix * p.r_cs + n + 4);
-                    } else {
-                        const us8 r8 = *(const us8*)((const bf16_t*)p.res + pix * p.r_cs + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rv[e] = bf16_to_f32(r8[e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = p.res_after ? apply_act(v[e], p.act) + rv[e] : apply_act(v[e] + rv[e], p.act);
-                if (p.out_dt == NPS_DT_F32) {
-                    float* yp = (float*)p.y + pix * p.y_cs + n;
-                    *(f32x4*)(yp) = *(const f32x4*)(v);
-                    *(f32x4*)(yp + 4) = *(const f32x4*)(v + 4);
-                } else if (p.out_dt == NPS_DT_FP8) {
-                    *(uint2*)((unsigned char*)p.y + pix * p.y_cs + n) = f32x8_to_fp8(v);
-                } else {
-                    us8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
-                    *(us8*)((bf16_t*)p.y + pix * p.y_cs + n) = o;
-                }
-            } else {
-                for (int e = 0; e < 8 && n + e < p.N; ++e) {
-                    float x = v[e] * (p.scale ? p.scale[n + e] : 1.f) + (p.bias ? p.bias[(long long)bz * p.bias_bs + n + e] : 0.f);
-                    float r = 0.f;
-                    if (p.res)
-                        r = (p.out_dt == NPS_DT_F32) ? ((const float*)p.res)[pix * p.r_cs + n + e]
-                                                     : bf16_to_f32(((const bf16_t*)p.res)[pix * p.r_cs + n + e]);
-                    x = p.res_after ? apply_act(x, p.act) + r : apply_act(x + r, p.act);
-                    if (p.out_dt == NPS_DT_F32) ((float*)p.y)[pix * p.y_cs + n + e] = x;
-                    else ((bf16_t*)p.y)[pix * p.y_cs + n + e] = f32_to_bf16(x);
-                }
-            }
-        }
-        if (pass + 1 < NPASS) __syncthreads();
-    }
-}
 
 // TA = element type of x in memory (float with T = bf16_t is the mixed mode: f32 activations are rounded to
 // bf16 while being staged, weights are bf16, MFMA runs at the bf16 rate).
@@ -327,7 +203,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // fragment reads are removed by an XOR swizzle applied on the SOURCE side (the lane that fills physical
 // 16-byte slot pc of row r fetches logical slot pc ^ ((r>>1)&7)) and again on the read.
 // Padding taps / rows beyond M / channels beyond N get an out-of-range buffer offset (the load returns zeros).
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BM, int BN, int NSTAGE = 2, int WAVES_M = 2, int BKT = 64>
 __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? (BKT == 32 ? 4 : 2) : 1) void conv_igemm_glds_kernel(const ConvParams p) {

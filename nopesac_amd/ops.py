@@ -111,10 +111,12 @@ class ConvTuner:
 TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
+CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
+P8_VARIANT = [0]                       # scheduling variant handed to nopesac_conv2d_nhwc_p8 (tuning aid)
 LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
-                   10: "conv3x3_halo_kernel<16, 8>"}
+                   10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel"}
 
 
 def _frag_weights(w: torch.Tensor) -> torch.Tensor:
@@ -179,7 +181,16 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     halo_ok = (bfrag_ok and KH == 3 and KW == 3 and stride == 1 and pad == 1 and residual is None and x_cs == Cin and y_cs == Cout
                and out_dtype == torch.bfloat16 and scale is not None and bias is not None and (act & ~0xff) == 0)
 
+    p8_ok = (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not batched_weights and Cin % 64 == 0 and Cout % 256 == 0
+             and x_cs % 8 == 0 and KH * KW <= 32 and (act & ~(0xff | ACT_RES_AFTER)) == 0
+             and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31)
+
     def launch(cfg):
+        if cfg == CFG_P8:
+            rc = _L().nopesac_conv2d_nhwc_p8(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW, stride,
+                                             pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], P8_VARIANT[0], _stream())
+            _lib.check(rc, "nopesac_conv2d_nhwc_p8")
+            return
         if cfg in (CFG_HALO16, CFG_HALO8):
             rc = _L().nopesac_conv3x3_halo_bf16(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(out), B, H, W, Cin, Cout, act,
                                                 0 if cfg == CFG_HALO16 else 1, _stream())
@@ -200,8 +211,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     if TUNER.measuring or TUNER.best or TUNER.loaded:
         # everything that decides which kernel configurations are eligible (bfrag_ok / halo_ok) is part of the key
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0,
-               scale is not None, bias is not None, act, bfrag_ok, halo_ok)
-        cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ()))
+               scale is not None, bias is not None, act, bfrag_ok, halo_ok, p8_ok)
+        cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ())
+                           + ((CFG_P8,) if p8_ok else ()))
     launch(cfg)
     LAST_CONV_CFG[0] = cfg             # read by bench.py's per-launch timer to attribute the launch to a kernel
     return out

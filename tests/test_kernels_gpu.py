@@ -558,3 +558,57 @@ def test_stem_fused_raw_equals_preprocess_plus_stem(device):
     a = ops.stem_fused(ops.preprocess(img, mean, std, 4, torch.bfloat16), w, sc, bi)
     b = ops.stem_fused_raw(img, mean, std, w, sc, bi)
     assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1),      # 10 tiles, 36 K-tiles (even)
+                                  (3, 31, 29, 128, 256, 3, 2, 1),      # stride 2, M tail (720 rows = 2.8 tiles), 18 K-tiles
+                                  (2, 24, 32, 512, 512, 1, 1, 0),      # 1x1, two channel tiles, 8 K-tiles
+                                  (1, 15, 20, 64, 256, 3, 1, 1),       # 9 K-tiles (odd), Cin = 64: every K-tile is another tap
+                                  (2, 9, 7, 64, 256, 1, 1, 0),         # ONE K-tile, 126 rows (half-empty tile)
+                                  (1, 17, 16, 128, 256, 1, 1, 0),      # two K-tiles
+                                  (1, 12, 20, 192, 256, 1, 1, 0)])     # three K-tiles
+@pytest.mark.parametrize("variant", [0, 1, 2, 32])
+def test_conv2d_p8(device, case, variant):
+    """256x256-tile phase-interleaved conv kernel (csrc/conv_p8.hip) vs F.conv2d on bf16-rounded operands, f32 output (the only
+    rounding left is the accumulation order): K loops of 1, 2, 3, odd and even tile counts (every prologue / tail branch of the
+    counted-vmcnt schedule), M tails, stride 2, padding taps, two channel tiles; repeated launches must agree bit for bit (a
+    DMA / LDS race would show up as run-to-run differences)."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    xd, rd = _nhwc(x).to(device, torch.bfloat16), _nhwc(res).to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    sd, bd = scale.to(device), bias.to(device)
+    outs = []
+    for rep in range(3):
+        y = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device=device)
+        rc = _lib.load().nopesac_conv2d_nhwc_p8(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(),
+                                                 B, H, W, Cin, Cout, k, k, s, p, Cin, Cout, Cout, ops.ACT_RELU, 0, variant,
+                                                 torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert _rel(outs[0].permute(0, 3, 1, 2), ref) < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_conv2d_p8_through_the_tuner_route(device, monkeypatch):
+    """ops.conv2d routed to the p8 configuration (as the autotuner would): bf16 output, no residual."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 60, 80, 256, 256
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    ref = ops.conv2d(x, w, sc, bi, pad=1, act=ops.ACT_RELU)
+    monkeypatch.setattr(ops.TUNER, "measuring", True)
+    monkeypatch.setattr(ops.TUNER, "choose", lambda key, launch, extra=(): ops.CFG_P8 if ops.CFG_P8 in extra else 0)
+    y = ops.conv2d(x, w, sc, bi, pad=1, act=ops.ACT_RELU)
+    assert ops.LAST_CONV_CFG[0] == ops.CFG_P8
+    assert _rel(y.float(), ref.float()) < 1e-2
