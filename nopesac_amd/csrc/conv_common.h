@@ -22,6 +22,7 @@ struct ConvParams {
     int batched;       // 1: grid.y = batch index, per-batch weights
     int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1, bias_bs;
     int tiles_m, tiles_n;
+    int dbg_tile;
     unsigned long long* dbg;   // tuning builds only: per-workgroup cycle stamps (nullptr in product launches)
 };
 

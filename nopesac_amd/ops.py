@@ -112,7 +112,7 @@ TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
-P8_VARIANT = [0]                       # scheduling variant handed to nopesac_conv2d_nhwc_p8 (tuning aid)
+P8_VARIANT = [32]                      # variant handed to nopesac_conv2d_nhwc_p8: 32 = channel-major K order (better L2 reuse of the taps)
 LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
@@ -183,7 +183,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
 
     p8_ok = (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not batched_weights and Cin % 64 == 0 and Cout % 256 == 0
              and x_cs % 8 == 0 and KH * KW <= 32 and (act & ~(0xff | ACT_RES_AFTER)) == 0
-             and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31)
+             and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31 and B * H * W < 2 ** 23 and x_cs < 2 ** 24 and KH * KW * Cin < 2 ** 24
+             and Cout * KH * KW * Cin * 2 < 2 ** 31 and out_dtype in _DT and x_cs % 8 == 0
+             and (y_cs % (4 if out_dtype == torch.float32 else 8) == 0))
 
     def launch(cfg):
         if cfg == CFG_P8:

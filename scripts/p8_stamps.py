@@ -13,6 +13,8 @@ dev = torch.device("cuda:0")
 L = _lib.load()
 L.nps_p8_debug_buffer.argtypes = [ctypes.c_void_p]
 L.nps_p8_debug_buffer.restype = None
+L.nps_p8_debug_tile.argtypes = [ctypes.c_int]
+L.nps_p8_debug_tile.restype = None
 st = torch.cuda.current_stream().cuda_stream
 shape = [int(v) for v in sys.argv[1:8]] if len(sys.argv) > 7 else [64, 60, 80, 256, 256, 3, 1]
 B, H, W, Cin, Cout, k, s = shape
@@ -24,24 +26,26 @@ sc, bi = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
 y = torch.empty(B, OH, OW, Cout, device=dev, dtype=torch.bfloat16)
 nwg = ((B * OH * OW + 255) // 256) * (Cout // 256)
 nk = k * k * Cin // 64
-for variant in (24, 25, 31):
-    buf = torch.zeros(nwg * 8 * 10, dtype=torch.int64, device=dev)
+for variant, which in ((24, 0), (24, 1), (24, 2)):
+    buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device=dev)
     L.nps_p8_debug_buffer(buf.data_ptr())
+    L.nps_p8_debug_tile(which)
     for _ in range(12):
         rc = L.nopesac_conv2d_nhwc_p8(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, k, k, s, pad,
-                                      Cin, Cout, 0, 1, 1, variant, st)
+                                      Cin, Cout, 0, 1, 1, variant, st)  # act relu, bf16 out -> EPI 1
         assert rc == 0
     torch.cuda.synchronize()
-    t = buf.view(nwg, 8, 10).cpu().double()
+    t = buf.view(nwg, 8, 16).cpu().double()
+    live = t[:, 0, 0] > 0                       # persistent grid: only the first min(tiles, CUs) workgroup slots exist
+    t = t[live]
     pro, loop, epi = (t[:, :, 1] - t[:, :, 0]), (t[:, :, 2] - t[:, :, 1]), (t[:, :, 3] - t[:, :, 2])
-    t0 = t[:, :, 0].min()
-    start = (t[:, 0, 0] - t0)
-    end = (t[:, 0, 3] - t0)
-    print("variant %d: %d workgroups, %d K-tiles: prologue %.0f  loop %.0f (= %.0f per K-tile, %.0f per interval)  epilogue %.0f cycles (mean over waves); "
-          "kernel span %.0f counter ticks" % (variant, nwg, nk, pro.mean(), loop.mean(), loop.mean() / nk, loop.mean() / nk / 8, epi.mean(), end.max()))
-    e = t[:, :, 4:10] - t[:, :, 2:3]
-    print("   epilogue stamps relative to its start (mean): pass0 staged %.0f, synced %.0f, stores issued %.0f | pass1 staged %.0f, synced %.0f, stores issued %.0f | all done %.0f" % (
-        *[float(e[:, :, i].mean()) for i in range(6)], float(epi.mean())))
+    print("variant %d: %d tiles on %d persistent workgroups, %d K-tiles; tile #%d of every workgroup: prologue %.0f  loop %.0f (= %.0f per K-tile, "
+          "%.0f per interval)  epilogue incl. store drain %.0f cycles (mean over waves)" % (
+              variant, nwg, int(live.sum()), nk, which, pro.mean(), loop.mean(), loop.mean() / nk, loop.mean() / nk / 8, epi.mean()))
+    e = t[:, :, 4:16] - t[:, :, 2:3]
+    names = ["pass0 done", "pass1 done", "pass2 done", "pass3 done", "prefetch issued", "set_tile done", "DMAs issued", "p0 staged", "p0 synced", "p0 scaled",
+             "p0 act done"]
+    order = [4, 5, 6, 7, 8, 9, 10, 0, 1, 2, 3]
+    print("   after the K loop's end (mean cycles): " + ", ".join("%s %.0f" % (names[i], float(e[:, :, i].mean())) for i in order))
     print("   per-wave loop cycles of workgroup 0:", [int(v) for v in loop[0].tolist()])
-    print("   start-time quantiles of workgroups (ticks):", [int(v) for v in torch.quantile(start, torch.tensor([0.0, 0.2, 0.4, 0.6, 0.8, 1.0], dtype=torch.float64)).tolist()])
 L.nps_p8_debug_buffer(None)

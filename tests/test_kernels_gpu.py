@@ -566,8 +566,9 @@ def test_stem_fused_raw_equals_preprocess_plus_stem(device):
                                   (1, 15, 20, 64, 256, 3, 1, 1),       # 9 K-tiles (odd), Cin = 64: every K-tile is another tap
                                   (2, 9, 7, 64, 256, 1, 1, 0),         # ONE K-tile, 126 rows (half-empty tile)
                                   (1, 17, 16, 128, 256, 1, 1, 0),      # two K-tiles
-                                  (1, 12, 20, 192, 256, 1, 1, 0)])     # three K-tiles
-@pytest.mark.parametrize("variant", [0, 1, 2, 32])
+                                  (1, 12, 20, 192, 256, 1, 1, 0),      # three K-tiles
+                                  (5, 60, 80, 64, 512, 3, 1, 1)])      # 188 tiles in two channel columns
+@pytest.mark.parametrize("variant", [0, 32, 64, 0 | (3 << 8), 32 | (1 << 8)])     # + 32: channel-major K order, + 64: generic epilogue, 3 / 1 persistent workgroups
 def test_conv2d_p8(device, case, variant):
     """256x256-tile phase-interleaved conv kernel (csrc/conv_p8.hip) vs F.conv2d on bf16-rounded operands, f32 output (the only
     rounding left is the accumulation order): K loops of 1, 2, 3, odd and even tile counts (every prologue / tail branch of the
@@ -612,3 +613,27 @@ def test_conv2d_p8_through_the_tuner_route(device, monkeypatch):
     y = ops.conv2d(x, w, sc, bi, pad=1, act=ops.ACT_RELU)
     assert ops.LAST_CONV_CFG[0] == ops.CFG_P8
     assert _rel(y.float(), ref.float()) < 1e-2
+
+
+@pytest.mark.parametrize("act", ["ACT_RELU", "ACT_NONE", "ACT_LEAKY", "ACT_SIGMOID"])
+def test_conv2d_p8_specialised_epilogues_match_the_generic_build(device, act):
+    """The no-residual / bf16-output epilogue builds (activation fixed at compile time: 20 KB of code instead of 60 KB) must give
+    bit for bit what the generic build (variant + 64) gives; several tiles per persistent workgroup (grid capped at 4)."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k = 3, 40, 48, 128, 512, 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    outs = []
+    for variant in (0, 64, 0 | (4 << 8), 32 | 64 | (4 << 8)):
+        y = torch.zeros(B, H, W, Cout, device=device, dtype=torch.bfloat16)
+        rc = _lib.load().nopesac_conv2d_nhwc_p8(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout,
+                                                 k, k, 1, 1, Cin, Cout, 0, getattr(ops, act), 1, variant, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    ref = ops.conv2d(x, w, sc, bi, pad=1, act=getattr(ops, act))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert _rel(outs[3].float(), outs[0].float()) < 1e-2        # channel-major K order: another summation order
+    assert _rel(outs[0].float(), ref.float()) < 1e-2
