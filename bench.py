@@ -336,7 +336,8 @@ def main():
         if raw_stem:       # bf16: the fused stem normalises the f32 NCHW images while it loads them (no preprocess launch)
             d = model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=raws[slot])
             cam = d["cam"]
-            rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B)
+            rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B,
+                                      nonfinite=cam.get("nonfinite"))
             return d, rows
         x = ops.preprocess(raws[slot], model.pixel_mean, model.pixel_std, model.backbone.STEM_CIN_PAD, model.compute_dtype)
         if args.ablate:
@@ -350,7 +351,8 @@ def main():
             return None, zero_rows
         d = model.forward_tensors(x, B, 480, 640, forced=forced)
         cam = d["cam"]
-        rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B)
+        rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], rank * B,
+                                      nonfinite=cam.get("nonfinite"))
         return d, rows
 
     def step(i=0):
@@ -421,6 +423,9 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pairs_per_s = world * B * args.steps / elapsed
     m_mean = float(host[:, 9].mean())
+    nonfinite = int(host[:, 13].max())            # Inf / NaN count of the last step's batches, gathered with the rows
+    if nonfinite:
+        sys.exit("bench.py: %d non-finite values in the predicted poses - the measurement is void" % nonfinite)
     if args.ablate:
         if rank == 0:
             print(json.dumps({"INVALID_ablation": args.ablate, "ms_per_step": round(ms_per_step, 3)}))
@@ -507,7 +512,7 @@ def main():
                       "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph, "autotuned_shapes": tuned,
                       "routing_file": os.path.relpath(args.routing, ROOT) if args.routing else None, "routing_entries_loaded": routing_loaded,
                       "routing_entries_measured_now": routing_new, "host_launch_ms_per_step": round(host_launch_ms, 2),
-                      "gflop_per_pair_algorithmic": GFLOP_PER_PAIR.get(K)},
+                      "gflop_per_pair_algorithmic": GFLOP_PER_PAIR.get(K), "nonfinite_outputs": nonfinite},
            "roofline": roofline}
     if stage_ms:
         out["stage_ms_main_stream"] = stage_ms

@@ -337,6 +337,11 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
  * optionally flip the sign so that component 0 >= 0 (camera_head.py:436-437,695-696). */
 int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream);
 
+/* Adds the number of non-finite (Inf / NaN) values of x[0..n) to *count (int32 on the device, zeroed by the caller).  The reference
+ * traps NaN poses with pdb.set_trace() (camera_net/camera_head.py:185-187, 681-682, 1072-1074); the drop-in counts them on the
+ * device and raises FloatingPointError when the results are fetched (MODEL.AMD.CHECK_FINITE). */
+int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream);
+
 /* One GNN layer of the plane matcher (transformer/gnn.py:73-96) for n_sets plane sets, one workgroup per set, bf16 MFMA
  * operands / f32 residual stream (csrc/gnn_layer.hip).  Feature buffers are f32 [sets][nq][256] (nq <= 64); workgroup b updates
  * set x_off + b attending to set src_off + b (same buffer and offset = 'self' layer) and writes set out_off + b of `out`

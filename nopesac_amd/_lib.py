@@ -60,6 +60,7 @@ SIGNATURES = {
     "nopesac_ransac_soft_vote": [P] * 21 + [I, I, I] + [P] * 6 + [P],
     "nopesac_refilter_assignment": [P, P, P, P, P, P, P, I, I, P, P],
     "nopesac_normalize_rows": [P, P, I, I, I, P],
+    "nopesac_count_nonfinite": [P, L, P, P],
 }
 _RESTYPE = {"nopesac_last_error": c_char_p}
 

@@ -267,6 +267,8 @@ def add_amd_defaults(cfg) -> CfgNode:
         OUTPUT_RLE=True,              # COCO RLE "segmentation" + "bbox" in every `instances` entry (siamese_planeTR.py:703-720)
         USE_HIP_GRAPH=False,          # capture the static-shape forward in a hipGraph
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
+        CHECK_FINITE=True,            # count Inf / NaN in the returned poses / plane parameters on the device; `model(...)` raises
+                                      # FloatingPointError when the results are fetched (the reference drops into pdb instead)
         BACKBONE_FP8=False,           # BASELINE config 5: the 3x3 convs of the res3-res5 bottlenecks (44 % of the backbone FLOPs, its
                                       # MFMA-bound layers) on the fp8 (e4m3fn) K = 64 MFMA: per-output-channel weight scales, static
                                       # per-layer activation scales (PlaneTR_NopeSAC.calibrate_fp8); needs COMPUTE_DTYPE bfloat16

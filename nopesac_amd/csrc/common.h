@@ -45,12 +45,11 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case NPS_ACT_RELU: return v > 0.f ? v : 0.f;
-        case NPS_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
-        case NPS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        default: return v;
-    }
+    // branch-free for none / ReLU / LeakyReLU (`act` is wave-uniform: the selects below are scalar); only the sigmoid branches.
+    // A switch here, inlined per element into unrolled epilogue loops, compiled to thousands of scalar branches.
+    if (act == NPS_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    const float neg = act == NPS_ACT_RELU ? 0.f : (act == NPS_ACT_LEAKY ? 0.01f * v : v);
+    return v > 0.f ? v : neg;
 }
 
 // The epilogue form: 8 values at a time, ONE wave-uniform decision per vector instead of a switch per element (a per-element

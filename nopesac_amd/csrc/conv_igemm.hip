@@ -141,6 +141,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // f32 (parity) path: TWO-LEVEL accumulation.  One MFMA accumulator chain over K = 2304 .. 4608 terms carries a rounding error
+    // ~sqrt(K) ulp; the reference's CPU GEMMs sum in 8-16 parallel lanes and blocks, i.e. with a much shorter chain.  Every
+    // FLUSH K-tiles (128 terms) the running accumulator is added into a second-level one and cleared: error ~sqrt(128) + sqrt(K/128)
+    // ulp - about 5x smaller for the long-K layers - which is what keeps pred_plane / camera.tran inside the ABSOLUTE 1e-4 gate
+    // against the reference (they sit at 0.5-1e-4 with a single chain).  Not used in the bf16 / mixed modes.
+    constexpr bool TWO_LEVEL = sizeof(T) == 4;
+    constexpr int FLUSH = 8;
+    f32x16 acc_hi[TWO_LEVEL ? TM : 1][TWO_LEVEL ? TN : 1];
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_hi[i][j][r] = 0.f;
+    }
     const int nk = (p.K + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
@@ -188,8 +204,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr (TWO_LEVEL) {
+            if ((kt % FLUSH) == FLUSH - 1 && kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { acc_hi[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+            }
+        }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_hi[i][j][r];
     }
 
     conv_epilogue<BM, BN, TM, TN>(acc, reinterpret_cast<float*>(lds), (int)sizeof(lds), p, m0, n0, bz, wm, wn, lane, tid);

@@ -532,3 +532,25 @@ extern "C" int nopesac_normalize_rows(const float* x, float* y, int rows, int D,
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, y, rows, D, canonical_sign);
     NPS_LAUNCH_RET();
 }
+
+// ---- finite check (the reference drops into pdb on NaN, camera_head.py:185-187,681-682,1072-1074; here: an error path)
+namespace nps {
+__global__ void count_nonfinite_kernel(const float* __restrict__ x, long long n, int* __restrict__ count) {
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(x[i]);
+        bad += ((u & 0x7f800000u) == 0x7f800000u) ? 1 : 0;               // exponent all ones: Inf or NaN
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+}  // namespace nps
+
+extern "C" int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && count && n > 0, "count_nonfinite: bad args");
+    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, count);
+    NPS_LAUNCH_RET();
+}

@@ -51,6 +51,7 @@ class PlaneTR_NopeSAC(nn.Module):
             mod.gemm_dtype = self.compute_dtype     # bf16 => head GEMMs run f32-activation x bf16-weight MFMA
         self.infer_iter = 0
         self.two_streams = bool(amd.TWO_STREAMS)
+        self.check_finite = bool(amd.CHECK_FINITE)
         self._side_stream = None
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 
@@ -143,6 +144,9 @@ class PlaneTR_NopeSAC(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
         cam = head(feats, sel, self.matching_head, B, diagnostics, forced_assignment=forced_A, pose=pose, mark=mark)
         mark("refine")
+        if self.check_finite and is_cuda:
+            # Inf / NaN anywhere in what the caller gets back (poses of every stage, kept plane parameters): one int32 on the device
+            cam["nonfinite"] = ops.count_nonfinite([t for pair in cam["cameras"].values() for t in pair] + [sel["planes"]])
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
 
@@ -206,6 +210,9 @@ class PlaneTR_NopeSAC(nn.Module):
         flags = cpu(sel["flags"]).tolist()
         cams = {k: (cpu(t).numpy(), cpu(r).numpy()) for k, (t, r) in cam["cameras"].items()}
         m = cpu(cam["m"]).tolist()
+        if "nonfinite" in cam and int(cpu(cam["nonfinite"])[0]) != 0:
+            raise FloatingPointError("nopesac_amd: %d non-finite values in the predicted poses / plane parameters of this batch "
+                                     "(the reference traps this case with pdb.set_trace(), camera_head.py:1072-1074)" % int(cpu(cam["nonfinite"])[0]))
         ass = {k: cpu(cam[k]) for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
         onepp_t, onepp_r = cpu(cam["refine"]["maps"]["trans_all"]).numpy(), cpu(cam["refine"]["maps"]["rots_all"]).numpy()
         rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]) if self.output_rle else None

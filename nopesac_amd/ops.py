@@ -479,6 +479,16 @@ def transpose_hw_rows(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return y
 
 
+def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32[1] device counter += number of Inf / NaN values in the given f32 tensors (no host synchronisation)."""
+    if counter is None:
+        counter = torch.zeros(1, device=tensors[0].device, dtype=torch.int32)
+    for t in tensors:
+        _chk(t, torch.float32)
+        _lib.check(_L().nopesac_count_nonfinite(_p(t), t.numel(), _p(counter), _stream()), "nopesac_count_nonfinite")
+    return counter
+
+
 def normalize_rows(x: torch.Tensor, canonical_sign: bool = False) -> torch.Tensor:
     _chk(x, torch.float32)
     D = x.shape[-1]

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-METRIC_WIDTH = 16   # [t(3), q(4), n1, n2, m, T_err, R_err, pair_idx, pad(3)]
+METRIC_WIDTH = 16   # [t(3), q(4), n1, n2, m, T_err, R_err, pair_idx, nonfinite count of the pair's batch, pad(2)]
 
 
 def init_distributed(backend: Optional[str] = None):
@@ -80,7 +80,8 @@ def translation_error(t_pred: np.ndarray, t_ref: np.ndarray) -> np.ndarray:
 
 
 def metric_rows(trans: torch.Tensor, rot: torch.Tensor, n1: torch.Tensor, n2: torch.Tensor, m: torch.Tensor,
-                pair_idx0: int, t_err: Optional[torch.Tensor] = None, r_err: Optional[torch.Tensor] = None) -> torch.Tensor:
+                pair_idx0: int, t_err: Optional[torch.Tensor] = None, r_err: Optional[torch.Tensor] = None,
+                nonfinite: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Pack per-pair results into [B, 16] fp32 rows on the tensors' device (no host sync)."""
     B = trans.shape[0]
     rows = torch.zeros(B, METRIC_WIDTH, device=trans.device, dtype=torch.float32)
@@ -91,6 +92,8 @@ def metric_rows(trans: torch.Tensor, rot: torch.Tensor, n1: torch.Tensor, n2: to
     if r_err is not None:
         rows[:, 11] = r_err
     rows[:, 12] = torch.arange(pair_idx0, pair_idx0 + B, device=trans.device, dtype=torch.float32)
+    if nonfinite is not None:                 # device int32[1] from ops.count_nonfinite: travels with the rows (no host sync here)
+        rows[:, 13] = nonfinite.to(torch.float32)
     return rows
 
 
