@@ -9,7 +9,9 @@ that consumes the hot path's outputs: per-pair pose errors and their summary tab
   * dump(output_dir)          ~ :330-341 (`eval_full_scene`): `NopeSAC_instances_predictions.pth` (torch.save of the
     per-pair prediction dicts, schema of :193-257) and `continuous.pkl` (`get_optimized_dict` :259-313 + `save_dict`
     :852-860) - the two files the reference's offline eval.py / vis tools read.
-Plane AP and matching P/R (COCO tooling, pycocotools) stay out of scope.
+  * evaluate_for_matchings()  ~ :746-849: plane-matching precision / recall / F-score from the predictions' RLE instances, the
+    GT annotations' RLE masks and `gt_corrs` (mask IoU from nopesac_amd/rle.py instead of pycocotools.mask.iou).
+Plane AP (COCO tooling, pycocotools.cocoeval) stays out of scope.
 """
 from __future__ import annotations
 
@@ -115,6 +117,54 @@ class PoseEvaluator:
             if has_gt.any():
                 res[k] = camera_metrics(r[has_gt, o:o + 3], r[has_gt, o + 3:o + 7], r[has_gt, 0:3], r[has_gt, 3:7])
         return res
+
+
+def evaluate_for_matchings(predictions: List[dict], dataset_dict: Dict[str, dict], iou_thresh: float = 0.5) -> Dict[str, dict]:
+    """Plane-matching precision / recall / F-score (mp3d_evaluation.py:746-849).  For every pair: each predicted plane of a view
+    is assigned the GT plane with the highest mask IoU (instances[k]["segmentation"] vs the GT annotations' RLE masks); a
+    predicted correspondence (i, j) counts as correct when both IoUs reach `iou_thresh` and [gt_i, gt_j] is one of the pair's
+    `gt_corrs`.  precision = TP / #predicted, recall = TP / #GT, over all pairs, separately for every "*assignment*" key of the
+    predictions.  Returns {assignment key: {"precision", "recall", "F-score", "TP", "Pred. Num.", "GT Num."}} - the reference logs
+    one table per key and returns only the last one; it also ignores its iou_thresh argument (0.5 is hard-coded, :830) and divides by
+    zero when nothing was matched (here: 0.0).  GT masks must be RLE dicts (compressed or not); polygon annotations need
+    cocoapi's rasteriser (frPyObjects), which is not part of this package."""
+    from . import rle
+    keys = [k for k in predictions[0] if "assignment" in k] if predictions else []
+    stats = {k: {"tp": 0, "pred": 0} for k in keys}
+    gt_total = 0
+    for pred in predictions:
+        pair = dataset_dict[pred["0"]["image_id"] + "__" + pred["1"]["image_id"]]
+        gt_corr = {(int(a), int(b)) for a, b in pair["gt_corrs"]}
+        gt_total += len(pair["gt_corrs"])
+        best_iou, best_gt = [], []
+        for v in ("0", "1"):
+            gt_rles = []
+            for ann in pair[v]["annotations"]:
+                seg = ann["segmentation"]
+                if not isinstance(seg, dict):
+                    raise TypeError("evaluate_for_matchings: GT segmentation must be an RLE dict (polygons need cocoapi frPyObjects)")
+                gt_rles.append(seg)
+            m = rle.iou([ins["segmentation"] for ins in pred[v]["instances"]], gt_rles, [0] * len(gt_rles))
+            if m.shape[1] == 0:
+                best_iou.append(np.zeros(m.shape[0])); best_gt.append(np.full(m.shape[0], -1))
+            else:
+                best_iou.append(m.max(-1)); best_gt.append(m.argmax(-1))       # first maximum, like torch.max
+        for k in keys:
+            A = pred[k]
+            A = A.detach().cpu().numpy() if torch.is_tensor(A) else np.asarray(A)
+            idx = np.argwhere(A != 0)
+            stats[k]["pred"] += int(idx.shape[0])
+            for i, j in idx:
+                if best_iou[0][i] >= iou_thresh and best_iou[1][j] >= iou_thresh and (int(best_gt[0][i]), int(best_gt[1][j])) in gt_corr:
+                    stats[k]["tp"] += 1
+    out = {}
+    for k in keys:
+        tp, npred = stats[k]["tp"], stats[k]["pred"]
+        prec = tp / npred if npred else 0.0
+        rec = tp / gt_total if gt_total else 0.0
+        out[k] = {"precision": prec, "recall": rec, "F-score": 2 * prec * rec / (prec + rec) if prec + rec > 0 else 0.0,
+                  "TP": tp, "Pred. Num.": npred, "GT Num.": gt_total}
+    return out
 
 
 def optimized_dict(predictions: List[dict]) -> Dict[int, dict]:

@@ -60,3 +60,51 @@ def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Ten
             planes.append({"segmentation": {"size": [H, W], "counts": s}, "bbox": bbox})
         out.append(planes)
     return out
+
+
+# ---- reading side (evaluation): what pycocotools.mask.iou does for the matching evaluator (mp3d_evaluation.py:806-812)
+def counts_of(rle: dict) -> np.ndarray:
+    """Run lengths of a COCO RLE dict: `counts` is either the list of an uncompressed RLE or the compressed bytes / str
+    (cocoapi rleFrString: 5 data bits per character + continuation bit, runs > 2 stored as differences)."""
+    c = rle["counts"]
+    if not isinstance(c, (bytes, str)):
+        return np.asarray(c, dtype=np.int64)
+    if isinstance(c, str):
+        c = c.encode("ascii")
+    out, p = [], 0
+    while p < len(c):
+        x, k, more = 0, 0, True
+        while more:
+            ch = c[p] - 48
+            x |= (ch & 0x1F) << (5 * k)
+            more = bool(ch & 0x20)
+            p += 1
+            k += 1
+            if not more and (ch & 0x10):
+                x |= -1 << (5 * k)
+        if len(out) > 2:
+            x += out[-2]
+        out.append(x)
+    return np.asarray(out, dtype=np.int64)
+
+
+def decode(rle: dict) -> np.ndarray:
+    """bool [H,W] mask of a COCO RLE (column-major runs, starting with zeros)."""
+    h, w = rle["size"]
+    counts = counts_of(rle)
+    assert int(counts.sum()) == h * w, "RLE run lengths do not cover the image"
+    vals = (np.arange(len(counts)) & 1).astype(np.uint8)
+    return np.repeat(vals, counts).reshape((h, w), order="F").astype(bool)
+
+
+def iou(dt: List[dict], gt: List[dict], iscrowd=None) -> np.ndarray:
+    """[len(dt), len(gt)] float64 mask IoU (intersection / union; iscrowd[j] truthy: intersection / area(dt), as cocoapi rleIou)."""
+    if len(dt) == 0 or len(gt) == 0:
+        return np.zeros((len(dt), len(gt)), np.float64)
+    D = np.stack([decode(r).reshape(-1) for r in dt]).astype(np.float64)
+    G = np.stack([decode(r).reshape(-1) for r in gt]).astype(np.float64)
+    inter = D @ G.T
+    ad, ag = D.sum(1)[:, None], G.sum(1)[None, :]
+    crowd = np.zeros(len(gt), bool) if iscrowd is None else np.asarray(iscrowd, bool)
+    union = np.where(crowd[None, :], ad, ad + ag - inter)
+    return np.where(union > 0, inter / np.maximum(union, 1e-300), 0.0)

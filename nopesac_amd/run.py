@@ -23,7 +23,7 @@ import torch
 
 from . import runner
 from .config import get_cfg
-from .evaluation import PoseEvaluator, create_small_table, dump_predictions
+from .evaluation import PoseEvaluator, create_small_table, dump_predictions, evaluate_for_matchings
 from .registry import build_model
 from .synth import synth_pair, synth_state_dict
 
@@ -45,6 +45,8 @@ def default_argument_parser():
     ap.add_argument("--structured", action="store_true", help="structured synthetic images instead of noise")
     ap.add_argument("--synthetic-weights", action="store_true", help="name-seeded checkpoint instead of cfg.MODEL.WEIGHTS")
     ap.add_argument("--output", default="", help="write the result summary JSON here")
+    ap.add_argument("--eval-matchings", action="store_true", help="plane-matching precision / recall / F-score (mp3d_evaluation.py:746-849): "
+                    "needs pairs with `gt_corrs` and RLE `annotations` (the dataset json's own fields)")
     ap.add_argument("--dump-dir", default="", help="write NopeSAC_instances_predictions.pth + continuous.pkl here (eval_full_scene)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides")
     return ap
@@ -87,7 +89,7 @@ def load_pairs(args, cfg=None):
     return pairs
 
 
-def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int):
+def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_outputs: list = None):
     """Batch loop of detectron2's inference_on_dataset (eval mode, no_grad, timing log)."""
     evaluator.reset()
     model.eval()
@@ -101,6 +103,10 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int):
                 torch.cuda.synchronize()
             t_compute += time.perf_counter() - t1
             evaluator.process(batch, outputs)
+            if keep_outputs is not None:         # what evaluate_for_matchings reads: ids, RLE instances, assignment matrices
+                for out in outputs:
+                    keep_outputs.append({**{v: {"image_id": out[v]["image_id"], "instances": out[v]["instances"]} for v in "01"},
+                                         **{k: out[k].cpu() for k in out if "assignment" in k}})
             n_done += len(batch)
             if (i // pairs_per_batch) % 10 == 0:
                 logger.info("Inference done %d/%d pairs. %.4f s / pair", n_done, len(pairs), t_compute / max(n_done, 1))
@@ -128,8 +134,22 @@ def _main_rank(args):
     lo, hi = runner.shard_range(len(pairs), rank, world)
     logger.info("rank %d/%d: weights=%s pairs [%d,%d) of %d", rank, world, src, lo, hi, len(pairs))
     evaluator = PoseEvaluator(keep_predictions=bool(args.dump_dir))
-    timing = inference_on_dataset(model, pairs[lo:hi], evaluator, args.pairs_per_batch)
+    kept = [] if args.eval_matchings else None
+    timing = inference_on_dataset(model, pairs[lo:hi], evaluator, args.pairs_per_batch, kept)
     results = evaluator.evaluate()
+    if args.eval_matchings:
+        if world > 1:                            # comm.gather semantics: rank-ordered concatenation
+            parts = [None] * world
+            torch.distributed.all_gather_object(parts, kept)
+            kept = [p for part in parts for p in part]
+        dataset_dict = {p["0"]["image_id"] + "__" + p["1"]["image_id"]: p for p in pairs if "gt_corrs" in p}
+        if rank == 0 and dataset_dict:
+            results["matching"] = evaluate_for_matchings([k for k in kept if k["0"]["image_id"] + "__" + k["1"]["image_id"] in dataset_dict],
+                                                         dataset_dict)
+            for k, v in results["matching"].items():
+                logger.info("Plane metrics (%s):\n%s", k, create_small_table({kk: float(vv) for kk, vv in v.items()}))
+        elif rank == 0:
+            logger.warning("--eval-matchings: no pair carries gt_corrs / annotations; nothing to evaluate")
     results["timing(rank0)"] = timing
     if args.dump_dir:            # eval_full_scene dumps (mp3d_evaluation.py:330-341)
         files = dump_predictions(evaluator._predictions, args.dump_dir)

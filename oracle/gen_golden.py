@@ -68,6 +68,81 @@ def save(name, **arrays):
                         **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
 
 
+def matching_eval_golden(rep):
+    """G: the reference's evaluate_for_matchings (evaluation/mp3d_evaluation.py:746-849) on the seeded case of
+    tests/golden_inputs.py::matching_eval_case.  The function is compiled from the reference file on its own (its module imports
+    COCO tooling / visualisers that do not exist here), with the shim's pycocotools.mask stand-ins (run-merging IoU); it is called
+    once per assignment key because it returns only the last key's table.  Stored: the six numbers per key."""
+    import logging
+    from nopesac_amd import evaluation as E
+    mask_util = sys.modules["pycocotools.mask"]
+    ns = {"np": np, "torch": torch, "mask_util": types_ns(encode=mask_util.encode, iou=ref_shim._mask_iou, frPyObjects=None, merge=None),
+          "create_small_table": E.create_small_table}
+    ref_fn = ref_shim.load_reference_function("NopeSAC_Net/evaluation/mp3d_evaluation.py", "evaluate_for_matchings", ns)
+    print("G: evaluate_for_matchings")
+    for seed in (3, 4):
+        case = GI.matching_eval_case(seed)
+        preds, dataset = [], {}
+        for pi, pr in enumerate(case):
+            ids = (f"s{seed}p{pi}a", f"s{seed}p{pi}b")
+            pred = {}
+            entry = {"gt_corrs": pr["gt_corrs"]}
+            for v, vid in zip("01", ids):
+                view = pr["views"][int(v)]
+                pred[v] = {"image_id": vid, "instances": [{"segmentation": mask_util.encode(np.asfortranarray(m.astype(np.uint8)))} for m in view["pred"]]}
+                entry[v] = {"annotations": [{"height": m.shape[0], "width": m.shape[1],
+                                             "segmentation": mask_util.encode(np.asfortranarray(m.astype(np.uint8)))} for m in view["gt"]]}
+            dataset[ids[0] + "__" + ids[1]] = entry
+            preds.append(pred)
+        keys = ("pred_assignment", "pred_assignment_afterRef0", "pred_assignment_beforeRef0")
+        out = {}
+        for k in keys:
+            one = []
+            for pred, pr in zip(preds, case):
+                q = dict(pred)
+                q[k] = torch.from_numpy(pr[k])
+                one.append(q)
+            try:
+                with quiet():
+                    m = ref_fn(one, dataset, _logger=logging.getLogger("gen_golden.null"))
+                vals = [m["precision"], m["recall"], m["F-score"], m["TP"], m["Pred. Num."], m["GT Num."]]
+            except ZeroDivisionError:                           # the reference divides by the number of predicted matches
+                vals = [float("nan")] * 6
+            out[k] = np.asarray(vals, np.float64)
+            # the product's evaluator on the same case, its own RLE route (compressed strings, dense IoU)
+            mine = E.evaluate_for_matchings(*product_matching_inputs(case, seed, [k]))[k]
+            got = [mine["precision"], mine["recall"], mine["F-score"], mine["TP"], mine["Pred. Num."], mine["GT Num."]]
+            if not np.isnan(vals[0]):
+                rep.check(f"G.seed{seed}.{k}", torch.tensor(got, dtype=torch.float64), torch.tensor(vals, dtype=torch.float64), 1e-12)
+            else:
+                assert got[4] == 0 and got[0] == 0.0
+        save(f"G_matching_eval_{seed}", **out)
+
+
+def types_ns(**kw):
+    import types as _t
+    return _t.SimpleNamespace(**kw)
+
+
+def product_matching_inputs(case, seed, keys):
+    """The seeded case in the PRODUCT's input format: instances / annotations as compressed COCO RLE strings made by
+    oracle/rle_oracle.py (the same strings nopesac_amd.rle.compress produces, tests/test_rle_cpu.py)."""
+    from oracle import rle_oracle as R
+    preds, dataset = [], {}
+    for pi, pr in enumerate(case):
+        ids = (f"s{seed}p{pi}a", f"s{seed}p{pi}b")
+        pred, entry = {}, {"gt_corrs": pr["gt_corrs"]}
+        for v, vid in zip("01", ids):
+            view = pr["views"][int(v)]
+            pred[v] = {"image_id": vid, "instances": [{"segmentation": R.encode(m)} for m in view["pred"]]}
+            entry[v] = {"annotations": [{"height": m.shape[0], "width": m.shape[1], "segmentation": R.encode(m)} for m in view["gt"]]}
+        for k in keys:
+            pred[k] = torch.from_numpy(pr[k])
+        dataset[ids[0] + "__" + ids[1]] = entry
+        preds.append(pred)
+    return preds, dataset
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     rep = Report()
@@ -258,6 +333,7 @@ def main():
                     rep.check(f"e2e.{tag}{idx}.{k}", o[k], r[k], exact=True)
                     out[k] = r[k]
             save(f"e2e_{tag}_{idx}", **out)
+    matching_eval_golden(rep)
     worst = max(e for _, e, _ in rep.rows)
     print(f"\n{len(rep.rows)} checks passed; worst relative error {worst:.2e}")
 

@@ -204,6 +204,53 @@ def _mask_to_bbox(rle):
     return np.array([x0, y0, x1 - x0, y1 - y0], dtype=np.float64)
 
 
+def _mask_iou(dt, gt, iscrowd):
+    """pycocotools.mask.iou (cocoapi rleIou) restated by MERGING RUNS (the product decodes to dense masks: two independent
+    routes to the same number).  dt / gt: RLE dicts with uncompressed `counts` lists (what _mask_encode produces)."""
+    out = np.zeros((len(dt), len(gt)), np.float64)
+    for i, d in enumerate(dt):
+        for j, g in enumerate(gt):
+            ca, cb = list(d["counts"]), list(g["counts"])
+            ia = ib = 0
+            ra, rb = ca[0], cb[0]
+            va = vb = 0
+            inter = union = 0
+            while True:
+                step = min(ra, rb)
+                if va and vb:
+                    inter += step
+                if va or vb:
+                    union += step
+                ra -= step; rb -= step
+                if ra == 0:
+                    ia += 1
+                    if ia == len(ca):
+                        break
+                    ra, va = ca[ia], va ^ 1
+                if rb == 0:
+                    ib += 1
+                    if ib == len(cb):
+                        break
+                    rb, vb = cb[ib], vb ^ 1
+            if iscrowd[j]:
+                union = sum(ca[1::2])
+            out[i, j] = inter / union if union > 0 else 0.0
+    return out
+
+
+def load_reference_function(rel_path: str, name: str, namespace: dict):
+    """Compile ONE top-level function of a reference source file in `namespace` (this container only; nothing is written to the
+    repo): used for functions whose module cannot be imported because of unrelated heavy imports (COCO tooling, visualisers)."""
+    import ast
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fn) == 1, (name, path)
+    mod = ast.Module(body=fn, type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace[name]
+
+
 _INSTALLED = False
 
 

@@ -106,3 +106,48 @@ def feature_maps(seed: int, h5: int = 15, w5: int = 20, batch: int = 1):
                              align_corners=False)
         out[name] = F.relu(0.6 * x + 1.2 * lowf + 0.3)
     return out
+
+
+def matching_eval_case(seed: int, h: int = 48, w: int = 64, n_pairs: int = 3):
+    """Inputs of the plane-matching evaluator (mp3d_evaluation.py:746-849) as plain arrays: per pair, per view GT masks (a
+    partition of the image into blobs), predicted masks (eroded / shifted copies of some GT blobs + a spurious one), the GT
+    correspondences, and three predicted assignment matrices (perfect on the detected planes / one swapped match / empty)."""
+    import numpy as np
+    g = _g(seed)
+    rng = np.random.default_rng(seed)
+    pairs = []
+    for pi in range(n_pairs):
+        views = []
+        for v in range(2):
+            n_gt = 4 + int(torch.randint(0, 3, (1,), generator=g))
+            yy, xx = np.mgrid[0:h, 0:w]
+            cx, cy = rng.uniform(0, w, n_gt), rng.uniform(0, h, n_gt)
+            lab = np.argmin((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2, 0)
+            gt = np.stack([lab == k for k in range(n_gt)])
+            preds, src = [], []
+            for k in range(n_gt):
+                if rng.uniform() < 0.8:
+                    m = np.roll(gt[k], int(rng.integers(-1, 2)), axis=int(rng.integers(0, 2)))
+                    if rng.uniform() < 0.3:                      # a poor detection: IoU with its GT blob drops below 0.5
+                        m = m & (xx % 3 == 0)
+                    preds.append(m); src.append(k)
+            preds.append((xx + yy) % 7 == 0); src.append(-1)     # spurious plane
+            views.append({"gt": gt, "pred": np.stack(preds), "src": np.asarray(src)})
+        n0, n1 = len(views[0]["src"]), len(views[1]["src"])
+        ng = min(views[0]["gt"].shape[0], views[1]["gt"].shape[0])
+        gt_corrs = [[k, (k * 2 + pi) % views[1]["gt"].shape[0]] for k in range(ng) if k % 3 != 2]
+        corr = dict(map(tuple, gt_corrs))
+        A_good = np.zeros((n0, n1), np.float32)
+        for i, k in enumerate(views[0]["src"]):
+            if k in corr:
+                js = np.flatnonzero(views[1]["src"] == corr[k])
+                if len(js):
+                    A_good[i, js[0]] = 1.0
+        A_swap = A_good.copy()
+        rows = np.flatnonzero(A_good.sum(1))
+        if len(rows) >= 2:
+            A_swap[[rows[0], rows[1]]] = A_swap[[rows[1], rows[0]]]
+        A_swap[n0 - 1, n1 - 1] = 1.0                             # the spurious planes matched to each other
+        pairs.append({"views": views, "gt_corrs": gt_corrs, "pred_assignment": A_good, "pred_assignment_afterRef0": A_swap,
+                      "pred_assignment_beforeRef0": np.zeros((n0, n1), np.float32)})
+    return pairs

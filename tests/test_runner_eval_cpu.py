@@ -119,3 +119,56 @@ def test_prediction_dumps(tmp_path):
     assert set(cont[0]) == {"n_corr", "cost", "best_camera", "gt_camera", "best_assignment", "plane_param_override", "image_ids"}
     assert cont[0]["n_corr"] == 1 and cont[0]["image_ids"] == {"0": "a_0", "1": "a_1"}
     assert cont[0]["plane_param_override"]["1"].shape == (3, 3) and cont[0]["gt_camera"]["position"] == [0.0, 0, 1]
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_evaluate_for_matchings_matches_the_reference(seed):
+    """Plane-matching P / R / F (mp3d_evaluation.py:746-849) on the seeded case of tests/golden_inputs.py against the numbers the
+    imported reference function produced (tests/golden/G_matching_eval_*.npz, oracle/gen_golden.py stage G).  The product decodes
+    compressed COCO RLE strings and takes the IoU on dense masks; the fixture side used run-merging on uncompressed RLEs."""
+    from nopesac_amd import evaluation as E
+    from nopesac_amd import rle
+    from oracle import rle_oracle as R
+    from tests import golden_inputs as GI
+    from tests.util import gold
+    case = GI.matching_eval_case(seed)
+    g = gold(f"G_matching_eval_{seed}")
+    keys = ("pred_assignment", "pred_assignment_afterRef0", "pred_assignment_beforeRef0")
+    preds, dataset = [], {}
+    for pi, pr in enumerate(case):
+        ids = (f"a{pi}", f"b{pi}")
+        pred, entry = {}, {"gt_corrs": pr["gt_corrs"]}
+        for v, vid in zip("01", ids):
+            view = pr["views"][int(v)]
+            segs = [R.encode(m) for m in view["pred"]]
+            assert all(np.array_equal(rle.decode(s), m) for s, m in zip(segs, view["pred"]))       # product decoder round trip
+            pred[v] = {"image_id": vid, "instances": [{"segmentation": s} for s in segs]}
+            entry[v] = {"annotations": [{"segmentation": {"size": list(m.shape), "counts": R.run_lengths(m)}} for m in view["gt"]]}   # uncompressed
+        for k in keys:
+            pred[k] = torch.from_numpy(pr[k])
+        dataset[ids[0] + "__" + ids[1]] = entry
+        preds.append(pred)
+    res = E.evaluate_for_matchings(preds, dataset)
+    assert set(res) == set(keys)
+    for k in keys:
+        want = g[k].numpy()
+        got = np.array([res[k][n] for n in ("precision", "recall", "F-score", "TP", "Pred. Num.", "GT Num.")], np.float64)
+        if np.isnan(want[0]):                 # the reference divides by zero when nothing was matched; the drop-in reports zeros
+            assert got[4] == 0 and got[0] == 0.0 and got[2] == 0.0
+        else:
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert 0 < res["pred_assignment_afterRef0"]["precision"] < res["pred_assignment"]["precision"] <= 1.0
+    with pytest.raises(TypeError, match="RLE dict"):
+        bad = {k: ({**v, "0": {"annotations": [{"segmentation": [[0, 0, 1, 1, 2, 2]]}]}} if isinstance(v, dict) else v) for k, v in dataset.items()}
+        E.evaluate_for_matchings(preds, bad)
+
+
+def test_rle_iou_small_cases():
+    from nopesac_amd import rle
+    from oracle import rle_oracle as R
+    a = np.zeros((4, 5), bool); a[1:3, 1:4] = True
+    b = np.zeros((4, 5), bool); b[2:4, 2:5] = True
+    m = rle.iou([R.encode(a), R.encode(b)], [R.encode(a), R.encode(b), R.encode(np.zeros((4, 5), bool))])
+    assert m.shape == (2, 3) and m[0, 0] == 1.0 and m[1, 1] == 1.0 and abs(m[0, 1] - 2 / 10) < 1e-12 and m[0, 2] == 0.0
+    assert rle.iou([], [R.encode(a)]).shape == (0, 1)
+    assert abs(rle.iou([R.encode(b)], [R.encode(a)], [1])[0, 0] - 2 / 6) < 1e-12          # crowd: intersection / area(dt)
