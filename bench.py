@@ -250,6 +250,7 @@ def main():
                          "driver, PMC, rocprofv3 - launches identical kernels; shapes it does not list are tuned and added")
     ap.add_argument("--retune", action="store_true", help="ignore the routing file's contents, tune every shape again and rewrite it")
     ap.add_argument("--no-fp32-path", action="store_true", help="skip the fp32 parity path's own throughput figure")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the drop-in boundary figure (model(list[dict]) -> list[dict], host tensors in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
@@ -531,6 +532,8 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_accuracy:
             out["pose_err_vs_fp32_path"].update(accuracy_vs_fp32(model, device, nq))
+    if rank == 0 and world == 1 and not args.no_boundary and args.dtype == "bfloat16":
+        out["boundary"] = boundary_rate(model, raw, forced, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
@@ -579,6 +582,73 @@ def bench_workload_pose_error(m16, m32, device, B, K, nq, raw=None, forced=None)
     if len(set(out["m_bf16"])) == 1 and out["m_bf16"] == out["m_fp32"]:          # compact form for the JSON line
         out["m_all_pairs"] = out["m_bf16"][0]
     return out
+
+
+def boundary_rate(model, raw, forced, B, steps=4):
+    """The rate AT the drop-in boundary (what the reference's consumer, MP3DEvaluator.process, sees): a list of B input dicts with
+    HOST image tensors goes in, the list of per-pair result dicts comes out - H2D copies, the whole forward, `package()` (the
+    reference's result schema, siamese_planeTR.py:384-450) and the COCO RLE `instances` of every kept plane included; the same
+    K-forced workload as the headline figure (so every view keeps K planes: 2 B K RLE strings per step).  One batch at a time (the
+    results are consumed before the next call, as inference_on_dataset does)."""
+    host = raw.cpu().pin_memory()
+    inputs = [{"0": {"image": host[i], "image_id": "a%d" % i, "file_name": ""}, "1": {"image": host[B + i], "image_id": "b%d" % i, "file_name": ""}}
+              for i in range(B)]
+    rle_saved, model.output_rle = model.output_rle, True
+    t_pack = [0.0]
+
+    def one():
+        with torch.no_grad():
+            imgs = model.stack_images(inputs)                                   # H2D (pinned, non_blocking) + stack
+            d = model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=imgs)
+            t1 = time.perf_counter()
+            res = model.package(inputs, d)                                      # the single host sync + result dicts + RLE
+            t_pack[0] += time.perf_counter() - t1
+        return res
+
+    try:
+        res = one()
+        n_rle = sum(len(r[v]["instances"]) for r in res for v in "01")
+        assert all("segmentation" in ins for r in res for v in "01" for ins in r[v]["instances"])
+        torch.cuda.synchronize()
+        t_pack[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        # the same with TWO batches in flight: batch i+1's copies and forward are enqueued (their own HIP stream) before batch i's
+        # results are fetched and packaged - what a prefetching evaluation loop does; results are still complete per-pair dicts
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+        def submit(slot):
+            with torch.no_grad(), torch.cuda.stream(streams[slot]):
+                imgs = model.stack_images(inputs)
+                return slot, model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=imgs)
+
+        def finish(h):
+            with torch.no_grad(), torch.cuda.stream(streams[h[0]]):
+                return model.package(inputs, h[1])
+
+        finish(submit(0))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for i in range(2 * steps):
+            h = submit(i % 2)
+            if pending is not None:
+                finish(pending)
+            pending = h
+        finish(pending)
+        torch.cuda.synchronize()
+        el2 = (time.perf_counter() - t0) / 2
+    finally:
+        model.output_rle = rle_saved
+    return {"value": round(B * steps / el2, 2), "unit": "pairs/s", "ms_per_step": round(1e3 * el2 / steps, 2), "steps": 2 * steps, "pairs_per_step": B,
+            "batches_in_flight": 2, "rle_instances_per_step": n_rle,
+            "one_batch_at_a_time": {"value": round(B * steps / el, 2), "ms_per_step": round(1e3 * el / steps, 2),
+                                    "package_incl_wait_for_the_gpu_ms": round(1e3 * t_pack[0] / steps, 2)},
+            "note": "model(list[dict]) -> list[dict]: HOST images in, H2D + forward + package() + COCO RLE instances of every kept plane; "
+                    "value = two batches in flight (next batch enqueued before the previous one is packaged), one_batch_at_a_time = strictly serial"}
 
 
 def fp32_path_throughput(m32, raw, forced, B, steps=4):

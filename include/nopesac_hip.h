@@ -398,6 +398,11 @@ int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_kept, const 
 /* HOST function (no device work): one mask's flip positions -> COCO compressed "counts" string (not NUL terminated,
  *   returns its length or < 0) and bbox4 = [x, y, w, h] (cocoapi rleToString / rleToBbox). */
 int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W, char* out, int cap, double* bbox4);
+/* Batch form of nopesac_rle_compress_host: mask i owns positions[offsets[i] .. +counts[i]); strings are packed back to back into
+ * `out` (mask i at out + out_off[i], out_off[n_masks] = total), boxes at bbox4 + 4 i.  Returns the total length or < 0. */
+long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long long* offsets, const int* counts, int n_masks,
+                                          int H, int W, char* out, long long cap, long long* out_off, double* bbox4);
+
 
 #ifdef __cplusplus
 }

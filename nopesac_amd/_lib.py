@@ -39,6 +39,7 @@ SIGNATURES = {
     "nopesac_rle_labels": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_rle_transitions": [P, P, P, P, P, I, I, I, P],
     "nopesac_rle_compress_host": [P, I, I, I, P, I, P],
+    "nopesac_rle_compress_batch_host": [P, P, P, I, I, I, P, L, P, P],
     "nopesac_preprocess_nchw_to_nhwc": [P, P, P, P, I, I, I, I, I, I, P],
     "nopesac_maxpool_nhwc": [P, P, I, I, I, I, I, I, I, I, P],
     "nopesac_upsample2x_bilinear_nhwc": [P, P, P, I, I, I, I, I, I, P],
@@ -62,7 +63,7 @@ SIGNATURES = {
     "nopesac_normalize_rows": [P, P, I, I, I, P],
     "nopesac_count_nonfinite": [P, L, P, P],
 }
-_RESTYPE = {"nopesac_last_error": c_char_p}
+_RESTYPE = {"nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64}
 
 _lib = None
 

@@ -18,7 +18,7 @@ namespace nps {
 
 // TA = element type of x in memory (float with T = bf16_t is the mixed mode: f32 activations are rounded to
 // bf16 while being staged, weights are bf16, MFMA runs at the bf16 rate).
-template <typename TA, typename T, int BM, int BN, int VEC, int KMUL = 1>
+template <typename TA, typename T, int BM, int BN, int VEC, int KMUL = 1, bool TWO_LEVEL_ACC = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // KMUL > 1: deeper K-tile (fewer, fatter pipeline steps) for the small latency-bound head GEMMs
     constexpr int BK = Cfg<T>::BK * KMUL;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // FLUSH K-tiles (128 terms) the running accumulator is added into a second-level one and cleared: error ~sqrt(128) + sqrt(K/128)
     // ulp - about 5x smaller for the long-K layers - which is what keeps pred_plane / camera.tran inside the ABSOLUTE 1e-4 gate
     // against the reference (they sit at 0.5-1e-4 with a single chain).  Not used in the bf16 / mixed modes.
-    constexpr bool TWO_LEVEL = sizeof(T) == 4;
+    constexpr bool TWO_LEVEL = sizeof(T) == 4 && TWO_LEVEL_ACC;        // the launcher picks this build for f32 layers with K >= 512
     constexpr int FLUSH = 8;
     f32x16 acc_hi[TWO_LEVEL ? TM : 1][TWO_LEVEL ? TN : 1];
     if constexpr (TWO_LEVEL) {
@@ -581,6 +581,13 @@ static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
         // head GEMMs (a few hundred blocks, K >= 128): BK = 128 halves/quarters the number of exposed-latency steps
         if (vec == VW && p.K % 128 == 0 && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048) {
             hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 4>), grid, dim3(256), 0, stream, p);
+            return 0;
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        // f32 parity path, long K: two-level accumulation (a second accumulator set costs registers: only where the chain is long)
+        if (vec == VW && p.K >= 512) {
+            hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 1, true>), grid, dim3(256), 0, stream, p);
             return 0;
         }
     }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void p8_epilogue_prefetch(P8EpiRegs& R, const ConvPar
         *(f32x4*)(R.bs) = *(const f32x4*)(p.bias + n);
         *(f32x4*)(R.bs + 4) = *(const f32x4*)(p.bias + n + 4);
     }
-    if (EPI == 0 && p.res && p.out_dt != NPS_DT_F32) {
+    if (EPI == 4 || (EPI == 0 && p.res && p.out_dt != NPS_DT_F32)) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rs = it * 16 + rg;
@@ -97,7 +97,8 @@ __device__ __forceinline__ void p8_epilogue_prefetch(P8EpiRegs& R, const ConvPar
 }
 
 // EPI: 0 = generic (residual kind, activation and output type decided at run time: ~2100 lines of ISA per pass);
-//      1 / 2 / 3 = no residual, bf16 output, activation ReLU / none / LeakyReLU fixed at compile time (~200 lines per pass).
+//      1 / 2 / 3 = no residual, bf16 output, activation ReLU / none / LeakyReLU fixed at compile time (~200 lines per pass);
+//      4 = bf16 residual added before a ReLU, bf16 output (the expand conv of a bottleneck).
 // The whole kernel with the generic epilogue is 60 KB of code - the instruction cache (64 KB per CU pair) then re-fetches the
 // tile-boundary code on every tile: the measured 10 k cycles for ~600 instructions of index math were instruction misses.
 template <bool STAMP, int EPI>
@@ -108,9 +109,9 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[4][2], unsigned char* 
     const int n = n0 + c8 * 8;
     const float (&sc)[8] = R.sc;
     const float (&bs)[8] = R.bs;
-    const bool res16 = EPI == 0 && p.res && p.out_dt != NPS_DT_F32;   // bf16 residual rows: prefetched per pass
+    const bool res16 = EPI == 4 || (EPI == 0 && p.res && p.out_dt != NPS_DT_F32);   // bf16 residual rows: prefetched per pass
     const bool res32 = EPI == 0 && p.res && p.out_dt == NPS_DT_F32;
-    const int act = EPI == 0 ? p.act : (EPI == 1 ? NPS_ACT_RELU : EPI == 2 ? NPS_ACT_NONE : NPS_ACT_LEAKY);
+    const int act = EPI == 0 ? p.act : ((EPI == 1 || EPI == 4) ? NPS_ACT_RELU : EPI == 2 ? NPS_ACT_NONE : NPS_ACT_LEAKY);
     const int res_after = EPI == 0 ? p.res_after : 0;
     const int out_dt = EPI == 0 ? p.out_dt : NPS_DT_BF16;
     auto do_pass = [&](auto PASSC) {
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             // would wait vmcnt(0) at the first use of scale / bias - i.e. for the DMAs' HBM round trip (measured: 12 k cycles)
 #pragma unroll
             for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(epr.sc[e]), "v"(epr.bs[e]));
-            if (EPI == 0 && p.res && p.out_dt != NPS_DT_F32) {
+            if (EPI == 4 || (EPI == 0 && p.res && p.out_dt != NPS_DT_F32)) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(epr.r0[it]));
             }
@@ -637,6 +638,7 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     // epilogue specialisation (code size, see p8_epilogue): the common no-residual / bf16-output forms get their own build
     int epi = 0;
     if (!residual && out_dt == NPS_DT_BF16 && !res_after) epi = act == NPS_ACT_RELU ? 1 : act == NPS_ACT_NONE ? 2 : act == NPS_ACT_LEAKY ? 3 : 0;
+    if (residual && out_dt == NPS_DT_BF16 && !res_after && act == NPS_ACT_RELU) epi = 4;
     if (generic_epi) epi = 0;
     const hipStream_t st = (hipStream_t)stream;
     if (variant == 24) {
@@ -646,6 +648,7 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     } else if (epi == 1) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 1>), grid, dim3(512), 0, st, p);
     else if (epi == 2) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 2>), grid, dim3(512), 0, st, p);
     else if (epi == 3) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 3>), grid, dim3(512), 0, st, p);
+    else if (epi == 4) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 4>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 0>), grid, dim3(512), 0, st, p);
     NPS_LAUNCH_RET();
 }

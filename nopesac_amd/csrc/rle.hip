@@ -182,3 +182,26 @@ extern "C" int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, i
     bbox4[0] = (double)xs; bbox4[1] = (double)ys; bbox4[2] = (double)(xe - xs + 1); bbox4[3] = (double)(ye - ys + 1);
     return len;
 }
+
+// Host-only, batch form: n_masks masks at once (one ctypes call per batch instead of one per plane - the per-plane calls were
+// 2/3 of package()'s 32 ms per 32-pair step).  Mask i owns positions[offsets[i] .. offsets[i] + counts[i]); its string is written
+// at out + out_off[i] (out_off[n_masks] = total bytes used), its box at bbox4 + 4 i.  Returns the total length or < 0.
+extern "C" long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long long* offsets, const int* counts, int n_masks,
+                                                     int H, int W, char* out, long long cap, long long* out_off, double* bbox4) {
+    using namespace nps;
+    if (!((positions || n_masks == 0) && offsets && counts && n_masks >= 0 && out && out_off && bbox4)) {
+        set_error("rle_compress_batch: bad args");
+        return NPS_E_ARG;
+    }
+    long long used = 0;
+    for (int i = 0; i < n_masks; ++i) {
+        out_off[i] = used;
+        const long long room = cap - used;
+        const int n = nopesac_rle_compress_host(counts[i] ? positions + offsets[i] : nullptr, counts[i], H, W, out + used,
+                                                (int)(room > 0x7fffffff ? 0x7fffffff : room), bbox4 + 4 * (long long)i);
+        if (n < 0) return n;
+        used += n;
+    }
+    out_off[n_masks] = used;
+    return used;
+}

@@ -45,6 +45,7 @@ class HipResNet50(ParamModule):
         self.act_scale: dict = {}
         self._calib: dict | None = None
         self._q8: dict = {}
+        self.unfused_wide_tails = os.environ.get("NOPESAC_TAIL_RES4_FUSED", "0") != "1"
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -158,7 +159,12 @@ class HipResNet50(ParamModule):
             c3 = P[p + ".conv3"]
             cfg_next = (cmid, cout, nxt.cout if nxt is not None else 0, cin if proj else 0)
             cfg_solo = (cmid, cout, 0, cin if proj else 0)
-            if fuse and (cfg_next in ops.BOTTLENECK_TAIL_CONFIGS or cfg_solo in ops.BOTTLENECK_TAIL_CONFIGS):
+            # res4 (C4 = 1024): the fused tail re-streams 1 MB of weights from L2 per 32-64 pixels and is L2-bound (2.3 TB/s of HBM
+            # traffic); as separate launches on the 256x256 persistent conv kernel the expand conv + residual streams at ~4.8 TB/s
+            # and the whole tail is 6-24 % faster although y is read once more (scripts/tail_vs_p8.py).  fp8 mode keeps the fused
+            # form (its conv1 output is written as fp8 by the tail).
+            wide_unfused = self.unfused_wide_tails and cmid >= 256 and not self.fp8_conv2
+            if fuse and not wide_unfused and (cfg_next in ops.BOTTLENECK_TAIL_CONFIGS or cfg_solo in ops.BOTTLENECK_TAIL_CONFIGS):
                 # conv3 + shortcut + ReLU (+ the next block's conv1) in one launch (csrc/pwchain.hip)
                 use_next = cfg_next in ops.BOTTLENECK_TAIL_CONFIGS and nxt is not None
                 kw = {}

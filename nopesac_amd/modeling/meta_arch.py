@@ -86,7 +86,7 @@ class PlaneTR_NopeSAC(nn.Module):
         imgs = [x["0"]["image"] for x in batched_inputs] + [x["1"]["image"] for x in batched_inputs]
         sizes = {tuple(i.shape) for i in imgs}
         assert len(sizes) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
-        x = torch.stack([i.to(self.device, torch.float32, non_blocking=True) for i in imgs], 0).contiguous()
+        x = self._to_device_batch(imgs)
         return ops.preprocess(x, self.pixel_mean, self.pixel_std, self.backbone.STEM_CIN_PAD, self.compute_dtype)
 
     def stack_images(self, batched_inputs: List[dict]) -> torch.Tensor:
@@ -95,7 +95,15 @@ class PlaneTR_NopeSAC(nn.Module):
         imgs = [x["0"]["image"] for x in batched_inputs] + [x["1"]["image"] for x in batched_inputs]
         sizes = {tuple(i.shape) for i in imgs}
         assert len(sizes) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
-        return torch.stack([i.to(self.device, torch.float32, non_blocking=True) for i in imgs], 0).contiguous()
+        return self._to_device_batch(imgs)
+
+    def _to_device_batch(self, imgs) -> torch.Tensor:
+        """[2B,3,H,W] f32 on the device: every image is copied straight into its slice of ONE buffer (async from pinned host memory;
+        no per-image device tensor, no torch.stack pass over the batch)."""
+        out = torch.empty((len(imgs),) + tuple(imgs[0].shape), device=self.device, dtype=torch.float32)
+        for k, im in enumerate(imgs):
+            out[k].copy_(im, non_blocking=True)
+        return out
 
     def forward_device(self, batched_inputs: List[dict], diagnostics: bool = False) -> dict:
         """All device work for B pairs; returns device tensors only (no synchronisation)."""

@@ -46,19 +46,38 @@ def compress(positions: np.ndarray, H: int, W: int):
     return buf.raw[:n], [float(b) for b in bbox]
 
 
+def compress_batch(positions: np.ndarray, offsets: np.ndarray, counts: np.ndarray, H: int, W: int):
+    """All masks of a batch in ONE library call: -> (list of counts bytes, bbox float64 [n,4])."""
+    L = _lib.load()
+    n = int(len(counts))
+    positions = np.ascontiguousarray(positions, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    cap = 6 * (int(counts.sum()) + n) + 16
+    buf = np.empty(cap, np.uint8)
+    out_off = np.empty(n + 1, np.int64)
+    bbox = np.empty((max(n, 1), 4), np.float64)
+    r = L.nopesac_rle_compress_batch_host(positions.ctypes.data if positions.size else None, offsets.ctypes.data, counts.ctypes.data, n, H, W,
+                                          buf.ctypes.data, cap, out_off.ctypes.data, bbox.ctypes.data)
+    if r < 0:
+        _lib.check(int(r), "nopesac_rle_compress_batch_host")
+    raw = buf.tobytes()
+    return [raw[out_off[i]:out_off[i + 1]] for i in range(n)], bbox[:n]
+
+
 def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor) -> List[List[dict]]:
     """Per view, per kept plane (query order): {"segmentation": {"size": [H,W], "counts": bytes}, "bbox": [x,y,w,h]}."""
     V, H, W = winner.shape
     counts, offsets, pos = flip_positions(winner, kept_idx, n_kept, flags)
     n_list = n_kept.cpu().tolist()
-    out = []
-    for v in range(V):
-        planes = []
-        for p in range(n_list[v]):
-            o, c = int(offsets[v, p]), int(counts[v, p])
-            s, bbox = compress(pos[o:o + c], H, W)
-            planes.append({"segmentation": {"size": [H, W], "counts": s}, "bbox": bbox})
-        out.append(planes)
+    sel = [(v, p) for v in range(V) for p in range(n_list[v])]
+    if not sel:
+        return [[] for _ in range(V)]
+    vi, pi = np.array([s[0] for s in sel]), np.array([s[1] for s in sel])
+    strings, boxes = compress_batch(pos, offsets.numpy()[vi, pi], counts.numpy()[vi, pi], H, W)
+    out = [[] for _ in range(V)]
+    for k, (v, p) in enumerate(sel):
+        out[v].append({"segmentation": {"size": [H, W], "counts": strings[k]}, "bbox": boxes[k].tolist()})
     return out
 
 

@@ -50,10 +50,21 @@ def _check_pair(res, ref, g=None, soft_masks=False, ref64=None):
     for k in ref:
         if "camera" in k:
             assert k in res, k
-            assert abs_err(res[k]["tran"], ref[k]["tran"]) < TOL, k
-            assert quat_abs_err(res[k]["rot"], ref[k]["rot"]) < TOL, k
+            if ref64 is not None and k in ref64:
+                # absolute 1e-4 against the float64 evaluation of the reference algorithm; against the fp32 CPU result the
+                # reference's own rounding noise is allowed on top (refined poses reach |t| ~ 12 with the synthetic weights:
+                # 1e-4 there is 8e-6 relative, ~100 ulp)
+                nt, nr = abs_err(ref[k]["tran"].astype("float64"), ref64[k]["tran"]), quat_abs_err(ref[k]["rot"].astype("float64"), ref64[k]["rot"])
+                assert abs_err(res[k]["tran"].astype("float64"), ref64[k]["tran"]) < TOL, (k, nt)
+                assert quat_abs_err(res[k]["rot"].astype("float64"), ref64[k]["rot"]) < TOL, (k, nr)
+                assert abs_err(res[k]["tran"], ref[k]["tran"]) < TOL + nt, (k, nt)
+                assert quat_abs_err(res[k]["rot"], ref[k]["rot"]) < TOL + nr, (k, nr)
+            else:
+                assert abs_err(res[k]["tran"], ref[k]["tran"]) < TOL, k
+                assert quat_abs_err(res[k]["rot"], ref[k]["rot"]) < TOL, k
             if g is not None:
-                assert abs_err(res[k]["tran"], g[k + "_tran"]) < TOL and quat_abs_err(res[k]["rot"], g[k + "_rot"]) < TOL, k
+                gt_tol = TOL if ref64 is None else 2 * TOL        # fixture = the imported reference's fp32 result
+                assert abs_err(res[k]["tran"], g[k + "_tran"]) < gt_tol and quat_abs_err(res[k]["rot"], g[k + "_rot"]) < gt_tol, k
         if "assignment" in k:
             assert torch.equal(res[k], ref[k]), k
     assert set(k for k in res if "camera" in k) == set(k for k in ref if "camera" in k)
@@ -260,8 +271,7 @@ def test_nonfinite_outputs_raise(device):
     inp = [synth_pair(5)]
     model(inp)                                                     # finite: no error
     head = model.camera_head_list[0]
-    key = "fc_trans.weight" if head.has("fc_trans.weight") else next(k for k in head.state_dict() if k.endswith("weight"))
-    w = head.raw(key)
+    w = head.raw("trans.weight")                                  # the last linear of the pixel pose net: no ReLU behind it swallows the NaN
     saved = w.detach().clone()
     try:
         with torch.no_grad():
