@@ -66,6 +66,76 @@ constexpr int P8_LDS = P8_TAB_OFF + P8_BM * 8;                     // 131 KB
 // (v * scale + bias, residual before or after the activation): results are identical to the other conv kernels'.
 // `drain_dma`: the next tile's first DMAs were issued before this epilogue - wait for them (vmcnt(0)) before the LAST pass's
 // stores (the earlier passes' stores are a few thousand cycles old by then and mostly acknowledged).
+// Builds 1-3 (no residual, bf16 output): the whole epilogue arithmetic happens in the ACCUMULATOR layout, before staging - a lane
+// owns, for its pixel row, the 32 channels wc*64 + j*32 + 8q + 4*(lane >> 5) + e: their scale / bias values sit in 64 registers
+// (loaded once per tile, before the next tile's DMAs), the staged tile is bf16 (half the LDS bytes of the f32 staging) and the
+// second stage is a pure 16-byte LDS -> global copy.
+struct P8EpiRegs16 {
+    float sc[2][4][4], bs[2][4][4];
+};
+
+__device__ __forceinline__ void p8_epilogue16_prefetch(P8EpiRegs16& R, const ConvParams& p, int n0, int wc, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wc * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+            f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) s4 = *(const f32x4*)(p.scale + n);
+            if (p.bias) b4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { R.sc[j][q][e] = s4[e]; R.bs[j][q][e] = b4[e]; }
+        }
+}
+
+constexpr int P8_ELD16 = P8_BN + 8;                             // bf16 elements per staged row (528 bytes)
+
+template <int EPI>
+__device__ __forceinline__ void p8_epilogue16(f32x16 (&acc)[4][2], unsigned char* lds, const ConvParams& p, int m0, int n0, int wr, int wc,
+                                              int lane, int tid, bool drain_dma, const P8EpiRegs16& R) {
+    bf16_t* epi = reinterpret_cast<bf16_t*>(lds + P8_EPI_OFF);
+    const int c8 = tid & 31, rg = tid >> 5;
+    constexpr int act = EPI == 1 ? NPS_ACT_RELU : (EPI == 2 ? NPS_ACT_NONE : NPS_ACT_LEAKY);
+    auto do_pass = [&](auto PASSC) {
+        constexpr int pass = decltype(PASSC)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[pass][j][4 * q + e] * R.sc[j][q][e];
+                    t += R.bs[j][q][e];
+                    t += 0.f;                                    // the generic epilogue adds the (absent) residual 0: -0 -> +0
+                    if (act == NPS_ACT_RELU) t = t > 0.f ? t : 0.f;
+                    else if (act == NPS_ACT_LEAKY) t = t > 0.f ? t : 0.01f * t;
+                    v[e] = t;
+                }
+                const uint2 o = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+                *(uint2*)(epi + (wr * 32 + (lane & 31)) * P8_ELD16 + wc * 64 + j * 32 + 8 * q + 4 * (lane >> 5)) = o;
+            }
+        if constexpr (pass == 3) {                              // as late as possible: the DMAs had the whole epilogue to land
+            if (drain_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        P8_LDS_SYNC();
+        uint4 o[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) o[it] = *(const uint4*)(epi + (it * 16 + rg) * P8_ELD16 + c8 * 8);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rs = it * 16 + rg;
+            const int m = m0 + (rs >> 5) * 128 + pass * 32 + (rs & 31);
+            if (m < p.M) *(uint4*)((bf16_t*)p.y + (long long)m * p.y_cs + n0 + c8 * 8) = o[it];
+        }
+        P8_LDS_SYNC();
+    };
+    do_pass(IC<0>{});
+    do_pass(IC<1>{});
+    do_pass(IC<2>{});
+    do_pass(IC<3>{});
+}
+
 struct P8EpiRegs {                 // what the epilogue loads BEFORE the next tile's DMAs are issued (vmcnt retires in order: a
     float sc[8], bs[8];            // load issued behind the DMAs could only be consumed after they - an HBM burst - have landed)
     us8 r0[4];                     // bf16 residual rows of pass 0
@@ -515,8 +585,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = tile + stride;
         const bool more = next < run_end;
+        constexpr bool EPI16 = EPI >= 1 && EPI <= 3;             // arithmetic in the accumulator layout + bf16 staging
         P8EpiRegs epr;
-        p8_epilogue_prefetch<EPI>(epr, p, cur_m0, cur_n0, tid);       // BEFORE the DMAs (in-order vmcnt)
+        P8EpiRegs16 epr16;
+        if constexpr (EPI16) p8_epilogue16_prefetch(epr16, p, cur_n0, wc, lane);
+        else p8_epilogue_prefetch<EPI>(epr, p, cur_m0, cur_n0, tid);  // BEFORE the DMAs (in-order vmcnt)
         if constexpr (STAMP) {
             if (stamp_now) est[4] = __builtin_readcyclecounter();
         }
@@ -527,8 +600,17 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             }
             // retire the prefetch loads HERE: behind the conditional DMAs the compiler cannot count (0 or 8 younger operations) and
             // would wait vmcnt(0) at the first use of scale / bias - i.e. for the DMAs' HBM round trip (measured: 12 k cycles)
+            if constexpr (EPI16) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(epr.sc[e]), "v"(epr.bs[e]));
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) asm volatile("" :: "v"(epr16.sc[j][q][e]), "v"(epr16.bs[j][q][e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(epr.sc[e]), "v"(epr.bs[e]));
+            }
             if (EPI == 4 || (EPI == 0 && p.res && p.out_dt != NPS_DT_F32)) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(epr.r0[it]));
@@ -538,7 +620,8 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 if (stamp_now) est[6] = __builtin_readcyclecounter();
             }
         }
-        p8_epilogue<STAMP, EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr, est);
+        if constexpr (EPI16) p8_epilogue16<EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr16);
+        else p8_epilogue<STAMP, EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr, est);
         if constexpr (STAMP) {
             if (stamp_now) {
                 ts[3] = __builtin_readcyclecounter();

@@ -19,6 +19,16 @@ FP8 = 3                    # NPS_DT_FP8: OCP e4m3fn bytes
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
 
+class OpsArgumentError(AssertionError, ValueError):
+    """A wrapper's argument check failed.  Raised explicitly (not `assert`): the checks stay in force under `python -O`.
+    (Subclasses AssertionError so that callers written against the first version keep working.)"""
+
+
+def _require(cond, msg="argument check failed"):
+    if not cond:
+        raise OpsArgumentError(msg if isinstance(msg, str) else repr(msg))
+
+
 def _L():
     return _lib.load()
 
@@ -30,16 +40,16 @@ def _stream():
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    assert t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)"
+    _require(t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)")
     return t.data_ptr()
 
 
 def _chk(t: torch.Tensor, dtype=None, contiguous=True):
-    assert t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)"
+    _require(t.is_cuda, "nopesac_amd ops need device tensors (there is no CPU path)")
     if dtype is not None:
-        assert t.dtype == dtype, (t.dtype, dtype)
+        _require(t.dtype == dtype, (t.dtype, dtype))
     if contiguous:
-        assert t.is_contiguous()
+        _require(t.is_contiguous(), 'argument check failed: t.is_contiguous()')
     return t
 
 
@@ -103,7 +113,7 @@ class ConvTuner:
         import json
         with open(path) as f:
             doc = json.load(f)
-        assert doc.get("format") == "nopesac_amd.ConvTuner/1", "not a ConvTuner routing file"
+        _require(doc.get("format") == "nopesac_amd.ConvTuner/1", "not a ConvTuner routing file")
         self.loaded = {k: int(v) for k, v in doc["routing"].items()}
         return len(self.loaded)
 
@@ -140,39 +150,39 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     """NHWC conv / linear.  x: [B,H,W,Cx] (a channel slice view of a wider buffer is allowed: only the
     last-dim stride may exceed the channel count); w: [Cout,KH,KW,Cin] or [B,Cout,KH,KW,Cin] when
     `batched_weights`.  `out` may be a channel-slice view of a wider NHWC buffer."""
-    assert x.dim() == 4 and x.stride(3) == 1
+    _require(x.dim() == 4 and x.stride(3) == 1, 'argument check failed: x.dim() == 4 and x.stride(3) == 1')
     B, H, W, Cx = x.shape
     x_cs = x.stride(2)
-    assert x.stride(1) == W * x_cs and x.stride(0) == H * W * x_cs, "x must be pixel-dense NHWC"
+    _require(x.stride(1) == W * x_cs and x.stride(0) == H * W * x_cs, "x must be pixel-dense NHWC")
     if batched_weights:
-        assert w.dim() == 5 and w.shape[0] == B and w.is_contiguous()
+        _require(w.dim() == 5 and w.shape[0] == B and w.is_contiguous(), 'argument check failed: w.dim() == 5 and w.shape[0] == B and w.is_contiguous()')
         Cout, KH, KW, Cin = w.shape[1:]
         w_bs = Cout * KH * KW * Cin
     else:
-        assert w.dim() == 4 and w.is_contiguous()
+        _require(w.dim() == 4 and w.is_contiguous(), 'argument check failed: w.dim() == 4 and w.is_contiguous()')
         Cout, KH, KW, Cin = w.shape
         w_bs = 0
-    assert Cin == (x_channels or Cx), (Cin, Cx)
+    _require(Cin == (x_channels or Cx), (Cin, Cx))
     mixed = x.dtype == torch.float32 and w.dtype == torch.bfloat16     # f32 activations x bf16 weights
-    assert w.dtype == x.dtype or mixed
+    _require(w.dtype == x.dtype or mixed, 'argument check failed: w.dtype == x.dtype or mixed')
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
     out_dtype = out_dtype or (out.dtype if out is not None else x.dtype)
     if out is None:
         out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=out_dtype)
-    assert out.shape == (B, OH, OW, Cout) and out.stride(3) == 1 and out.dtype == out_dtype
+    _require(out.shape == (B, OH, OW, Cout) and out.stride(3) == 1 and out.dtype == out_dtype, 'argument check failed: out.shape == (B, OH, OW, Cout) and out.stride(3) == 1 and out.dtype == out_dtype')
     y_cs = out.stride(2)
-    assert out.stride(1) == OW * y_cs and out.stride(0) == OH * OW * y_cs
+    _require(out.stride(1) == OW * y_cs and out.stride(0) == OH * OW * y_cs, 'argument check failed: out.stride(1) == OW * y_cs and out.stride(0) == OH * OW * y_cs')
     r_cs = 0
     if residual is not None:
-        assert residual.shape == out.shape and residual.dtype == out_dtype and residual.stride(3) == 1
+        _require(residual.shape == out.shape and residual.dtype == out_dtype and residual.stride(3) == 1, 'argument check failed: residual.shape == out.shape and residual.dtype == out_dtype and residual.stride(3) == 1')
         r_cs = residual.stride(2)
     if batched_weights and bias is not None and bias.numel() == B * Cout and B > 1:
         act |= ACT_BIAS_BATCHED                                   # per-batch bias rows [B, Cout]
     for v in (scale, bias):
         if v is not None:
             _chk(v, torch.float32)
-            assert v.numel() == Cout or (v is bias and (act & ACT_BIAS_BATCHED))
+            _require(v.numel() == Cout or (v is bias and (act & ACT_BIAS_BATCHED)), 'argument check failed: v.numel() == Cout or (v is bias and (act & ACT_BIAS_BATCHED))')
     # "A through LDS, B from L2" kernel (fragment-major weights, cached per weight tensor): only the autotuner selects it
     bfrag_ok = (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not batched_weights and Cin % 64 == 0 and Cout % 128 == 0
                 and x_cs % 8 == 0 and KH * KW <= 32 and (act & ~(0xff | ACT_RES_AFTER)) == 0
@@ -224,12 +234,12 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
 def _rows4d(t: torch.Tensor, width: int) -> torch.Tensor:
     """View `t` ([..., width]: contiguous, or a column slice of a contiguous wider buffer) as a
     [1,1,rows,width] NHWC tensor whose pixel stride is the buffer's row stride."""
-    assert t.stride(-1) == 1 and t.shape[-1] == width
+    _require(t.stride(-1) == 1 and t.shape[-1] == width, 'argument check failed: t.stride(-1) == 1 and t.shape[-1] == width')
     rows = t.numel() // width
     rs = width if t.is_contiguous() else t.stride(-2)
     if t.dim() > 2 and not t.is_contiguous():
         for d in range(t.dim() - 2):     # leading dims must be dense multiples of the row stride
-            assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "unsupported row layout"
+            _require(t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "unsupported row layout")
     return torch.as_strided(t, (1, 1, rows, width), (rows * rs, rows * rs, rs, 1), t.storage_offset())
 
 
@@ -258,7 +268,7 @@ def stem_fused(x: torch.Tensor, w224: torch.Tensor, scale: torch.Tensor, bias: t
     """bf16 conv7x7/s2 + BN + ReLU + maxpool3x3/s2 in one kernel.  x [B,H,W,4] bf16, w224 [64,224] bf16."""
     _chk(x, torch.bfloat16); _chk(w224, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
     B, H, W, C = x.shape
-    assert C == 4 and w224.shape == (64, 224)
+    _require(C == 4 and w224.shape == (64, 224), 'argument check failed: C == 4 and w224.shape == (64, 224)')
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
     y = torch.empty((B, PH, PW, 64), device=x.device, dtype=torch.bfloat16)
@@ -272,7 +282,7 @@ def stem_fused_raw(images: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, 
     _chk(images, torch.float32); _chk(mean, torch.float32); _chk(std, torch.float32)
     _chk(w224, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
     B, C, H, W = images.shape
-    assert C == 3 and mean.numel() == 3 and std.numel() == 3 and w224.shape == (64, 224)
+    _require(C == 3 and mean.numel() == 3 and std.numel() == 3 and w224.shape == (64, 224), 'argument check failed: C == 3 and mean.numel() == 3 and std.numel() == 3 and w224.shape == (64, 224)')
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
     y = torch.empty((B, PH, PW, 64), device=images.device, dtype=torch.bfloat16)
@@ -290,7 +300,7 @@ def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:
     """[N,K] (N % 32 == 0, K % 16 == 0) -> same shape, re-ordered [N/32][K/16][2][32][8]: the order in which a wave's 64 lanes
     consume the matrix as v_mfma_f32_32x32x16_bf16 operands (lane = 32*(k%16 >= 8) + n%32 holds 8 consecutive k)."""
     N, K = w2d.shape
-    assert N % 32 == 0 and K % 16 == 0
+    _require(N % 32 == 0 and K % 16 == 0, 'argument check failed: N % 32 == 0 and K % 16 == 0')
     return w2d.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
@@ -298,7 +308,7 @@ def mfma_fragment_major_fp8(w2d: torch.Tensor) -> torch.Tensor:
     """[N,K] one-byte elements (N % 32 == 0, K % 64 == 0) -> same shape, re-ordered [N/32][K/64][2][64][16]: the two 16-byte
     pieces h = 0, 1 that lane l = 32*half + n%32 feeds to v_mfma_f32_32x32x64_f8f6f4 hold k = kf*64 + 32*half + 16*h + 0..15."""
     N, K = w2d.shape
-    assert N % 32 == 0 and K % 64 == 0 and w2d.element_size() == 1
+    _require(N % 32 == 0 and K % 64 == 0 and w2d.element_size() == 1, 'argument check failed: N % 32 == 0 and K % 64 == 0 and w2d.element_size() == 1')
     return w2d.view(N // 32, 32, K // 64, 2, 2, 16).permute(0, 2, 4, 3, 1, 5).contiguous().view(N, K)
 
 
@@ -318,17 +328,17 @@ def conv2d_fp8(x: torch.Tensor, w8frag: torch.Tensor, scale: torch.Tensor, bias:
                act=ACT_NONE, out_dtype=torch.bfloat16, residual=None, variant: int = 0) -> torch.Tensor:
     """fp8 (e4m3fn) NHWC conv on the K = 64 fp8 MFMA.  x [B,H,W,Cin] float8_e4m3fn, w8frag from `quantize_weights_fp8`
     ([Cout, k*k*Cin]); `scale` carries the de-quantisation (bn_scale * w_scale * x_scale).  variant 0 = by Cin."""
-    assert x.dtype == torch.float8_e4m3fn and w8frag.dtype == torch.float8_e4m3fn and x.is_contiguous() and w8frag.is_contiguous()
+    _require(x.dtype == torch.float8_e4m3fn and w8frag.dtype == torch.float8_e4m3fn and x.is_contiguous() and w8frag.is_contiguous(), 'argument check failed: x.dtype == torch.float8_e4m3fn and w8frag.dtype == torch.float8_e4m3fn and x.is_contiguous() and w8frag.is_contiguous()')
     B, H, W, Cin = x.shape
     Cout = w8frag.shape[0]
-    assert w8frag.shape[1] == ksize * ksize * Cin
+    _require(w8frag.shape[1] == ksize * ksize * Cin, 'argument check failed: w8frag.shape[1] == ksize * ksize * Cin')
     _chk(scale, torch.float32); _chk(bias, torch.float32)
     OH = (H + 2 * pad - ksize) // stride + 1
     OW = (W + 2 * pad - ksize) // stride + 1
     out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=out_dtype)
     if residual is not None:
         _chk(residual, out_dtype)
-        assert residual.shape == out.shape
+        _require(residual.shape == out.shape, 'argument check failed: residual.shape == out.shape')
     if not variant:
         variant = 3 if Cin % 128 == 0 else 32
     rc = _L().nopesac_conv2d_nhwc_fp8(_p(x), _p(w8frag), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, ksize, ksize,
@@ -347,12 +357,12 @@ def bottleneck_tail(b, w3, s3, b3, *, residual=None, x2=None, wsc=None, ssc=None
     C4 = w3.shape[0]
     CN = 0 if w1 is None else w1.shape[0]
     C2 = 0 if x2 is None else x2.shape[3]
-    assert (C, C4, CN, C2) in BOTTLENECK_TAIL_CONFIGS, (C, C4, CN, C2)
+    _require((C, C4, CN, C2) in BOTTLENECK_TAIL_CONFIGS, (C, C4, CN, C2))
     y = torch.empty((B, OH, OW, C4), device=b.device, dtype=torch.bfloat16)
     o = torch.empty((B, OH, OW, CN), device=b.device, dtype=torch.float8_e4m3fn if o_fp8 else torch.bfloat16) if CN else None
     if residual is not None:
         _chk(residual, torch.bfloat16)
-        assert residual.shape == y.shape
+        _require(residual.shape == y.shape, 'argument check failed: residual.shape == y.shape')
     if x2 is not None:
         _chk(x2, torch.bfloat16); _chk(wsc, torch.bfloat16)
     H2, W2 = (x2.shape[1], x2.shape[2]) if x2 is not None else (0, 0)
@@ -378,7 +388,7 @@ def upsample2x_bilinear(x: torch.Tensor, addend=None, act=ACT_NONE) -> torch.Ten
     y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=x.dtype)
     if addend is not None:
         _chk(addend, x.dtype)
-        assert addend.shape == y.shape
+        _require(addend.shape == y.shape, 'argument check failed: addend.shape == y.shape')
     _lib.check(_L().nopesac_upsample2x_bilinear_nhwc(_p(x), _p(addend), _p(y), B, H, W, C, act, _DT[x.dtype], _stream()),
                "nopesac_upsample2x_bilinear_nhwc")
     return y
@@ -387,7 +397,7 @@ def upsample2x_bilinear(x: torch.Tensor, addend=None, act=ACT_NONE) -> torch.Ten
 def upsample2x_nearest_add(x: torch.Tensor, lateral: torch.Tensor) -> torch.Tensor:
     _chk(x); _chk(lateral, x.dtype)
     B, H, W, C = x.shape
-    assert lateral.shape == (B, 2 * H, 2 * W, C)
+    _require(lateral.shape == (B, 2 * H, 2 * W, C), 'argument check failed: lateral.shape == (B, 2 * H, 2 * W, C)')
     y = torch.empty_like(lateral)
     _lib.check(_L().nopesac_upsample2x_nearest_add_nhwc(_p(x), _p(lateral), _p(y), B, H, W, C, _DT[x.dtype], _stream()),
                "nopesac_upsample2x_nearest_add_nhwc")
@@ -413,7 +423,7 @@ def layernorm(x: torch.Tensor, gamma, beta, res=None, addend=None, eps=1e-5):
     y2 = torch.empty_like(x) if addend is not None else None
     if res is not None:
         _chk(res, torch.float32)
-        assert res.shape == x.shape
+        _require(res.shape == x.shape, 'argument check failed: res.shape == x.shape')
     a_rows = 0 if addend is None else _chk(addend, torch.float32).numel() // D
     _lib.check(_L().nopesac_layernorm(_p(x), _p(res), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(y),
                                       _p(addend), a_rows, _p(y2), rows, D, eps, _stream()), "nopesac_layernorm")
@@ -427,12 +437,12 @@ def layernorm_ex(x: torch.Tensor, gamma, beta, res=None, addend=None, eps=1e-5, 
     D = x.shape[-1]
     rows = x.numel() // D
     out = {k: torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if k.endswith("16") else torch.float32) for k in want}
-    assert set(want) <= {"y", "y16", "y2", "y2_16"} and want
+    _require(set(want) <= {"y", "y16", "y2", "y2_16"} and want, 'argument check failed: set(want) <= {"y", "y16", "y2", "y2_16"} and want')
     if res is not None:
         _chk(res, torch.float32)
-        assert res.shape == x.shape
+        _require(res.shape == x.shape, 'argument check failed: res.shape == x.shape')
     a_rows = 0 if addend is None else _chk(addend, torch.float32).numel() // D
-    assert addend is not None or not ({"y2", "y2_16"} & set(want))
+    _require(addend is not None or not ({"y2", "y2_16"} & set(want)), 'argument check failed: addend is not None or not ({"y2", "y2_16"} & set(want))')
     _lib.check(_L().nopesac_layernorm_ex(_p(x), _p(res), _p(_chk(gamma, torch.float32)), _p(_chk(beta, torch.float32)), _p(out.get("y")),
                                          _p(addend), a_rows, _p(out.get("y2")), _p(out.get("y16")), _p(out.get("y2_16")), rows, D, eps,
                                          _stream()), "nopesac_layernorm_ex")
@@ -460,9 +470,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Lq: int
     """q [B*Lq, >=heads*32] etc. as (possibly column-sliced) row-major matrices -> o [B*Lq, heads*32]."""
     io16 = q.dtype == torch.bfloat16          # bf16 q/k/v in memory -> bf16 o (MFMA kernel only)
     for t in (q, k, v):
-        assert t.is_cuda and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1
-    assert q.dtype == torch.float32 or (io16 and mfma_bf16)
-    assert q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk
+        _require(t.is_cuda and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1, 'argument check failed: t.is_cuda and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1')
+    _require(q.dtype == torch.float32 or (io16 and mfma_bf16), 'argument check failed: q.dtype == torch.float32 or (io16 and mfma_bf16)')
+    _require(q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk, 'argument check failed: q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk')
     o = torch.empty((B * Lq, heads * 32), device=q.device, dtype=q.dtype)
     fn = _L().nopesac_attention_small_bf16io if io16 else (_L().nopesac_attention_small_bf16 if mfma_bf16 else _L().nopesac_attention_small)
     rc = fn(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0), B, Lq, Lk,
@@ -505,7 +515,7 @@ def postselect_planes(cls_logits, mask_prob, params, query_feat, H, W, score_thr
         _, nq2, h, w = mask_prob.shape
     else:
         _, h, w, nq2 = mask_prob.shape
-    assert nq2 == nq
+    _require(nq2 == nq, 'argument check failed: nq2 == nq')
     D = query_feat.shape[-1]
     dev = cls_logits.device
     i32 = dict(device=dev, dtype=torch.int32)
@@ -631,10 +641,10 @@ def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out:
     W: fragment-major bf16 weights "wq" (pre-scaled), "wk", "wv", "wm", "w0", "w2" and f32 "g1", "b1", "g2", "b2"."""
     for t in (x, src, out):
         _chk(t, torch.float32)
-        assert t.dim() == 3 and t.shape[2] == 256
+        _require(t.dim() == 3 and t.shape[2] == 256, 'argument check failed: t.dim() == 3 and t.shape[2] == 256')
     nq = x.shape[1]
-    assert nq <= 64 and src.shape[1] == nq and out.shape[1] == nq
-    assert x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0]
+    _require(nq <= 64 and src.shape[1] == nq and out.shape[1] == nq, 'argument check failed: nq <= 64 and src.shape[1] == nq and out.shape[1] == nq')
+    _require(x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0], 'argument check failed: x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0]')
     if lens is not None:
         _chk(lens, torch.int32)
     rc = _L().nopesac_gnn_layer_bf16(_p(x), x_off, _p(src), src_off, _p(out), out_off, n_sets, nq, _p(lens), _p(lens),
@@ -649,7 +659,7 @@ def encoder_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, pos=None, want=
     attn bf16 [M,256], src f32 [M,256]; W: fragment-major bf16 "wo", "w1", "w2" + f32 "bo", "g1", "be1", "b1", "b2", "g2", "be2"."""
     _chk(attn, torch.bfloat16); _chk(src, torch.float32)
     M = src.shape[0]
-    assert attn.shape == (M, 256) and src.shape == (M, 256)
+    _require(attn.shape == (M, 256) and src.shape == (M, 256), 'argument check failed: attn.shape == (M, 256) and src.shape == (M, 256)')
     out = {k: torch.empty(M, 256, device=src.device, dtype=torch.float32 if k == "y" else torch.bfloat16) for k in want}
     if pos is not None:
         _chk(pos, torch.float32)
@@ -676,7 +686,7 @@ def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scal
     _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
     B, H, W, C = c1.shape
     nq = mask_w.shape[1]
-    assert C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0
+    _require(C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0, 'argument check failed: C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0')
     mw = torch.zeros(B, 64, 256, device=c1.device, dtype=torch.bfloat16)
     mw[:, :nq] = mask_w
     mw = mw.view(B, 2, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()          # per-image MFMA fragment-major
@@ -696,7 +706,7 @@ def decoder_tail(attn: torch.Tensor, tgt: torch.Tensor, W: dict, pos=None, want=
     want: "y" (f32 residual stream), "y16" / "ypos16" (bf16 of the normalised result / + pos), "yn" (f32 normalised)."""
     _chk(attn, torch.bfloat16); _chk(tgt, torch.float32)
     M = tgt.shape[0]
-    assert attn.shape == (M, 256) and tgt.shape == (M, 256)
+    _require(attn.shape == (M, 256) and tgt.shape == (M, 256), 'argument check failed: attn.shape == (M, 256) and tgt.shape == (M, 256)')
     out = {k: torch.empty(M, 256, device=tgt.device, dtype=torch.float32 if k in ("y", "yn") else torch.bfloat16) for k in want}
     if pos is not None:
         _chk(pos, torch.float32)
@@ -711,7 +721,7 @@ def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: tor
     """bf16 3x3/s1/p1 conv 64 -> 64 + BN + act from an LDS halo tile (csrc/conv3x3_c64.hip).  x [B,H,W,64], w [64,3,3,64]."""
     _chk(x, torch.bfloat16); _chk(w, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)
     B, H, W, C = x.shape
-    assert C == 64 and tuple(w.shape) == (64, 3, 3, 64)
+    _require(C == 64 and tuple(w.shape) == (64, 3, 3, 64), 'argument check failed: C == 64 and tuple(w.shape) == (64, 3, 3, 64)')
     y = torch.empty_like(x)
     _lib.check(_L().nopesac_conv3x3_c64_bf16(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(y), B, H, W, act, _stream()),
                "nopesac_conv3x3_c64_bf16")

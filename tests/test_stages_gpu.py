@@ -226,6 +226,28 @@ def test_camera_head_ragged_batch(device, model, O, sd50):
             assert rel_err(out["refine"]["maps"]["trans_all"][b, : m + 1].cpu(), g["camera_onePP_tran"]) < 1e-4
 
 
+def test_backbone_full_resolution_fp32_and_bf16(device, model, O, sd50):
+    """The backbone at the REAL input size (480x640, the only one the architecture accepts) against the oracle - the 64x96 probe
+    above is the reference-pinned fixture, this is the size every e2e test and the benchmark run: fp32 path within 2e-5 of the
+    oracle on every returned level (res2..res5); the bf16 path (fused stem, halo 3x3, fused tails, 256x256 conv kernel - all of
+    them) judged against the SAME fp32 oracle, not against this implementation's own kernels: relative error of a 50-layer bf16
+    network, bounded at 3e-2 of each level's range."""
+    from nopesac_amd.synth import synth_pair
+    from tests.util import make_model
+    pair = synth_pair(21, structured=True)
+    imgs = [pair["0"]["image"], pair["1"]["image"]]
+    ref = O.backbone(sd50, O.preprocess(imgs, O.OracleConfig()))
+    with torch.no_grad():
+        f32 = model.backbone(model.preprocess_image([pair]))
+        m16 = make_model(device, dtype="bfloat16")
+        f16 = m16.backbone(None, raw=(m16.stack_images([pair]), m16.pixel_mean, m16.pixel_std))
+    for k in ref:
+        assert tuple(f32[k].shape) == (2,) + tuple(ref[k].shape[2:]) + (ref[k].shape[1],)
+        assert rel_err(nchw(f32[k].float()), ref[k]) < 2e-5, k
+        e16 = rel_err(nchw(f16[k].float()), ref[k])
+        assert e16 < 3e-2, (k, e16)
+
+
 def test_fused_gnn_layers_match_per_launch_bf16_path(device):
     """bf16 mode: the fused one-workgroup-per-set GNN layer kernel (csrc/gnn_layer.hip) vs the per-launch bf16 path on ragged
     plane sets, all 18 layers chained.  The two differ only in rounding (1/sqrt(32) folded into Wq, LayerNorm summation
