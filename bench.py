@@ -193,6 +193,18 @@ class ConvTimer:
             d["launches"] += 1
         return out
 
+    def split_by_bound(self, kernel_prefix, dtype="torch.bfloat16", ridge=2500e12 / 8e12):
+        """The launches of one kernel template split at the machine's ridge point (peak MFMA FLOP/s / peak HBM B/s = 312 FLOP/B):
+        layers above it are priced against the MFMA peak, layers below it against the HBM peak (their algorithmic bytes)."""
+        torch.cuda.synchronize()
+        out = {"mfma_bound": {"flops": 0.0, "bytes": 0.0, "ms": 0.0, "launches": 0}, "hbm_bound": {"flops": 0.0, "bytes": 0.0, "ms": 0.0, "launches": 0}}
+        for dt, fl, e0, e1, nb, desc in self.records:
+            if dt != dtype or "[" not in desc or not desc[desc.rindex("[") + 1:-1].startswith(kernel_prefix):
+                continue
+            d = out["mfma_bound" if fl / max(nb, 1.0) >= ridge else "hbm_bound"]
+            d["flops"] += fl; d["bytes"] += nb; d["ms"] += e0.elapsed_time(e1); d["launches"] += 1
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -476,13 +488,26 @@ def main():
             if hit:
                 traffic = round(sum(kv["read_bytes_per_step"] + kv["write_bytes_per_step"] for kv in hit) / sum(kv["launches_per_step"] for kv in hit))
             traffic_src = os.path.relpath(path, ROOT)
+    split = timer.split_by_bound(dom_name, key) if args.dtype == "bfloat16" else None
+    by_bound = None
+    if split:
+        mb, hb = split["mfma_bound"], split["hbm_bound"]
+        by_bound = {"ridge_flop_per_byte": 312.5,
+                    "mfma_bound_layers": {"launches": mb["launches"], "ms": round(mb["ms"], 3), "TFLOP/s": round(mb["flops"] / max(mb["ms"], 1e-9) / 1e9, 1),
+                                          "frac_of_mfma_peak": round(mb["flops"] / max(mb["ms"], 1e-9) / 1e9 / peak, 4)},
+                    "hbm_bound_layers": {"launches": hb["launches"], "ms": round(hb["ms"], 3), "TB/s_algorithmic": round(hb["bytes"] / max(hb["ms"], 1e-9) / 1e9, 2),
+                                         "frac_of_hbm_peak": round(hb["bytes"] / max(hb["ms"], 1e-9) / 1e9 / 8.0, 4),
+                                         "TFLOP/s": round(hb["flops"] / max(hb["ms"], 1e-9) / 1e9, 1)},
+                    "note": "launches of the dominant kernel split at the ridge point of the machine (2.5 PFLOP/s / 8 TB/s): the 1x1 convs with "
+                            "K <= 1024 and their residual streams are HBM-bound whatever the kernel does; `frac` above prices ALL launches "
+                            "against the MFMA peak"}
     roofline = {"bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (PMC)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
-                "step_share": round(dom["ms"] / ms_per_step, 3),
+                "step_share": round(dom["ms"] / ms_per_step, 3), "by_bound": by_bound,
                 "instantiations": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"],
                                        "avg_launch_us": round(1e3 * v["ms"] / max(v["launches"], 1), 2)} for k, v in inst.items() if k.split("<")[0] == dom_name},
                 "conv_family": {"note": "every bf16 conv / fused-conv launch of the step (MFMA- and HBM-bound layers together)",
