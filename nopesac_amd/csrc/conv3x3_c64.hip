@@ -40,12 +40,24 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
 
     // ---- halo tile -> LDS (zero outside the image)
     const bf16_t* xb = x + (long long)b * H * W * C3_C;
-    for (int i = tid; i < C3_HT * C3_HT * 8; i += 256) {
-        const int px = i >> 3, ch = (i & 7) * 8;
-        const int iy = y0 - 1 + px / C3_HT, ix = x0 - 1 + px % C3_HT;
-        us8 v = us8{};
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const us8*>(xb + ((long long)iy * W + ix) * C3_C + ch);
-        *reinterpret_cast<us8*>(lds + px * C3_PXB + ch * 2) = v;
+    {   // all 11 loads of a thread go out before the first LDS write (the rolled load -> ds_write loop exposed one memory round trip
+        // per iteration: the workgroup spent ~40 k cycles staging for 4.6 k cycles of MFMA work per wave)
+        constexpr int NIT = (C3_HT * C3_HT * 8 + 255) / 256;
+        us8 hv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int px = i >> 3, ch = (i & 7) * 8;
+            const int iy = y0 - 1 + px / C3_HT, ix = x0 - 1 + px % C3_HT;
+            hv[it] = us8{};
+            if (i < C3_HT * C3_HT * 8 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                hv[it] = *reinterpret_cast<const us8*>(xb + ((long long)iy * W + ix) * C3_C + ch);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < C3_HT * C3_HT * 8) *reinterpret_cast<us8*>(lds + (i >> 3) * C3_PXB + (i & 7) * 16) = hv[it];
+        }
     }
     __syncthreads();
 

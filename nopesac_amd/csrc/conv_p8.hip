@@ -503,6 +503,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             unsigned char* sb = lds + BUF * P8_STAGE;            // tile t (and tile t+2's A0 piece)
             unsigned char* nb = lds + (BUF ^ 1) * P8_STAGE;      // tile t+1
             const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            const bool pst = STAMP && stamp_now && t == 10;      // per-phase stamps of one mid-loop K-tile (tuning build)
             auto mfma_phase = [&](auto MIC, auto KHC) {
                 constexpr int MI = decltype(MIC)::value, KH = decltype(KHC)::value;
 #pragma unroll
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 }
             };
             // ---- phase 1: pixel half 0, K half 0.  reads A0 + B(kh0); stages BL(t+1)
+            if constexpr (STAMP) { if (pst) est[0] = __builtin_readcyclecounter(); }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bfr[j][0] = *(const bf16x8*)(sb + b_row_off + j * 32 * P8_ROWB + so0);
@@ -529,8 +531,10 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             load_a(0, so0, so1);
             if (has1) stage_b(nb, 0);
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[1] = __builtin_readcyclecounter(); }
             mfma_phase(IC<0>{}, IC<0>{});
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[2] = __builtin_readcyclecounter(); }
             // ---- phase 2: pixel half 0, K half 1.  reads A0 + B(kh1); stages BH(t+1); A1(t) must have landed before phase 3
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -545,14 +549,18 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[3] = __builtin_readcyclecounter(); }
             mfma_phase(IC<0>{}, IC<1>{});
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[4] = __builtin_readcyclecounter(); }
             // ---- phase 3: pixel half 1, K half 0.  reads A1; stages A1(t+1)
             load_a(1, so0, so1);
             if (has1) stage_a(nb, 1);
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[5] = __builtin_readcyclecounter(); }
             mfma_phase(IC<1>{}, IC<0>{});
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[6] = __builtin_readcyclecounter(); }
             // ---- phase 4: pixel half 1, K half 1.  reads A1; stages A0(t+2) into THIS buffer (A0 of tile t is dead since phase 2);
             //      A0 / BL / BH of tile t+1 must have landed before the next tile's phase 1
             load_a(1, so2, so3);
@@ -564,8 +572,10 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // newer than BH(t+1): A1(t+1)
             }
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[7] = __builtin_readcyclecounter(); }
             mfma_phase(IC<1>{}, IC<1>{});
             P8_BAR();
+            if constexpr (STAMP) { if (pst) est[8] = __builtin_readcyclecounter(); }
         };
         {
             int t = 0;
@@ -591,12 +601,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         if constexpr (EPI16) p8_epilogue16_prefetch(epr16, p, cur_n0, wc, lane);
         else p8_epilogue_prefetch<EPI>(epr, p, cur_m0, cur_n0, tid);  // BEFORE the DMAs (in-order vmcnt)
         if constexpr (STAMP) {
-            if (stamp_now) est[4] = __builtin_readcyclecounter();
+            if (stamp_now) est[9] = __builtin_readcyclecounter();
         }
         if (more) {
             set_tile(next);                                      // ALU work under the latency of the prefetch loads
             if constexpr (STAMP) {
-                if (stamp_now) est[5] = __builtin_readcyclecounter();
+                if (stamp_now) est[10] = __builtin_readcyclecounter();
             }
             // retire the prefetch loads HERE: behind the conditional DMAs the compiler cannot count (0 or 8 younger operations) and
             // would wait vmcnt(0) at the first use of scale / bias - i.e. for the DMAs' HBM round trip (measured: 12 k cycles)
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             }
             stage_first();
             if constexpr (STAMP) {
-                if (stamp_now) est[6] = __builtin_readcyclecounter();
+                if (stamp_now) est[11] = __builtin_readcyclecounter();
             }
         }
         if constexpr (EPI16) p8_epilogue16<EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr16);

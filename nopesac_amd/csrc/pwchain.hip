@@ -711,6 +711,8 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
     hipStream_t st = (hipStream_t)stream;
     const int c2 = x2 ? C2 : 0;
 #define PW_CASE(c, c4, cn, cc2, bm) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch<c, c4, cn, cc2, bm>(a, st); NPS_LAUNCH_RET(); }
+    // (measured in round 2: 64 pixels per workgroup for res3 - half the weight traffic from L2 but ONE 4-wave workgroup per CU - is
+    //  slower, 322 vs 272 us on the identity tail: the 32-pixel form stays)
     PW_CASE(64, 256, 64, 0, 64) PW_CASE(64, 256, 128, 0, 64) PW_CASE(64, 256, 64, 64, 64) PW_CASE(64, 256, 0, 0, 64) PW_CASE(64, 256, 0, 64, 64)
     PW_CASE(128, 512, 128, 0, 32) PW_CASE(128, 512, 256, 0, 32) PW_CASE(128, 512, 128, 256, 32) PW_CASE(128, 512, 0, 0, 32) PW_CASE(128, 512, 0, 256, 32)
 #undef PW_CASE

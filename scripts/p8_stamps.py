@@ -26,7 +26,7 @@ sc, bi = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
 y = torch.empty(B, OH, OW, Cout, device=dev, dtype=torch.bfloat16)
 nwg = ((B * OH * OW + 255) // 256) * (Cout // 256)
 nk = k * k * Cin // 64
-for variant, which in ((24, 0), (24, 1), (24, 2)):
+for variant, which in ((24, 1),):
     buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device=dev)
     L.nps_p8_debug_buffer(buf.data_ptr())
     L.nps_p8_debug_tile(which)
@@ -42,10 +42,13 @@ for variant, which in ((24, 0), (24, 1), (24, 2)):
     print("variant %d: %d tiles on %d persistent workgroups, %d K-tiles; tile #%d of every workgroup: prologue %.0f  loop %.0f (= %.0f per K-tile, "
           "%.0f per interval)  epilogue incl. store drain %.0f cycles (mean over waves)" % (
               variant, nwg, int(live.sum()), nk, which, pro.mean(), loop.mean(), loop.mean() / nk, loop.mean() / nk / 8, epi.mean()))
-    e = t[:, :, 4:16] - t[:, :, 2:3]
-    names = ["pass0 done", "pass1 done", "pass2 done", "pass3 done", "prefetch issued", "set_tile done", "DMAs issued", "p0 staged", "p0 synced", "p0 scaled",
-             "p0 act done"]
-    order = [4, 5, 6, 7, 8, 9, 10, 0, 1, 2, 3]
-    print("   after the K loop's end (mean cycles): " + ", ".join("%s %.0f" % (names[i], float(e[:, :, i].mean())) for i in order))
+    e = t[:, :, 4:16]
+    ph = e[:, :, 0:9]                                  # K-tile 10: phase starts / barrier-1 crossings
+    for grp, sl in (("leading waves 0-3", slice(0, 4)), ("lagging waves 4-7", slice(4, 8))):
+        d = (ph[:, sl, 1:] - ph[:, sl, :-1]).mean(dim=(0, 1))
+        print("   K-tile 10, %s: [load | mfma] intervals per phase: %s   (sum %.0f)" % (
+            grp, "  ".join("%.0f | %.0f" % (float(d[2 * k]), float(d[2 * k + 1])) for k in range(4)), float(d.sum())))
+    it = e[:, :, 9:12] - t[:, :, 2:3]
+    print("   after the K loop's end (mean cycles): prefetch issued %.0f, row table + addresses %.0f, DMAs issued %.0f" % tuple(float(it[:, :, k].mean()) for k in range(3)))
     print("   per-wave loop cycles of workgroup 0:", [int(v) for v in loop[0].tolist()])
 L.nps_p8_debug_buffer(None)
