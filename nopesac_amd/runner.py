@@ -29,7 +29,12 @@ def init_distributed(backend: Optional[str] = None):
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            try:      # bind the communicator to this rank's GPU (barrier() would otherwise guess the device from the rank)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            except TypeError:                                      # older torch: no device_id argument
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
