@@ -343,6 +343,15 @@ def test_encoder_tail(device, M):
     assert _rel(out["y"], ref["y"]) < 5e-3
     assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2
     assert float((out["y"] - ref["y"]).abs().mean()) < 2e-4 * float(ref["y"].abs().mean() + 1)
+    # ... and against an INDEPENDENT fp32 PyTorch reference of the same op (bf16 weights / attention input as given, everything
+    # else in f32 on the CPU): the only differences left are the bf16 roundings of the LN1 output and of the FFN hidden tile
+    a, sr = attn.float().cpu(), src.cpu()
+    s_ = a @ wo.float().cpu().T + bo.cpu() + sr
+    y1 = F.layer_norm(s_, (256,), g1.cpu(), be1.cpu(), 1e-5)
+    h_ = F.relu(y1 @ w1.float().cpu().T + b1.cpu())
+    y2 = F.layer_norm(h_ @ w2.float().cpu().T + b2.cpu() + y1, (256,), g2.cpu(), be2.cpu(), 1e-5)
+    assert _rel(out["y"].cpu(), y2) < 1.5e-2, _rel(out["y"].cpu(), y2)
+    assert float((out["y"].cpu() - y2).abs().mean()) < 2e-3 * float(y2.abs().mean() + 1)
 
 
 @pytest.mark.parametrize("H,W,OH,OW", [(968, 1296, 480, 640), (480, 640, 480, 640), (37, 53, 48, 64), (1000, 700, 480, 640)])
@@ -424,10 +433,17 @@ def test_decoder_tail(device, M, last):
     h = ops.linear(t16, w1, b1, act=ops.ACT_RELU, out_dtype=torch.bfloat16)
     u = ops.linear(h, w2, b2, residual=s, out_dtype=torch.float32)
     ref = ops.layernorm_ex(u, gn, ben, addend=qpos, want=("y", "y16", "y2_16"))
+    # independent fp32 PyTorch reference (pre-norm decoder tail: transformer.py:293-322 after the cross-attention)
+    a, tg = attn.float().cpu(), tgt.cpu()
+    s_ = a @ wo.float().cpu().T + bo.cpu() + tg
+    u_ = s_ + F.relu(F.layer_norm(s_, (256,), g3.cpu(), be3.cpu(), 1e-5) @ w1.float().cpu().T + b1.cpu()) @ w2.float().cpu().T + b2.cpu()
+    n_ = F.layer_norm(u_, (256,), gn.cpu(), ben.cpu(), 1e-5)
     if last:
         assert set(out) == {"yn"} and _rel(out["yn"], ref["y"]) < 5e-3
+        assert _rel(out["yn"].cpu(), n_) < 1.5e-2
     else:
         assert _rel(out["y"], u) < 5e-3
+        assert _rel(out["y"].cpu(), u_) < 1.5e-2
         assert _rel(out["y16"].float(), ref["y16"].float()) < 1e-2 and _rel(out["ypos16"].float(), ref["y2_16"].float()) < 1e-2
 
 

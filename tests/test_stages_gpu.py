@@ -273,7 +273,9 @@ def test_fused_gnn_layers_match_per_launch_bf16_path(device):
             worst_fused = max(worst_fused, rel_err(d[b, :n], f[b, :n]))
             worst_plain = max(worst_plain, rel_err(r[b, :n], f[b, :n]))
             assert rel_err(d[b, :n], r[b, :n]) < 6e-2
+    print("fused GNN vs fp32 path: worst rel err fused %.4f, per-launch bf16 %.4f" % (worst_fused, worst_plain))
     assert worst_fused < 1.25 * worst_plain + 5e-3, (worst_fused, worst_plain)
+    assert worst_fused < 5e-2, worst_fused        # against the fp32 path (itself oracle-checked): 18 bf16 layers, measured 0.028
     assert torch.isfinite(d0).all() and torch.isfinite(d1).all()
 
 
