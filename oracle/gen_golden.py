@@ -175,6 +175,17 @@ def main():
             probes[k + "_sum"] = f_ref[k].double().sum()
             probes[k + "_probe"] = f_ref[k].flatten()[:: max(f_ref[k].numel() // 64, 1)][:64]
         save("A_backbone_64x96", **probes)
+        # the same at the size every end-to-end test and the benchmark run (480 x 640): 64-value probes + sums per level
+        img = synth_pair(21, structured=True)["0"]["image"]
+        x_ref = model.preprocess_image([{"image": img}]).tensor
+        f_ref = model.backbone(x_ref)
+        f_or = O.backbone(sd, x_ref)
+        probes = {}
+        for k in f_ref:
+            rep.check(f"backbone480.{k}", f_or[k], f_ref[k], 2e-5)
+            probes[k + "_sum"] = f_ref[k].double().sum()
+            probes[k + "_probe"] = f_ref[k].flatten()[:: max(f_ref[k].numel() // 64, 1)][:64]
+        save("A_backbone_480x640", **probes)
 
         # ---- B plane head on small designed features --------------------------------------
         print("[B] plane head")

@@ -28,6 +28,18 @@ def test_backbone(sd50):
         assert abs(float(v.double().sum()) - float(g[k + "_sum"])) < 1e-4 * abs(float(g[k + "_sum"]))
 
 
+def test_backbone_full_resolution(sd50):
+    """The oracle's backbone at the real input size (480x640) against the imported reference's (fixture A_backbone_480x640)."""
+    from nopesac_amd.synth import synth_pair
+    img = synth_pair(21, structured=True)["0"]["image"]
+    with torch.no_grad():
+        f = O.backbone(sd50, O.preprocess([img], CFG))
+    g = gold("A_backbone_480x640")
+    for k, v in f.items():
+        assert rel_err(v.flatten()[:: max(v.numel() // 64, 1)][:64], g[k + "_probe"]) < 1e-5
+        assert abs(float(v.double().sum()) - float(g[k + "_sum"])) < 1e-4 * abs(float(g[k + "_sum"]))
+
+
 def test_plane_head(sd50):
     with torch.no_grad():
         out, q = O.plane_head(sd50, GI.feature_maps(21, 6, 8), CFG)

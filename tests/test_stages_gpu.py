@@ -241,9 +241,13 @@ def test_backbone_full_resolution_fp32_and_bf16(device, model, O, sd50):
         f32 = model.backbone(model.preprocess_image([pair]))
         m16 = make_model(device, dtype="bfloat16")
         f16 = m16.backbone(None, raw=(m16.stack_images([pair]), m16.pixel_mean, m16.pixel_std))
+    g = gold("A_backbone_480x640")               # the imported reference's backbone on view "0" of the same pair
     for k in ref:
         assert tuple(f32[k].shape) == (2,) + tuple(ref[k].shape[2:]) + (ref[k].shape[1],)
         assert rel_err(nchw(f32[k].float()), ref[k]) < 2e-5, k
+        v0 = nchw(f32[k][:1].float()).cpu()
+        assert rel_err(v0.flatten()[:: max(v0.numel() // 64, 1)][:64], g[k + "_probe"]) < 2e-5, k
+        assert abs(float(v0.double().sum()) - float(g[k + "_sum"])) < 2e-5 * float(v0.double().abs().sum()), k
         e16 = rel_err(nchw(f16[k].float()), ref[k])
         assert e16 < 3e-2, (k, e16)
 
