@@ -106,6 +106,38 @@ int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, con
                            int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* stream);
 
+/* ---- a stack of Linear(+bias)(+activation) layers in ONE launch (csrc/mlp_chain.hip) --------------------------------------------
+ * Replaces one nopesac_conv2d_nhwc launch per layer for the row-wise MLP stacks of the heads in bf16 mode (reference:
+ * camera_net/camera_head.py:957-990 geo_encoder / geo_proj_s1 / decoder_rot / geo_proj_s2 / decoder_tran / decoder_rot2 /
+ * decoder_tran2 / rots / trans; :685-735 rot_emb_proj / trans_emb_proj; :1090-1100 normal_score_proj / param_score_proj).
+ * Row r of the chain input = [ xb[r / xb_rows_per][0 .. xb_width) | x[r][0 .. x_width) ] (the broadcast prefix is optional:
+ * xb_width = 0).  Layer l: y = act(y_prev . W_l^T + bias_l); f32 accumulation, operands rounded to bf16 (RNE) exactly where the
+ * per-layer launches round them.  A layer with `out` != NULL also writes its f32 output rows to out[r * out_ld + n] (n < N); the
+ * last layer must.  Weights: bf16, packed for K padded to nopesac_mlp_padded_k(N, K) and N padded to a multiple of 32 (zeros) in
+ * MFMA fragment-major order [Np/32][Kp/16][64 lanes][8] (nopesac_amd.ops.mlp_pack); bias: f32[Np] (zero padded) or NULL.
+ * Limits: chain input <= NOPESAC_MLP_MAX_IN columns, every N <= NOPESAC_MLP_MAX_WIDTH, <= NOPESAC_MLP_MAX_LAYERS layers. */
+#define NOPESAC_MLP_MAX_IN 1280
+#define NOPESAC_MLP_MAX_WIDTH 1024
+#define NOPESAC_MLP_MAX_LAYERS 12
+typedef struct nopesac_mlp_layer {
+    const void* w;
+    const float* bias;
+    float* out;
+    int64_t out_ld;
+    int K, N, act, reserved;
+} nopesac_mlp_layer;
+typedef struct nopesac_mlp_chain {
+    const float* x;
+    int64_t x_ld;
+    const float* xb;
+    int64_t xb_ld;
+    int x_width, xb_width, xb_rows_per, rows, n_layers, reserved;
+    nopesac_mlp_layer layers[NOPESAC_MLP_MAX_LAYERS];
+} nopesac_mlp_chain;
+int nopesac_mlp_padded_k(int N, int K);
+int64_t nopesac_mlp_packed_elems(int N, int K);
+int nopesac_mlp_chain_bf16(const nopesac_mlp_chain* chain, void* stream);
+
 /* fp8 (OCP e4m3fn) conv on the gfx950 K=64 fp8 MFMA (v_mfma_f32_32x32x64_f8f6f4, unit block scales; 2x the bf16 MFMA rate): x is
  * fp8 NHWC, w_frag8 the fp8 [Cout][KH*KW*Cin] matrix in the fp8 fragment-major order
  *   [Cout/32][K/64][2][64][16]:  byte j of piece h of lane l = w[nt*32 + (l & 31)][kf*64 + 32*(l >> 5) + 16*h + j]
@@ -341,6 +373,9 @@ int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canoni
  * traps NaN poses with pdb.set_trace() (camera_net/camera_head.py:185-187, 681-682, 1072-1074); the drop-in counts them on the
  * device and raises FloatingPointError when the results are fetched (MODEL.AMD.CHECK_FINITE). */
 int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream);
+/* the same for up to NOPESAC_NONFINITE_MAX_TENSORS tensors in ONE launch: x / n are HOST arrays of device pointers / element counts */
+#define NOPESAC_NONFINITE_MAX_TENSORS 16
+int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n_tensors, int32_t* count, void* stream);
 
 /* One GNN layer of the plane matcher (transformer/gnn.py:73-96) for n_sets plane sets, one workgroup per set, bf16 MFMA
  * operands / f32 residual stream (csrc/gnn_layer.hip).  Feature buffers are f32 [sets][nq][256] (nq <= 64); workgroup b updates

@@ -62,8 +62,25 @@ SIGNATURES = {
     "nopesac_refilter_assignment": [P, P, P, P, P, P, P, I, I, P, P],
     "nopesac_normalize_rows": [P, P, I, I, I, P],
     "nopesac_count_nonfinite": [P, L, P, P],
+    "nopesac_count_nonfinite_batch": [P, P, I, P, P],
+    "nopesac_mlp_padded_k": [I, I],
+    "nopesac_mlp_packed_elems": [I, I],
+    "nopesac_mlp_chain_bf16": [P, P],
 }
-_RESTYPE = {"nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64}
+_RESTYPE = {"nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64}
+
+MLP_MAX_IN, MLP_MAX_WIDTH, MLP_MAX_LAYERS = 1280, 1024, 12       # NOPESAC_MLP_* of the header
+
+
+class MlpLayer(ctypes.Structure):           # nopesac_mlp_layer
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("out_ld", c_int64), ("K", c_int), ("N", c_int), ("act", c_int),
+                ("reserved", c_int)]
+
+
+class MlpChain(ctypes.Structure):           # nopesac_mlp_chain
+    _fields_ = [("x", c_void_p), ("x_ld", c_int64), ("xb", c_void_p), ("xb_ld", c_int64), ("x_width", c_int), ("xb_width", c_int),
+                ("xb_rows_per", c_int), ("rows", c_int), ("n_layers", c_int), ("reserved", c_int), ("layers", MlpLayer * MLP_MAX_LAYERS)]
+
 
 _lib = None
 

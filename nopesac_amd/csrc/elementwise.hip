@@ -545,7 +545,40 @@ __global__ void count_nonfinite_kernel(const float* __restrict__ x, long long n,
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
 }
+struct NonfiniteBatch {
+    const float* x[NOPESAC_NONFINITE_MAX_TENSORS];
+    long long n[NOPESAC_NONFINITE_MAX_TENSORS];
+};
+// blockIdx.y = tensor: the camera list + planes of a forward pass (13 small tensors) in one launch instead of one each
+__global__ void count_nonfinite_batch_kernel(const NonfiniteBatch b, int* __restrict__ count) {
+    const float* __restrict__ x = b.x[blockIdx.y];
+    const long long n = b.n[blockIdx.y];
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(x[i]);
+        bad += ((u & 0x7f800000u) == 0x7f800000u) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
 }  // namespace nps
+
+extern "C" int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n_tensors, int32_t* count, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && n && count && n_tensors > 0 && n_tensors <= NOPESAC_NONFINITE_MAX_TENSORS, "count_nonfinite_batch: bad args");
+    NonfiniteBatch b;
+    long long nmax = 0;
+    for (int i = 0; i < NOPESAC_NONFINITE_MAX_TENSORS; ++i) {
+        const int j = i < n_tensors ? i : 0;
+        NPS_CHECK_ARG(x[j] && n[j] > 0, "count_nonfinite_batch: null / empty tensor");
+        b.x[i] = x[j]; b.n[i] = n[j];
+        if (n[j] > nmax) nmax = n[j];
+    }
+    const int blocks = (int)((nmax + 255) / 256 > 256 ? 256 : (nmax + 255) / 256);
+    hipLaunchKernelGGL(count_nonfinite_batch_kernel, dim3(blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, b, count);
+    NPS_LAUNCH_RET();
+}
 
 extern "C" int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream) {
     using namespace nps;

@@ -19,7 +19,7 @@ from .. import ops
 from ..registry import CAMERA_HEAD_REGISTRY
 from ..synth import state_dict_spec
 from .params import ConvW, ParamModule, conv_bias, conv_bn, mlp_layers
-from .plane_head import run_mlp
+from .plane_head import run_mlp, run_stacks
 
 CAM_MODES = {"soft": 0, "avg-all": 1, "min-cost": 2, "max-score": 3}
 
@@ -107,24 +107,24 @@ class PlaneCameraHead(ParamModule):
             aff_p[..., :h * w] = aff
             aff = aff_p
 
-        def branch(name, fc):
+        def branch(name, fc, reg):
             t = aff
             for i in range(6):
                 t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY)
-            return ops.linear(t.reshape(B, -1), P[fc].w2d(gd), P[fc].bias, act=ops.ACT_RELU)
+            # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
+            feat, raw = run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], gd)
+            return feat, raw
 
-        trans_feat, rots_feat = branch("convs_trans", "fc_trans"), branch("convs_rots", "fc_rots")
-        trans0 = ops.linear(trans_feat, P["trans"].w2d(gd), P["trans"].bias)
-        rot0 = ops.normalize_rows(ops.linear(rots_feat, P["rots"].w2d(gd), P["rots"].bias), canonical_sign=True)  # :667, :436-437
+        (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
+        rot0 = ops.normalize_rows(rot_raw, canonical_sign=True)                                   # :667, :436-437
         return trans0, rot0, trans_feat, rots_feat
 
     # ---------------------------------------------------------------- (ii) AIM
     def aim(self, trans0, rot0):
         P, gd = self.packed, self.gemm_dtype
-        rot_feat = run_mlp(rot0, P["rot_emb_proj"], final_act=ops.ACT_RELU, gd=gd)                  # rot0 already has w >= 0 (:695-696)
-        rec_rot = ops.normalize_rows(ops.linear(rot_feat, P["rots"].w2d(gd), P["rots"].bias))
-        trans_feat = run_mlp(trans0 + 1e-10, P["trans_emb_proj"], final_act=ops.ACT_RELU, gd=gd)    # :718
-        rec_trans = ops.linear(trans_feat, P["trans"].w2d(gd), P["trans"].bias)
+        rot_feat, rot_raw = run_stacks(rot0, [(P["rot_emb_proj"], ops.ACT_RELU, True), ([P["rots"]], ops.ACT_NONE, True)], gd)  # rot0 has w >= 0 (:695-696)
+        rec_rot = ops.normalize_rows(rot_raw)
+        trans_feat, rec_trans = run_stacks(trans0 + 1e-10, [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
         return rec_trans, rec_rot, trans_feat, rot_feat
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
@@ -135,21 +135,17 @@ class PlaneCameraHead(ParamModule):
         geo_local, geo_global, sig, geo_enc, m = ops.geo_sequence(A0, planes1, planes2, n1, n2, rec_trans, rec_rot,
                                                                   self.warp_plane_in_cam_ref_on)
         rows = B * nq
-        geo = run_mlp(geo_enc.view(rows, 8), P["geo_encoder"], gd=gd)
-        cat1280 = torch.empty(rows, 1280, device=dev, dtype=torch.float32)
-        cat_r = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
-        cat_t = torch.empty(B, nq, 512, device=dev, dtype=torch.float32)
-        cat_r[:, :, :256] = rot_feat[:, None, :]                                             # :980-983 broadcast of the initial feats
-        cat_t[:, :, :256] = trans_feat[:, None, :]
-        run_mlp(geo, P["geo_proj_s1"], out=cat1280[:, :1024], gd=gd)
-        f_rot = run_mlp(cat1280[:, :1024], P["decoder_rot"], out=cat1280[:, 1024:], gd=gd)
-        cat_r.view(rows, 512)[:, 256:] = f_rot                                               # geo_fea_rot_all feeds two consumers
-        s2 = run_mlp(cat1280, P["geo_proj_s2"], gd=gd)
-        run_mlp(s2, P["decoder_tran"], out=cat_t.view(rows, 512)[:, 256:], gd=gd)
-        fused_rot = run_mlp(cat_r.view(rows, 512), P["decoder_rot2"], final_act=ops.ACT_RELU, gd=gd)
-        fused_tran = run_mlp(cat_t.view(rows, 512), P["decoder_tran2"], final_act=ops.ACT_RELU, gd=gd)
-        rot_raw = ops.linear(fused_rot, P["rots"].w2d(gd), P["rots"].bias).view(B, nq, 4)
-        trans_raw = ops.linear(fused_tran, P["trans"].w2d(gd), P["trans"].bias).view(B, nq, 3)
+        # (:957-990) row-wise MLP stacks; in bf16 GEMM mode each run_stacks call is ONE launch (csrc/mlp_chain.hip): 40 GEMMs -> 5
+        cat1280 = torch.empty(rows, 1280, device=dev, dtype=torch.float32)                   # [ geo_proj_s1 out | decoder_rot out ]
+        run_stacks(geo_enc.view(rows, 8), [(P["geo_encoder"], ops.ACT_NONE, None), (P["geo_proj_s1"], ops.ACT_NONE, cat1280[:, :1024])], gd)
+        f_rot = run_stacks(cat1280[:, :1024], [(P["decoder_rot"], ops.ACT_NONE, cat1280[:, 1024:])], gd)[0]   # geo_fea_rot_all: two consumers
+        f_tran = run_stacks(cat1280, [(P["geo_proj_s2"], ops.ACT_NONE, None), (P["decoder_tran"], ops.ACT_NONE, True)], gd)[1]
+        # (:980-983) the initial pose features are broadcast over the pair's planes and concatenated in front of the per-plane ones
+        fused_rot, rot_raw = run_stacks(f_rot, [(P["decoder_rot2"], ops.ACT_RELU, True), ([P["rots"]], ops.ACT_NONE, True)], gd,
+                                        x_bcast=rot_feat, rows_per=nq)
+        fused_tran, trans_raw = run_stacks(f_tran, [(P["decoder_tran2"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd,
+                                           x_bcast=trans_feat, rows_per=nq)
+        rot_raw, trans_raw = rot_raw.view(B, nq, 4), trans_raw.view(B, nq, 3)
         maps = ops.ransac_score_maps(geo_local, rot_raw, trans_raw, rec_rot, rec_trans, m, diagnostics=diagnostics)
         sf_rot = run_mlp(maps["normal_score"].view(B * (nq + 1), nq), P["normal_score_proj"], gd=gd).view(B, nq + 1, 64)
         sf_tran = run_mlp(maps["param_score"].view(B * (nq + 1), nq), P["param_score_proj"], gd=gd).view(B, nq + 1, 64)

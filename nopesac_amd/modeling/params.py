@@ -115,6 +115,14 @@ class ConvW:
     def w2d(self, dtype=torch.float32) -> torch.Tensor:
         return self.w(dtype).view(self.cout, -1)
 
+    def chain(self):
+        """This Linear packed for the chained-MLP kernel (ops.MlpLayer: bf16, K / N zero padded, MFMA fragment-major)."""
+        if "chain" not in self._w:
+            from .. import ops
+            assert self.kh == 1 and self.kw == 1
+            self._w["chain"] = ops.MlpLayer(self.w2d(torch.float32), self.bias)
+        return self._w["chain"]
+
     def wfrag(self, dtype=torch.bfloat16) -> torch.Tensor:
         """1x1 weights in MFMA fragment-major order (ops.mfma_fragment_major), for the fused bottleneck tail."""
         key = ("frag", dtype)

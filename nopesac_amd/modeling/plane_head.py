@@ -12,7 +12,7 @@ import math
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..registry import SEM_SEG_HEADS_REGISTRY
 from ..synth import state_dict_spec
 from .params import ConvW, ParamModule, conv_bias, conv_bn, mlp_layers
@@ -35,10 +35,49 @@ def sine_position_embedding(h: int, w: int, num_pos_feats: int = 128) -> torch.T
 
 
 def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE, gd=torch.float32):
+    if gd == torch.bfloat16 and x.dtype == torch.float32 and x.dim() == 2:
+        return run_stacks(x, [(layers, final_act, out)], gd)[0]
     for i, l in enumerate(layers):
         last = i == len(layers) - 1
         x = ops.linear(x, l.w2d(gd), l.bias, act=final_act if last else ops.ACT_RELU, out=out if last else None)
     return x
+
+
+def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1):
+    """Consecutive MLP stacks (each: ReLU between its layers, `final_act` after its last one) applied to the rows of x [rows, K] f32;
+    stacks = [(layers: [ConvW], final_act, out)], out = an f32 [rows, N] tensor (may be a column slice) that receives the stack's
+    output, True to allocate one, None if only the next stack consumes it (the last stack always returns its output).
+    x_bcast [P, Kb]: optional input prefix shared by `rows_per` consecutive rows.  Returns one entry per stack (tensor or None).
+    bf16 GEMM mode: ONE launch for everything (csrc/mlp_chain.hip, activations stay in LDS); fp32 mode: one launch per layer."""
+    rows = x.shape[0]
+    flat, last_of = [], []
+    for si, (layers, final_act, out) in enumerate(stacks):
+        for i, l in enumerate(layers):
+            last = i == len(layers) - 1
+            flat.append((l, final_act if last else ops.ACT_RELU))
+            last_of.append(si if last else -1)
+    want = [o for (_, _, o) in stacks]
+    want[-1] = True if want[-1] is None else want[-1]
+    results = [None] * len(stacks)
+    for si, o in enumerate(want):
+        if o is True:
+            results[si] = torch.empty(rows, stacks[si][0][-1].cout, device=x.device, dtype=torch.float32)
+        elif o is not None:
+            results[si] = o
+    k0 = x.shape[1] + (0 if x_bcast is None else x_bcast.shape[1])
+    if (gd == torch.bfloat16 and x.dtype == torch.float32 and len(flat) <= _lib.MLP_MAX_LAYERS and k0 <= _lib.MLP_MAX_IN
+            and all(l.cout <= _lib.MLP_MAX_WIDTH for l, _ in flat)):
+        ops.mlp_chain(x, [l.chain() for l, _ in flat], [a for _, a in flat], [results[si] if si >= 0 else None for si in last_of],
+                      x_bcast=x_bcast, rows_per=rows_per)
+        return results
+    if x_bcast is not None:                       # per-layer path: materialise the concatenated input once
+        full = torch.empty(rows, k0, device=x.device, dtype=torch.float32)
+        full.view(-1, rows_per, k0)[:, :, :x_bcast.shape[1]] = x_bcast[:, None, :]
+        full[:, x_bcast.shape[1]:] = x
+        x = full
+    for (l, a), si in zip(flat, last_of):
+        x = ops.linear(x, l.w2d(gd), l.bias, act=a, out=results[si] if si >= 0 else None)
+    return results
 
 
 @SEM_SEG_HEADS_REGISTRY.register()
@@ -286,10 +325,10 @@ class PlaneTRHead(ParamModule):
 
         p3 = up_stage(p4, "up_conv3", cbr(c3, "c3_conv"))
         p2 = up_stage(p3, "up_conv2", cbr(c2, "c2_conv"))
-        emb = run_mlp(hs, P["plane_embedding"], gd=gd)                                    # [B*nq, 256]
-        fold = ops.linear(emb, P["pe_fold"].w2d(gd))                                      # [B*nq, 264]: mask weights | bias | pad
+        # plane embedding MLP [B*nq, 256] -> folded mask-head operands [B*nq, 264]: mask weights | bias | pad
+        fold = run_stacks(hs, [(P["plane_embedding"], ops.ACT_NONE, None), ([P["pe_fold"]], ops.ACT_NONE, True)], gd)[1]
         heads = {
-            "pred_logits": ops.linear(hs, P["plane_prob"].w2d(gd), P["plane_prob"].bias).view(B, nq, 2),
+            "pred_logits": run_mlp(hs, [P["plane_prob"]], gd=gd).view(B, nq, 2),
             "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
             "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
         }

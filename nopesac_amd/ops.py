@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -304,6 +306,58 @@ def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:
     return w2d.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+def mlp_padded_k(N: int, K: int) -> int:
+    """K as the chained-MLP kernel pads it (csrc/mlp_chain.hip: two K blocks of the layer's width class)."""
+    return -(-K // 128) * 128
+
+
+class MlpLayer:
+    """One Linear of a chained MLP stack, packed for nopesac_mlp_chain_bf16: bf16 weights [Np, Kp] (zero padded, MFMA
+    fragment-major), f32 bias [Np]."""
+    __slots__ = ("w", "bias", "N", "K")
+
+    def __init__(self, w2d: torch.Tensor, bias: Optional[torch.Tensor]):
+        N, K = w2d.shape
+        _require(N <= _lib.MLP_MAX_WIDTH, f"mlp_pack: N = {N} exceeds NOPESAC_MLP_MAX_WIDTH")
+        Np, Kp = -(-N // 32) * 32, mlp_padded_k(N, K)
+        wp = torch.zeros(Np, Kp, device=w2d.device, dtype=torch.bfloat16)
+        wp[:N, :K] = w2d.to(torch.bfloat16)
+        self.w = mfma_fragment_major(wp)
+        self.bias = None
+        if bias is not None:
+            self.bias = torch.zeros(Np, device=w2d.device, dtype=torch.float32)
+            self.bias[:N] = bias.float()
+        self.N, self.K = N, K
+
+
+def mlp_chain(x: torch.Tensor, layers, acts, outs, x_bcast: Optional[torch.Tensor] = None, rows_per: int = 1):
+    """A stack of Linear(+bias)(+act) layers over the rows of x in ONE launch (bf16 MFMA operands, f32 activations: the rounding
+    points of one ops.linear per layer).  x [rows, Kx] f32 (may be a column slice of a wider row-major buffer); x_bcast [P, Kb]:
+    optional prefix columns shared by `rows_per` consecutive rows (row r reads x_bcast[r // rows_per]); layers: [MlpLayer];
+    acts: [ACT_*] per layer; outs: per layer None or an f32 [rows, N] tensor (may be a column slice) that receives the layer's
+    output - the last one is required."""
+    _require(len(layers) == len(acts) == len(outs) and 1 <= len(layers) <= _lib.MLP_MAX_LAYERS, "mlp_chain: layers / acts / outs")
+    _require(x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "mlp_chain: x must be f32 [rows, K] with unit column stride")
+    rows = x.shape[0]
+    c = _lib.MlpChain()
+    c.x, c.x_ld, c.x_width = _p(x), x.stride(0), x.shape[1]
+    c.xb, c.xb_ld, c.xb_width, c.xb_rows_per = None, 0, 0, 1
+    if x_bcast is not None:
+        _require(x_bcast.dtype == torch.float32 and x_bcast.dim() == 2 and x_bcast.stride(1) == 1 and rows_per >= 1
+                 and x_bcast.shape[0] * rows_per >= rows, "mlp_chain: x_bcast")
+        c.xb, c.xb_ld, c.xb_width, c.xb_rows_per = _p(x_bcast), x_bcast.stride(0), x_bcast.shape[1], rows_per
+    c.rows, c.n_layers = rows, len(layers)
+    for i, (l, a, o) in enumerate(zip(layers, acts, outs)):
+        e = c.layers[i]
+        e.w, e.bias, e.K, e.N, e.act = _p(l.w), _p(l.bias), l.K, l.N, a
+        e.out, e.out_ld = None, 0
+        if o is not None:
+            _require(o.dtype == torch.float32 and o.dim() == 2 and o.shape == (rows, l.N) and o.stride(1) == 1, "mlp_chain: out tensor")
+            e.out, e.out_ld = _p(o), o.stride(0)
+    _lib.check(_L().nopesac_mlp_chain_bf16(ctypes.byref(c), _stream()), "nopesac_mlp_chain_bf16")
+    return outs[-1]
+
+
 def mfma_fragment_major_fp8(w2d: torch.Tensor) -> torch.Tensor:
     """[N,K] one-byte elements (N % 32 == 0, K % 64 == 0) -> same shape, re-ordered [N/32][K/64][2][64][16]: the two 16-byte
     pieces h = 0, 1 that lane l = 32*half + n%32 feeds to v_mfma_f32_32x32x64_f8f6f4 hold k = kf*64 + 32*half + 16*h + 0..15."""
@@ -493,9 +547,14 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
     """int32[1] device counter += number of Inf / NaN values in the given f32 tensors (no host synchronisation)."""
     if counter is None:
         counter = torch.zeros(1, device=tensors[0].device, dtype=torch.int32)
-    for t in tensors:
-        _chk(t, torch.float32)
-        _lib.check(_L().nopesac_count_nonfinite(_p(t), t.numel(), _p(counter), _stream()), "nopesac_count_nonfinite")
+    tensors = [t for t in tensors if t.numel()]
+    for i in range(0, len(tensors), 16):                      # NOPESAC_NONFINITE_MAX_TENSORS per launch
+        grp = tensors[i:i + 16]
+        for t in grp:
+            _chk(t, torch.float32)
+        ptrs = (ctypes.c_void_p * len(grp))(*[_p(t) for t in grp])
+        cnts = (ctypes.c_int64 * len(grp))(*[t.numel() for t in grp])
+        _lib.check(_L().nopesac_count_nonfinite_batch(ptrs, cnts, len(grp), _p(counter), _stream()), "nopesac_count_nonfinite_batch")
     return counter
 
 

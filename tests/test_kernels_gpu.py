@@ -653,3 +653,76 @@ def test_conv2d_p8_specialised_epilogues_match_the_generic_build(device, act):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert _rel(outs[3].float(), outs[0].float()) < 1e-2        # channel-major K order: another summation order
     assert _rel(outs[0].float(), ref.float()) < 1e-2
+
+
+MLP_CHAIN_CASES = {
+    # name: (rows, x_width, bcast_width, rows_per, [(N, act, tapped)])
+    "geo_encoder+proj": (100, 8, 0, 1, [(1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (256, "ACT_NONE", True)]),
+    "bcast_prefix+taps": (75, 256, 256, 7, [(512, "ACT_RELU", False), (512, "ACT_RELU", False), (256, "ACT_RELU", True), (4, "ACT_NONE", True)]),
+    "score_proj_k50": (33, 50, 0, 1, [(128, "ACT_RELU", False), (128, "ACT_RELU", True), (64, "ACT_NONE", True)]),
+    "widest_1280_in_9_layers": (1600, 1280, 0, 1, [(1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (1024, "ACT_NONE", True),
+                                                    (512, "ACT_RELU", False), (512, "ACT_RELU", False), (512, "ACT_RELU", False),
+                                                    (512, "ACT_RELU", False), (512, "ACT_LEAKY", False), (256, "ACT_NONE", True)]),
+    "one_layer_n3": (32, 256, 0, 1, [(3, "ACT_NONE", True)]),
+    "odd_widths_sigmoid": (65, 19, 5, 3, [(96, "ACT_SIGMOID", True), (40, "ACT_NONE", True)]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MLP_CHAIN_CASES))
+def test_mlp_chain_matches_per_layer_launches_and_fp32(device, name):
+    """nopesac_mlp_chain_bf16 (whole MLP stack in one launch, activations in LDS) against (i) one ops.linear launch per layer with
+    the same bf16 weights - same rounding points, only the f32 summation order differs - and (ii) a plain fp32 torch reference
+    with the bf16 operand rounding applied explicitly.  Tapped intermediate outputs, the broadcast input prefix, row tails,
+    widths that are not multiples of 4 / 32 / 128, outputs written into column slices of wider buffers."""
+    from nopesac_amd import ops
+    rows, kx, kb, rows_per, spec = MLP_CHAIN_CASES[name]
+    g = torch.Generator().manual_seed(len(name) * 7 + rows)
+    x = torch.randn(rows, kx + 3, generator=g).to(device)[:, :kx] if kx % 4 else torch.randn(rows, kx, generator=g).to(device)
+    xb = torch.randn(-(-rows // rows_per), kb, generator=g).to(device) if kb else None
+    layers, acts, outs, ws = [], [], [], []
+    k = kx + kb
+    for (n, act, tap) in spec:
+        w = (torch.randn(n, k, generator=g) * (1.6 / math.sqrt(k))).to(device)
+        b = (0.2 * torch.randn(n, generator=g)).to(device)
+        ws.append((w, b))
+        layers.append(ops.MlpLayer(w, b))
+        acts.append(getattr(ops, act))
+        if tap:          # a column slice of a wider NaN-filled buffer: nothing outside the slice may be touched
+            buf = torch.full((rows, n + 8), float("nan"), device=device)
+            outs.append(buf[:, 4:4 + n] if n % 4 == 0 else buf[:, 1:1 + n])
+        else:
+            outs.append(None)
+        k = n
+    y = ops.mlp_chain(x, layers, acts, outs, x_bcast=xb, rows_per=rows_per)
+    torch.cuda.synchronize()
+    # references
+    full = x if xb is None else torch.cat([xb.repeat_interleave(rows_per, 0)[:rows], x], 1)
+    a_lin, a_ref = full.contiguous(), full.double()
+    act_fn = {"ACT_RELU": torch.relu, "ACT_NONE": lambda t: t, "ACT_LEAKY": lambda t: F.leaky_relu(t, 0.01), "ACT_SIGMOID": torch.sigmoid}
+    for i, ((w, b), (n, act, tap)) in enumerate(zip(ws, spec)):
+        a_lin = ops.linear(a_lin, w.to(torch.bfloat16).contiguous(), b, act=getattr(ops, act))
+        a_ref = act_fn[act](a_ref.float().bfloat16().double() @ w.bfloat16().double().t() + b.double())
+        if tap:
+            o = outs[i]
+            assert torch.isfinite(o).all(), (name, i)
+            bound = 2e-3 + 6e-4 * i          # bf16 roundings of nearly equal f32 values flip and propagate: grows with depth
+            assert _rel(o, a_lin) < bound, (name, i, _rel(o, a_lin))
+            assert _rel(o, a_ref) < bound, (name, i, _rel(o, a_ref))
+            buf = o._base if o._base is not None else o
+            mask = torch.ones_like(buf, dtype=torch.bool)
+            c0 = 4 if n % 4 == 0 else 1
+            mask[:, c0:c0 + n] = False
+            assert torch.isnan(buf[mask]).all(), "wrote outside its column slice"
+    assert y is outs[-1]
+
+
+def test_mlp_chain_rejects_bad_chains(device):
+    from nopesac_amd import _lib, ops
+    x = torch.randn(8, 256, device=device)
+    l1, l2 = ops.MlpLayer(torch.randn(128, 256, device=device), None), ops.MlpLayer(torch.randn(64, 100, device=device), None)
+    with pytest.raises(_lib.HipKernelError):                       # K of layer 2 is not the width of layer 1
+        ops.mlp_chain(x, [l1, l2], [0, 0], [None, torch.empty(8, 64, device=device)])
+    with pytest.raises(ops.OpsArgumentError):                      # no output for the last layer is an argument error before the launch
+        ops.mlp_chain(x, [l1], [0], [torch.empty(8, 100, device=device)])
+    with pytest.raises(_lib.HipKernelError):
+        ops.mlp_chain(x, [l1], [0], [None])
