@@ -390,8 +390,9 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
 
 /* Finest top-down level + mask head of the PlaneTR head in one launch (planeTR_head.py:148-162, 241-252), bf16:
  *   p1 = relu(scale * (w_lateral . c1) + bias) + relu(bilinear_2x(t1));   prob = [sigmoid](mask_w[b] . p1 + mask_b[b])
- * c1 [B,H,W,256], t1 [B,H/2,W/2,256] bf16; w_lateral [256][256] and mask_w [B][64][256] (rows >= nq zero) bf16 in MFMA
- * fragment-major order; mask_b f32 [B][64]; prob f32 [B,H,W,nq] (nq even, <= 64); p1_out optional bf16 [B,H,W,256].
+ * c1 [B,H,W,256], t1 [B,H/2,W/2,256] bf16; w_lateral [256][256] and mask_w [B][NQP][256] (rows >= nq zero) bf16 in MFMA
+ * fragment-major order; mask_b f32 [B][NQP]; NQP = 64 for nq <= 64, 128 for nq <= 128; prob f32 [B,H,W,nq] (nq even, <= 128);
+ * p1_out optional bf16 [B,H,W,256].
  * H*W must be a multiple of 128.  apply_sigmoid: bit 0 = apply the sigmoid, bit 1 = write prob planar, [B,nq,H,W]. */
 int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                            const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,

@@ -7,10 +7,14 @@
 //     out = x + LN2( relu([x | msg] W0^T) W2^T )
 //
 // The un-fused bf16 path issues 8-9 launches per layer and set group (234 launches for the 18 layers), each a tiny
-// GEMM over <= 3200 rows that cannot fill the chip.  A plane set is at most 64 x 256, so the whole layer fits on one CU:
+// GEMM over <= 3200 rows that cannot fill the chip.  A workgroup owns a block of 64 query rows of one plane set (one block for
+// nq <= 64, two for nq <= 128) and walks the source set in chunks of 64 keys with a running (flash-style) softmax, so the
+// LDS footprint does not depend on nq; K / V of a chunk are projected by every query block that needs them (2x redundant at
+// nq = 128, still one launch per layer).  With 64 x 256 operands the whole layer fits on one CU:
 //   * x (and s) are parked in LDS as bf16 operand tiles [64][256+8];
 //   * every projection is "LDS tile x fragment-major weights streamed from L2" (see pwchain.hip): weights are read
 //     exactly once per workgroup, 1 KB per load instruction, no LDS;
+//   * q stays in registers as MFMA operand fragments (accumulator -> operand layout by v_permlane32_swap);
 //   * K is kept row-major and V transposed (the V projection is issued with swapped MFMA operands so that its accumulator
 //     layout IS the transposed tile), attention runs entirely out of LDS, one head per wave, scores never leave registers;
 //   * both LayerNorms reduce across the eight waves through 4 KB of LDS, the 512-wide hidden tile never leaves the CU.
@@ -169,54 +173,74 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
     float* red = reinterpret_cast<float*>(Kt + GN_RC);      // [2][8][64]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x, nq = p.nq;
-    const float* xg = p.x + (long long)(p.x_off + b) * nq * GN_D;
+    const int nq = p.nq, nqb = (nq + 63) / 64;
+    const int b = blockIdx.x / nqb, qb = blockIdx.x % nqb, row0 = qb * 64;          // set, block of 64 query rows
+    const float* xg = p.x + ((long long)(p.x_off + b) * nq + row0) * GN_D;
     const float* sg = p.src + (long long)(p.src_off + b) * nq * GN_D;
     const bool self_layer = (p.x == p.src) && (p.x_off == p.src_off);
-    const int nrow = p.qlen ? min(p.qlen[p.x_off + b], nq) : nq;
+    const int nrow = (p.qlen ? min(p.qlen[p.x_off + b], nq) : nq) - row0;          // valid query rows of this block (may be <= 0)
     const int nkey = p.klen ? min(p.klen[p.src_off + b], nq) : nq;
+    const int nchunk = max(1, (nkey + 63) / 64);                                   // key chunks that hold a valid key
     GnRing ring;
     f32x16 acc[2];
 
-    gn_issue(ring, 0, p.wk, 16, 0, wave, lane);                            // step 0: K
-    gn_load_rows(xg, nq, X16, tid);
-    if (!self_layer) gn_load_rows(sg, nq, RB, tid);
+    gn_issue(ring, 0, p.wq, 16, 0, wave, lane);                            // step 0: Q
+    gn_load_rows(xg, nq - row0, X16, tid);
     __syncthreads();
-    const bf16_t* S16 = self_layer ? X16 : RB;
 
-    // ---- K (row-major) and V^T from the source set
-    gn_issue(ring, 1, p.wv, 16, 0, wave, lane);                            // step 1: V
-    gn_zero(acc);
-    gn_gemm<false>(ring, 0, S16, GN_LD, acc, lane);
-    gn_store_tile<false>(acc, Kt, GN_LD, wave, lane);
-    gn_issue(ring, 0, p.wq, 16, 0, wave, lane);                            // step 2: Q
-    gn_zero(acc);
-    gn_gemm<true>(ring, 1, S16, GN_LD, acc, lane);
-    // lane holds channel wave*32 + l31, tokens r*32 + 8q + 4*half + e
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            us4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[r][4 * q + e]);
-            *reinterpret_cast<us4*>(Vt + (wave * 32 + l31) * GN_VLD + r * 32 + 8 * q + 4 * half) = o;
-        }
-    __syncthreads();                                                        // s tile (RB) is dead: q goes there
-    gn_issue(ring, 1, p.wm, 16, 0, wave, lane);                            // step 3: merge (in flight during the attention)
+    // ---- q of this block's 64 rows: head = wave; kept in registers as the B operand of the score MFMAs
+    gn_issue(ring, 1, p.wk, 16, 0, wave, lane);                            // step 1: K of chunk 0
     gn_zero(acc);
     gn_gemm<false>(ring, 0, X16, GN_LD, acc, lane);
-    gn_store_tile<false>(acc, RB, GN_LD, wave, lane);
-    // ---- attention: head = wave = the channel tile this wave produced in K / V^T / q: no barrier needed; msg overwrites q in place
-    {
-        const int c0 = wave * 32;
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        unsigned int d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = gn_pack2(acc[r][2 * i], acc[r][2 * i + 1]);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                                       // k-step g: channels 16g .. 16g+15 of the head
+            auto r0 = __builtin_amdgcn_permlane32_swap(d[4 * g + 0], d[4 * g + 2], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(d[4 * g + 1], d[4 * g + 3], false, false);
+            const u32x4 pk = {r0[0], r1[0], r0[1], r1[1]};
+            qf[r][g] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    // running softmax state per query group r: max, sum, un-normalised output
+    float run_mx[2] = {-INFINITY, -INFINITY}, run_ps[2] = {0.f, 0.f};
+    f32x16 oacc[2];
+    gn_zero(oacc);
+    const int c0 = wave * 32;
+    for (int c = 0; c < nchunk; ++c) {
+        // ---- K (row-major) and V^T of key chunk c (source rows c*64 .. +63)
+        const bool own = self_layer && c == qb;                            // the chunk IS this block's rows: already in X16
+        if (c > 0) __syncthreads();                                         // every wave is done reading the previous chunk out of RB
+        if (!own) gn_load_rows(sg + (long long)c * 64 * GN_D, nq - c * 64, RB, tid);
+        __syncthreads();                                                    // RB staged
+        const bf16_t* S16 = own ? X16 : RB;
+        gn_issue(ring, 0, p.wv, 16, 0, wave, lane);                        // V of this chunk
+        gn_zero(acc);
+        gn_gemm<false>(ring, 1, S16, GN_LD, acc, lane);
+        gn_store_tile<false>(acc, Kt, GN_LD, wave, lane);
+        gn_issue(ring, 1, c + 1 < nchunk ? p.wk : p.wm, 16, 0, wave, lane);   // K of the next chunk, or the merge weights
+        gn_zero(acc);
+        gn_gemm<true>(ring, 0, S16, GN_LD, acc, lane);
+        // lane holds channel wave*32 + l31, tokens r*32 + 8q + 4*half + e
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[r][4 * q + e]);
+                *reinterpret_cast<us4*>(Vt + (wave * 32 + l31) * GN_VLD + r * 32 + 8 * q + 4 * half) = o;
+            }
+        // ---- attention over this chunk: head = wave = the channel tile this wave produced in K / V^T: no barrier needed
+        const int kbase = c * 64;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            bf16x8 qf[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(RB + (r * 32 + l31) * GN_LD + c0 + ks * 16 + half * 8);
             f32x16 s[2];
-            float mx = -INFINITY;
+            float mx = run_mx[r];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -224,26 +248,32 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + (kt * 32 + l31) * GN_LD + c0 + ks * 16 + half * 8);
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[r][ks], s[kt], 0, 0, 0);
                 }
-                // s[kt][e] = score(query r*32 + l31, key kt*32 + (e&3) + 8*(e>>2) + 4*half)
+                // s[kt][e] = score(query r*32 + l31, key kbase + kt*32 + (e&3) + 8*(e>>2) + 4*half)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                     if (key >= nkey) s[kt][e] = -INFINITY;
                     mx = fmaxf(mx, s[kt][e]);
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // first chunk: run_mx = -inf, nothing accumulated yet (scale irrelevant); a fully masked set keeps mx = -inf: msg = 0 below
+            const float scale = (c == 0 || mx == -INFINITY) ? 1.f : expf(run_mx[r] - mx);
+            const float sub = mx == -INFINITY ? 0.f : mx;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { s[kt][e] = expf(s[kt][e] - mx); ps += s[kt][e]; }
+                for (int e = 0; e < 16; ++e) { s[kt][e] = expf(s[kt][e] - sub); ps += s[kt][e]; }
             ps += __shfl_xor(ps, 32, 64);
-            f32x16 oacc;
+            run_ps[r] = run_ps[r] * scale + ps;
+            run_mx[r] = mx;
+            if (c > 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+                for (int e = 0; e < 16; ++e) oacc[r][e] *= scale;
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 unsigned int d[8];
@@ -256,19 +286,23 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
                     const u32x4 pk = {r0[0], r1[0], r0[1], r1[1]};
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + (c0 + l31) * GN_VLD + kt * 32 + g * 16 + half * 8);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+                    oacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[r], 0, 0, 0);
                 }
             }
-            // oacc[e] = msg(query r*32 + l31, channel c0 + (e&3) + 8*(e>>2) + 4*half)
-            const bool live = (r * 32 + l31) < nrow && nkey > 0;
-            const float inv = live ? 1.f / ps : 0.f;
+        }
+    }
+    __syncthreads();                                                        // every wave is done with RB (the last s chunk)
+    // oacc[r][e] = un-normalised msg(query r*32 + l31, channel c0 + (e&3) + 8*(e>>2) + 4*half) -> RB (operand of the merge GEMM)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                us4 o;
+    for (int r = 0; r < 2; ++r) {
+        const bool live = (r * 32 + l31) < nrow && nkey > 0;
+        const float inv = live ? 1.f / run_ps[r] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(live ? oacc[4 * q + e] * inv : 0.f);
-                *reinterpret_cast<us4*>(RB + (r * 32 + l31) * GN_LD + c0 + 8 * q + 4 * half) = o;
-            }
+        for (int q = 0; q < 4; ++q) {
+            us4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(live ? oacc[r][4 * q + e] * inv : 0.f);
+            *reinterpret_cast<us4*>(RB + (r * 32 + l31) * GN_LD + c0 + 8 * q + 4 * half) = o;
         }
     }
     __syncthreads();
@@ -303,11 +337,11 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
     gn_gemm<false>(ring, 0, Ht, GN_HLD, acc, lane);
     gn_gemm<false>(ring, 1, Ht + 256, GN_HLD, acc, lane);
     gn_layernorm(acc, p.g2, p.b2, red, wave, lane);
-    float* og = p.out + (long long)(p.out_off + b) * nq * GN_D;
+    float* og = p.out + ((long long)(p.out_off + b) * nq + row0) * GN_D;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int row = r * 32 + l31;
-        if (row >= nq) continue;
+        if (row0 + row >= nq) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = wave * 32 + 8 * q + 4 * half;
@@ -328,7 +362,7 @@ extern "C" int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* sr
                                       const float* ln2_g, const float* ln2_b, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && src && out && wq && wk && wv && wmerge && w0 && w2 && ln1_g && ln1_b && ln2_g && ln2_b, "gnn_layer: null pointer");
-    NPS_CHECK_ARG(n_sets > 0 && nq > 0 && nq <= 64 && x_off >= 0 && src_off >= 0 && out_off >= 0, "gnn_layer: bad sizes (nq <= 64)");
+    NPS_CHECK_ARG(n_sets > 0 && nq > 0 && nq <= 128 && x_off >= 0 && src_off >= 0 && out_off >= 0, "gnn_layer: bad sizes (nq <= 128)");
     // other workgroups still read x / src while this one writes out: same buffer only with disjoint set ranges
     auto disjoint = [&](const float* in, int in_off) { return in != out || in_off + n_sets <= out_off || out_off + n_sets <= in_off; };
     NPS_CHECK_ARG(disjoint(x, x_off) && disjoint(src, src_off), "gnn_layer: out overlaps x / src");
@@ -340,6 +374,6 @@ extern "C" int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* sr
     a.wq = (const bf16_t*)wq; a.wk = (const bf16_t*)wk; a.wv = (const bf16_t*)wv; a.wm = (const bf16_t*)wmerge;
     a.w0 = (const bf16_t*)w0; a.w2 = (const bf16_t*)w2; a.g1 = ln1_g; a.b1 = ln1_b; a.g2 = ln2_g; a.b2 = ln2_b;
     NPS_ENSURE_LDS((int)GN_LDS_BYTES, gnn_layer_kernel);
-    hipLaunchKernelGGL(gnn_layer_kernel, dim3(n_sets), dim3(512), GN_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gnn_layer_kernel, dim3(n_sets * ((nq + 63) / 64)), dim3(512), GN_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
 }

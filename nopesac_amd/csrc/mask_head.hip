@@ -19,15 +19,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 
-constexpr int MH_C = 256, MH_LD = MH_C + 8, MH_BM = 128, MH_RT = MH_BM / 32, MH_NQP = 64;
+constexpr int MH_C = 256, MH_LD = MH_C + 8, MH_BM = 128, MH_RT = MH_BM / 32, MH_NQP_MAX = 128;
 constexpr size_t MH_LDS_BYTES = (size_t)(2 * MH_BM * MH_LD);      // ONE 128 x 264 bf16 tile (67.6 KB): c1 rows -> p1 -> f32 output staging
 constexpr int MH_RING = 8;                                          // weight fragments in flight per wave (rolling ring)
-static_assert((size_t)MH_BM * MH_NQP * 4 <= 2 * (size_t)MH_BM * MH_LD, "output staging must fit the A tile");
+static_assert((size_t)MH_BM * MH_NQP_MAX * 4 <= 2 * (size_t)MH_BM * MH_LD, "output staging must fit the A tile");
 
 struct MaskHeadArgs {
     const bf16_t* c1; const bf16_t* t1;          // [B][H][W][256], [B][H/2][W/2][256]
     const bf16_t* wc; const float* sc; const float* bc;   // lateral conv (fragment-major) + folded BN
-    const bf16_t* mw; const float* mb;           // [B][64][256] fragment-major per image (rows >= nq zero), [B][64]
+    const bf16_t* mw; const float* mb;           // [B][NQP][256] fragment-major per image (rows >= nq zero), [B][NQP]; NQP = 64 or 128
     float* prob; bf16_t* p1;                     // [B][H][W][nq] f32; optional [B][H][W][256] bf16
     int B, H, W, nq, apply_sigmoid, planar;      // planar: prob is [B][nq][H][W] (one 512-byte run per plane and workgroup)
 };
@@ -35,7 +35,11 @@ struct MaskHeadArgs {
 // Two workgroups per CU (67.6 KB LDS, <= 128 registers): while one is in its load / bilinear / store phase the other one's MFMAs
 // run.  The weights stream through an 8-slot rolling register ring (16 k-steps per GEMM), the single LDS tile is reused in
 // place: c1 rows (A of the lateral GEMM) -> p1 (A of the mask GEMM) -> f32 probabilities.
+// NQP: planes padded to 64 (2 column tiles x 4 row tiles = one (tile, rows) pair per wave) or 128 (two pairs per wave: column tiles
+// wave & 1 and (wave & 1) + 2 of the same 32 rows).
+template <int NQP>
 __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p) {
+    constexpr int NPASS = NQP / 64, NTILES = NQP / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char mh_smem[];
     bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
 
     bf16x8 ring[MH_RING];
     const bf16_t* wlp = p.wc + ((long long)wave * 16 * 64 + lane) * 8;                              // lateral column tile `wave`
-    const bf16_t* wmp = p.mw + (((long long)b * 2 + (wave & 1)) * 16) * 512 + lane * 8;            // mask column tile wave & 1 of image b
+    const bf16_t* wmp = p.mw + (((long long)b * NTILES + (wave & 1)) * 16) * 512 + lane * 8;       // mask column tile wave & 1 of image b
 #pragma unroll
     for (int s = 0; s < MH_RING; ++s) ring[s] = *reinterpret_cast<const bf16x8*>(wlp + s * 512);
     // c1 rows -> LDS
@@ -143,31 +147,39 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
     }
     __syncthreads();
 
-    // ---- mask logits: 64 (padded) planes = 2 column tiles x 4 row tiles = 8 (tile, rows) pairs, one per wave
+    // ---- mask logits: NQP (padded) planes = NQP/32 column tiles x 4 row tiles = 8 * NPASS (tile, rows) pairs, NPASS per wave
     {
-        const int nt = wave & 1, r = wave >> 1;
-        f32x16 acc;
+        const int r = wave >> 1;
+        f32x16 acc[NPASS];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc, 0, 0, 0);
-            if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING) * 512);
+            for (int e = 0; e < 16; ++e) acc[ps][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
+                acc[ps] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc[ps], 0, 0, 0);
+                if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)ps * 32 + kk + MH_RING) * 512);
+                else if (ps + 1 < NPASS) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)(ps + 1) * 32 + kk + MH_RING - 16) * 512);
+            }
         }
         __syncthreads();                                      // p1 is dead: the tile becomes the [128][nq] f32 staging buffer
         float* St = reinterpret_cast<float*>(At);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = nt * 32 + 8 * q + 4 * half;
-            const f32x4 mbv = *reinterpret_cast<const f32x4*>(p.mb + (long long)b * MH_NQP + n);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int nt = (wave & 1) + 2 * ps;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (n + e < p.nq) {
-                    float v = acc[4 * q + e] + mbv[e];
-                    if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
-                    if (p.planar) St[(n + e) * MH_BM + r * 32 + l31] = v;
-                    else St[(r * 32 + l31) * p.nq + n + e] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int n = nt * 32 + 8 * q + 4 * half;
+                const f32x4 mbv = *reinterpret_cast<const f32x4*>(p.mb + (long long)b * NQP + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < p.nq) {
+                        float v = acc[ps][4 * q + e] + mbv[e];
+                        if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+                        if (p.planar) St[(n + e) * MH_BM + r * 32 + l31] = v;
+                        else St[(r * 32 + l31) * p.nq + n + e] = v;
+                    }
                 }
             }
         }
@@ -195,15 +207,20 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
     using namespace nps;
     NPS_CHECK_ARG(c1 && t1 && w_lateral && scale && bias && mask_w && mask_b && prob, "mask_head: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && (H * W) % MH_BM == 0, "mask_head: H*W must be a multiple of 128, H and W even");
-    NPS_CHECK_ARG(nq > 0 && nq <= MH_NQP && nq % 2 == 0, "mask_head: nq must be even and <= 64");
+    NPS_CHECK_ARG(nq > 0 && nq <= MH_NQP_MAX && nq % 2 == 0, "mask_head: nq must be even and <= 128");
     const void* ptrs[] = {c1, t1, w_lateral, scale, bias, mask_w, mask_b, prob, p1_out};
     for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "mask_head: pointers must be 16-byte aligned");
     MaskHeadArgs a;
     a.c1 = (const bf16_t*)c1; a.t1 = (const bf16_t*)t1; a.wc = (const bf16_t*)w_lateral; a.sc = scale; a.bc = bias;
     a.mw = (const bf16_t*)mask_w; a.mb = mask_b; a.prob = prob; a.p1 = (bf16_t*)p1_out;
     a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid & 1; a.planar = (apply_sigmoid >> 1) & 1;
-    NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel);
     const long long blocks = (long long)B * H * W / MH_BM;
-    hipLaunchKernelGGL(mask_head_kernel, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+    if (nq <= 64) {
+        NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<64>);
+        hipLaunchKernelGGL(mask_head_kernel<64>, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+    } else {
+        NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<128>);
+        hipLaunchKernelGGL(mask_head_kernel<128>, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+    }
     NPS_LAUNCH_RET();
 }

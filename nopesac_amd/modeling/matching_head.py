@@ -79,7 +79,7 @@ class MatchingHead(ParamModule):
         """app [2B,nq,256] (view-1 sets first), n_all int32[2B] -> GNN descriptors d0, d1 [B,nq,256]."""
         P, nq, gd = self.packed, self.num_queries, self.gemm_dtype
         f = ops.linear(app.reshape(2 * B * nq, 256), P["app"].w2d(gd), P["app"].bias)
-        if gd == torch.bfloat16 and nq <= 64 and self.fused_gnn:
+        if gd == torch.bfloat16 and nq <= 128 and self.fused_gnn:
             # one launch per layer step, one workgroup per plane set (csrc/gnn_layer.hip): 27 launches instead of 234
             cur, nxt = f.view(2 * B, nq, 256), torch.empty(2 * B, nq, 256, device=f.device, dtype=torch.float32)
             for i in range(18):

@@ -333,7 +333,7 @@ class PlaneTRHead(ParamModule):
             "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
         }
         h1, w1 = c1.shape[1], c1.shape[2]
-        if (self.fused_mask_head and cd == torch.bfloat16 and not want_logits and nq <= 64 and nq % 2 == 0 and (h1 * w1) % 128 == 0):
+        if (self.fused_mask_head and cd == torch.bfloat16 and not want_logits and nq <= 128 and nq % 2 == 0 and (h1 * w1) % 128 == 0):
             # finest lateral conv + bilinear add + mask GEMM in one launch: p1 never goes to HBM (csrc/mask_head.hip)
             c = P["up_conv1"]
             t1 = ops.conv2d(p2, c.w(cd), c.scale, c.bias, act=ops.ACT_NONE)

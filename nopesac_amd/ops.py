@@ -702,7 +702,7 @@ def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out:
         _chk(t, torch.float32)
         _require(t.dim() == 3 and t.shape[2] == 256, 'argument check failed: t.dim() == 3 and t.shape[2] == 256')
     nq = x.shape[1]
-    _require(nq <= 64 and src.shape[1] == nq and out.shape[1] == nq, 'argument check failed: nq <= 64 and src.shape[1] == nq and out.shape[1] == nq')
+    _require(nq <= 128 and src.shape[1] == nq and out.shape[1] == nq, 'gnn_layer: nq <= 128, src / out with the same nq')
     _require(x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0], 'argument check failed: x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0]')
     if lens is not None:
         _chk(lens, torch.int32)
@@ -745,11 +745,13 @@ def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scal
     _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
     B, H, W, C = c1.shape
     nq = mask_w.shape[1]
-    _require(C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0, 'argument check failed: C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 64 and nq % 2 == 0 and (H * W) % 128 == 0')
-    mw = torch.zeros(B, 64, 256, device=c1.device, dtype=torch.bfloat16)
+    _require(C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 128 and nq % 2 == 0 and (H * W) % 128 == 0,
+             'mask_head: C == 256, t1 at half resolution, nq even and <= 128, H * W a multiple of 128')
+    nqp = 64 if nq <= 64 else 128                                                       # planes padded to whole pairs of 32-wide MFMA tiles
+    mw = torch.zeros(B, nqp, 256, device=c1.device, dtype=torch.bfloat16)
     mw[:, :nq] = mask_w
-    mw = mw.view(B, 2, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()          # per-image MFMA fragment-major
-    mb = torch.zeros(B, 64, device=c1.device, dtype=torch.float32)
+    mw = mw.view(B, nqp // 32, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()    # per-image MFMA fragment-major
+    mb = torch.zeros(B, nqp, device=c1.device, dtype=torch.float32)
     mb[:, :nq] = mask_b
     prob = torch.empty((B, nq, H, W) if planar else (B, H, W, nq), device=c1.device, dtype=torch.float32)
     p1 = torch.empty(B, H, W, 256, device=c1.device, dtype=torch.bfloat16) if want_p1 else None

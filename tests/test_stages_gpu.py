@@ -252,18 +252,21 @@ def test_backbone_full_resolution_fp32_and_bf16(device, model, O, sd50):
         assert e16 < 3e-2, (k, e16)
 
 
-def test_fused_gnn_layers_match_per_launch_bf16_path(device):
-    """bf16 mode: the fused one-workgroup-per-set GNN layer kernel (csrc/gnn_layer.hip) vs the per-launch bf16 path on ragged
-    plane sets, all 18 layers chained.  The two differ only in rounding (1/sqrt(32) folded into Wq, LayerNorm summation
-    order), so each is judged against the fp32 path (itself parity-tested against the oracle): the fused kernel must be as
-    close to fp32 as the per-launch bf16 path is."""
+@pytest.mark.parametrize("nq", [50, 64, 100, 128])
+def test_fused_gnn_layers_match_per_launch_bf16_path(device, nq):
+    """bf16 mode: the fused GNN layer kernel (csrc/gnn_layer.hip: a workgroup per block of 64 query rows, keys in chunks of 64 with
+    a running softmax) vs the per-launch bf16 path on ragged plane sets, all 18 layers chained; nq = 100 / 128 take the
+    two-block / two-chunk route (BASELINE configs[4], K = 128), including sets whose valid planes end inside the first chunk.
+    The two differ only in rounding (1/sqrt(32) folded into Wq, LayerNorm summation order), so each is judged against the fp32
+    path (itself parity-tested against the oracle): the fused kernel must be as close to fp32 as the per-launch bf16 path is."""
     from tests.util import make_model
-    model = make_model(device, dtype="bfloat16")
-    mh, mh32 = model.matching_head, make_model(device).matching_head
-    B, nq = 5, mh.num_queries
+    model = make_model(device, dtype="bfloat16", nq=nq)
+    mh, mh32 = model.matching_head, make_model(device, nq=nq).matching_head
+    B = 5
+    assert mh.num_queries == nq
     g = torch.Generator().manual_seed(3)
     app = torch.randn(2 * B, nq, 256, generator=g).to(device)
-    n_all = torch.tensor([50, 1, 7, 32, 50, 3, 50, 20, 32, 9], dtype=torch.int32, device=device)
+    n_all = torch.tensor([nq, 1, 7, 32, nq, 3, nq, min(nq, 65), min(nq, 97), 9], dtype=torch.int32, device=device)
     mh.fused_gnn = True
     d0, d1 = mh.descriptors(app, n_all, B)
     mh.fused_gnn = False
@@ -283,9 +286,11 @@ def test_fused_gnn_layers_match_per_launch_bf16_path(device):
     assert torch.isfinite(d0).all() and torch.isfinite(d1).all()
 
 
-def test_fused_mask_head_matches_per_layer_bf16_path(device):
-    """bf16 mode: lateral conv + bilinear add + mask GEMM in one launch (csrc/mask_head.hip) vs the per-layer kernels."""
-    model = make_model(device, dtype="bfloat16")
+@pytest.mark.parametrize("nq", [50, 64, 100, 128])
+def test_fused_mask_head_matches_per_layer_bf16_path(device, nq):
+    """bf16 mode: lateral conv + bilinear add + mask GEMM in one launch (csrc/mask_head.hip) vs the per-layer kernels; nq > 64
+    takes the 128-plane build (two column-tile passes per wave; BASELINE configs[4], K = 128)."""
+    model = make_model(device, dtype="bfloat16", nq=nq)
     head = model.sem_seg_head
     g = torch.Generator().manual_seed(9)
     B = 2
@@ -297,19 +302,26 @@ def test_fused_mask_head_matches_per_layer_bf16_path(device):
     head.fused_mask_head = False
     b, qb = head(feats)
     head.fused_mask_head = True
-    assert torch.equal(qa, qb) and a["mask_prob"].shape == (B, 120, 160, 50)
+    assert torch.equal(qa, qb) and a["mask_prob"].shape == (B, 120, 160, nq)
     assert float((a["mask_prob"] - b["mask_prob"]).abs().max()) < 2e-3
     # planar output variant of the kernel ([B,nq,h,w], accepted by the post-selection): same numbers, transposed
     P, cd = head.packed, torch.bfloat16
     g2 = torch.Generator().manual_seed(10)
     c1 = (0.5 * torch.randn(B, 120, 160, 256, generator=g2)).to(device, cd)
     t1 = (0.5 * torch.randn(B, 60, 80, 256, generator=g2)).to(device, cd)
-    mw, mb = (torch.randn(B, 50, 256, generator=g2) / 16).to(device), torch.randn(B, 50, generator=g2).to(device)
+    mw, mb = (torch.randn(B, nq, 256, generator=g2) / 16).to(device), torch.randn(B, nq, generator=g2).to(device)
     l = P["c1_conv"]
     from nopesac_amd import ops
     pa = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, mw, mb)
     pb = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, mw, mb, planar=True)
-    assert pb.shape == (B, 50, 120, 160) and torch.equal(pa, pb.permute(0, 2, 3, 1))
+    assert pb.shape == (B, nq, 120, 160) and torch.equal(pa, pb.permute(0, 2, 3, 1))
+    # against a plain fp32 evaluation of the same formula on the bf16-rounded operands (p1 is rounded to bf16 before the mask GEMM)
+    w_lat = l.w2d(torch.float32).bfloat16().float()
+    lat = torch.relu((c1.float().reshape(-1, 256) @ w_lat.t()) * l.scale + l.bias).view(B, 120, 160, 256)
+    up = torch.relu(torch.nn.functional.interpolate(t1.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False))
+    p1 = (lat.bfloat16().float() + up.permute(0, 2, 3, 1)).bfloat16().float()
+    ref = torch.sigmoid(torch.einsum("bhwc,bqc->bhwq", p1, mw.bfloat16().float()) + mb[:, None, None, :])
+    assert float((pa - ref).abs().max()) < 4e-3
 
 
 def test_fused_decoder_tail_matches_per_layer_bf16_path(device):
