@@ -446,6 +446,21 @@ def main():
             print(json.dumps({"INVALID_ablation": args.ablate, "ms_per_step": round(ms_per_step, 3)}))
         return
 
+    # ---- engine clock under this load (outside the timed region): a few more steady-state steps with a one-wave probe on a side
+    #      stream in the middle of each (the MFMA-bound kernels are power-limited: the firmware grants ~1.9 of the nominal 2.4 GHz)
+    sclk_mhz = None
+    try:
+        probe_stream = torch.cuda.Stream(device=device)
+        probes = []
+        for i in range(2 * n_slots):
+            step(i)
+            probes.append(ops.clock_probe(400000, probe_stream))
+        barrier()
+        vals = [100.0 * float(t[0]) / float(t[1]) for t in (q.cpu() for q in probes) if int(t[1]) > 0]
+        sclk_mhz = round(sorted(vals)[len(vals) // 2], 1) if vals else None
+    except Exception as e:                                     # the probe is informative only
+        print("clock probe failed: %r" % (e,), file=sys.stderr)
+
     # ---- roofline of the dominant kernel: one extra instrumented step (outside the timed region)
     timer = ConvTimer().install()
     _timer_box["t"] = timer
@@ -510,6 +525,12 @@ def main():
                 "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
                 "step_share": round(dom["ms"] / ms_per_step, 3), "by_bound": by_bound,
+                "engine_clock": None if not sclk_mhz else {
+                    "sclk_mhz_under_benchmark_load": sclk_mhz, "nominal_mhz": 2400,
+                    "peak_at_measured_clock": round(peak * sclk_mhz / 2400.0, 1),
+                    "frac_at_measured_clock": round(achieved / (peak * sclk_mhz / 2400.0), 4),
+                    "note": "median of one-wave clock probes (shader cycles / 100 MHz reference ticks) on a side stream during steady-state steps; "
+                            "`peak` and `frac` above stay at the nominal 2.4 GHz figure"},
                 "instantiations": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "launches": v["launches"],
                                        "avg_launch_us": round(1e3 * v["ms"] / max(v["launches"], 1), 2)} for k, v in inst.items() if k.split("<")[0] == dom_name},
                 "conv_family": {"note": "every bf16 conv / fused-conv launch of the step (MFMA- and HBM-bound layers together)",

@@ -373,6 +373,11 @@ int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canoni
  * traps NaN poses with pdb.set_trace() (camera_net/camera_head.py:185-187, 681-682, 1072-1074); the drop-in counts them on the
  * device and raises FloatingPointError when the results are fetched (MODEL.AMD.CHECK_FINITE). */
 int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream);
+/* Engine-clock probe: one wave spins for spin_cycles shader cycles; out2[0] = shader cycles, out2[1] = 100 MHz reference ticks of
+ * the same interval (device memory, 2 x uint64).  Shader clock [MHz] = 100 * out2[0] / out2[1].  Meant to be launched on a side
+ * stream while a workload runs: it reads the clock the firmware grants under that load. */
+int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* stream);
+
 /* the same for up to NOPESAC_NONFINITE_MAX_TENSORS tensors in ONE launch: x / n are HOST arrays of device pointers / element counts */
 #define NOPESAC_NONFINITE_MAX_TENSORS 16
 int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n_tensors, int32_t* count, void* stream);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "nopesac_normalize_rows": [P, P, I, I, I, P],
     "nopesac_count_nonfinite": [P, L, P, P],
     "nopesac_count_nonfinite_batch": [P, P, I, P, P],
+    "nopesac_clock_probe": [P, L, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

@@ -587,3 +587,28 @@ extern "C" int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count
     hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, count);
     NPS_LAUNCH_RET();
 }
+
+
+// ---- engine-clock probe: one wave spins for `spin_cycles` shader cycles and reports (shader cycles, 100 MHz reference ticks) of the
+// interval: shader clock = cycles / ticks x 100 MHz.  Launched on a side stream WHILE a workload runs, it reads the clock the
+// power-management firmware actually grants under that load (the MFMA-bound conv kernels run at ~1.9 GHz, not the 2.4 GHz the
+// peak figures assume - scripts/power_probe.py); bench.py reports the roofline fraction at the measured clock next to the nominal one.
+namespace nps {
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long spin_cycles) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long c1 = c0;
+    while (c1 - c0 < spin_cycles) {
+        __builtin_amdgcn_s_sleep(32);
+        c1 = __builtin_readcyclecounter();
+    }
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+}  // namespace nps
+
+extern "C" int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(out2 && spin_cycles > 0 && spin_cycles <= 4000000000ll, "clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out2, (unsigned long long)spin_cycles);
+    NPS_LAUNCH_RET();
+}

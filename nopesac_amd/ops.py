@@ -558,6 +558,14 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
     return counter
 
 
+def clock_probe(spin_cycles: int = 400000, stream=None) -> torch.Tensor:
+    """Enqueue the engine-clock probe (one wave, ~0.2 ms) on `stream` (default: current); returns an int64[2] device tensor
+    (shader cycles, 100 MHz ticks) valid once the stream has passed it: MHz = 100 * t[0] / t[1]."""
+    out = torch.zeros(2, device="cuda", dtype=torch.int64)
+    _lib.check(_L().nopesac_clock_probe(_p(out), int(spin_cycles), stream.cuda_stream if stream is not None else _stream()), "nopesac_clock_probe")
+    return out
+
+
 def normalize_rows(x: torch.Tensor, canonical_sign: bool = False) -> torch.Tensor:
     _chk(x, torch.float32)
     D = x.shape[-1]
