@@ -373,6 +373,10 @@ int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canoni
  * traps NaN poses with pdb.set_trace() (camera_net/camera_head.py:185-187, 681-682, 1072-1074); the drop-in counts them on the
  * device and raises FloatingPointError when the results are fetched (MODEL.AMD.CHECK_FINITE). */
 int nopesac_count_nonfinite(const float* x, int64_t n, int32_t* count, void* stream);
+/* uint8 -> float32, exact (8-bit image planes handed over by the data mapper; the reference mapper converts on the host,
+ * data/planercnn_transforms.py:225-227, and sends 4 bytes per sample over PCIe).  x, y 16-byte aligned device pointers. */
+int nopesac_u8_to_f32(const uint8_t* x, float* y, int64_t n, void* stream);
+
 /* Engine-clock probe: one wave spins for spin_cycles shader cycles; out2[0] = shader cycles, out2[1] = 100 MHz reference ticks of
  * the same interval (device memory, 2 x uint64).  Shader clock [MHz] = 100 * out2[0] / out2[1].  Meant to be launched on a side
  * stream while a workload runs: it reads the clock the firmware grants under that load. */
@@ -439,6 +443,11 @@ int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_kept, const 
 /* HOST function (no device work): one mask's flip positions -> COCO compressed "counts" string (not NUL terminated,
  *   returns its length or < 0) and bbox4 = [x, y, w, h] (cocoapi rleToString / rleToBbox). */
 int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W, char* out, int cap, double* bbox4);
+/* The same on the device for n_masks masks at once (mask i owns positions[offsets[i] .. offsets[i] + counts[i]); all pointers device
+ * memory).  Pass 1, out == NULL: lens[i] = length of mask i's string, bbox4[4 i ..] = its [x, y, w, h] box.  Pass 2, out != NULL: the
+ * strings are written at out + out_off[i] (the caller's exclusive prefix sums of lens). */
+int nopesac_rle_compress_device(const uint32_t* positions, const int64_t* offsets, const int32_t* counts, int n_masks, int H, int W,
+                                int32_t* lens, double* bbox4, char* out, const int64_t* out_off, void* stream);
 /* Batch form of nopesac_rle_compress_host: mask i owns positions[offsets[i] .. +counts[i]); strings are packed back to back into
  * `out` (mask i at out + out_off[i], out_off[n_masks] = total), boxes at bbox4 + 4 i.  Returns the total length or < 0. */
 long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long long* offsets, const int* counts, int n_masks,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "nopesac_rle_labels": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_rle_transitions": [P, P, P, P, P, I, I, I, P],
     "nopesac_rle_compress_host": [P, I, I, I, P, I, P],
+    "nopesac_rle_compress_device": [P, P, P, I, I, I, P, P, P, P, P],
     "nopesac_rle_compress_batch_host": [P, P, P, I, I, I, P, L, P, P],
     "nopesac_preprocess_nchw_to_nhwc": [P, P, P, P, I, I, I, I, I, I, P],
     "nopesac_maxpool_nhwc": [P, P, I, I, I, I, I, I, I, I, P],
@@ -64,6 +65,7 @@ SIGNATURES = {
     "nopesac_count_nonfinite": [P, L, P, P],
     "nopesac_count_nonfinite_batch": [P, P, I, P, P],
     "nopesac_clock_probe": [P, L, P],
+    "nopesac_u8_to_f32": [P, P, L, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

@@ -612,3 +612,33 @@ extern "C" int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* st
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out2, (unsigned long long)spin_cycles);
     NPS_LAUNCH_RET();
 }
+
+
+// ---- uint8 image planes -> f32 (exact): lets the boundary take the decoder's 8-bit images over PCIe (a quarter of the bytes of the
+// reference mapper's float32 tensors, data/planercnn_transforms.py:225-227) and widen them on the device
+namespace nps {
+__global__ void u8_to_f32_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 q = reinterpret_cast<const uint4*>(x)[i];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        float4* o = reinterpret_cast<float4*>(y) + 4 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = make_float4((float)(w[j] & 0xff), (float)((w[j] >> 8) & 0xff), (float)((w[j] >> 16) & 0xff), (float)(w[j] >> 24));
+    }
+}
+__global__ void u8_to_f32_tail_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, long long n0, long long n) {
+    const long long i = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+}  // namespace nps
+
+extern "C" int nopesac_u8_to_f32(const uint8_t* x, float* y, int64_t n, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && y && n > 0, "u8_to_f32: bad args");
+    NPS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "u8_to_f32: pointers must be 16-byte aligned");
+    const long long n16 = n / 16;
+    if (n16) hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(n16)), dim3(256), 0, (hipStream_t)stream, x, y, n16);
+    if (n % 16) hipLaunchKernelGGL(u8_to_f32_tail_kernel, dim3(1), dim3(16), 0, (hipStream_t)stream, x, y, n16 * 16, (long long)n);
+    NPS_LAUNCH_RET();
+}

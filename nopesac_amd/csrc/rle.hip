@@ -12,7 +12,8 @@
 // Device side (this file): the n masks of a view are never materialised.  One pass turns the row-major winner map
 // into a column-major map of plane ordinals (0xFF = no kept plane); then one workgroup per (view, plane) streams that
 // 300 KB map (L2 resident) 16 bytes per lane and compacts the positions where "pixel belongs to plane p" flips.
-// Host side: nopesac_rle_compress_host turns one plane's flip positions into the COCO string + bbox.
+// String side: nopesac_rle_compress_device (a workgroup per mask, two passes: sizes + boxes, then the characters) turns the flip
+// positions into the COCO strings + boxes on the device; nopesac_rle_compress_host is the plain-C single-mask form.
 #include "common.h"
 
 namespace nps {
@@ -134,6 +135,128 @@ extern "C" int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_k
     NPS_CHECK_ARG(V > 0 && N > 0 && nq > 0 && nq <= 128, "rle_transitions: bad sizes");
     hipLaunchKernelGGL(rle_transitions_kernel, dim3(nq, V), dim3(256), 0, (hipStream_t)stream, labels, n_kept,
                        (const long long*)offsets, counts, positions, N, nq);
+    NPS_LAUNCH_RET();
+}
+
+// ---- device-side string compression ------------------------------------------------------------------------------------------
+// A 32-pair step with K kept planes per view has 2 B K masks and millions of flip positions: compressing them on one host core
+// (and copying 4 bytes per flip over PCIe first) was 2/3 of package()'s time.  The string format is local - character group i
+// depends on runs i and i-2 only - so a workgroup per mask encodes 256 runs at a time (1..6 characters each), block-scans
+// the lengths and writes the characters; pass 1 (out == nullptr) only sizes the strings and reduces the box.
+namespace nps {
+
+// characters of one count (cocoapi rleToString): 5 data bits per character, bit 5 = more, + 48
+__device__ __forceinline__ int rle_chars(long long x, char (&c)[8]) {
+    int n = 0;
+    bool more = true;
+    while (more) {
+        char ch = (char)(x & 0x1f);
+        x >>= 5;
+        more = (ch & 0x10) ? x != -1 : x != 0;
+        if (more) ch |= 0x20;
+        c[n++] = (char)(ch + 48);
+    }
+    return n;
+}
+
+// grid = masks (mask i owns positions[offsets[i] .. + counts[i])).  out == nullptr: lens[i] = string length, bbox4[4 i ..] = box.
+// out != nullptr: the string is written at out + out_off[i].
+__global__ __launch_bounds__(256) void rle_compress_kernel(const uint32_t* __restrict__ positions, const long long* __restrict__ offsets,
+                                                           const int* __restrict__ counts, int H, int W, int* __restrict__ lens,
+                                                           double* __restrict__ bbox4, char* __restrict__ out,
+                                                           const long long* __restrict__ out_off) {
+    __shared__ int wave_tot[4];
+    __shared__ long long red[4][4];
+    __shared__ int red_full[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pos = counts[i];
+    const uint32_t* pos = positions + offsets[i];
+    const long long N = (long long)H * W;
+    const int m = n_pos + 1;                                  // runs: [pos0, pos1-pos0, ..., N-pos_last]
+    auto edge = [&](int j) -> long long { return j < 0 ? 0 : (j >= n_pos ? N : (long long)pos[j]); };     // end of run j
+    char* o = out ? out + out_off[i] : nullptr;
+    int base = 0;
+    const int me = (m / 2) * 2;
+    long long xs = W, ys = H, xe = -1, ye = -1;
+    int full = 0;
+    for (int j0 = 0; j0 < m; j0 += 256) {
+        const int j = j0 + tid;
+        char c[8];
+        int n = 0;
+        if (j < m) {
+            long long x = edge(j) - edge(j - 1);
+            if (j > 2) x -= edge(j - 2) - edge(j - 3);
+            n = rle_chars(x, c);
+            if (!out && j < me) {                             // tight box of the ones (rleToBbox): runs 1, 3, 5, ... are ones
+                const long long t = edge(j) - (j % 2), y = t % H, xx = (t - y) / H;
+                if (j % 2 == 1) {
+                    const long long tp = edge(j - 1), xp = (tp - tp % H) / H;
+                    if (xp < xx) full = 1;
+                }
+                xs = xx < xs ? xx : xs; xe = xx > xe ? xx : xe;
+                ys = y < ys ? y : ys; ye = y > ye ? y : ye;
+            }
+        }
+        int incl = n;                                         // block exclusive scan of the lengths
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int t = wave_tot[w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        if (o) {
+            char* q = o + base + wbase + incl - n;
+            for (int e = 0; e < n; ++e) q[e] = c[e];
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (out) return;
+    // box reduction across the block
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const long long a = __shfl_xor(xs, d, 64), b = __shfl_xor(ys, d, 64), cx = __shfl_xor(xe, d, 64), cy = __shfl_xor(ye, d, 64);
+        xs = a < xs ? a : xs; ys = b < ys ? b : ys; xe = cx > xe ? cx : xe; ye = cy > ye ? cy : ye;
+        full |= __shfl_xor(full, d, 64);
+    }
+    if (lane == 0) { red[wave][0] = xs; red[wave][1] = ys; red[wave][2] = xe; red[wave][3] = ye; red_full[wave] = full; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            xs = red[w][0] < xs ? red[w][0] : xs; ys = red[w][1] < ys ? red[w][1] : ys;
+            xe = red[w][2] > xe ? red[w][2] : xe; ye = red[w][3] > ye ? red[w][3] : ye;
+            full |= red_full[w];
+        }
+        lens[i] = base;
+        double* bb = bbox4 + 4 * (long long)i;
+        if (me == 0) { bb[0] = bb[1] = bb[2] = bb[3] = 0.0; }
+        else {
+            if (full) { ys = 0; ye = H - 1; }
+            bb[0] = (double)xs; bb[1] = (double)ys; bb[2] = (double)(xe - xs + 1); bb[3] = (double)(ye - ys + 1);
+        }
+    }
+}
+
+}  // namespace nps
+
+// Device-side counterpart of nopesac_rle_compress_batch_host.  positions / offsets / counts: device memory (mask i owns
+// positions[offsets[i] .. offsets[i] + counts[i])).  Pass 1 (out == NULL): lens[i] = string length of mask i, bbox4[4 i ..] = its box.
+// Pass 2 (out != NULL): the strings are written at out + out_off[i] (out_off = exclusive prefix sums of lens, device).
+extern "C" int nopesac_rle_compress_device(const uint32_t* positions, const int64_t* offsets, const int32_t* counts, int n_masks, int H, int W,
+                                           int32_t* lens, double* bbox4, char* out, const int64_t* out_off, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(offsets && counts && n_masks > 0 && H > 0 && W > 0, "rle_compress_device: bad args");
+    NPS_CHECK_ARG(out ? (out_off != nullptr) : (lens && bbox4), "rle_compress_device: pass 1 needs lens + bbox4, pass 2 needs out + out_off");
+    hipLaunchKernelGGL(rle_compress_kernel, dim3(n_masks), dim3(256), 0, (hipStream_t)stream, positions, (const long long*)offsets, counts, H, W,
+                       lens, bbox4, out, (const long long*)out_off);
     NPS_LAUNCH_RET();
 }
 

@@ -60,7 +60,10 @@ class PairMapper:
     """dataset dict -> model input dict (the `image` tensors stay on the host unless `device` is given, exactly like the
     reference mapper's output; ScanNet images pass through the GPU resize kernel)."""
 
-    def __init__(self, cfg, dataset_name: str = "", device=None):
+    def __init__(self, cfg, dataset_name: str = "", device=None, uint8: bool = False):
+        """uint8: keep the decoded 8-bit samples (uint8 CHW tensors; the model widens them on the device - bit-identical results,
+        a quarter of the host-to-device bytes) instead of the reference mapper's float32 tensors."""
+        self.uint8 = uint8
         self.img_format = cfg.INPUT.FORMAT
         self.root_dir = cfg.DATASETS.ROOT_DIR
         name = dataset_name or (cfg.DATASETS.TEST[0] if len(cfg.DATASETS.TEST) else "")
@@ -73,9 +76,9 @@ class PairMapper:
             from . import ops
             dev = self.device or torch.device("cuda", torch.cuda.current_device())
             img_t = ops.resize_bilinear_u8(torch.from_numpy(img.copy()).to(dev), 480, 640)
-            t = img_t.permute(2, 0, 1).float()
+            t = img_t.permute(2, 0, 1).contiguous() if self.uint8 else img_t.permute(2, 0, 1).float()
             return t if self.device is not None else t.cpu()
-        t = torch.as_tensor(img.transpose(2, 0, 1).astype("float32"))
+        t = torch.as_tensor(np.ascontiguousarray(img.transpose(2, 0, 1)) if self.uint8 else img.transpose(2, 0, 1).astype("float32"))
         return t.to(self.device) if self.device is not None else t
 
     def __call__(self, dataset_dict: dict) -> dict:

@@ -53,6 +53,12 @@ class PlaneTR_NopeSAC(nn.Module):
         self.two_streams = bool(amd.TWO_STREAMS)
         self.check_finite = bool(amd.CHECK_FINITE)
         self._side_stream = None
+        # MODEL.AMD.USE_HIP_GRAPH: the whole static-shape forward of a batch as ONE hipGraph replay (~280 launches, 8 ms of Python /
+        # ctypes launch time per 32-pair batch -> < 1 ms).  GRAPH_SLOTS independent captures (own input buffer, own outputs) are
+        # used round-robin, so a caller may keep GRAPH_SLOTS - 1 earlier results un-packaged while it submits the next batch.
+        self.use_hip_graph = bool(amd.USE_HIP_GRAPH)
+        self.graph_slots = 2
+        self._graphs = {}
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 
     @classmethod
@@ -100,19 +106,30 @@ class PlaneTR_NopeSAC(nn.Module):
     def _to_device_batch(self, imgs) -> torch.Tensor:
         """[2B,3,H,W] f32 on the device: every image is copied straight into its slice of ONE buffer (async from pinned host memory;
         no per-image device tensor, no torch.stack pass over the batch)."""
-        out = torch.empty((len(imgs),) + tuple(imgs[0].shape), device=self.device, dtype=torch.float32)
+        return self._copy_images(imgs, torch.empty((len(imgs),) + tuple(imgs[0].shape), device=self.device, dtype=torch.float32))
+
+    def _copy_images(self, imgs, out: torch.Tensor, staging: torch.Tensor = None) -> torch.Tensor:
+        """imgs (host or device, float32 as the reference mapper makes them or uint8 as PairMapper(uint8=True) does) -> `out`
+        (f32 [2B,3,H,W], device).  uint8 images cross PCIe as bytes (a quarter of the traffic) and are widened on the device."""
+        if imgs[0].dtype == torch.uint8 and self.device.type == "cuda":
+            u8 = staging if staging is not None else torch.empty(out.shape, device=self.device, dtype=torch.uint8)
+            for k, im in enumerate(imgs):
+                u8[k].copy_(im, non_blocking=True)
+            return ops.u8_to_f32(u8, out)
         for k, im in enumerate(imgs):
-            out[k].copy_(im, non_blocking=True)
+            out[k].copy_(im, non_blocking=True)               # (a uint8 image on the CPU path is widened by copy_)
         return out
 
-    def forward_device(self, batched_inputs: List[dict], diagnostics: bool = False) -> dict:
+    def forward_device(self, batched_inputs: List[dict], diagnostics: bool = False, forced: dict = None) -> dict:
         """All device work for B pairs; returns device tensors only (no synchronisation)."""
         B = len(batched_inputs)
         H, W = batched_inputs[0]["0"]["image"].shape[-2:]
+        if (self.use_hip_graph and not diagnostics and self.device.type == "cuda" and self.compute_dtype == torch.bfloat16
+                and self.backbone.fused_stem and getattr(self, "stage_events", None) is None and not ops.TUNER.measuring):
+            return self._forward_graph(batched_inputs, B, H, W, forced)
         if self.compute_dtype == torch.bfloat16 and self.backbone.fused_stem:
-            return self.forward_tensors(None, B, H, W, diagnostics, raw_images=self.stack_images(batched_inputs))
-        x = self.preprocess_image(batched_inputs)
-        return self.forward_tensors(x, B, H, W, diagnostics)
+            return self.forward_tensors(None, B, H, W, diagnostics, forced=forced, raw_images=self.stack_images(batched_inputs))
+        return self.forward_tensors(self.preprocess_image(batched_inputs), B, H, W, diagnostics, forced=forced)
 
     def forward_tensors(self, x_nhwc: torch.Tensor, B: int, H: int, W: int, diagnostics: bool = False,
                         forced: dict = None, raw_images: torch.Tensor = None) -> dict:
@@ -157,6 +174,41 @@ class PlaneTR_NopeSAC(nn.Module):
             cam["nonfinite"] = ops.count_nonfinite([t for pair in cam["cameras"].values() for t in pair] + [sel["planes"]])
         return {"B": B, "H": H, "W": W, "sel": sel, "cam": cam, "head_out": head_out if diagnostics else None,
                 "feats": feats if diagnostics else None, "query_feat": query_feat if diagnostics else None}
+
+    def _forward_graph(self, batched_inputs: List[dict], B: int, H: int, W: int, forced: dict = None) -> dict:
+        """forward_device through a captured hipGraph (MODEL.AMD.USE_HIP_GRAPH): per (B, H, W, K control) and slot, the first call
+        runs eagerly (warm-up: weight packing, kernel attributes), the second captures, later calls copy the host images into the
+        slot's static input buffer and replay.  The returned tensors are the slot's static outputs: valid until the slot is
+        replayed again (graph_slots calls later)."""
+        imgs = [x["0"]["image"] for x in batched_inputs] + [x["1"]["image"] for x in batched_inputs]
+        assert len({tuple(i.shape) for i in imgs}) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
+        slot = self.infer_iter % self.graph_slots
+        key = (B, H, W, None if forced is None else id(forced), slot)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"in": torch.empty((2 * B, 3, H, W), device=self.device, dtype=torch.float32), "graph": None, "out": None,
+                                      "calls": 0}
+        buf = st["in"]
+        if imgs[0].dtype == torch.uint8 and "in_u8" not in st:
+            st["in_u8"] = torch.empty(buf.shape, device=self.device, dtype=torch.uint8)
+        self._copy_images(imgs, buf, st.get("in_u8"))
+        st["calls"] += 1
+        if st["graph"] is not None:
+            st["graph"].replay()
+            return st["out"]
+        if st["calls"] == 1:                                   # warm-up pass, eager
+            return self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
+        cur = torch.cuda.current_stream()
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(cur)
+        with torch.cuda.graph(g, stream=cap):
+            out = self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
+        cur.wait_stream(cap)
+        out["static_outputs"] = True                           # package() must not hand out views of graph-owned memory
+        st["graph"], st["out"] = g, out
+        g.replay()                                             # capture does not execute: run this batch
+        return out
 
     def calibrate_fp8(self, batched_inputs: List[dict]) -> dict:
         """Static activation scales of the fp8 backbone mode (MODEL.AMD.BACKBONE_FP8) from representative pairs; returns them."""
@@ -224,28 +276,35 @@ class PlaneTR_NopeSAC(nn.Module):
         ass = {k: cpu(cam[k]) for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
         onepp_t, onepp_r = cpu(cam["refine"]["maps"]["trans_all"]).numpy(), cpu(cam["refine"]["maps"]["rots_all"]).numpy()
         rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]) if self.output_rle else None
+        if d.get("static_outputs"):       # hipGraph mode: the device tensors below are overwritten by the slot's next replay
+            sel = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
+        # the per-view tensors below are VIEWS of this call's private host copies (one D2H copy per field, no per-view clone);
+        # scalars come from .tolist() once (indexing a tensor per instance cost 4 ms per 32-pair step)
+        kept_l, scores_l = kept_idx.tolist(), scores.tolist()
         results = []
         for i in range(B):
             res = {}
             for v, j in (("0", i), ("1", B + i)):
                 n = n_kept[j]
-                idx = kept_idx[j, :n]
                 inp = batched_inputs[i][v]
-                view = {"image_id": inp.get("image_id"), "file_name": inp.get("file_name"),
-                        "pred_plane": planes[j, :n].clone(), "pred_plane_feats": sel["feats"][j:j + 1, :n],
-                        "pred_plane_oriIdxs": [int(q) for q in idx], "pred_plane_ins_center": centers[j, :n].clone(),
-                        "pred_plane_scores": scores[j, :n].clone(), "pred_plane_areas": areas[j, :n].clone(),
+                image_id, file_name = inp.get("image_id"), inp.get("file_name")
+                view = {"image_id": image_id, "file_name": file_name,
+                        "pred_plane": planes[j, :n], "pred_plane_feats": sel["feats"][j:j + 1, :n],
+                        "pred_plane_oriIdxs": kept_l[j][:n], "pred_plane_ins_center": centers[j, :n],
+                        "pred_plane_scores": scores[j, :n], "pred_plane_areas": areas[j, :n],
                         "winner_map": sel["winner"][j], "fallback_mask": bool(flags[j] & 2)}
                 if self.output_masks:
-                    view["pred_plane_masks"] = decode_masks(sel["winner"][j], idx.to(sel["winner"].device), bool(flags[j] & 2))
-                view["instances"] = []
+                    view["pred_plane_masks"] = decode_masks(sel["winner"][j], kept_idx[j, :n].to(sel["winner"].device), bool(flags[j] & 2))
+                inst = []
+                sc_j = scores_l[j]
+                rl_j = rles[j] if rles is not None else None
                 for k in range(n):       # siamese_planeTR.py:705-720 (bbox_mode 1 = XYWH_ABS)
-                    ins = {"image_id": inp.get("image_id"), "file_name": inp.get("file_name"), "category_id": 0,
-                           "score": float(scores[j, k])}
-                    if rles is not None:
-                        ins["segmentation"], ins["bbox"] = rles[j][k]["segmentation"], rles[j][k]["bbox"]
+                    ins = {"image_id": image_id, "file_name": file_name, "category_id": 0, "score": sc_j[k]}
+                    if rl_j is not None:
+                        ins["segmentation"], ins["bbox"] = rl_j[k]["segmentation"], rl_j[k]["bbox"]
                     ins["bbox_mode"] = 1
-                    view["instances"].append(ins)
+                    inst.append(ins)
+                view["instances"] = inst
                 res[v] = view
             res["pred_aff"] = None
             res["depth"] = {"0": None, "1": None}
@@ -255,7 +314,7 @@ class PlaneTR_NopeSAC(nn.Module):
                 res["camera_onePP"] = {"tran": onepp_t[i, :m[i] + 1], "rot": onepp_r[i, :m[i] + 1]}
             n1, n2 = n_kept[i], n_kept[B + i]
             for k, A in ass.items():
-                res[k] = A[i, :n1, :n2].clone()
+                res[k] = A[i, :n1, :n2]
             res["matched_num"] = m[i]
             results.append(res)
         return results

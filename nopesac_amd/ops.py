@@ -558,6 +558,17 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
     return counter
 
 
+def u8_to_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 tensor -> float32 (exact), e.g. the image planes of a batch after an 8-bit host-to-device copy."""
+    _chk(x, torch.uint8)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _chk(out, torch.float32)
+    _require(out.numel() == x.numel(), "u8_to_f32: sizes differ")
+    _lib.check(_L().nopesac_u8_to_f32(_p(x), _p(out), x.numel(), _stream()), "nopesac_u8_to_f32")
+    return out
+
+
 def clock_probe(spin_cycles: int = 400000, stream=None) -> torch.Tensor:
     """Enqueue the engine-clock probe (one wave, ~0.2 ms) on `stream` (default: current); returns an int64[2] device tensor
     (shader cycles, 100 MHz ticks) valid once the stream has passed it: MHz = 100 * t[0] / t[1]."""
@@ -701,6 +712,27 @@ def rle_transitions(labels: torch.Tensor, n_kept: torch.Tensor, nq: int, offsets
                                             _p(positions) if positions is not None else None, V, W * H, nq, _stream()),
                "nopesac_rle_transitions")
     return counts
+
+
+def rle_compress(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.Tensor, H: int, W: int):
+    """Flip positions of n masks (device: positions int32 buffer, offsets int64 [n], counts int32 [n]) -> COCO counts strings on
+    the device: (bytes uint8 [total], out_off int64 [n], lens int32 [n], bbox float64 [n,4]) - all device tensors; one host
+    sync inside (the total string length sizes the byte buffer)."""
+    _chk(positions, torch.int32); _chk(offsets, torch.int64); _chk(counts, torch.int32)
+    n = counts.numel()
+    dev = counts.device
+    lens = torch.empty(n, device=dev, dtype=torch.int32)
+    bbox = torch.empty(n, 4, device=dev, dtype=torch.float64)
+    L = _L()
+    _lib.check(L.nopesac_rle_compress_device(_p(positions), _p(offsets), _p(counts), n, H, W, _p(lens), _p(bbox), None, None, _stream()),
+               "nopesac_rle_compress_device")
+    ends = torch.cumsum(lens.to(torch.int64), 0)
+    out_off = (ends - lens).contiguous()
+    total = int(ends[-1].item())                                         # host sync
+    out = torch.empty(max(total, 1), device=dev, dtype=torch.uint8)
+    _lib.check(L.nopesac_rle_compress_device(_p(positions), _p(offsets), _p(counts), n, H, W, None, None, _p(out), _p(out_off), _stream()),
+               "nopesac_rle_compress_device")
+    return out[:total], out_off, lens, bbox
 
 
 def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict):

@@ -3,8 +3,9 @@ meta_arch/siamese_planeTR.py:685-720, 741-766).
 
 Device: nopesac_rle_labels + nopesac_rle_transitions (csrc/rle.hip) produce, for every (view, kept plane), the
 positions where the plane's mask flips along the column-major scan; no [n,H,W] mask tensor is ever built.
-Host: nopesac_rle_compress_host (same library, plain C) turns one plane's flips into the compressed counts string and
-the [x, y, w, h] box.  The only host sync is the size read between the count and the fill pass.
+nopesac_rle_compress_device (a workgroup per mask) turns the flips into the compressed counts strings and the [x, y, w, h]
+boxes, still on the device; the host receives finished byte strings.  Host syncs: two size reads (positions buffer, byte buffer).
+nopesac_rle_compress_host / _batch_host (same library, plain C) are the host forms of the same encoder.
 """
 from __future__ import annotations
 
@@ -66,18 +67,30 @@ def compress_batch(positions: np.ndarray, offsets: np.ndarray, counts: np.ndarra
 
 
 def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor) -> List[List[dict]]:
-    """Per view, per kept plane (query order): {"segmentation": {"size": [H,W], "counts": bytes}, "bbox": [x,y,w,h]}."""
+    """Per view, per kept plane (query order): {"segmentation": {"size": [H,W], "counts": bytes}, "bbox": [x,y,w,h]}.
+    Flip positions AND the compressed strings are produced on the device (csrc/rle.hip); the host receives the finished byte
+    strings (about 2 bytes per run instead of 4 per flip position) and only slices them."""
     V, H, W = winner.shape
-    counts, offsets, pos = flip_positions(winner, kept_idx, n_kept, flags)
-    n_list = n_kept.cpu().tolist()
-    sel = [(v, p) for v in range(V) for p in range(n_list[v])]
-    if not sel:
-        return [[] for _ in range(V)]
-    vi, pi = np.array([s[0] for s in sel]), np.array([s[1] for s in sel])
-    strings, boxes = compress_batch(pos, offsets.numpy()[vi, pi], counts.numpy()[vi, pi], H, W)
-    out = [[] for _ in range(V)]
-    for k, (v, p) in enumerate(sel):
-        out[v].append({"segmentation": {"size": [H, W], "counts": strings[k]}, "bbox": boxes[k].tolist()})
+    nq = kept_idx.shape[1]
+    labels = ops.rle_labels(winner, kept_idx, n_kept, flags)
+    counts = ops.rle_transitions(labels, n_kept, nq)
+    c64 = counts.view(-1).to(torch.int64)
+    ends = torch.cumsum(c64, 0)
+    offsets = (ends - c64).contiguous()
+    total = int(ends[-1].item())                                         # host sync (sizes the positions buffer)
+    pos = torch.empty(max(total, 1), device=winner.device, dtype=torch.int32)
+    if total:
+        ops.rle_transitions(labels, n_kept, nq, offsets=offsets.view(V, nq), positions=pos)
+    data, out_off, lens, bbox = ops.rle_compress(pos, offsets, counts.view(-1).contiguous(), H, W)
+    raw = data.cpu().numpy().tobytes()
+    out_off, lens, bbox, n_list = out_off.cpu().tolist(), lens.cpu().tolist(), bbox.cpu().tolist(), n_kept.cpu().tolist()
+    out = []
+    for v in range(V):
+        row = []
+        for p in range(n_list[v]):
+            k = v * nq + p
+            row.append({"segmentation": {"size": [H, W], "counts": raw[out_off[k]:out_off[k] + lens[k]]}, "bbox": bbox[k]})
+        out.append(row)
     return out
 
 

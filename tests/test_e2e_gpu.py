@@ -189,6 +189,53 @@ def test_bf16_backbone_pose_error(device):
         assert np.isfinite(y["camera"]["tran"]).all() and np.isfinite(y["camera"]["rot"]).all()
 
 
+def test_hip_graph_mode_reproduces_the_eager_results(device):
+    """MODEL.AMD.USE_HIP_GRAPH: the forward of a batch as one hipGraph replay (warm-up call eager, capture on a slot's second
+    call, replays afterwards; two slots round-robin).  Every call must return exactly what the eager bf16 model returns for the
+    same inputs (same kernels, same order), for changing inputs, and results handed out earlier must not change when the
+    slot's static buffers are overwritten by later replays."""
+    import copy
+    from nopesac_amd.synth import synth_pair
+    eager = make_model(device, dtype="bfloat16")
+    graph = make_model(device, ["MODEL.AMD.USE_HIP_GRAPH", True], dtype="bfloat16")
+    assert graph.use_hip_graph and not eager.use_hip_graph
+    kept = []
+    for it in range(7):                                   # slots 1, 0, 1, 0, ...: eager, eager, capture, capture, replay x 3
+        inp = [synth_pair(3 * it + i) for i in range(2)]
+        a, b = eager(inp), graph(inp)
+        for x, y in zip(a, b):
+            for k in ("camera", "camera_init", "camera_initRec", "camera_softRef0"):
+                assert np.array_equal(x[k]["tran"], y[k]["tran"]) and np.array_equal(x[k]["rot"], y[k]["rot"]), (it, k)
+            assert x["matched_num"] == y["matched_num"] and torch.equal(x["pred_assignment"], y["pred_assignment"])
+            for v in "01":
+                assert torch.equal(x[v]["pred_plane"], y[v]["pred_plane"]) and x[v]["pred_plane_oriIdxs"] == y[v]["pred_plane_oriIdxs"]
+                assert torch.equal(x[v]["pred_plane_feats"], y[v]["pred_plane_feats"]) and torch.equal(x[v]["winner_map"], y[v]["winner_map"])
+                assert [i["segmentation"] for i in x[v]["instances"]] == [i["segmentation"] for i in y[v]["instances"]]
+        kept.append((b, [{v: (r[v]["pred_plane_feats"].clone(), r[v]["winner_map"].clone()) for v in "01"} for r in b]))
+    assert len(graph._graphs) == 2 and all(st["graph"] is not None for st in graph._graphs.values())
+    for b, snap in kept:                                  # earlier results are untouched by the later replays
+        for r, s0 in zip(b, snap):
+            for v in "01":
+                assert torch.equal(r[v]["pred_plane_feats"], s0[v][0]) and torch.equal(r[v]["winner_map"], s0[v][1])
+
+
+def test_uint8_images_give_the_float32_results(device):
+    """uint8 CHW image tensors at the boundary (data.PairMapper(uint8=True)) are widened on the device: the results are identical
+    to those for the reference mapper's float32 tensors, in the fp32 path (preprocess kernel) and the bf16 path (raw-input stem)."""
+    from nopesac_amd.synth import synth_pair
+    for dtype in ("float32", "bfloat16"):
+        model = make_model(device, dtype=dtype)
+        inp = [synth_pair(40 + i) for i in range(2)]
+        inp8 = [{v: dict(p[v], image=p[v]["image"].round().clamp(0, 255).to(torch.uint8)) if v in "01" else p[v] for v in p} for p in inp]
+        inpf = [{v: dict(p[v], image=p[v]["image"].float()) if v in "01" else p[v] for v in p} for p in inp8]
+        a, b = model(inpf), model(inp8)
+        for x, y in zip(a, b):
+            for k in ("camera", "camera_init"):
+                assert np.array_equal(x[k]["tran"], y[k]["tran"]) and np.array_equal(x[k]["rot"], y[k]["rot"]), (dtype, k)
+            for v in "01":
+                assert torch.equal(x[v]["pred_plane"], y[v]["pred_plane"]) and torch.equal(x[v]["winner_map"], y[v]["winner_map"])
+
+
 def test_cli_runner_end_to_end(device, tmp_path):
     """`python -m nopesac_amd.run` flow (cfg -> build_model -> checkpoint -> batch loop -> evaluator) on the GPU."""
     import json

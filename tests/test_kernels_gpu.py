@@ -206,16 +206,19 @@ def test_stem_fused(device, B, H, W):
     assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1e-2
 
 
-@pytest.mark.parametrize("V,H,W,nq,seed", [(3, 48, 64, 50, 0), (2, 37, 53, 50, 1), (2, 480, 640, 128, 2), (1, 5, 3, 50, 3)])
+@pytest.mark.parametrize("V,H,W,nq,seed", [(3, 48, 64, 50, 0), (2, 37, 53, 50, 1), (2, 480, 640, 128, 2), (1, 5, 3, 50, 3), (2, 120, 97, 6, 4)])
 def test_rle_from_winner_map(device, V, H, W, nq, seed):
-    """RLE kernels + host compressor vs the numpy COCO restatement on blocky synthetic winner maps
-    (ragged n_kept, a fallback view, sizes with H*W not a multiple of 16, ids up to 127)."""
+    """RLE kernels + device string compressor vs the numpy COCO restatement on blocky synthetic winner maps
+    (ragged n_kept, a fallback view, sizes with H*W not a multiple of 16, ids up to 127); seed 4 = per-pixel noise: thousands of
+    short runs per mask (many 256-run chunks per workgroup, negative run differences)."""
     from nopesac_amd import rle
     from oracle import rle_oracle as R
     g = torch.Generator().manual_seed(seed)
     bh, bw = max(H // 6, 1), max(W // 5, 1)
     coarse = torch.randint(0, nq, (V, (H + bh - 1) // bh, (W + bw - 1) // bw), generator=g)
     ids = coarse.repeat_interleave(bh, 1).repeat_interleave(bw, 2)[:, :H, :W]
+    if seed == 4:
+        ids = torch.randint(0, nq, (V, H, W), generator=g)
     passed = torch.rand(V, H, W, generator=g) < 0.8
     winner = (ids | (passed.long() << 7)).to(torch.uint8)
     n_kept = torch.tensor([min(nq, 1 + 7 * v) for v in range(V)], dtype=torch.int32)
