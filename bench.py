@@ -581,7 +581,7 @@ def main():
         if not args.no_accuracy:
             out["pose_err_vs_fp32_path"].update(accuracy_vs_fp32(model, device, nq))
     if rank == 0 and world == 1 and not args.no_boundary and args.dtype == "bfloat16":
-        out["boundary"] = boundary_rate(model, raw, forced, B)
+        out["boundary"] = boundary_rate(model, raw, forced, B, streams=streams)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
@@ -632,7 +632,7 @@ def bench_workload_pose_error(m16, m32, device, B, K, nq, raw=None, forced=None)
     return out
 
 
-def boundary_rate(model, raw, forced, B, steps=4):
+def boundary_rate(model, raw, forced, B, steps=4, streams=None):
     """The rate AT the drop-in boundary (what the reference's consumer, MP3DEvaluator.process, sees): a list of B input dicts with
     HOST image tensors goes in, the list of per-pair result dicts comes out - H2D copies, the whole forward, `package()` (the
     reference's result schema, siamese_planeTR.py:384-450) and the COCO RLE `instances` of every kept plane included; the same
@@ -668,7 +668,10 @@ def boundary_rate(model, raw, forced, B, steps=4):
         assert all("segmentation" in ins for r in res for v in "01" for ins in r[v]["instances"])
         return (time.perf_counter() - t0) / n, t_pack / n
 
-    streams = [torch.cuda.Stream() for _ in range(4)]
+    # the caller's HIP streams when it has some: a process multiplexes its streams onto a few hardware queues (4 by default), streams
+    # created on top of the timed loop's 4 + 4 side streams shared queues with each other and lost a quarter of the overlap
+    streams = list(streams or [])
+    streams += [torch.cuda.Stream() for _ in range(4 - len(streams))]
 
     def pipelined(n, depth=2):
         # `depth` batches in flight: batch i's copies and forward are enqueued (their own HIP stream) before the results of batch
@@ -676,22 +679,33 @@ def boundary_rate(model, raw, forced, B, steps=4):
         def submit(slot):
             with torch.no_grad(), torch.cuda.stream(streams[slot]):
                 model.infer_iter += 1
-                return slot, model.forward_device(cur[0], forced=forced)
+                d = model.forward_device(cur[0], forced=forced)
+                ev = torch.cuda.Event()
+                ev.record()
+                return slot, d, ev
 
         def finish(h):
+            h[2].synchronize()                                                  # the batch's forward is complete
             with torch.no_grad(), torch.cuda.stream(streams[h[0]]):
                 return model.package(cur[0], h[1])
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pending = []
+        ts, tf = 0.0, 0.0
         for i in range(n):
+            a = time.perf_counter()
             pending.append(submit(i % depth))
+            bq = time.perf_counter()
+            ts += bq - a
             if len(pending) >= depth:
                 finish(pending.pop(0))
+                tf += time.perf_counter() - bq
         while pending:
             finish(pending.pop(0))
         torch.cuda.synchronize()
+        if os.environ.get("NOPESAC_BD_DEBUG"):
+            print("pipelined depth %d n %d: %.2f ms/step, submit %.2f finish %.2f" % (depth, n, 1e3 * (time.perf_counter() - t0) / n, 1e3 * ts / n, 1e3 * tf / n), file=sys.stderr)
         return (time.perf_counter() - t0) / n
 
     out = {}

@@ -264,18 +264,29 @@ class PlaneTR_NopeSAC(nn.Module):
         """Build the reference's per-pair result dicts (siamese_planeTR.py:384-450); the only host sync."""
         B, sel, cam = d["B"], d["sel"], d["cam"]
         H, W = d["H"], d["W"]
-        cpu = lambda t: t.detach().to("cpu")
-        n_kept, kept_idx = cpu(sel["n_kept"]).tolist(), cpu(sel["kept_idx"])
-        planes, centers, scores, areas = cpu(sel["planes"]), cpu(sel["centers"]), cpu(sel["scores"]), cpu(sel["areas"])
-        flags = cpu(sel["flags"]).tolist()
-        cams = {k: (cpu(t).numpy(), cpu(r).numpy()) for k, (t, r) in cam["cameras"].items()}
-        m = cpu(cam["m"]).tolist()
-        if "nonfinite" in cam and int(cpu(cam["nonfinite"])[0]) != 0:
+        # every small device tensor the result dicts need, in ONE device-to-host copy (a uint8 concatenation -> a pinned host buffer
+        # -> one wait) instead of ~25 synchronous pageable copies
+        need = {"n_kept": sel["n_kept"], "kept_idx": sel["kept_idx"], "planes": sel["planes"], "centers": sel["centers"],
+                "scores": sel["scores"], "areas": sel["areas"], "flags": sel["flags"], "m": cam["m"],
+                "onepp_t": cam["refine"]["maps"]["trans_all"], "onepp_r": cam["refine"]["maps"]["rots_all"]}
+        for k, (t, r) in cam["cameras"].items():
+            need["cam_t:" + k], need["cam_r:" + k] = t, r
+        for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment"):
+            need["ass:" + k] = cam[k]
+        if "nonfinite" in cam:
+            need["nonfinite"] = cam["nonfinite"]
+        hostd = ops.gather_to_host(need)
+        n_kept, kept_idx = hostd["n_kept"].tolist(), hostd["kept_idx"]
+        planes, centers, scores, areas = hostd["planes"], hostd["centers"], hostd["scores"], hostd["areas"]
+        flags = hostd["flags"].tolist()
+        cams = {k: (hostd["cam_t:" + k].numpy(), hostd["cam_r:" + k].numpy()) for k in cam["cameras"]}
+        m = hostd["m"].tolist()
+        if "nonfinite" in cam and int(hostd["nonfinite"][0]) != 0:
             raise FloatingPointError("nopesac_amd: %d non-finite values in the predicted poses / plane parameters of this batch "
-                                     "(the reference traps this case with pdb.set_trace(), camera_head.py:1072-1074)" % int(cpu(cam["nonfinite"])[0]))
-        ass = {k: cpu(cam[k]) for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
-        onepp_t, onepp_r = cpu(cam["refine"]["maps"]["trans_all"]).numpy(), cpu(cam["refine"]["maps"]["rots_all"]).numpy()
-        rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]) if self.output_rle else None
+                                     "(the reference traps this case with pdb.set_trace(), camera_head.py:1072-1074)" % int(hostd["nonfinite"][0]))
+        ass = {k: hostd["ass:" + k] for k in ("pred_assignment_beforeRef0", "pred_assignment_afterRef0", "pred_assignment")}
+        onepp_t, onepp_r = hostd["onepp_t"].numpy(), hostd["onepp_r"].numpy()
+        rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"], n_kept_host=n_kept) if self.output_rle else None
         if d.get("static_outputs"):       # hipGraph mode: the device tensors below are overwritten by the slot's next replay
             sel = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
         # the per-view tensors below are VIEWS of this call's private host copies (one D2H copy per field, no per-view clone);

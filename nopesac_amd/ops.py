@@ -558,6 +558,32 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
     return counter
 
 
+def gather_to_host(tensors: dict) -> dict:
+    """{name: tensor} -> {name: host tensor of the same dtype / shape}.  Device tensors travel together: their bytes are concatenated
+    on the device (8-byte aligned segments), copied once into a fresh pinned host buffer and waited for once; the returned tensors
+    are views of that buffer (it lives as long as any of them)."""
+    dev = [(k, t.detach().contiguous()) for k, t in tensors.items() if t.is_cuda]
+    out = {k: t.detach() for k, t in tensors.items() if not t.is_cuda}
+    if not dev:
+        return out
+    parts, spans, off = [], {}, 0
+    for k, t in dev:
+        b = t.view(-1).view(torch.uint8) if t.numel() else t.new_empty(0, dtype=torch.uint8)
+        pad = (-b.numel()) % 8
+        spans[k] = (off, b.numel(), t.dtype, tuple(t.shape))
+        parts.append(b)
+        if pad:
+            parts.append(b.new_zeros(pad))
+        off += b.numel() + pad
+    flat = torch.cat(parts)
+    host = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
+    host.copy_(flat, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    for k, (o, n, dt, shape) in spans.items():
+        out[k] = host[o:o + n].view(dt).view(shape)
+    return out
+
+
 def u8_to_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """uint8 tensor -> float32 (exact), e.g. the image planes of a batch after an 8-bit host-to-device copy."""
     _chk(x, torch.uint8)

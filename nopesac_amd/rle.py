@@ -66,10 +66,11 @@ def compress_batch(positions: np.ndarray, offsets: np.ndarray, counts: np.ndarra
     return [raw[out_off[i]:out_off[i + 1]] for i in range(n)], bbox[:n]
 
 
-def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor) -> List[List[dict]]:
+def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor, n_kept_host=None) -> List[List[dict]]:
     """Per view, per kept plane (query order): {"segmentation": {"size": [H,W], "counts": bytes}, "bbox": [x,y,w,h]}.
     Flip positions AND the compressed strings are produced on the device (csrc/rle.hip); the host receives the finished byte
-    strings (about 2 bytes per run instead of 4 per flip position) and only slices them."""
+    strings (about 2 bytes per run instead of 4 per flip position) in one copy and only slices them.
+    n_kept_host: n_kept as a Python list, when the caller has it already."""
     V, H, W = winner.shape
     nq = kept_idx.shape[1]
     labels = ops.rle_labels(winner, kept_idx, n_kept, flags)
@@ -82,8 +83,13 @@ def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Ten
     if total:
         ops.rle_transitions(labels, n_kept, nq, offsets=offsets.view(V, nq), positions=pos)
     data, out_off, lens, bbox = ops.rle_compress(pos, offsets, counts.view(-1).contiguous(), H, W)
-    raw = data.cpu().numpy().tobytes()
-    out_off, lens, bbox, n_list = out_off.cpu().tolist(), lens.cpu().tolist(), bbox.cpu().tolist(), n_kept.cpu().tolist()
+    need = {"data": data, "out_off": out_off, "lens": lens, "bbox": bbox}
+    if n_kept_host is None:
+        need["n_kept"] = n_kept
+    h = ops.gather_to_host(need)
+    raw = h["data"].numpy().tobytes()
+    out_off, lens, bbox = h["out_off"].tolist(), h["lens"].tolist(), h["bbox"].tolist()
+    n_list = n_kept_host if n_kept_host is not None else h["n_kept"].tolist()
     out = []
     for v in range(V):
         row = []

@@ -1,8 +1,7 @@
-"""GPU box: where the host time of the drop-in boundary goes (model(list[dict]) -> list[dict] with RLE instances): cProfile of a few
-serial boundary steps on the benchmark workload."""
-import cProfile
+"""GPU box: where the time of the drop-in boundary goes (model(list[dict]) -> list[dict] with RLE instances) with several batches in
+flight: host time to submit a batch, host time blocked waiting for the oldest batch's GPU work, host time of the packaging proper."""
+import gc
 import os
-import pstats
 import sys
 import time
 
@@ -15,40 +14,62 @@ from nopesac_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 B, K = 32, 32
+DEPTH = int(os.environ.get("DEPTH", "4"))
+U8 = os.environ.get("U8", "1") == "1"
+GRAPH = os.environ.get("GRAPH", "1") == "1"
 model = bench.build_model(dev, 50, "bfloat16")
 ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r2.json"))
 forced = bench.make_forced(B, K, 50, dev, 7)
 g = torch.Generator().manual_seed(0)
-raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float()
-host = raw.pin_memory()
+raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g)
+host = (raw.to(torch.uint8) if U8 else raw.float()).pin_memory()
 inputs = [{"0": {"image": host[i], "image_id": "a%d" % i, "file_name": ""}, "1": {"image": host[B + i], "image_id": "b%d" % i, "file_name": ""}}
           for i in range(B)]
 model.output_rle = True
+model.use_hip_graph = GRAPH
+model.graph_slots = DEPTH
+gc.collect(); gc.freeze()
+streams = [torch.cuda.Stream() for _ in range(DEPTH)]
+t_sub, t_wait, t_pack = [], [], []
 
 
-def one(times):
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        imgs = model.stack_images(inputs)
-        t1 = time.perf_counter()
-        d = model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=imgs)
-        t2 = time.perf_counter()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        res = model.package(inputs, d)
-        t4 = time.perf_counter()
-    times.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
-    return res
+def submit(slot):
+    t0 = time.perf_counter()
+    with torch.no_grad(), torch.cuda.stream(streams[slot]):
+        model.infer_iter += 1
+        d = model.forward_device(inputs, forced=forced)
+        ev = torch.cuda.Event(); ev.record()
+    t_sub.append(time.perf_counter() - t0)
+    return slot, d, ev
 
 
-tm = []
-for _ in range(3):
-    one(tm)
-tm = []
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(4):
-    one(tm)
-pr.disable()
-print("ms per step: stack_images(host) %.2f  forward enqueue %.2f  wait for GPU %.2f  package %.2f" % tuple(1e3 * sum(t[i] for t in tm) / len(tm) for i in range(4)))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+def finish(h):
+    t0 = time.perf_counter()
+    h[2].synchronize()
+    t1 = time.perf_counter()
+    with torch.no_grad(), torch.cuda.stream(streams[h[0]]):
+        r = model.package(inputs, h[1])
+    t_wait.append(t1 - t0); t_pack.append(time.perf_counter() - t1)
+    return r
+
+
+def run(n):
+    pending = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        pending.append(submit(i % DEPTH))
+        if len(pending) >= DEPTH:
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+run(3 * DEPTH)
+t_sub.clear(); t_wait.clear(); t_pack.clear()
+el = run(8 * DEPTH)
+ms = lambda v: 1e3 * sum(v) / len(v)
+print("depth %d u8 %s graph %s: %.2f ms/step = %.0f pairs/s | host per step: submit %.2f  wait-for-forward %.2f  package %.2f ms"
+      % (DEPTH, U8, GRAPH, 1e3 * el, B / el, ms(t_sub), ms(t_wait), ms(t_pack)))
