@@ -61,6 +61,12 @@ class PlaneTR_NopeSAC(nn.Module):
         self._graphs = {}
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 
+    # captured hipGraphs hold the addresses of the packed weights of the moment of capture: any change of the parameters
+    # (checkpoint load, .to(), .half() ...) drops them - the next call of a shape re-captures
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_graphs"] = {}
+        return super()._apply(fn, *a, **k)
+
     @classmethod
     def from_config(cls, cfg):
         return {"num_queries": cfg.MODEL.SEM_SEG_HEAD.NUM_OBJECT_QUERIES, "pixel_mean": cfg.MODEL.PIXEL_MEAN,
@@ -76,6 +82,7 @@ class PlaneTR_NopeSAC(nn.Module):
         if "model" in state_dict and isinstance(state_dict["model"], dict):
             state_dict = state_dict["model"]
         sd = {k: v for k, v in state_dict.items() if not k.startswith("criterion.")}
+        self.__dict__["_graphs"] = {}                       # captured hipGraphs point at the old packed weights
         return super().load_state_dict(sd, strict=strict)
 
     # ------------------------------------------------------------------------------------------

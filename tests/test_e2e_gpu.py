@@ -217,6 +217,23 @@ def test_hip_graph_mode_reproduces_the_eager_results(device):
         for r, s0 in zip(b, snap):
             for v in "01":
                 assert torch.equal(r[v]["pred_plane_feats"], s0[v][0]) and torch.equal(r[v]["winner_map"], s0[v][1])
+    # a checkpoint load drops the captured graphs (they hold the addresses of the old packed weights): the new weights take effect
+    sd = {k: v.clone() for k, v in eager.state_dict().items()}
+    sd["camera_head_list.0.trans.weight"] = sd["camera_head_list.0.trans.weight"] * 1.5
+    old = {k: v.clone() for k, v in eager.state_dict().items()}
+    try:
+        eager.load_state_dict(sd)
+        graph.load_state_dict(sd)
+        assert graph._graphs == {}
+        inp = [synth_pair(90 + i) for i in range(2)]
+        for it in range(3):
+            a, b = eager(inp), graph(inp)
+            for x, y in zip(a, b):
+                assert np.array_equal(x["camera_init"]["tran"], y["camera_init"]["tran"]) and np.array_equal(x["camera"]["tran"], y["camera"]["tran"])
+        assert not np.array_equal(kept[-1][0][0]["camera_init"]["tran"], b[0]["camera_init"]["tran"])
+    finally:                                              # the models are shared with other tests (tests/util.make_model cache)
+        eager.load_state_dict(old)
+        graph.load_state_dict(old)
 
 
 def test_uint8_images_give_the_float32_results(device):
