@@ -20,7 +20,13 @@ __device__ __forceinline__ float group_sum(float v, int tg) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
+// NT threads, ZREG coupling entries per lane and phase kept in registers.  1024 threads: a group of tg lanes (largest power of two
+// with 1024 / tg >= rows) owns a row in the row phase and a column in the column phase; <1024, 16> covers nq <= 127 (tg >= 8),
+// <1024, 36> nq = 128 (tg = 4, 33 entries; 148 B of spills at the 128-VGPR cap).  The first version ran 256 threads: nq = 64
+// (BASELINE configs[2]) and above fell to an LDS loop with one or two LANES per row - 1.77 ms per launch at nq = 64, 6.9 ms at
+// nq = 128 (configs[4]); now 0.72 / 2.77 ms; nq = 50: 0.88 -> 0.63 ms (32 pairs, full plane sets, 200 iterations; scripts/sinkhorn_one.py).
+template <int NT, int ZREG>
+__global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
     const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
     const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
     const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
     // ---- couplings
     const float bin = bin_score[0];
     const float* dd = desc_dot + (long long)b * nq * nq;
-    for (int e = tid; e < R1 * C1; e += 256) {
+    for (int e = tid; e < R1 * C1; e += NT) {
         const int i = e / C1, j = e % C1;
         float val = bin;
         if (i < n1 && j < n2) {
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
         Z[i * LD + j] = val;
     }
     const float norm = -logf((float)(n1 + n2));
-    for (int i = tid; i < R; i += 256) {
+    for (int i = tid; i < R; i += NT) {
         u[i] = 0.f; v[i] = 0.f;
         lmu[i] = i < n1 ? norm : logf((float)n2) + norm;
         lnu[i] = i < n2 ? norm : logf((float)n1) + norm;
@@ -97,9 +103,8 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
     // ---- Sinkhorn: lane groups of tg lanes per row / column
     const int big = max(R1, C1);
     int tg = 64;
-    while (tg > 1 && (256 / tg) < big) tg >>= 1;       // largest pow2 group with enough groups; may still need >1 pass
-    const int ngroups = 256 / tg, grp = tid / tg, gl = tid % tg;
-    constexpr int ZREG = 16;                                    // coupling entries a lane can keep in registers per phase
+    while (tg > 1 && (NT / tg) < big) tg >>= 1;       // largest pow2 group with enough groups; may still need >1 pass
+    const int ngroups = NT / tg, grp = tid / tg, gl = tid % tg;
     if (ngroups >= big && (big + tg - 1) / tg <= ZREG) {
         // Every lane group owns exactly one row (row phase) and one column (column phase): the lane's slice of both is
         // loop invariant, so it is read from LDS ONCE and the 200 iterations run out of registers (same partition, same
@@ -172,31 +177,31 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_kernel(
         __syncthreads();
     }
     // ---- final scores (kept in LDS for the assignment) + padded output
-    for (int e = tid; e < R1 * C1; e += 256) {
+    for (int e = tid; e < R1 * C1; e += NT) {
         const int i = e / C1, j = e % C1;
         Z[i * LD + j] = Z[i * LD + j] + u[i] + v[j] - norm;
     }
     __syncthreads();
     float* out = log_scores + (long long)b * R * R;
-    for (int e = tid; e < R * R; e += 256) {
+    for (int e = tid; e < R * R; e += NT) {
         const int i = e / R, j = e % R;
         const int si = i < n1 ? i : (i == nq ? n1 : -1), sj = j < n2 ? j : (j == nq ? n2 : -1);
         out[e] = (si >= 0 && sj >= 0) ? Z[si * LD + sj] : NEG_PAD;
     }
     // ---- mutual nearest neighbours over the plane block
-    for (int i = tid; i < n1; i += 256) {
+    for (int i = tid; i < n1; i += NT) {
         float m = -INFINITY; int a = 0;
         for (int j = 0; j < n2; ++j) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = j; } }
         max0[i] = m; idx0[i] = a;
     }
-    for (int j = tid; j < n2; j += 256) {
+    for (int j = tid; j < n2; j += NT) {
         float m = -INFINITY; int a = 0;
         for (int i = 0; i < n1; ++i) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = i; } }
         idx1[j] = a;
     }
     __syncthreads();
     float* A = assignment + (long long)b * nq * nq;
-    for (int e = tid; e < nq * nq; e += 256) {
+    for (int e = tid; e < nq * nq; e += NT) {
         const int i = e / nq, j = e % nq;
         float a = 0.f;
         if (i < n1 && j < n2 && n2 > 0 && idx0[i] == j && idx1[j] == i && expf(max0[i]) > match_thr) a = 1.f;
@@ -264,9 +269,15 @@ extern "C" int nopesac_matcher_sinkhorn(const float* desc_dot, const float* plan
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && iters >= 0, "sinkhorn: bad dims (nq<=128)");
     const int R = nq + 1, LD = (R & 1) ? R : R + 1;
     const size_t lds = sizeof(float) * ((size_t)R * LD + 4 * R + 11 * nq + R + 2 * R);
-    if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, matcher_sinkhorn_kernel);   // per device, only when it is needed
-    hipLaunchKernelGGL(matcher_sinkhorn_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
-                       cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    if (nq + 1 <= 128) {              // 1024 threads: lane groups of 8-64 lanes per row / column, <= 16 entries per lane (no spills)
+        if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, (matcher_sinkhorn_kernel<1024, 16>));
+        hipLaunchKernelGGL((matcher_sinkhorn_kernel<1024, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
+                           cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    } else {                          // nq = 128: groups of 4 lanes x 33 entries
+        if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, (matcher_sinkhorn_kernel<1024, 36>));
+        hipLaunchKernelGGL((matcher_sinkhorn_kernel<1024, 36>), dim3(B), dim3(1024), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
+                           cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    }
     NPS_LAUNCH_RET();
 }
 
