@@ -118,6 +118,7 @@ class PlaneTR_NopeSAC(nn.Module):
     def _copy_images(self, imgs, out: torch.Tensor, staging: torch.Tensor = None) -> torch.Tensor:
         """imgs (host or device, float32 as the reference mapper makes them or uint8 as PairMapper(uint8=True) does) -> `out`
         (f32 [2B,3,H,W], device).  uint8 images cross PCIe as bytes (a quarter of the traffic) and are widened on the device."""
+        assert len({i.dtype for i in imgs}) == 1, "all images of a batch must share one dtype (float32 or uint8)"
         if imgs[0].dtype == torch.uint8 and self.device.type == "cuda":
             u8 = staging if staging is not None else torch.empty(out.shape, device=self.device, dtype=torch.uint8)
             for k, im in enumerate(imgs):

@@ -71,6 +71,7 @@ def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1):
                       x_bcast=x_bcast, rows_per=rows_per)
         return results
     if x_bcast is not None:                       # per-layer path: materialise the concatenated input once
+        assert rows == x_bcast.shape[0] * rows_per, "run_stacks: x_bcast rows x rows_per must equal the rows of x"
         full = torch.empty(rows, k0, device=x.device, dtype=torch.float32)
         full.view(-1, rows_per, k0)[:, :, :x_bcast.shape[1]] = x_bcast[:, None, :]
         full[:, x_bcast.shape[1]:] = x

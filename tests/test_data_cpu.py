@@ -60,6 +60,10 @@ def test_mp3d_mapper(tmp_path):
         assert img.dtype == torch.float32 and img.shape == (3, 480, 640) and not img.is_cuda
         assert torch.equal(img, torch.from_numpy(files[int(v)][1].transpose(2, 0, 1).astype("float32")))
     assert "image" not in entry["0"] and out["rel_pose"] == entry["rel_pose"]            # deep copy, pose passed through
+    u8 = data.PairMapper(_cfg(), "mp3d_test", uint8=True)(entry)            # 8-bit hand-over: the same samples, a quarter of the bytes
+    for v in "01":
+        assert u8[v]["image"].dtype == torch.uint8 and u8[v]["image"].is_contiguous()
+        assert torch.equal(u8[v]["image"].float(), out[v]["image"])
     bgr = data.PairMapper(_cfg(["INPUT.FORMAT", "BGR"]), "mp3d_test")(entry)
     assert torch.equal(bgr["0"]["image"], out["0"]["image"].flip(0))
     moved = dict(entry, **{"0": dict(entry["0"], file_name=data.MP3D_ORIGINAL_ROOT + "x.png")})
