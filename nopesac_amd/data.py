@@ -94,9 +94,9 @@ class PairMapper:
         return d
 
 
-def build_inference_pairs(cfg, dataset_name: str, datasets_dir: str = "./datasets", limit: int = 0, device=None) -> List[dict]:
+def build_inference_pairs(cfg, dataset_name: str, datasets_dir: str = "./datasets", limit: int = 0, device=None, uint8: bool = False) -> List[dict]:
     pairs = load_pairs_json(dataset_json(dataset_name, datasets_dir))
     if limit:
         pairs = pairs[:limit]
-    mapper = PairMapper(cfg, dataset_name, device)
+    mapper = PairMapper(cfg, dataset_name, device, uint8=uint8)
     return [mapper(p) for p in pairs]

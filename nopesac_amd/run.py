@@ -41,6 +41,8 @@ def default_argument_parser():
                     "through the PairMapper (nopesac_amd/data.py); default = cfg.DATASETS.TEST[0] when its json exists")
     ap.add_argument("--datasets-dir", default="./datasets")
     ap.add_argument("--limit", type=int, default=0, help="use only the first N pairs of the dataset")
+    ap.add_argument("--uint8-images", action="store_true", help="hand the decoded 8-bit images to the model as uint8 tensors (widened on the device: "
+                    "identical results, a quarter of the host-to-device bytes) instead of the reference mapper's float32 tensors")
     ap.add_argument("--synthetic-pairs", type=int, default=0)
     ap.add_argument("--structured", action="store_true", help="structured synthetic images instead of noise")
     ap.add_argument("--synthetic-weights", action="store_true", help="name-seeded checkpoint instead of cfg.MODEL.WEIGHTS")
@@ -80,7 +82,7 @@ def load_pairs(args, cfg=None):
     if name:
         from . import data
         if args.dataset or os.path.exists(data.dataset_json(name, args.datasets_dir)):
-            return data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit)
+            return data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit, uint8=args.uint8_images)
     n = args.synthetic_pairs or 8
     pairs = []
     for i in range(n):
