@@ -10,8 +10,8 @@
 // in flight while the current one is multiplied, and only the layer outputs a consumer needs are written to HBM (f32).
 //
 //   rows 32 per workgroup: in 82 KB (width <= 1280) + out 66 KB (width <= 1024) of LDS; 1600 rows = 50 workgroups
-//   a wave owns output-channel tiles t = wave + 8 i (i < 4): per 64-channel K block it loads 16 weight fragments (1 KB each,
-//   coalesced) and issues 16 v_mfma_f32_32x32x16_bf16; each activation fragment read from LDS feeds 4 of them
+//   a wave has 4 fragment slots: 4 channel tiles (t = wave + 8 i) of a wide layer, or 2 / 1 tiles x 2 / 4 K ranges of a narrow one;
+//   per block it loads 16 weight fragments (1 KB each, coalesced) and issues 16 v_mfma_f32_32x32x16_bf16
 #include "common.h"
 
 namespace nps {
@@ -34,52 +34,69 @@ constexpr size_t MC_LDS_BYTES = 2 * (size_t)MC_BM * (MC_LD0 + MC_LD1);
         asm volatile("" ::: "memory");                         \
     } while (0)
 
-constexpr int MC_TPW = 4, MC_KB = 4;                            // channel tiles per wave, k-steps (16 channels) per K block
-__host__ __device__ constexpr int mc_kpad(int K) { return (K + 127) / 128 * 128; }      // an even number of 64-channel K blocks
+constexpr int MC_TPW = 4, MC_KB = 4;                            // fragment slots per wave and k-step, k-steps (16 channels) per slot and block
+// Slot use by layer width: a wave owns `tpw` channel tiles (1 / 2 / 4 for <= 8 / <= 16 / more tiles of 32 channels); with fewer than 4
+// the spare slots take OTHER K RANGES of the same tiles (ksplit = 4 / tpw: slot i -> tile wave + 8 (i % tpw), K part i / tpw), their
+// accumulators are summed in the epilogue - a 256-wide layer walks its K in a quarter of the block steps (each block step is one L2
+// round trip of latency for a workgroup that streams its weights alone).
+__host__ __device__ constexpr int mc_tpw(int N) { return N <= 256 ? 1 : (N <= 512 ? 2 : 4); }
+// K padded to an EVEN number of blocks of 64 * ksplit channels
+__host__ __device__ constexpr int mc_kpad(int K, int N) { return (K + 128 * (4 / mc_tpw(N)) - 1) / (128 * (4 / mc_tpw(N))) * (128 * (4 / mc_tpw(N))); }
 
-// Two slots of 16 weight fragments (128 VGPRs): entry kk * 4 + i of a slot = k-step kk of the block, channel tile wave + 8 i.
-// ONE code shape for every layer width: layers with fewer than 32 channel tiles leave tile slots idle - those re-load and
-// re-multiply a valid tile (results dropped in the epilogue) so that the load and MFMA counts stay static and the compiler can
-// count vmcnt exactly; width classes as separate instantiations spilled 150 VGPRs and put a branch around every MFMA.
+// Two slots of 16 weight fragments (128 VGPRs): entry kk * 4 + i of a slot = k-step kk of fragment slot i.
+// ONE code shape for every layer width (tile / K-part of a slot are wave-uniform run-time values): the load and MFMA counts stay
+// static and the compiler counts vmcnt exactly; width classes as separate instantiations spilled 150 VGPRs and put a branch around
+// every MFMA.
 struct McRing {
     bf16x8 f[2][16];
 };
 
+struct McShape {                // per layer, wave-uniform
+    const bf16_t* w;
+    int ksteps, ntiles, tpw, ksplit;
+};
+__device__ __forceinline__ McShape mc_shape(const nopesac_mlp_layer& L) {
+    const int tpw = mc_tpw(L.N);
+    return McShape{(const bf16_t*)L.w, mc_kpad(L.K, L.N) / 16, (L.N + 31) / 32, tpw, 4 / tpw};
+}
+
 template <int SLOT>
-__device__ __forceinline__ void mc_issue(McRing& ring, const bf16_t* __restrict__ w, int ksteps, int blk, int wave, int ntiles, int lane) {
+__device__ __forceinline__ void mc_issue(McRing& ring, const McShape& S, int blk, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < MC_TPW; ++i) {
-        int t = wave + 8 * i;
-        t = t < ntiles ? t : ntiles - 1;
-        const bf16_t* base = w + (size_t)(t * ksteps + blk * MC_KB) * 512;      // wave-uniform
+        int t = wave + 8 * (i % S.tpw);                                          // (tpw is 1, 2 or 4: the compiler sees and / shift)
+        t = t < S.ntiles ? t : S.ntiles - 1;                                     // idle tiles (N not a multiple of 256 * tpw) re-load a valid one
+        const int k0 = (blk * S.ksplit + i / S.tpw) * MC_KB;                     // first k-step of this slot in this block
+        const bf16_t* base = S.w + (size_t)(t * S.ksteps + k0) * 512;            // wave-uniform
 #pragma unroll
         for (int kk = 0; kk < MC_KB; ++kk) ring.f[SLOT][kk * MC_TPW + i] = *reinterpret_cast<const bf16x8*>(base + kk * 512 + lane * 8);
     }
 }
 
 template <int SLOT>
-__device__ __forceinline__ void mc_gemm(const McRing& ring, const bf16_t* src, int ld, int blk, f32x16 (&acc)[MC_TPW], int lane) {
+__device__ __forceinline__ void mc_gemm(const McRing& ring, const McShape& S, const bf16_t* src, int ld, int blk, f32x16 (&acc)[MC_TPW], int lane) {
     const int l31 = lane & 31, half = lane >> 5;
+    const bf16_t* row = src + l31 * ld + half * 8;
+    {
 #pragma unroll
-    for (int kk = 0; kk < MC_KB; ++kk) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(src + l31 * ld + (blk * MC_KB + kk) * 16 + half * 8);
+        for (int kk = 0; kk < MC_KB; ++kk) {
 #pragma unroll
-        for (int i = 0; i < MC_TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[SLOT][kk * MC_TPW + i], b, acc[i], 0, 0, 0);
+            for (int i = 0; i < MC_TPW; ++i) {
+                const int ks = (blk * S.ksplit + i / S.tpw) * MC_KB + kk;
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(row + ks * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[SLOT][kk * MC_TPW + i], b, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);               // at most four activation fragments live (all sixteen hoisted = 64 VGPRs: spills)
+        }
     }
 }
 
-struct McNext {                 // first block of the layer after this one (issued under this layer's last block)
-    const bf16_t* w;
-    int ksteps, ntiles;
-};
-
 // One layer: dst[row][n] = bf16(act(src[row][:] . W[n][:] + bias[n])), optional f32 copy to HBM.  On entry the weights of K block 0
 // are in flight in ring slot 0 (issued by the previous layer / the kernel prologue); on exit block 0 of `next` is in flight.
-__device__ __forceinline__ void mc_layer(const nopesac_mlp_layer& L, const McNext& next, const bf16_t* src, int sld, bf16_t* dst, int dld,
-                                         long long row0, int rows, int wave, int lane, McRing& ring) {
-    const int ksteps = mc_kpad(L.K) / 16, nblk = ksteps / MC_KB;                  // nblk is even
-    const int ntiles = (L.N + 31) / 32;
-    const bf16_t* w = (const bf16_t*)L.w;
+__device__ __forceinline__ void mc_layer(const nopesac_mlp_layer& L, const McShape& S, const McShape& next, const bf16_t* src, int sld, bf16_t* dst,
+                                         int dld, long long row0, int rows, int wave, int lane, McRing& ring) {
+    const int nblk = S.ksteps / (MC_KB * S.ksplit);                               // even
+    const int ntiles = S.ntiles;
     f32x16 acc[MC_TPW];
 #pragma unroll
     for (int i = 0; i < MC_TPW; ++i)
@@ -88,15 +105,23 @@ __device__ __forceinline__ void mc_layer(const nopesac_mlp_layer& L, const McNex
     for (int blk = 0; blk < nblk; blk += 2) {
         // every issue is unconditional and pinned in front of the multiply of the OTHER slot: the compiler counts vmcnt(16) for the
         // slot being consumed and the 16 loads in flight have a whole block's MFMAs (16 x 64 cycles x 2 waves per SIMD) of cover
-        mc_issue<1>(ring, w, ksteps, blk + 1, wave, ntiles, lane);
+        mc_issue<1>(ring, S, blk + 1, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mc_gemm<0>(ring, src, sld, blk, acc, lane);
+        mc_gemm<0>(ring, S, src, sld, blk, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         const bool last = blk + 2 >= nblk;                    // next block: this layer's, or block 0 of the next layer (`next` = this
-        mc_issue<0>(ring, last ? next.w : w, last ? next.ksteps : ksteps, last ? 0 : blk + 2, wave, last ? next.ntiles : ntiles, lane);   // layer again after the last one: a harmless re-load)
+        mc_issue<0>(ring, last ? next : S, last ? 0 : blk + 2, wave, lane);                    // layer again after the last one: a harmless re-load)
         __builtin_amdgcn_sched_barrier(0);
-        mc_gemm<1>(ring, src, sld, blk + 1, acc, lane);
+        mc_gemm<1>(ring, S, src, sld, blk + 1, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the K parts of a tile meet: slot i + tpw, i + 2 tpw ... hold the same tile as slot i
+    if (S.ksplit == 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    } else if (S.ksplit == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[0][e] += acc[2][e]; acc[1][e] += acc[3][e]; }
     }
     // ---- epilogue: lane holds row (lane & 31), channels t*32 + 8q + 4*(lane >> 5) .. +3 for q = 0..3
     const int l31 = lane & 31, half = lane >> 5;
@@ -106,7 +131,7 @@ __device__ __forceinline__ void mc_layer(const nopesac_mlp_layer& L, const McNex
 #pragma unroll
     for (int i = 0; i < MC_TPW; ++i) {
         const int t = wave + 8 * i;
-        if (t >= ntiles) continue;
+        if (i >= S.tpw || t >= ntiles) continue;
         float v[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -167,10 +192,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long row0 = (long long)blockIdx.x * MC_BM;
     McRing ring;
-    {   // weights of layer 0, K block 0
-        const nopesac_mlp_layer L = layer_at(0);
-        mc_issue<0>(ring, (const bf16_t*)L.w, mc_kpad(L.K) / 16, 0, wave, (L.N + 31) / 32, lane);
-    }
+    McShape shape = mc_shape(layer_at(0));
+    mc_issue<0>(ring, shape, 0, wave, lane);                                        // weights of layer 0, K block 0
     // ---- LDS: zeros everywhere (padding columns meet zero weights, but must not be NaN patterns), then the input rows
     for (int i = tid; i < (int)(MC_LDS_BYTES / 16); i += 512) reinterpret_cast<uint4*>(mc_smem)[i] = make_uint4(0u, 0u, 0u, 0u);
     MC_LDS_SYNC();
@@ -204,15 +227,12 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
     MC_LDS_SYNC();
     for (int l = 0; l < p.n_layers; ++l) {
         const nopesac_mlp_layer L = layer_at(l);
-        McNext next = {(const bf16_t*)L.w, mc_kpad(L.K) / 16, (L.N + 31) / 32};
-        if (l + 1 < p.n_layers) {
-            const nopesac_mlp_layer Ln = layer_at(l + 1);
-            next = {(const bf16_t*)Ln.w, mc_kpad(Ln.K) / 16, (Ln.N + 31) / 32};
-        }
+        const McShape next = l + 1 < p.n_layers ? mc_shape(layer_at(l + 1)) : shape;
         const bf16_t* src = (l & 1) ? R1 : R0;
         bf16_t* dst = (l & 1) ? R0 : R1;
         const int sld = (l & 1) ? MC_LD1 : MC_LD0, dld = (l & 1) ? MC_LD0 : MC_LD1;
-        mc_layer(L, next, src, sld, dst, dld, row0, p.rows, wave, lane, ring);
+        mc_layer(L, shape, next, src, sld, dst, dld, row0, p.rows, wave, lane, ring);
+        shape = next;
         MC_LDS_SYNC();
     }
 }
@@ -221,10 +241,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
 
 extern "C" int64_t nopesac_mlp_packed_elems(int N, int K) {
     if (N <= 0 || K <= 0 || N > NOPESAC_MLP_MAX_WIDTH) return 0;
-    return (int64_t)((N + 31) / 32 * 32) * nps::mc_kpad(K);
+    return (int64_t)((N + 31) / 32 * 32) * nps::mc_kpad(K, N);
 }
 
-extern "C" int nopesac_mlp_padded_k(int N, int K) { return (N <= 0 || K <= 0) ? 0 : nps::mc_kpad(K); }
+extern "C" int nopesac_mlp_padded_k(int N, int K) { return (N <= 0 || K <= 0) ? 0 : nps::mc_kpad(K, N); }
 
 extern "C" int nopesac_mlp_chain_bf16(const nopesac_mlp_chain* chain, void* stream) {
     using namespace nps;
@@ -237,7 +257,7 @@ extern "C" int nopesac_mlp_chain_bf16(const nopesac_mlp_chain* chain, void* stre
     for (int l = 0; l < chain->n_layers; ++l) {
         const nopesac_mlp_layer& L = chain->layers[l];
         NPS_CHECK_ARG(L.w && L.K == width && L.N > 0 && L.N <= MC_W1, "mlp_chain: layer K must equal the previous width, N <= NOPESAC_MLP_MAX_WIDTH");
-        NPS_CHECK_ARG(mc_kpad(L.K) <= ((l & 1) ? MC_W1 : MC_W0), "mlp_chain: padded K exceeds the LDS region");
+        NPS_CHECK_ARG(mc_kpad(L.K, L.N) <= ((l & 1) ? MC_W1 : MC_W0), "mlp_chain: padded K exceeds the LDS region");
         NPS_CHECK_ARG(((uintptr_t)L.w & 15) == 0 && ((uintptr_t)L.bias & 15) == 0 && ((uintptr_t)L.out & 3) == 0, "mlp_chain: w / bias must be 16-byte aligned");
         NPS_CHECK_ARG(!L.out || L.out_ld >= L.N, "mlp_chain: out_ld");
         NPS_CHECK_ARG(L.act == NPS_ACT_NONE || L.act == NPS_ACT_RELU || L.act == NPS_ACT_LEAKY || L.act == NPS_ACT_SIGMOID, "mlp_chain: act");

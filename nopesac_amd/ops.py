@@ -308,7 +308,8 @@ def mfma_fragment_major(w2d: torch.Tensor) -> torch.Tensor:
 
 def mlp_padded_k(N: int, K: int) -> int:
     """K as the chained-MLP kernel pads it (csrc/mlp_chain.hip: two K blocks of the layer's width class)."""
-    return -(-K // 128) * 128
+    q = 128 * (4 if N <= 256 else 2 if N <= 512 else 1)        # an even number of blocks of 64 * ksplit channels (ksplit = 4 / tiles per wave)
+    return -(-K // q) * q
 
 
 class MlpLayer:
