@@ -269,6 +269,12 @@ def add_amd_defaults(cfg) -> CfgNode:
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
         CHECK_FINITE=True,            # count Inf / NaN in the returned poses / plane parameters on the device; `model(...)` raises
                                       # FloatingPointError when the results are fetched (the reference drops into pdb instead)
+        AUTOTUNE=True,                # runner (nopesac_amd/run.py), bfloat16 mode: before the first batch, time the library's equivalent
+                                      # kernel configurations for every conv / GEMM shape of a (pairs-per-batch, 480, 640) forward and
+                                      # keep the fastest (PlaneTR_NopeSAC.autotune: a few seconds; +10-15 % throughput, same results up
+                                      # to the summation order).  Library users call model.autotune(pairs) themselves
+        ROUTING_FILE="",              # JSON of kernel-routing decisions (ops.ConvTuner): loaded if it exists (listed shapes are not
+                                      # re-measured), written back by rank 0 when the tuning pass measured new shapes
         BACKBONE_FP8=False,           # BASELINE config 5: the 3x3 convs of the res3-res5 bottlenecks (44 % of the backbone FLOPs, its
                                       # MFMA-bound layers) on the fp8 (e4m3fn) K = 64 MFMA: per-output-channel weight scales, static
                                       # per-layer activation scales (PlaneTR_NopeSAC.calibrate_fp8); needs COMPUTE_DTYPE bfloat16

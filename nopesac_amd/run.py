@@ -116,6 +116,34 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
     return {"pairs": n_done, "total_s": total, "compute_s": t_compute, "s_per_pair": t_compute / max(n_done, 1)}
 
 
+def tune_kernels(model, cfg, pairs_per_batch: int, rank: int = 0) -> int:
+    """MODEL.AMD.AUTOTUNE / ROUTING_FILE: load-time kernel selection for the shapes of a `pairs_per_batch` forward (bfloat16 mode on a
+    GPU only; the fp32 parity path keeps the built-in heuristic).  Returns the number of shapes measured now."""
+    from . import ops
+    from .config import amd_options
+    amd = amd_options(cfg)
+    if not (next(model.parameters()).is_cuda and model.compute_dtype == torch.bfloat16):
+        return 0
+    path = str(amd.ROUTING_FILE or "")
+    if path and os.path.exists(path):
+        logger.info("kernel routing: %d entries from %s", ops.TUNER.load(path), path)
+    if not amd.AUTOTUNE:
+        return 0
+    t0 = time.perf_counter()
+    n_before = len(ops.TUNER.log)
+    model.autotune(pairs_per_batch)
+    measured = len(ops.TUNER.log) - n_before
+    logger.info("kernel autotuning: %d conv / GEMM shapes measured in %.1f s (%d decisions in force)", measured, time.perf_counter() - t0,
+                len(ops.TUNER.best))
+    if path and rank == 0 and measured:
+        merged = dict(ops.TUNER.loaded)
+        merged.update({ops.TUNER.key_str(k): int(v) for k, v in ops.TUNER.best.items()})
+        with open(path, "w") as f:
+            json.dump({"format": "nopesac_amd.ConvTuner/1", "meta": {"written_by": "nopesac_amd.run"},
+                       "kernels": {str(k): v for k, v in ops.CONV_CFG_KERNEL.items()}, "routing": dict(sorted(merged.items()))}, f, indent=1)
+    return measured
+
+
 def main(argv=None):
     """Entry point (test_NopeSAC.py:207-216): `--num-gpus N` outside a torchrun environment starts N ranks itself."""
     args = default_argument_parser().parse_args(argv)
@@ -132,6 +160,7 @@ def _main_rank(args):
         torch.cuda.set_device(local)
     model = build_model(cfg)
     src = load_checkpoint(model, cfg, args.synthetic_weights)
+    tune_kernels(model, cfg, args.pairs_per_batch, rank)
     pairs = load_pairs(args, cfg)
     lo, hi = runner.shard_range(len(pairs), rank, world)
     logger.info("rank %d/%d: weights=%s pairs [%d,%d) of %d", rank, world, src, lo, hi, len(pairs))

@@ -266,6 +266,38 @@ def test_cli_runner_end_to_end(device, tmp_path):
     assert json.load(open(out))["pairs"]["count"] == 3
 
 
+def test_cli_runner_autotunes_and_keeps_a_routing_file(device, tmp_path):
+    """bfloat16 mode of the runner: MODEL.AMD.AUTOTUNE times the kernel candidates of every conv / GEMM shape of a pairs-per-batch
+    forward before the first batch, MODEL.AMD.ROUTING_FILE persists the decisions; a second run loads them and measures nothing;
+    the poses of the two runs agree (the routed kernels compute the same convolutions)."""
+    import json
+    import os
+    from nopesac_amd import ops, run
+    from tests.util import ROOT
+    routing = tmp_path / "routing.json"
+    saved = (ops.TUNER.best, ops.TUNER.loaded, ops.TUNER.log)
+    ops.TUNER.best, ops.TUNER.loaded, ops.TUNER.log = {}, {}, []
+    try:
+        head = ["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights", "--synthetic-pairs", "4",
+                "--pairs-per-batch", "2"]
+        opts = ["MODEL.DEVICE", str(device), "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", str(routing)]
+        a = run.main(head + ["--output", str(tmp_path / "a.json")] + opts)
+        doc = json.load(open(routing))
+        assert doc["format"] == "nopesac_amd.ConvTuner/1" and len(doc["routing"]) > 40
+        n_measured = len(ops.TUNER.log)
+        assert n_measured > 40
+        ops.TUNER.best, ops.TUNER.log = {}, []                     # a fresh process would start like this
+        b = run.main(head + ["--output", str(tmp_path / "b.json")] + opts)
+        assert len(ops.TUNER.log) == 0 and len(ops.TUNER.loaded) == len(doc["routing"])
+        assert a["pairs"]["count"] == b["pairs"]["count"] == 4
+        ja, jb = json.load(open(tmp_path / "a.json")), json.load(open(tmp_path / "b.json"))
+        for k in ja["pairs"]:
+            if isinstance(ja["pairs"][k], float):
+                assert abs(ja["pairs"][k] - jb["pairs"][k]) <= 1e-6 * (1 + abs(ja["pairs"][k])), k
+    finally:
+        ops.TUNER.best, ops.TUNER.loaded, ops.TUNER.log = saved
+
+
 @pytest.mark.parametrize("nq", [64, 128])
 def test_e2e_more_queries(device, nq):
     """BASELINE configs 3/5 need NUM_OBJECT_QUERIES = 64 / 128: end-to-end parity at those sizes."""
