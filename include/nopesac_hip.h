@@ -440,6 +440,13 @@ int nopesac_rle_labels(const uint8_t* winner, const int32_t* kept_idx, const int
  *   (call once with NULLs to size, exclusive-scan the counts, call again). */
 int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_kept, const int64_t* offsets, int32_t* counts,
                             uint32_t* positions, int V, int N, int nq, void* stream);
+/* Dense boolean masks of the kept planes of V views in one launch (`pred_plane_masks`, siamese_planeTR.py:685 / :743): for view v and
+ * its p-th kept plane, masks[(offsets[v] + p) * H * W + pixel] = 1 iff the pixel's arg-max query is kept_idx[v][p] and the pixel
+ * passed the mask threshold (bit 7 of the winner byte) or the view is a fallback view (flags bit 1).  offsets: device int64 [V],
+ * exclusive prefix sums of n_kept.  masks: uint8 [sum(n_kept), H, W]. */
+int nopesac_decode_masks(const uint8_t* winner, const int32_t* kept_idx, const int32_t* n_kept, const int32_t* flags,
+                         const int64_t* offsets, uint8_t* masks, int V, int H, int W, int nq, void* stream);
+
 /* HOST function (no device work): one mask's flip positions -> COCO compressed "counts" string (not NUL terminated,
  *   returns its length or < 0) and bbox4 = [x, y, w, h] (cocoapi rleToString / rleToBbox). */
 int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W, char* out, int cap, double* bbox4);

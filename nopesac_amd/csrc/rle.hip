@@ -138,6 +138,52 @@ extern "C" int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_k
     NPS_LAUNCH_RET();
 }
 
+// ---- dense masks of the kept planes of ALL views in one launch (the reference's `pred_plane_masks`, siamese_planeTR.py:685 / :743):
+// masks[offsets[v] + p][pixel] = (arg-max query of the pixel == kept_idx[v][p]) && (above the mask threshold || fallback view).
+// Replaces three torch launches per view (192 per 32-pair batch).
+namespace nps {
+__global__ __launch_bounds__(256) void decode_masks_kernel(const uint8_t* __restrict__ winner, const int* __restrict__ kept_idx,
+                                                           const int* __restrict__ n_kept, const int* __restrict__ flags,
+                                                           const long long* __restrict__ offsets, uint8_t* __restrict__ masks, int N, int nq) {
+    __shared__ int kept[128];
+    const int v = blockIdx.y, tid = threadIdx.x;
+    const int n = min(n_kept[v], nq);
+    if (tid < n) kept[tid] = kept_idx[(long long)v * nq + tid];
+    __syncthreads();
+    const bool fallback = (flags[v] & 2) != 0;
+    const long long base = (long long)blockIdx.x * 256 * 16 + tid * 16;          // 16 pixels per thread: 16-byte loads and stores
+    if (base >= N) return;
+    const uint8_t* wv = winner + (long long)v * N + base;
+    uint8_t w[16];
+    const bool full = base + 16 <= N && ((((uintptr_t)wv) & 15) == 0);
+    if (full) *reinterpret_cast<uint4*>(w) = *reinterpret_cast<const uint4*>(wv);
+    else
+        for (int j = 0; j < 16; ++j) w[j] = base + j < N ? wv[j] : 0;
+    uint8_t* out = masks + offsets[v] * N + base;
+    for (int p = 0; p < n; ++p) {
+        const int q = kept[p];
+        uint8_t m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m[j] = ((w[j] & 0x7F) == q && (fallback || (w[j] & 0x80))) ? 1 : 0;
+        uint8_t* o = out + (long long)p * N;
+        if (full && ((((uintptr_t)o) & 15) == 0)) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(m);
+        else
+            for (int j = 0; j < 16 && base + j < N; ++j) o[j] = m[j];
+    }
+}
+}  // namespace nps
+
+extern "C" int nopesac_decode_masks(const uint8_t* winner, const int32_t* kept_idx, const int32_t* n_kept, const int32_t* flags,
+                                    const int64_t* offsets, uint8_t* masks, int V, int H, int W, int nq, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(winner && kept_idx && n_kept && flags && offsets && masks, "decode_masks: null pointer");
+    NPS_CHECK_ARG(V > 0 && H > 0 && W > 0 && nq > 0 && nq <= 128, "decode_masks: bad sizes (nq <= 128)");
+    const int N = H * W;
+    hipLaunchKernelGGL(decode_masks_kernel, dim3((N + 4095) / 4096, V), dim3(256), 0, (hipStream_t)stream, winner, kept_idx, n_kept, flags,
+                       (const long long*)offsets, masks, N, nq);
+    NPS_LAUNCH_RET();
+}
+
 // ---- device-side string compression ------------------------------------------------------------------------------------------
 // A 32-pair step with K kept planes per view has 2 B K masks and millions of flip positions: compressing them on one host core
 // (and copying 4 bytes per flip over PCIe first) was 2/3 of package()'s time.  The string format is local - character group i

@@ -300,6 +300,12 @@ class PlaneTR_NopeSAC(nn.Module):
         # the per-view tensors below are VIEWS of this call's private host copies (one D2H copy per field, no per-view clone);
         # scalars come from .tolist() once (indexing a tensor per instance cost 4 ms per 32-pair step)
         kept_l, scores_l = kept_idx.tolist(), scores.tolist()
+        masks_all, mask_off = None, [0]
+        if self.output_masks:
+            for nk in n_kept:
+                mask_off.append(mask_off[-1] + nk)
+            if sel["winner"].is_cuda:              # all views in one launch (was three torch launches per view)
+                masks_all = ops.decode_masks(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"], mask_off[-1])
         results = []
         for i in range(B):
             res = {}
@@ -313,7 +319,8 @@ class PlaneTR_NopeSAC(nn.Module):
                         "pred_plane_scores": scores[j, :n], "pred_plane_areas": areas[j, :n],
                         "winner_map": sel["winner"][j], "fallback_mask": bool(flags[j] & 2)}
                 if self.output_masks:
-                    view["pred_plane_masks"] = decode_masks(sel["winner"][j], kept_idx[j, :n].to(sel["winner"].device), bool(flags[j] & 2))
+                    view["pred_plane_masks"] = (masks_all[mask_off[j]:mask_off[j] + n] if masks_all is not None else
+                                                decode_masks(sel["winner"][j], kept_idx[j, :n].to(sel["winner"].device), bool(flags[j] & 2)))
                 inst = []
                 sc_j = scores_l[j]
                 rl_j = rles[j] if rles is not None else None

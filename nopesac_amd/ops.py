@@ -741,6 +741,19 @@ def rle_transitions(labels: torch.Tensor, n_kept: torch.Tensor, nq: int, offsets
     return counts
 
 
+def decode_masks(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor, total: int) -> torch.Tensor:
+    """bool [total, H, W]: the dense masks of every kept plane of every view, view after view (total = sum(n_kept), known to the
+    caller); one launch for the whole batch."""
+    _chk(winner, torch.uint8); _chk(kept_idx, torch.int32); _chk(n_kept, torch.int32); _chk(flags, torch.int32)
+    V, H, W = winner.shape
+    n64 = n_kept.to(torch.int64)
+    offsets = (torch.cumsum(n64, 0) - n64).contiguous()
+    masks = torch.empty((max(total, 1), H, W), device=winner.device, dtype=torch.uint8)
+    _lib.check(_L().nopesac_decode_masks(_p(winner), _p(kept_idx), _p(n_kept), _p(flags), _p(offsets), _p(masks), V, H, W, kept_idx.shape[1],
+                                         _stream()), "nopesac_decode_masks")
+    return masks[:total].view(torch.bool)
+
+
 def rle_compress(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.Tensor, H: int, W: int):
     """Flip positions of n masks (device: positions int32 buffer, offsets int64 [n], counts int32 [n]) -> COCO counts strings on
     the device: (bytes uint8 [total], out_off int64 [n], lens int32 [n], bbox float64 [n,4]) - all device tensors; one host

@@ -242,6 +242,32 @@ def test_rle_from_winner_map(device, V, H, W, nq, seed):
             assert out[v][p]["bbox"] == R.to_bbox(ref).tolist()
 
 
+@pytest.mark.parametrize("V,H,W,nq", [(3, 48, 64, 50), (2, 37, 53, 50), (2, 480, 640, 128), (1, 5, 3, 50)])
+def test_decode_masks_all_views_in_one_launch(device, V, H, W, nq):
+    """nopesac_decode_masks (dense `pred_plane_masks` of every kept plane of every view, one launch) against the per-view formula
+    (siamese_planeTR.py:685, :743 in the fallback case): ragged n_kept, a fallback view, H*W not a multiple of 16, ids up to 127."""
+    from nopesac_amd import ops
+    from nopesac_amd.modeling.meta_arch import decode_masks
+    g = torch.Generator().manual_seed(V * 100 + H)
+    winner = torch.randint(0, 256, (V, H, W), generator=g).to(torch.uint8)
+    winner = ((winner & 0x80) | (torch.randint(0, nq, (V, H, W), generator=g).to(torch.uint8))).to(device)
+    n_kept = torch.tensor([min(nq, 1 + 9 * v) for v in range(V)], dtype=torch.int32)
+    kept = torch.full((V, nq), -1, dtype=torch.int32)
+    for v in range(V):
+        kept[v, : int(n_kept[v])] = torch.randperm(nq, generator=g)[: int(n_kept[v])].sort().values.int()
+    flags = torch.zeros(V, dtype=torch.int32)
+    flags[V - 1] = 2
+    total = int(n_kept.sum())
+    m = ops.decode_masks(winner, kept.to(device), n_kept.to(device), flags.to(device), total)
+    assert m.dtype == torch.bool and m.shape == (total, H, W)
+    off = 0
+    for v in range(V):
+        n = int(n_kept[v])
+        ref = decode_masks(winner[v], kept[v, :n].to(device), bool(int(flags[v]) & 2))
+        assert torch.equal(m[off:off + n], ref), v
+        off += n
+
+
 @pytest.mark.parametrize("C,proj,CN,stride,M_odd", [
     (64, False, 64, 1, False), (64, False, 128, 1, True), (64, True, 64, 1, False), (64, False, 0, 1, False), (64, True, 0, 1, True),
     (128, False, 128, 1, True), (128, False, 256, 1, False), (128, True, 128, 2, True), (128, True, 0, 2, False), (128, False, 0, 1, False),
