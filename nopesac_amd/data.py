@@ -94,9 +94,61 @@ class PairMapper:
         return d
 
 
-def build_inference_pairs(cfg, dataset_name: str, datasets_dir: str = "./datasets", limit: int = 0, device=None, uint8: bool = False) -> List[dict]:
+class LazyPairs:
+    """The pairs of a dataset split, decoded and mapped ON DEMAND by a small pool of threads that runs ahead of the consumer (the
+    reference: a torch DataLoader with DATALOADER.NUM_WORKERS worker processes, batch size 1).  Materialising a split up front is
+    7.4 MB of float32 pixels per pair (1.8 MB as uint8) and one PIL decode after the other; here at most `prefetch` mapped pairs exist
+    at a time.  Sequence protocol: len(), integer index (mapped dict), slice (another LazyPairs over the same json entries: rank
+    shards), iteration and iter_batches() in order."""
+
+    def __init__(self, entries: List[dict], mapper: "PairMapper", workers: int = 4, prefetch: int = 64):
+        self.entries, self.mapper = entries, mapper
+        self.workers, self.prefetch = max(1, int(workers)), max(1, int(prefetch))
+
+    def __len__(self) -> int:
+        return len(self.entries)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return LazyPairs(self.entries[idx], self.mapper, self.workers, self.prefetch)
+        return self.mapper(self.entries[idx])
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        if not self.entries:
+            return
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            pending, nxt = deque(), 0
+            while nxt < len(self.entries) and len(pending) < self.prefetch:
+                pending.append(pool.submit(self.mapper, self.entries[nxt]))
+                nxt += 1
+            while pending:
+                item = pending.popleft().result()
+                if nxt < len(self.entries):
+                    pending.append(pool.submit(self.mapper, self.entries[nxt]))
+                    nxt += 1
+                yield item
+
+    def iter_batches(self, pairs_per_batch: int):
+        batch = []
+        for item in self:
+            batch.append(item)
+            if len(batch) == pairs_per_batch:
+                yield batch
+                batch = []
+        if batch:
+            yield batch
+
+
+def build_inference_pairs(cfg, dataset_name: str, datasets_dir: str = "./datasets", limit: int = 0, device=None, uint8: bool = False,
+                          lazy: bool = False, prefetch: int = 64):
+    """The split as a list of mapped input dicts - or, `lazy`, as a LazyPairs that decodes ahead of the consumer with
+    cfg.DATALOADER.NUM_WORKERS threads."""
     pairs = load_pairs_json(dataset_json(dataset_name, datasets_dir))
     if limit:
         pairs = pairs[:limit]
     mapper = PairMapper(cfg, dataset_name, device, uint8=uint8)
+    if lazy:
+        return LazyPairs(pairs, mapper, workers=int(getattr(cfg.DATALOADER, "NUM_WORKERS", 4)) or 1, prefetch=prefetch)
     return [mapper(p) for p in pairs]

@@ -35,7 +35,7 @@ def default_argument_parser():
     ap.add_argument("--config-file", default="", metavar="FILE")
     ap.add_argument("--eval-only", action="store_true")
     ap.add_argument("--num-gpus", type=int, default=1)
-    ap.add_argument("--pairs-per-batch", type=int, default=8)
+    ap.add_argument("--pairs-per-batch", type=int, default=32, help="pairs per model call (the reference: 1; throughput saturates around 32)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight on separate HIP streams (1 = strictly serial, like the reference loop)")
     ap.add_argument("--pairs-file", default="", help="torch-saved list of input dicts (reference mapper format)")
     ap.add_argument("--dataset", default="", help="registered split name (mp3d_test, scannet_test, ...): read <datasets-dir>/<split json> "
@@ -83,7 +83,8 @@ def load_pairs(args, cfg=None):
     if name:
         from . import data
         if args.dataset or os.path.exists(data.dataset_json(name, args.datasets_dir)):
-            return data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit, uint8=args.uint8_images)
+            return data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit, uint8=args.uint8_images, lazy=True,
+                                              prefetch=max(64, 3 * args.pairs_per_batch))
     n = args.synthetic_pairs or 8
     pairs = []
     for i in range(n):
@@ -122,9 +123,11 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
         with torch.cuda.stream(st):
             return batch, model.package(batch, dev_out)
 
+    # a lazily decoded split (data.LazyPairs) hands out its batches itself, decoding ahead with its thread pool
+    batches = pairs.iter_batches(pairs_per_batch) if hasattr(pairs, "iter_batches") else (pairs[i:i + pairs_per_batch]
+                                                                                         for i in range(0, len(pairs), pairs_per_batch))
     with torch.no_grad():
-        for bi, i in enumerate(range(0, len(pairs), pairs_per_batch)):
-            batch = pairs[i:i + pairs_per_batch]
+        for bi, batch in enumerate(batches):
             t1 = time.perf_counter()
             if depth > 1:
                 st = streams[bi % depth]
@@ -217,7 +220,8 @@ def _main_rank(args):
             parts = [None] * world
             torch.distributed.all_gather_object(parts, kept)
             kept = [p for part in parts for p in part]
-        dataset_dict = {p["0"]["image_id"] + "__" + p["1"]["image_id"]: p for p in pairs if "gt_corrs" in p}
+        annotated = pairs.entries if hasattr(pairs, "entries") else pairs           # (a LazyPairs keeps the json entries: no pixels needed here)
+        dataset_dict = {p["0"]["image_id"] + "__" + p["1"]["image_id"]: p for p in annotated if "gt_corrs" in p}
         if rank == 0 and dataset_dict:
             results["matching"] = evaluate_for_matchings([k for k in kept if k["0"]["image_id"] + "__" + k["1"]["image_id"] in dataset_dict],
                                                          dataset_dict)

@@ -88,3 +88,32 @@ def test_resize_oracle_invariants():
     assert np.all(np.diff(r2[0, :, 0]) >= 0) and abs(int(r2[0, 50, 0]) - 99) <= 2        # monotone, midpoint preserved
     half = resize_bilinear_u8(np.array([[[0], [100]], [[200], [60]]], np.uint8).repeat(1, 2), 1, 1)
     assert int(half[0, 0, 0]) == 90                                                      # 2x2 -> 1x1: the mean of the four
+
+
+def test_lazy_pairs_decode_ahead_in_order(tmp_path):
+    """data.LazyPairs (what the runner iterates for a real split): same mapped dicts as the eager mapper, in order, through the
+    thread pool; slicing = rank shards; a ragged last batch."""
+    from nopesac_amd import data
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    entries = []
+    for k in range(7):
+        pair = {}
+        for v in "01":
+            arr = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+            f = tmp_path / f"p{k}_{v}.png"
+            Image.fromarray(arr).save(f)
+            pair[v] = {"file_name": str(f), "image_id": f"h_{k}_{v}", "height": 480, "width": 640}
+        entries.append(pair)
+    jf = tmp_path / "cached_set_test.json"
+    json.dump({"categories": [], "data": entries}, open(jf, "w"))
+    mapper = data.PairMapper(_cfg(), "mp3d_test", uint8=True)
+    lazy = data.LazyPairs(data.load_pairs_json(str(jf)), mapper, workers=3, prefetch=4)
+    assert len(lazy) == 7 and len(lazy[2:5]) == 3 and lazy[1]["0"]["image_id"] == "h_1_0"
+    got = list(lazy.iter_batches(3))
+    assert [len(b) for b in got] == [3, 3, 1]
+    flat = [p for b in got for p in b]
+    for k, p in enumerate(flat):
+        ref = mapper(entries[k])
+        assert p["0"]["image_id"] == f"h_{k}_0" and torch.equal(p["0"]["image"], ref["0"]["image"]) and torch.equal(p["1"]["image"], ref["1"]["image"])
+    assert [p["0"]["image_id"] for p in lazy[5:]] == ["h_5_0", "h_6_0"]

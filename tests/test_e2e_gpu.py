@@ -266,6 +266,32 @@ def test_cli_runner_end_to_end(device, tmp_path):
     assert json.load(open(out))["pairs"]["count"] == 3
 
 
+def test_cli_runner_on_a_dataset_split_from_disk(device, tmp_path):
+    """The runner on a (tiny) Matterport3D-style split on disk: json -> LazyPairs (decoder threads running ahead) -> uint8 images ->
+    batches in flight -> evaluator; 5 pairs, 2 per batch (ragged last batch), pose rows for every pair with a rel_pose."""
+    import json
+    import os
+    from PIL import Image
+    from nopesac_amd import run
+    from tests.util import ROOT
+    rng = np.random.default_rng(11)
+    root = tmp_path / "datasets" / "mp3d_dataset"
+    (root / "mp3d_planercnn_json").mkdir(parents=True)
+    entries = []
+    for k in range(5):
+        pair = {"rel_pose": {"position": [0.1 * k, 0.2, 0.3], "rotation": [1.0, 0.0, 0.0, 0.0]}}
+        for v in "01":
+            f = root / f"img_{k}_{v}.png"
+            Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)).save(f)
+            pair[v] = {"file_name": str(f), "image_id": f"house_{k}_{v}", "height": 480, "width": 640}
+        entries.append(pair)
+    json.dump({"categories": [], "data": entries}, open(root / "mp3d_planercnn_json" / "cached_set_test.json", "w"))
+    res = run.main(["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights",
+                    "--dataset", "mp3d_test", "--datasets-dir", str(tmp_path / "datasets"), "--pairs-per-batch", "2", "--uint8-images",
+                    "--inflight", "2", "MODEL.DEVICE", str(device), "MODEL.AMD.AUTOTUNE", False])
+    assert res["pairs"]["count"] == 5 and res["timing(rank0)"]["pairs"] == 5 and res["timing(rank0)"]["batches_in_flight"] == 2
+
+
 def test_cli_runner_autotunes_and_keeps_a_routing_file(device, tmp_path):
     """bfloat16 mode of the runner: MODEL.AMD.AUTOTUNE times the kernel candidates of every conv / GEMM shape of a pairs-per-batch
     forward before the first batch, MODEL.AMD.ROUTING_FILE persists the decisions; a second run loads them and measures nothing;
