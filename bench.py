@@ -556,7 +556,9 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("fp8(backbone 3x3 convs)+bf16" if args.fp8 else "bf16") if args.dtype == "bfloat16" else "f32", "data": "synthetic",
            "config": {"workload": "configs/" + CONFIG_FILES[args.config] + ", %d synthetic 480x640 pairs/GPU/step, ResNet-50 + pyramids in %s, "
-                                  "heads fp32, K=%d matched planes forced (m mean %.1f), nq=%d" % (B, args.dtype, K, m_mean, nq),
+                                  "head GEMMs %s, K=%d matched planes forced (m mean %.1f), nq=%d"
+                                  % (B, args.dtype, "bf16 operands with f32 accumulate / residual stream / LayerNorm / softmax" if args.dtype == "bfloat16"
+                                     else "f32", K, m_mean, nq),
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
                       "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph, "autotuned_shapes": tuned,
                       "routing_file": os.path.relpath(args.routing, ROOT) if args.routing else None, "routing_entries_loaded": routing_loaded,

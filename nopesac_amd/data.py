@@ -69,13 +69,17 @@ class PairMapper:
         name = dataset_name or (cfg.DATASETS.TEST[0] if len(cfg.DATASETS.TEST) else "")
         self.scannet = "scannet" in name
         self.device = device
+        # decoder threads start with current device 0: remember the device of the thread that builds the mapper (the rank's)
+        self._resize_device = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                                 if torch.cuda.is_available() else None)
 
     def _image(self, path: str) -> torch.Tensor:
         img = read_image(path, self.img_format)
         if self.scannet and img.shape[:2] != (480, 640):
             from . import ops
-            dev = self.device or torch.device("cuda", torch.cuda.current_device())
-            img_t = ops.resize_bilinear_u8(torch.from_numpy(img.copy()).to(dev), 480, 640)
+            dev = self._resize_device
+            with torch.cuda.device(dev):
+                img_t = ops.resize_bilinear_u8(torch.from_numpy(img.copy()).to(dev), 480, 640)
             t = img_t.permute(2, 0, 1).contiguous() if self.uint8 else img_t.permute(2, 0, 1).float()
             return t if self.device is not None else t.cpu()
         t = torch.as_tensor(np.ascontiguousarray(img.transpose(2, 0, 1)) if self.uint8 else img.transpose(2, 0, 1).astype("float32"))

@@ -65,12 +65,14 @@ class PoseEvaluator:
             pred[v]["file_name"] = inp[v].get("file_name")
             if out[v] is not None and "instances" in out[v]:
                 pred[v]["instances"] = out[v]["instances"]
-            pred[v]["pred_plane"] = out[v]["pred_plane"].detach().cpu()
+            pred[v]["pred_plane"] = out[v]["pred_plane"].detach().cpu().clone()      # package() hands out views of one pinned buffer per batch
         for k, val in out.items():
             if "camera" in k and "cls" not in k:
-                pred[k] = {"pred": val, "gts": gt_cam}
+                # own copies: package() hands out numpy views of the batch's pinned host buffer, which would stay alive with the record
+                pred[k] = {"pred": {kk: (np.array(vv) if isinstance(vv, np.ndarray) else vv) for kk, vv in val.items()} if isinstance(val, dict) else val,
+                           "gts": gt_cam}
             elif "assignment" in k:
-                pred[k] = val.detach().cpu()
+                pred[k] = val.detach().cpu().clone()
         pred["corrs"] = {"0": {}, "1": {}}
         return pred
 

@@ -14,7 +14,7 @@ from .. import ops
 from ..config import amd_options
 from ..registry import BACKBONE_REGISTRY
 from ..synth import RES_STAGES, state_dict_spec
-from .params import ParamModule, conv_bn
+from .params import DERIVED_EPOCH, ParamModule, conv_bn
 
 
 class ShapeSpec:
@@ -88,6 +88,7 @@ class HipResNet50(ParamModule):
             self.fp8_conv2, self._calib = was, None
         self.act_scale = {k: max(v, 1e-6) * headroom / ops.FP8_MAX for k, v in amax.items()}
         self._q8 = {}
+        DERIVED_EPOCH[0] += 1
         return dict(self.act_scale)
 
     def _quant(self, p: str) -> dict:

@@ -21,6 +21,7 @@ from .. import ops, rle
 from ..config import amd_options
 from ..registry import META_ARCH_REGISTRY, configurable
 from .backbone import build_backbone
+from .params import DERIVED_EPOCH
 from .camera_head import build_camera_head
 from .matching_head import build_matching_head
 from .plane_head import build_planeTR_head, post_select
@@ -192,6 +193,13 @@ class PlaneTR_NopeSAC(nn.Module):
         assert len({tuple(i.shape) for i in imgs}) == 1, "all images of a batch must share one size (size_divisibility 0, no padding)"
         slot = self.infer_iter % self.graph_slots
         key = (B, H, W, None if forced is None else id(forced), slot)
+        epoch = (DERIVED_EPOCH[0], len(ops.TUNER.best))
+        if self._graphs and self.__dict__.get("_graph_epoch") != epoch:
+            # packed weights re-built (ParamModule.invalidate / load), fp8 scales re-calibrated or new kernel routing decisions since
+            # the capture: the recorded launches point at stale tensors / kernels - drop every slot's graph and capture again
+            torch.cuda.synchronize()
+            self._graphs = {}
+        self.__dict__["_graph_epoch"] = epoch
         st = self._graphs.get(key)
         if st is None:
             st = self._graphs[key] = {"in": torch.empty((2 * B, 3, H, W), device=self.device, dtype=torch.float32), "graph": None, "out": None,
@@ -201,6 +209,8 @@ class PlaneTR_NopeSAC(nn.Module):
             st["in_u8"] = torch.empty(buf.shape, device=self.device, dtype=torch.uint8)
         self._copy_images(imgs, buf, st.get("in_u8"))
         st["calls"] += 1
+        if st.get("clone_done") is not None:                   # the previous results of this slot are still being copied out
+            torch.cuda.current_stream().wait_event(st.pop("clone_done"))
         if st["graph"] is not None:
             st["graph"].replay()
             return st["out"]
@@ -214,6 +224,7 @@ class PlaneTR_NopeSAC(nn.Module):
             out = self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
         cur.wait_stream(cap)
         out["static_outputs"] = True                           # package() must not hand out views of graph-owned memory
+        out["_owner"] = st
         st["graph"], st["out"] = g, out
         g.replay()                                             # capture does not execute: run this batch
         return out
@@ -221,7 +232,9 @@ class PlaneTR_NopeSAC(nn.Module):
     def calibrate_fp8(self, batched_inputs: List[dict]) -> dict:
         """Static activation scales of the fp8 backbone mode (MODEL.AMD.BACKBONE_FP8) from representative pairs; returns them."""
         with torch.no_grad():
-            return self.backbone.calibrate_fp8(self.preprocess_image(batched_inputs))
+            scales = self.backbone.calibrate_fp8(self.preprocess_image(batched_inputs))
+        DERIVED_EPOCH[0] += 1                                  # captured graphs hold the old scales / fp8 weight copies
+        return scales
 
     def autotune(self, pairs: int, height: int = 480, width: int = 640) -> int:
         """One dedicated single-stream forward on zeros that lets ops.TUNER pick, per conv/GEMM shape of this
@@ -297,6 +310,10 @@ class PlaneTR_NopeSAC(nn.Module):
         rles = rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"], n_kept_host=n_kept) if self.output_rle else None
         if d.get("static_outputs"):       # hipGraph mode: the device tensors below are overwritten by the slot's next replay
             sel = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
+            if sel["winner"].is_cuda:     # ... which must not start before these copies have run (whatever stream packages)
+                ev = torch.cuda.Event()
+                ev.record()
+                d["_owner"]["clone_done"] = ev
         # the per-view tensors below are VIEWS of this call's private host copies (one D2H copy per field, no per-view clone);
         # scalars come from .tolist() once (indexing a tensor per instance cost 4 ms per 32-pair step)
         kept_l, scores_l = kept_idx.tolist(), scores.tolist()

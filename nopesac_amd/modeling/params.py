@@ -11,6 +11,9 @@ import torch
 from torch import nn
 
 _BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+# bumped whenever packed / derived weights of ANY ParamModule are dropped, fp8 scales change or the kernel routing gains a decision:
+# PlaneTR_NopeSAC re-captures its hipGraphs when the epoch they were captured under is no longer current
+DERIVED_EPOCH = [0]
 
 
 class _Node(nn.Module):
@@ -61,6 +64,7 @@ class ParamModule(nn.Module):
     _DERIVED_CACHES = ("_fused_w", "_enc_tail_w", "_dec_tail_w", "_mlp_chain_w")
 
     def _drop_derived(self):
+        DERIVED_EPOCH[0] += 1          # anything that holds addresses of packed tensors (captured hipGraphs) is stale now
         self._packed = None
         for name in self._DERIVED_CACHES:
             self.__dict__.pop(name, None)

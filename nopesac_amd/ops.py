@@ -77,8 +77,18 @@ class ConvTuner:
         if cfg is not None or not self.measuring:
             return cfg if (cfg is not None and cfg in cands) else 0     # a remembered cfg this call is not eligible for -> heuristic
         times = {}
+        ok = []
         for c in cands:
-            launch(c)                                     # warm (first-touch, icache)
+            try:
+                launch(c)                                 # warm (first-touch, icache)
+                ok.append(c)
+            except _lib.HipKernelError:
+                # the C side rejects this shape for this configuration (an eligibility test above that does not mirror every
+                # check of the entry point, or a stale routing entry): the candidate is dropped, tuning goes on.  Configuration 0
+                # (the library's own heuristic) must work - its failure is the caller's error
+                if c == 0:
+                    raise
+        cands = tuple(ok)
         for rnd in range(3):                              # three interleaved rounds, keep each candidate's best: robust to
             for c in cands:                               # a noisy neighbour / clock ramp during one candidate's window
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,7 +207,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
              and x_cs % 8 == 0 and KH * KW <= 32 and (act & ~(0xff | ACT_RES_AFTER)) == 0
              and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31 and B * H * W < 2 ** 23 and x_cs < 2 ** 24 and KH * KW * Cin < 2 ** 24
              and Cout * KH * KW * Cin * 2 < 2 ** 31 and out_dtype in _DT and x_cs % 8 == 0
-             and (y_cs % (4 if out_dtype == torch.float32 else 8) == 0))
+             and (y_cs % (4 if out_dtype == torch.float32 else 8) == 0)
+             and (residual is None or (r_cs % (4 if out_dtype == torch.float32 else 8) == 0 and out_dtype != torch.float8_e4m3fn))
+             and all(t is None or t.data_ptr() % 16 == 0 for t in (x, w, out, residual, scale, bias)))
 
     def launch(cfg):
         if cfg == CFG_P8:
@@ -228,7 +240,13 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
                scale is not None, bias is not None, act, bfrag_ok, halo_ok, p8_ok)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ())
                            + ((CFG_P8,) if p8_ok else ()))
-    launch(cfg)
+    try:
+        launch(cfg)
+    except _lib.HipKernelError:
+        if cfg == 0:
+            raise
+        TUNER.best[key] = cfg = 0      # a stale routing entry the entry point rejects for this shape: heuristic from now on
+        launch(0)
     LAST_CONV_CFG[0] = cfg             # read by bench.py's per-launch timer to attribute the launch to a kernel
     return out
 

@@ -118,7 +118,7 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
         if keep_outputs is not None:         # what evaluate_for_matchings reads: ids, RLE instances, assignment matrices
             for out in outputs:
                 keep_outputs.append({**{v: {"image_id": out[v]["image_id"], "instances": out[v]["instances"]} for v in "01"},
-                                     **{k: out[k].cpu() for k in out if "assignment" in k}})
+                                     **{k: out[k].detach().cpu().clone() for k in out if "assignment" in k}})   # (a view of the batch's pinned buffer)
         n_done += len(batch)
 
     def finish(item):
@@ -141,6 +141,11 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
                     ev = torch.cuda.Event()
                     ev.record()
                 pending.append((batch, dev_out, ev, st))
+                if bi == 0:
+                    # the model builds its shared, lazily packed tensors (packed / fragment-major weights, fp8 copies, position
+                    # encodings) with kernels on THIS batch's stream: the other streams must not read them before they are
+                    # complete, so the first batch runs to the end before a second stream is used
+                    torch.cuda.synchronize()
                 done = [finish(pending.pop(0))] if len(pending) >= depth else []
             else:
                 outputs = model(batch)
