@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--no-fp32-path", action="store_true", help="skip the fp32 parity path's own throughput figure")
     ap.add_argument("--no-boundary", action="store_true", help="skip the drop-in boundary figure (model(list[dict]) -> list[dict], host tensors in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[2] (scannet yaml, K = 64) and "
+                    "configs[4] at one GPU (fp8 backbone 3x3 convs, K = 128) that the default run appends as `other_configs`")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight (HIP streams) per GPU")
@@ -334,10 +336,9 @@ def main():
         return bool(t and t.enabled) or getattr(model, "stage_events", None) is not None
 
     n_slots = max(1, args.inflight)
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_slots)]
+    loop = runner.InflightLoop(n_slots, B, device, world)      # streams, pinned row buffers and events of the in-flight slots
+    streams, host_bufs, done = loop.streams, loop.host_bufs, loop.done
     raws = [raw] + [raw.clone() for _ in range(n_slots - 1)]
-    host_bufs = [torch.empty(world * B, runner.METRIC_WIDTH, dtype=torch.float32).pin_memory() for _ in range(n_slots)]
-    done = [None] * n_slots
     last = {}
 
     graphs = [None] * n_slots          # optional: one captured hipGraph per slot (static shapes, static buffers)
@@ -370,36 +371,18 @@ def main():
                                       nonfinite=cam.get("nonfinite"))
         return d, rows
 
+    def slot_step(slot):
+        if graphs[slot] is not None and not timer_enabled():
+            graphs[slot].replay()
+            return None, graph_rows[slot]
+        return device_step(slot)
+
     def step(i=0):
-        slot = i % n_slots
-        if done[slot] is not None:
-            done[slot].synchronize()                           # slot's previous results have reached the host
-        t_host = time.perf_counter()
-        with torch.no_grad(), torch.cuda.stream(streams[slot]):
-            if graphs[slot] is not None and not timer_enabled():
-                graphs[slot].replay()
-                d, rows = None, graph_rows[slot]
-            else:
-                d, rows = device_step(slot)
-            allrows = runner.gather_metrics(rows)              # the only collective (RCCL all_gather, KBs)
-            host_bufs[slot].copy_(allrows, non_blocking=True)  # results leave the device once per step
-            ev = torch.cuda.Event()
-            ev.record()
-            done[slot] = ev
-            last["d"], last["slot"] = d, slot
-        last["host_s"] = last.get("host_s", 0.0) + time.perf_counter() - t_host
-        return d, host_bufs[slot]
+        d, host = loop.step(i, slot_step)
+        last["d"], last["slot"] = d, i % n_slots
+        return d, host
 
-    def drain():
-        for ev in done:
-            if ev is not None:
-                ev.synchronize()
-
-    def barrier():
-        drain()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    drain, barrier = loop.drain, loop.barrier
 
     for i in range(args.warmup):
         step(i)
@@ -424,11 +407,11 @@ def main():
         except Exception as e:                                 # keep the eager path if capture is not possible
             print("hipGraph capture failed, staying eager: %r" % (e,), file=sys.stderr)
             graphs = [None] * n_slots
-    last["host_s"] = 0.0
+    loop.host_seconds = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         d, host = step(i)
-    host_launch_ms = 1e3 * last["host_s"] / args.steps
+    host_launch_ms = 1e3 * loop.host_seconds / args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -543,6 +526,12 @@ def main():
                 "other_dtype_gemms": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms": round(v["ms"], 3),
                                           "launches": v["launches"]} for k, v in conv.items() if k != key}}
 
+    f8 = conv.get("torch.float8_e4m3fn")
+    if f8 and f8["ms"] > 0:                                  # BASELINE configs[4]: the fp8 MFMA launches against THEIR peak (5 PFLOP/s dense)
+        t8 = f8["flops"] / (f8["ms"] * 1e-3) / 1e12
+        roofline["fp8_kernels"] = {"kernel": "conv_igemm_bfrag_kernel<FP8>", "bound": "mfma", "achieved": round(t8, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                                   "frac": round(t8 / 5000.0, 4), "launches_per_step": f8["launches"], "ms": round(f8["ms"], 3),
+                                   "share_of_conv_family_flops": round(f8["flops"] / max(f8["flops"] + fam["flops"], 1.0), 3)}
     stage_ms = None
     if args.stages:
         model.stage_events = []
@@ -584,6 +573,11 @@ def main():
             out["pose_err_vs_fp32_path"].update(accuracy_vs_fp32(model, device, nq))
     if rank == 0 and world == 1 and not args.no_boundary and args.dtype == "bfloat16":
         out["boundary"] = boundary_rate(model, raw, forced, B, streams=streams)
+    if (rank == 0 and world == 1 and not args.no_other_configs and args.dtype == "bfloat16" and not args.fp8 and args.config == "mp3d"
+            and K == 32 and not args.ablate):
+        del model
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
@@ -597,6 +591,36 @@ def main():
 # matcher / refine stages would not take part in the comparison
 LOOSE = ["TEST.OVERLAP_THRESHOLD", 0.0, "TEST.PLANE_SCORE_THRESHOLD", 0.5, "TEST.MATCHING_SCORE_THRESHOLD", 0.0,
          "TEST.MASK_PROB_THRESHOLD", 0.3]
+
+
+def other_configs(args, steps=12, warmup=4):
+    """BASELINE configs[2] and configs[4] (its single-GPU half) measured by THIS file in short child runs - outside the timed region of
+    the headline line, each in its own process (own model, own kernel routing: nq = 64 / 128 change the head GEMM shapes) - so that the
+    driver's record carries them: {"scannet_k64": {...}, "fp8_k128": {...}} with value / ms_per_step / roofline of each."""
+    import subprocess
+    runs = {"scannet_k64": ["--config", "scannet", "--k", "64"], "fp8_k128": ["--fp8", "--k", "128"]}
+    res = {}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--pairs", str(args.pairs),
+               "--inflight", str(args.inflight), "--no-cpu-baseline", "--no-accuracy", "--no-fp32-path", "--no-boundary", "--no-other-configs",
+               "--routing", os.path.join(ROOT, "profiles", "routing_r3_%s.json" % name)] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[name] = {"error": (r.stderr or r.stdout)[-400:]}
+                continue
+            j = json.loads(line[-1])
+            rf = j.get("roofline") or {}
+            res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
+                         "workload": j["config"]["workload"], "K": j["config"]["K"], "host_launch_ms_per_step": j["config"]["host_launch_ms_per_step"],
+                         "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us",
+                                                             "by_bound", "fp8_kernels")},
+                         "wall_s_of_the_child_run": round(time.perf_counter() - t0, 1)}
+        except Exception as e:                                 # the headline line must not depend on these
+            res[name] = {"error": repr(e)[:400]}
+    return res
 
 
 def bench_workload_pose_error(m16, m32, device, B, K, nq, raw=None, forced=None):

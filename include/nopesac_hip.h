@@ -365,6 +365,14 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
                                 const int32_t* n1, const int32_t* n2, const float* rot, const float* trans,
                                 int B, int nq, float* assignment_out, void* stream);
 
+/* BENCHMARK-ONLY K control (not part of the reference: it has no such knob - the reference benchmark would need
+ * trained weights to keep K planes per view).  Per pair b: the K highest-scoring queries of view 1 (score = logits[b,q,0] -
+ * logits[b,q,1], logits f32 [>=B, nq, n_cls]) in ascending query order become rows 0..K-1 of feats[b] (query_feat f32 [>=B,nq,D]);
+ * feats[B+b, k] = feats[b, perm[b,k]] + noise[b,k] (perm int64 [B,K], noise f32 [B,K,D]); rows >= K are zeroed; n_kept[0..2B) = K.
+ * One launch (the first version was 18 torch launches inside bench.py's timed region). */
+int nopesac_force_k_select(const float* logits, int n_cls, const float* query_feat, const int64_t* perm, const float* noise,
+                           int B, int nq, int K, int D, float* feats, int32_t* n_kept, void* stream);
+
 /* small pose utilities on [B,*]: L2-normalise rows of a [rows,D] matrix (F.normalize, eps 1e-12),
  * optionally flip the sign so that component 0 >= 0 (camera_head.py:436-437,695-696). */
 int nopesac_normalize_rows(const float* x, float* y, int rows, int D, int canonical_sign, void* stream);

@@ -668,6 +668,229 @@ static int pw_launch_stream(const PwArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Four-row-tile variant for the identity blocks of res2 / res3 (round 3).  PMC on the res3 tail above (32 pixels per workgroup,
+// profiles/r2_pmc_res3_tail.json): 3.74 GB of L2 requests for 0.79 GB of HBM traffic - every 32 pixels re-stream the block's
+// 262 KB of 1x1 weights from L2 - MFMA-busy 15 %, 2.85 TB/s.  Here a 4-wave workgroup owns BM = 128 pixels and y is produced in
+// 128-channel chunks, i.e. exactly ONE 32-channel column tile per wave: no two waves ever load the same weight fragment and every
+// fragment feeds FOUR MFMAs (the four 32-pixel row tiles) - a quarter of the L2 -> CU weight traffic, without staging weights in
+// LDS.  Chunk c: y_c = relu(bn3(b W3_c^T) + x_c) is written in place over its residual in a [128][128] LDS tile, leaves for HBM as
+// 256-byte row segments and is at once K-slice c of the next block's conv1, whose accumulators stay in registers across the
+// chunks (pw_chain_stream_kernel's scheme with 4 instead of 8 waves).  LDS = b tile + one y chunk = 53-70 KB: two workgroups per
+// CU, so one's load / store phases run under the other's MFMAs.  The residual of chunk c+1 is in flight (registers) during GEMM 2
+// of chunk c; w1 fragments of chunk c are requested before GEMM 1 of chunk c, w3 fragments of chunk c+1 before GEMM 2 of chunk c.
+// Same arithmetic (MFMA K order, f32 epilogue order, bf16 rounding points) as pw_chain_kernel: bit-identical results.
+template <int C, int C4, int CN>
+struct PwRt4 {
+    static constexpr int BM = 128, CH = 128, NCH = C4 / CH;
+    static constexpr int A_LD = C + 8, Y_LD = CH + 8, O_LD = CN + 8;
+    static constexpr int KF1 = C / 16, KF2 = CH / 16;                   // weight fragments per column tile: expand conv / one K-slice of conv1
+    static constexpr int NR2 = CN >= 128 ? 4 : 2;                       // row tiles per wave in GEMM 2 (CN = 64: two column tiles x two row pairs)
+    static constexpr size_t BYTES = 2 * (size_t)(BM * A_LD + BM * Y_LD) + 2 * C4 * sizeof(float);   // + bn3 scale / shift (f32)
+    static_assert(C % 16 == 0 && C4 % CH == 0 && (CN == 0 || CN == 64 || CN == 128), "rt4 tail: shapes");
+    static_assert(CN == 0 || BM * O_LD <= BM * Y_LD, "the a' staging tile aliases the y chunk");
+};
+
+template <int C, int C4, int CN>
+__global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
+    typedef PwRt4<C, C4, CN> S;
+    constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, A_LD = S::A_LD, Y_LD = S::Y_LD, O_LD = S::O_LD, KF1 = S::KF1, KF2 = S::KF2, NR2 = S::NR2;
+    constexpr int RCH = BM * (CH / 8) / 256;                 // 16-byte chunks per thread of one [BM][CH] tile (8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* Y = A1 + BM * A_LD;
+    bf16_t* O = Y;                                           // aliases the y chunk once the last chunk has been consumed
+    // bn3 scale / shift of all C4 channels, parked once: the chunk epilogues read them with ds_read_b128 (as global loads they were
+    // eight exposed L2 round trips per chunk, each behind every older load of the wave: vmcnt retires in order)
+    float* S3 = reinterpret_cast<float*>(Y + BM * Y_LD);
+    float* B3 = S3 + C4;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+    // GEMM 2 ownership: CN >= 128: column tile = wave, all four row tiles; CN = 64: column tile wave & 1, row tiles 2 * (wave >> 1) + {0, 1}
+    const int nt2 = CN >= 128 ? wave : (wave & 1);
+    const int r2 = CN >= 128 ? 0 : 2 * (wave >> 1);
+
+    bf16x8 wa[KF1], wb[CN ? KF2 : 1];
+    auto load_wa = [&](int c) {                              // expand-conv fragments of y channels c*128 + wave*32 .. +32
+        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + wave) * KF1) * 64 + lane) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+    };
+    auto load_wb = [&](int c) {                              // conv1 fragments of this wave's column tile, K-slice c
+        if constexpr (CN > 0) {
+            const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KF2; ++kk) wb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+        }
+    };
+    // tile-relative addressing: wave-uniform 64-bit bases + ONE 32-bit per-thread offset (row tid >> 4, 16-byte column tid & 15); the
+    // eight rows a thread touches are 16 rows apart = compile-time byte distances (64-bit per-row addresses, hoisted out of the chunk
+    // loop, were 50 registers: spills)
+    const int trow = tid >> 4;
+    const unsigned toff = (unsigned)(trow * C4 + (tid & 15) * 8) * 2u;                  // bytes
+    const char* res_b = reinterpret_cast<const char*>(p.res + m0 * C4);
+    char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
+    us8 rres[RCH];
+    auto fetch_res = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            rres[i] = *reinterpret_cast<const us8*>(res_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2)));
+        }
+    };
+    auto park_res = [&]() {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const int ch = tid + i * 256, row = ch >> 4, col = (ch & 15) * 8;
+            *reinterpret_cast<us8*>(Y + row * Y_LD + col) = rres[i];
+        }
+    };
+    // ---- prologue: every global read goes out first (b tile, residual chunk 0, the first weight fragments)
+    {
+        constexpr int CPR = C / 8, NB = BM * CPR / 256;
+        us8 rb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
+            rb[i] = *reinterpret_cast<const us8*>(p.a1 + (m0 + row) * C + col);
+        }
+        fetch_res(0);
+        load_wa(0);
+        for (int i = tid; i < C4 / 4; i += 256) {
+            *reinterpret_cast<f32x4*>(S3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
+            *reinterpret_cast<f32x4*>(B3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
+            *reinterpret_cast<us8*>(A1 + row * A_LD + col) = rb[i];
+        }
+        park_res();
+    }
+    __syncthreads();
+
+    f32x16 acc2[CN ? NR2 : 1];
+#pragma unroll
+    for (int r = 0; r < (CN ? NR2 : 1); ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[r][e] = 0.f;
+    // (fully unrolled: a run-time `c + 1 < NCH` around the prefetches is a branch the s_waitcnt pass cannot count loads across)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load_wb(c);
+        // ---- GEMM 1: y chunk c, this wave's 32 channels x 128 pixels, as two passes over 64 pixels (the weight fragments stay
+        //      in registers for both: half the accumulator registers, no extra weight traffic)
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KF1; ++kk)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(A1 + ((2 * rp + r) * 32 + l31) * A_LD + kk * 16 + half * 8);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk], af, acc[r], 0, 0, 0);
+                    if (r == 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every k-step's LDS reads (spills)
+                }
+            // lane holds, for pixel (2 rp + r)*32 + l31, channels wave*32 + 8q + 4*half + {0..3} of the chunk
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wave * 32 + 8 * q + 4 * half, n = c * CH + nl;
+                const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n), b3 = *reinterpret_cast<const f32x4*>(B3 + n);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    bf16_t* yp = Y + ((2 * rp + r) * 32 + l31) * Y_LD + nl;
+                    const us4 r4 = *reinterpret_cast<const us4*>(yp);
+                    us4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[r][4 * q + e] * s3[e];
+                        v += b3[e];
+                        v += bf16_to_f32(r4[e]);
+                        o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                    *reinterpret_cast<us4*>(yp) = o4;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                     // y chunk complete
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const us8 v = *reinterpret_cast<const us8*>(Y + (trow + 16 * i) * Y_LD + (tid & 15) * 8);
+            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2))) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the store's staging registers are dead before the prefetches below go live)
+        if (c + 1 < NCH) {
+            load_wa(c + 1);                                  // (wa is dead until the next chunk's GEMM 1)
+            fetch_res(c + 1);                                // into the registers the GEMM 1 accumulators just left; lands during GEMM 2
+        }
+        if constexpr (CN > 0) {
+            // ---- GEMM 2: a' += y_c W1'[:, chunk c]^T
+#pragma unroll
+            for (int kk = 0; kk < KF2; ++kk)
+#pragma unroll
+                for (int r = 0; r < NR2; ++r) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(Y + ((r2 + r) * 32 + l31) * Y_LD + kk * 16 + half * 8);
+                    acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk], af, acc2[r], 0, 0, 0);
+                    if (r == NR2 - 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        __syncthreads();                                     // every wave is done with chunk c
+        if (c + 1 < NCH) {
+            park_res();
+            __syncthreads();
+        }
+    }
+    if constexpr (CN > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = nt2 * 32 + 8 * q + 4 * half;
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+#pragma unroll
+            for (int r = 0; r < NR2; ++r) {
+                us4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc2[r][4 * q + e] * s1[e];
+                    v += b1[e];
+                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o4;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = CN / 8, RPI = 256 / CPR;          // 16-byte chunks per row, rows per pass of the 256 threads
+        static_assert(CN == 0 || BM * CPR % 256 == 0, "a' tile chunking");
+        const int orow = tid / CPR, ocol = tid % CPR;
+        unsigned char* o_b = reinterpret_cast<unsigned char*>(p.o) + m0 * CN * (p.o_fp8 ? 1 : 2);
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int row = orow + i * RPI;
+            const us8 v = *reinterpret_cast<const us8*>(O + row * O_LD + ocol * 8);
+            if (p.o_fp8) {                                   // e4m3fn bytes for an fp8 conv2 (saturating RNE)
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+                *reinterpret_cast<uint2*>(o_b + (unsigned)(row * CN + ocol * 8)) = f32x8_to_fp8(f);
+            } else {
+                *reinterpret_cast<us8*>(o_b + (unsigned)(row * CN + ocol * 8) * 2u) = v;
+            }
+        }
+    }
+}
+
+template <int C, int C4, int CN>
+static int pw_launch_rt4(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwRt4<C, C4, CN>::BYTES;
+    NPS_ENSURE_LDS((int)lds, pw_chain_rt4_kernel<C, C4, CN>);
+    hipLaunchKernelGGL((pw_chain_rt4_kernel<C, C4, CN>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    return 0;
+}
+
 template <int C, int C4, int CN, int C2, int BM>
 static int pw_launch(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
@@ -710,6 +933,14 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
     a.o_fp8 = o_dt == NPS_DT_FP8 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int c2 = x2 ? C2 : 0;
+    // identity blocks of res2 / res3: the four-row-tile kernel (a quarter of the L2 weight traffic); NOPESAC_TAIL_NO_RT4=1 keeps the
+    // round-1 form (A/B comparisons: scripts/tail_one.py)
+    static const bool no_rt4 = getenv("NOPESAC_TAIL_NO_RT4") != nullptr;
+    if (!x2 && !no_rt4 && a.M % 128 == 0) {
+#define PW_RT4(c, c4, cn) if (C == c && C4 == c4 && CN == cn) { pw_launch_rt4<c, c4, cn>(a, st); NPS_LAUNCH_RET(); }
+        PW_RT4(128, 512, 128) PW_RT4(128, 512, 0) PW_RT4(64, 256, 64) PW_RT4(64, 256, 128) PW_RT4(64, 256, 0)
+#undef PW_RT4
+    }
 #define PW_CASE(c, c4, cn, cc2, bm) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch<c, c4, cn, cc2, bm>(a, st); NPS_LAUNCH_RET(); }
     // (measured in round 2: 64 pixels per workgroup for res3 - half the weight traffic from L2 but ONE 4-wave workgroup per CU - is
     //  slower, 322 vs 272 us on the identity tail: the 32-pixel form stays)

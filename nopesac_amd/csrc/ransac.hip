@@ -263,7 +263,59 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
     }
 }
 
+// BENCHMARK-ONLY K control (PlaneTR_NopeSAC._force_k, oracle force_k): with the name-seeded random weights the
+// threshold-based selection keeps ~1 plane per view, so the stages behind it would see K = 1.  One workgroup per pair: the K
+// highest-scoring queries of view 1 (score = logit 0 - logit 1; ascending query order, as topk(..).indices.sort() gives them) become
+// the kept planes of view 1; view 2 gets the SAME embeddings permuted (+ 1 % noise).  Everything the 18 torch launches of the first
+// version did (topk, sort, two gathers, add, zero fill, scatter), in one launch: feats [2B,nq,D] is written completely.
+__global__ __launch_bounds__(256) void force_k_select_kernel(const float* __restrict__ logits, int n_cls, const float* __restrict__ query_feat,
+                                                             const long long* __restrict__ perm, const float* __restrict__ noise, int B, int nq,
+                                                             int K, int D, float* __restrict__ feats, int32_t* __restrict__ n_kept) {
+    __shared__ float sc[128];
+    __shared__ int sel[128];                                 // sel[k] = query index of the k-th kept plane (ascending)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < nq) sc[tid] = logits[((long long)b * nq + tid) * n_cls] - logits[((long long)b * nq + tid) * n_cls + 1];
+    __syncthreads();
+    if (tid < nq) {
+        // rank by descending score (ties: lower index first); kept iff rank < K; its slot = number of kept queries below it
+        const float s = sc[tid];
+        int rank = 0;
+        for (int j = 0; j < nq; ++j) rank += (sc[j] > s) || (sc[j] == s && j < tid);
+        sc[tid] = rank < K ? 1.f : 0.f;                      // (every thread has read all scores: barrier below)
+    }
+    __syncthreads();
+    if (tid < nq && sc[tid] != 0.f) {
+        int pos = 0;
+        for (int j = 0; j < tid; ++j) pos += sc[j] != 0.f;
+        sel[pos] = tid;
+    }
+    if (tid == 0) { n_kept[b] = K; n_kept[B + b] = K; }
+    __syncthreads();
+    for (int k = 0; k < nq; ++k) {
+        float* o1 = feats + ((long long)b * nq + k) * D;
+        float* o2 = feats + ((long long)(B + b) * nq + k) * D;
+        if (k < K) {
+            const float* f1 = query_feat + ((long long)b * nq + sel[k]) * D;
+            const float* f2 = query_feat + ((long long)b * nq + sel[(int)perm[(long long)b * K + k]]) * D;
+            const float* nz = noise + ((long long)b * K + k) * D;
+            for (int c = tid; c < D; c += 256) { o1[c] = f1[c]; o2[c] = f2[c] + nz[c]; }
+        } else {
+            for (int c = tid; c < D; c += 256) { o1[c] = 0.f; o2[c] = 0.f; }
+        }
+    }
+}
+
 }  // namespace nps
+
+extern "C" int nopesac_force_k_select(const float* logits, int n_cls, const float* query_feat, const int64_t* perm, const float* noise, int B,
+                                      int nq, int K, int D, float* feats, int32_t* n_kept, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(logits && query_feat && perm && noise && feats && n_kept, "force_k_select: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && K > 0 && K <= nq && n_cls >= 2 && D > 0, "force_k_select: bad dims (K <= nq <= 128)");
+    hipLaunchKernelGGL(force_k_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, n_cls, query_feat, (const long long*)perm, noise,
+                       B, nq, K, D, feats, n_kept);
+    NPS_LAUNCH_RET();
+}
 
 extern "C" int nopesac_geo_sequence(const float* assignment, const float* planes1, const float* planes2,
                                     const int32_t* n1, const int32_t* n2, const float* init_trans,

@@ -42,6 +42,15 @@ class PlaneCameraHead(ParamModule):
         spec = {k[len("camera_head_list.0."):]: v for k, v in state_dict_spec(self.num_queries).items()
                 if k.startswith("camera_head_list.0.")}
         super().__init__(spec)
+        # MODEL.AMD.POSE_FP32_PARTS: stages of this head that keep f32 operands in bf16 mode (scripts/bf16_attribution.py tables what
+        # each one contributes to the bf16 pose error): "decoder" (pixel decoder + the six backbone-side convs), "branches" (the
+        # affinity volume and the 2 x 6 strided convs), "fc" (FC + pose regressors), "aim" (re-embedding MLPs), "refine" (RANSAC MLPs)
+        from ..config import amd_options
+        self.fp32_parts = frozenset(str(amd_options(cfg).POSE_FP32_PARTS).replace(",", " ").split())
+        assert self.fp32_parts <= {"decoder", "branches", "fc", "aim", "refine"}, self.fp32_parts
+
+    def _gd(self, part: str):
+        return torch.float32 if part in self.fp32_parts else self.gemm_dtype
 
     # ---------------------------------------------------------------- packing
     def pack(self) -> dict:
@@ -74,9 +83,10 @@ class PlaneCameraHead(ParamModule):
     def pixel_pose_net(self, feats: dict, B: int):
         """feats: NHWC res3..res5 for 2B images (view-1 images first) -> trans0 [B,3], rot0 [B,4] (unit, w>=0),
         trans_feat, rots_feat [B,256]."""
-        P, gd = self.packed, self.gemm_dtype
+        P, gd = self.packed, self._gd("decoder")
         r3, r4, r5 = feats["res3"], feats["res4"], feats["res5"]
-        cd = r5.dtype
+        if "decoder" in self.fp32_parts and r5.dtype != torch.float32:
+            r3, r4, r5 = r3.float(), r4.float(), r5.float()
 
         def cv(x, nm, pad=0, stride=1, act=ops.ACT_NONE, out_dtype=None):
             c = P[nm]
@@ -105,6 +115,7 @@ class PlaneCameraHead(ParamModule):
         # bf16 GEMM mode: the branch convs round their f32 activations to bf16 while staging them anyway, so the affinity volume and
         # the activations between the branch convs are STORED as bf16 (the same values) - the twelve convs then run on the bf16
         # conv kernels instead of the register-staged mixed-precision one (0.43 -> 0.2 ms per step) and move half the bytes
+        gd = self._gd("branches")
         act_dt = torch.bfloat16 if gd == torch.bfloat16 else aff.dtype
         if (h * w) % 8 or act_dt != aff.dtype:           # zero-padded channels (see pack): 300 -> 304
             aff_p = torch.zeros(B, h, w, self.CORR_PAD if (h * w) % 8 else h * w, device=aff.device, dtype=act_dt)
@@ -116,7 +127,7 @@ class PlaneCameraHead(ParamModule):
             for i in range(6):
                 t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY, out_dtype=torch.float32 if i == 5 else None)
             # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
-            feat, raw = run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], gd)
+            feat, raw = run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], self._gd("fc"))
             return feat, raw
 
         (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
@@ -125,7 +136,7 @@ class PlaneCameraHead(ParamModule):
 
     # ---------------------------------------------------------------- (ii) AIM
     def aim(self, trans0, rot0):
-        P, gd = self.packed, self.gemm_dtype
+        P, gd = self.packed, self._gd("aim")
         rot_feat, rot_raw = run_stacks(rot0, [(P["rot_emb_proj"], ops.ACT_RELU, True), ([P["rots"]], ops.ACT_NONE, True)], gd)  # rot0 has w >= 0 (:695-696)
         rec_rot = ops.normalize_rows(rot_raw)
         trans_feat, rec_trans = run_stacks(trans0 + 1e-10, [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
@@ -133,7 +144,7 @@ class PlaneCameraHead(ParamModule):
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
     def refine(self, A0, planes1, planes2, n1, n2, rec_trans, rec_rot, trans_feat, rot_feat, diagnostics=False):
-        P, nq, gd = self.packed, self.num_queries, self.gemm_dtype
+        P, nq, gd = self.packed, self.num_queries, self._gd("refine")
         B = A0.shape[0]
         dev = A0.device
         geo_local, geo_global, sig, geo_enc, m = ops.geo_sequence(A0, planes1, planes2, n1, n2, rec_trans, rec_rot,

@@ -267,17 +267,13 @@ class PlaneTR_NopeSAC(nn.Module):
         ~1 plane per view, so the stages after post-selection would see K = 1.  The selection kernels still
         run (their outputs are overwritten): every view gets its K highest-scoring queries, view-2 appearance
         = permuted view-1 appearance + 1% noise, plane parameters and the K matches come from `forced`."""
-        K, nq = forced["K"], self.num_queries
-        score = head_out["pred_logits"][:B, :, 0] - head_out["pred_logits"][:B, :, 1]
-        idx = torch.topk(score, K, dim=1).indices.sort(dim=1).values                             # [B,K] ascending
-        f1 = torch.gather(query_feat[:B], 1, idx.unsqueeze(-1).expand(B, K, 256))
-        f2 = torch.gather(f1, 1, forced["perm"].unsqueeze(-1).expand(B, K, 256)) + forced["noise"]
-        feats = torch.zeros(2 * B, nq, 256, device=f1.device, dtype=torch.float32)
-        feats[:B, :K], feats[B:, :K] = f1, f2
+        K = forced["K"]
+        # one launch (csrc/ransac.hip: force_k_select_kernel; the first version was 18 torch launches inside the timed region)
+        feats, n_kept = ops.force_k_select(head_out["pred_logits"].contiguous(), query_feat.contiguous(), forced["perm"], forced["noise"], B, K)
         out = dict(sel)
         out["feats"] = feats
         out["planes"] = forced["planes"]
-        out["n_kept"] = torch.full((2 * B,), K, device=f1.device, dtype=torch.int32)
+        out["n_kept"] = n_kept
         return out, forced["assignment"]
 
     # ------------------------------------------------------------------------------------------

@@ -734,6 +734,19 @@ def refilter_assignment(assignment, planes1, planes2, n1, n2, rot, trans):
     return out
 
 
+def force_k_select(logits: torch.Tensor, query_feat: torch.Tensor, perm: torch.Tensor, noise: torch.Tensor, B: int, K: int):
+    """Benchmark-only K control in one launch (include/nopesac_hip.h: nopesac_force_k_select) -> feats f32 [2B,nq,D], n_kept int32 [2B]."""
+    _chk(logits, torch.float32); _chk(query_feat, torch.float32); _chk(perm, torch.int64); _chk(noise, torch.float32)
+    nq, n_cls, D = logits.shape[1], logits.shape[2], query_feat.shape[2]
+    _require(logits.shape[0] >= B and query_feat.shape[0] >= B and query_feat.shape[1] == nq and perm.shape == (B, K) and noise.shape == (B, K, D),
+             "force_k_select: shapes")
+    feats = torch.empty(2 * B, nq, D, device=logits.device, dtype=torch.float32)
+    n_kept = torch.empty(2 * B, device=logits.device, dtype=torch.int32)
+    _lib.check(_L().nopesac_force_k_select(_p(logits), n_cls, _p(query_feat), _p(perm), _p(noise), B, nq, K, D, _p(feats), _p(n_kept), _stream()),
+               "nopesac_force_k_select")
+    return feats, n_kept
+
+
 def rle_labels(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:
     """winner uint8 [V,H,W] -> column-major uint8 [V,W,H] map of kept-plane ordinals (0xFF = none)."""
     _chk(winner, torch.uint8); _chk(kept_idx, torch.int32); _chk(n_kept, torch.int32); _chk(flags, torch.int32)

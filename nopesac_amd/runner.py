@@ -120,3 +120,57 @@ def summarize(rows: torch.Tensor) -> dict:
     r = rows.detach().cpu().numpy()
     return {"pairs": int(r.shape[0]), "mean_T_err": float(r[:, 10].mean()), "mean_R_err": float(r[:, 11].mean()),
             "mean_planes": float((r[:, 7] + r[:, 8]).mean() / 2), "mean_matches": float(r[:, 9].mean())}
+
+
+class InflightLoop:
+    """`n_slots` batches in flight: step i runs on HIP stream i % n_slots (its own stream, its own pinned host buffer for the
+    gathered rows), so the latency-bound head stages of one batch overlap with the HBM / MFMA-bound backbone of the next.  Per
+    step and rank there is exactly ONE collective (`gather_metrics`, an all_gather of [B,16] rows), issued in step order on every
+    rank - collectives of different slots go through the same communicator in the same order everywhere.  A slot's results are
+    complete when its event has fired (checked before the slot is reused and by `drain`).  On a CPU (the gloo tests) the same
+    control flow runs without streams / events."""
+
+    def __init__(self, n_slots: int, rows_per_rank: int, device=None, world: int = 1):
+        self.n_slots = max(1, int(n_slots))
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_slots)] if self.cuda else [None] * self.n_slots
+        self.host_bufs = [torch.empty(world * rows_per_rank, METRIC_WIDTH, dtype=torch.float32) for _ in range(self.n_slots)]
+        if self.cuda:
+            self.host_bufs = [b.pin_memory() for b in self.host_bufs]
+        self.done = [None] * self.n_slots
+        self.host_seconds = 0.0
+        self.last = None
+
+    def step(self, i: int, device_step):
+        """device_step(slot) -> (anything, rows [B,16] on the device); returns (anything, this slot's host buffer)."""
+        import contextlib
+        import time
+        slot = i % self.n_slots
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()                      # the slot's previous results have reached the host
+        t0 = time.perf_counter()
+        ctx = torch.cuda.stream(self.streams[slot]) if self.cuda else contextlib.nullcontext()
+        with torch.no_grad(), ctx:
+            d, rows = device_step(slot)
+            allrows = gather_metrics(rows)                     # the only collective (RCCL all_gather, KBs)
+            self.host_bufs[slot].copy_(allrows, non_blocking=True)   # results leave the device once per step
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self.done[slot] = ev
+        self.host_seconds += time.perf_counter() - t0
+        self.last = (d, slot)
+        return d, self.host_bufs[slot]
+
+    def drain(self):
+        for ev in self.done:
+            if ev is not None:
+                ev.synchronize()
+
+    def barrier(self):
+        self.drain()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+        if self.cuda:
+            torch.cuda.synchronize()
+

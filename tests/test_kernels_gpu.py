@@ -755,3 +755,24 @@ def test_mlp_chain_rejects_bad_chains(device):
         ops.mlp_chain(x, [l1], [0], [torch.empty(8, 100, device=device)])
     with pytest.raises(_lib.HipKernelError):
         ops.mlp_chain(x, [l1], [0], [None])
+
+
+@pytest.mark.parametrize("B,nq,K", [(3, 50, 32), (2, 64, 64), (2, 128, 128), (1, 50, 1)])
+def test_force_k_select_matches_the_torch_formulation(device, B, nq, K):
+    """The benchmark-only K control as one launch vs the torch formulation the oracle uses (topk -> sorted indices -> gathers):
+    identical feats / n_kept, including rows >= K zeroed and a larger leading dimension of the inputs (2B views)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    logits = torch.randn(2 * B, nq, 2, generator=g).to(device)
+    qf = torch.randn(2 * B, nq, 256, generator=g).to(device)
+    perm = torch.stack([torch.randperm(K, generator=g) for _ in range(B)]).to(device)
+    noise = (0.01 * torch.randn(B, K, 256, generator=g)).to(device)
+    feats, n_kept = ops.force_k_select(logits, qf, perm, noise, B, K)
+    score = logits[:B, :, 0] - logits[:B, :, 1]
+    idx = torch.topk(score, K, dim=1).indices.sort(dim=1).values
+    f1 = torch.gather(qf[:B], 1, idx.unsqueeze(-1).expand(B, K, 256))
+    f2 = torch.gather(f1, 1, perm.unsqueeze(-1).expand(B, K, 256)) + noise
+    want = torch.zeros(2 * B, nq, 256, device=device)
+    want[:B, :K], want[B:, :K] = f1, f2
+    assert torch.equal(feats, want)
+    assert n_kept.tolist() == [K] * (2 * B)

@@ -95,3 +95,53 @@ def test_launch_spawns_one_rank_per_gpu(tmp_path, monkeypatch):
     a, b = np.load(tmp_path / "rows_0.npy"), np.load(tmp_path / "rows_1.npy")
     assert a.shape == (6, 16) and a[:, 12].tolist() == list(range(6))
     np.testing.assert_array_equal(a, b)
+
+
+def _inflight_worker(rank, world, port, steps, slots, B, out_dir):
+    """bench.py's timed loop (runner.InflightLoop: `slots` batches in flight, ONE gather_metrics per step) with a stub model."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nopesac_amd import runner
+    r, w, _ = runner.init_distributed("gloo")
+    loop = runner.InflightLoop(slots, B, None, w)
+    seen = []
+
+    def device_step_for(i):
+        def device_step(slot):
+            assert slot == i % slots
+            t = torch.full((B, 3), float(i)) + torch.arange(B, dtype=torch.float32).view(-1, 1) / 100 + r * 1000.0
+            q = torch.nn.functional.normalize(torch.ones(B, 4), dim=-1)
+            rows = runner.metric_rows(t, q, torch.full((B,), 5), torch.full((B,), 6), torch.full((B,), 32), r * B)
+            return {"step": i}, rows
+        return device_step
+
+    for i in range(steps):
+        d, host = loop.step(i, device_step_for(i))
+        assert d == {"step": i} and host.shape == (w * B, runner.METRIC_WIDTH)
+        seen.append(host.clone())                         # (a slot's buffer is overwritten `slots` steps later)
+    loop.barrier()
+    assert loop.host_seconds > 0 and loop.last == ({"step": steps - 1}, (steps - 1) % slots)
+    np.save(os.path.join(out_dir, f"inflight_{r}.npy"), torch.stack(seen).numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_bench_inflight_loop_world2(tmp_path):
+    """The multi-GPU form of bench.py's timed region on CPU: world size 2 over gloo, 4 slots, 9 steps (more steps than slots: every
+    slot is reused), one all_gather per step and rank.  Both ranks must see identical [world*B, 16] blocks for every step, rank-major
+    with contiguous pair indices, and the loop must terminate (no deadlock from the per-slot ordering of the collectives)."""
+    steps, slots, B, world = 9, 4, 3, 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_inflight_worker, args=(r, world, port, steps, slots, B, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "rank did not finish (deadlock?)"
+    a, b = np.load(tmp_path / "inflight_0.npy"), np.load(tmp_path / "inflight_1.npy")
+    assert a.shape == (steps, world * B, 16)
+    np.testing.assert_array_equal(a, b)
+    for i in range(steps):
+        assert a[i, :, 12].tolist() == list(range(world * B))                      # rank-major, contiguous pair indices
+        np.testing.assert_allclose(a[i, :B, 0], i + np.arange(B) / 100, rtol=1e-6)           # rank 0's rows of step i
+        np.testing.assert_allclose(a[i, B:, 0], 1000 + i + np.arange(B) / 100, rtol=1e-6)    # rank 1's rows of step i
+        assert (a[i, :, 9] == 32).all()
