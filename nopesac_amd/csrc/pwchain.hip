@@ -680,30 +680,38 @@ static int pw_launch_stream(const PwArgs& a, hipStream_t stream) {
 // CU, so one's load / store phases run under the other's MFMAs.  The residual of chunk c+1 is in flight (registers) during GEMM 2
 // of chunk c; w1 fragments of chunk c are requested before GEMM 1 of chunk c, w3 fragments of chunk c+1 before GEMM 2 of chunk c.
 // Same arithmetic (MFMA K order, f32 epilogue order, bf16 rounding points) as pw_chain_kernel: bit-identical results.
-template <int C, int C4, int CN>
+template <int C, int C4, int CN, int C2 = 0>
 struct PwRt4 {
     static constexpr int BM = 128, CH = 128, NCH = C4 / CH;
-    static constexpr int A_LD = C + 8, Y_LD = CH + 8, O_LD = CN + 8;
+    static constexpr int A_LD = C + 8, A2_LD = C2 + 8, Y_LD = CH + 8, O_LD = CN + 8;
+    static constexpr int KF1S = C2 / 16;                                // shortcut-conv fragments per column tile (projection blocks)
     static constexpr int KF1 = C / 16, KF2 = CH / 16;                   // weight fragments per column tile: expand conv / one K-slice of conv1
     static constexpr int NR2 = CN >= 128 ? 4 : 2;                       // row tiles per wave in GEMM 2 (CN = 64: two column tiles x two row pairs)
-    static constexpr size_t BYTES = 2 * (size_t)(BM * A_LD + BM * Y_LD) + 2 * C4 * sizeof(float);   // + bn3 scale / shift (f32)
+    static constexpr size_t BYTES = 2 * (size_t)(BM * A_LD + (C2 ? BM * A2_LD : 0) + BM * Y_LD) + (C2 ? 4 : 2) * C4 * sizeof(float);   // + bn scale / shift (f32)
     static_assert(C % 16 == 0 && C4 % CH == 0 && (CN == 0 || CN == 64 || CN == 128), "rt4 tail: shapes");
     static_assert(CN == 0 || BM * O_LD <= BM * Y_LD, "the a' staging tile aliases the y chunk");
 };
 
-template <int C, int C4, int CN>
+// EARLY = how many of the 8 residual loads of chunk c+1 go out BEFORE GEMM 1 of chunk c.
+// C2 > 0: PROJECTION block with a same-resolution source (res2.0: x2 = the stem output): the shortcut bn_sc(Wsc x2) is a second GEMM
+// of every chunk out of a second LDS operand tile, kept in f32 until it is added (like pw_chain_kernel); no residual is read.
+template <int C, int C4, int CN, int EARLY, int C2 = 0>
 __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
-    typedef PwRt4<C, C4, CN> S;
+    typedef PwRt4<C, C4, CN, C2> S;
     constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, A_LD = S::A_LD, Y_LD = S::Y_LD, O_LD = S::O_LD, KF1 = S::KF1, KF2 = S::KF2, NR2 = S::NR2;
     constexpr int RCH = BM * (CH / 8) / 256;                 // 16-byte chunks per thread of one [BM][CH] tile (8)
     extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
     bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
-    bf16_t* Y = A1 + BM * A_LD;
+    bf16_t* A2 = A1 + BM * A_LD;
+    bf16_t* Y = A2 + (C2 ? BM * S::A2_LD : 0);
     bf16_t* O = Y;                                           // aliases the y chunk once the last chunk has been consumed
     // bn3 scale / shift of all C4 channels, parked once: the chunk epilogues read them with ds_read_b128 (as global loads they were
     // eight exposed L2 round trips per chunk, each behind every older load of the wave: vmcnt retires in order)
     float* S3 = reinterpret_cast<float*>(Y + BM * Y_LD);
     float* B3 = S3 + C4;
+    float* SSC = B3 + C4;                                    // (projection blocks only)
+    float* BSC = SSC + C4;
+    constexpr int KF1S = S::KF1S, A2_LD = S::A2_LD;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * BM;
@@ -711,11 +719,16 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     const int nt2 = CN >= 128 ? wave : (wave & 1);
     const int r2 = CN >= 128 ? 0 : 2 * (wave >> 1);
 
-    bf16x8 wa[KF1], wb[CN ? KF2 : 1];
-    auto load_wa = [&](int c) {                              // expand-conv fragments of y channels c*128 + wave*32 .. +32
+    bf16x8 wa[KF1], wb[CN ? KF2 : 1], ws[C2 ? KF1S : 1];
+    auto load_wa = [&](int c) {                              // expand-conv (+ shortcut-conv) fragments of y channels c*128 + wave*32 .. +32
         const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + wave) * KF1) * 64 + lane) * 8;
 #pragma unroll
         for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+        if constexpr (C2 > 0) {
+            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + wave) * KF1S) * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KF1S; ++kk) ws[kk] = *reinterpret_cast<const bf16x8*>(v + kk * 512);
+        }
     };
     auto load_wb = [&](int c) {                              // conv1 fragments of this wave's column tile, K-slice c
         if constexpr (CN > 0) {
@@ -729,13 +742,13 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     // loop, were 50 registers: spills)
     const int trow = tid >> 4;
     const unsigned toff = (unsigned)(trow * C4 + (tid & 15) * 8) * 2u;                  // bytes
-    const char* res_b = reinterpret_cast<const char*>(p.res + m0 * C4);
+    const char* res_b = reinterpret_cast<const char*>(C2 ? p.y : p.res) + m0 * C4 * 2;   // (never read in a projection block)
     char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
     us8 rres[RCH];
-    auto fetch_res = [&](int c) {
+    auto fetch_res = [&](int c, int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < RCH; ++i) {
-            rres[i] = *reinterpret_cast<const us8*>(res_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2)));
+            if (i >= i0 && i < i1) rres[i] = *reinterpret_cast<const us8*>(res_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2)));
         }
     };
     auto park_res = [&]() {
@@ -754,18 +767,40 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
             const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
             rb[i] = *reinterpret_cast<const us8*>(p.a1 + (m0 + row) * C + col);
         }
-        fetch_res(0);
+        constexpr int CPR2 = C2 ? C2 / 8 : 1, NB2 = C2 ? BM * CPR2 / 256 : 1;
+        us8 rb2[NB2];
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const int ch = tid + i * 256, row = ch / CPR2, col = (ch % CPR2) * 8;
+                rb2[i] = *reinterpret_cast<const us8*>(p.a2 + (m0 + row) * C2 + col);
+            }
+        } else {
+            fetch_res(0, 0, RCH);
+        }
         load_wa(0);
         for (int i = tid; i < C4 / 4; i += 256) {
             *reinterpret_cast<f32x4*>(S3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
             *reinterpret_cast<f32x4*>(B3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+            if constexpr (C2 > 0) {
+                *reinterpret_cast<f32x4*>(SSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
+                *reinterpret_cast<f32x4*>(BSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
             *reinterpret_cast<us8*>(A1 + row * A_LD + col) = rb[i];
         }
-        park_res();
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const int ch = tid + i * 256, row = ch / CPR2, col = (ch % CPR2) * 8;
+                *reinterpret_cast<us8*>(A2 + row * A2_LD + col) = rb2[i];
+            }
+        } else {
+            park_res();
+        }
     }
     __syncthreads();
 
@@ -778,15 +813,16 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         load_wb(c);
+        if (C2 == 0 && EARLY > 0 && c + 1 < NCH) fetch_res(c + 1, 0, EARLY);   // in flight during BOTH GEMMs of chunk c (4 live registers each in GEMM 1)
         // ---- GEMM 1: y chunk c, this wave's 32 channels x 128 pixels, as two passes over 64 pixels (the weight fragments stay
         //      in registers for both: half the accumulator registers, no extra weight traffic)
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {
-            f32x16 acc[2];
+            f32x16 acc[2], accs[C2 ? 2 : 1];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+                for (int e = 0; e < 16; ++e) { acc[r][e] = 0.f; if (C2 > 0) accs[r][e] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < KF1; ++kk)
 #pragma unroll
@@ -795,21 +831,40 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk], af, acc[r], 0, 0, 0);
                     if (r == 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every k-step's LDS reads (spills)
                 }
+            if constexpr (C2 > 0) {
+#pragma unroll
+                for (int kk = 0; kk < KF1S; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(A2 + ((2 * rp + r) * 32 + l31) * A2_LD + kk * 16 + half * 8);
+                        accs[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[kk], af, accs[r], 0, 0, 0);
+                        if (r == 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
             // lane holds, for pixel (2 rp + r)*32 + l31, channels wave*32 + 8q + 4*half + {0..3} of the chunk
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = wave * 32 + 8 * q + 4 * half, n = c * CH + nl;
                 const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n), b3 = *reinterpret_cast<const f32x4*>(B3 + n);
+                f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n); bs = *reinterpret_cast<const f32x4*>(BSC + n); }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     bf16_t* yp = Y + ((2 * rp + r) * 32 + l31) * Y_LD + nl;
-                    const us4 r4 = *reinterpret_cast<const us4*>(yp);
+                    us4 r4 = {0, 0, 0, 0};
+                    if constexpr (C2 == 0) r4 = *reinterpret_cast<const us4*>(yp);
                     us4 o4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[r][4 * q + e] * s3[e];
                         v += b3[e];
-                        v += bf16_to_f32(r4[e]);
+                        if constexpr (C2 > 0) {
+                            float sc = accs[r][4 * q + e] * ss[e];
+                            sc += bs[e];
+                            v += sc;
+                        } else {
+                            v += bf16_to_f32(r4[e]);
+                        }
                         o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
                     }
                     *reinterpret_cast<us4*>(yp) = o4;
@@ -826,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
         __builtin_amdgcn_sched_barrier(0);                   // (the store's staging registers are dead before the prefetches below go live)
         if (c + 1 < NCH) {
             load_wa(c + 1);                                  // (wa is dead until the next chunk's GEMM 1)
-            fetch_res(c + 1);                                // into the registers the GEMM 1 accumulators just left; lands during GEMM 2
+            if (C2 == 0 && EARLY < RCH) fetch_res(c + 1, EARLY, RCH);   // the rest: into the registers the GEMM 1 accumulators just left; lands during GEMM 2
         }
         if constexpr (CN > 0) {
             // ---- GEMM 2: a' += y_c W1'[:, chunk c]^T
@@ -840,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
                 }
         }
         __syncthreads();                                     // every wave is done with chunk c
-        if (c + 1 < NCH) {
+        if (C2 == 0 && c + 1 < NCH) {
             park_res();
             __syncthreads();
         }
@@ -883,11 +938,28 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     }
 }
 
+template <int C, int C4, int CN, int C2>
+static int pw_launch_rt4_proj(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwRt4<C, C4, CN, C2>::BYTES;
+    NPS_ENSURE_LDS((int)lds, pw_chain_rt4_kernel<C, C4, CN, 0, C2>);
+    hipLaunchKernelGGL((pw_chain_rt4_kernel<C, C4, CN, 0, C2>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    return 0;
+}
+
 template <int C, int C4, int CN>
 static int pw_launch_rt4(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwRt4<C, C4, CN>::BYTES;
-    NPS_ENSURE_LDS((int)lds, pw_chain_rt4_kernel<C, C4, CN>);
-    hipLaunchKernelGGL((pw_chain_rt4_kernel<C, C4, CN>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    static const bool late = getenv("NOPESAC_TAIL_RT4_LATE") != nullptr;       // A/B switch: residual prefetch behind GEMM 1
+    // measured (profiles/r3_c_tail_ab.txt): res2 (C = 64) gains 3-6 % from the residual prefetch going out before GEMM 1 (308 vs 326 us,
+    // 361 vs 371 us); res3 (C = 128, 248 registers without it) loses 2 % even with only three of the eight loads early (197 vs 192 us)
+    constexpr int EARLY = C >= 128 ? 0 : 8;
+    if (late) {
+        NPS_ENSURE_LDS((int)lds, pw_chain_rt4_kernel<C, C4, CN, 0>);
+        hipLaunchKernelGGL((pw_chain_rt4_kernel<C, C4, CN, 0>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    } else {
+        NPS_ENSURE_LDS((int)lds, pw_chain_rt4_kernel<C, C4, CN, EARLY>);
+        hipLaunchKernelGGL((pw_chain_rt4_kernel<C, C4, CN, EARLY>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    }
     return 0;
 }
 
@@ -940,6 +1012,11 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
 #define PW_RT4(c, c4, cn) if (C == c && C4 == c4 && CN == cn) { pw_launch_rt4<c, c4, cn>(a, st); NPS_LAUNCH_RET(); }
         PW_RT4(128, 512, 128) PW_RT4(128, 512, 0) PW_RT4(64, 256, 64) PW_RT4(64, 256, 128) PW_RT4(64, 256, 0)
 #undef PW_RT4
+    }
+    // res2.0: projection shortcut from a same-resolution source (the stem output), in the same 128-pixel form
+    if (x2 && !no_rt4 && a.M % 128 == 0 && x2_stride == 1 && x2_H == OH && x2_W == OW) {
+        if (C == 64 && C4 == 256 && CN == 64 && c2 == 64) { pw_launch_rt4_proj<64, 256, 64, 64>(a, st); NPS_LAUNCH_RET(); }
+        if (C == 64 && C4 == 256 && CN == 0 && c2 == 64) { pw_launch_rt4_proj<64, 256, 0, 64>(a, st); NPS_LAUNCH_RET(); }
     }
 #define PW_CASE(c, c4, cn, cc2, bm) if (C == c && C4 == c4 && CN == cn && c2 == cc2) { pw_launch<c, c4, cn, cc2, bm>(a, st); NPS_LAUNCH_RET(); }
     // (measured in round 2: 64 pixels per workgroup for res3 - half the weight traffic from L2 but ONE 4-wave workgroup per CU - is

@@ -46,6 +46,9 @@ class HipResNet50(ParamModule):
         self._calib: dict | None = None
         self._q8: dict = {}
         self.unfused_wide_tails = os.environ.get("NOPESAC_TAIL_RES4_FUSED", "0") != "1"
+        # res3's edge blocks un-fused onto the 128-pixel identity tail: measured 5.39 ms vs 5.35 ms for the whole backbone with the edge
+        # blocks left on the 32-pixel fused kernel (profiles/r3_c_tail_ab.txt) - off; NOPESAC_RES3_EDGES_UNFUSED=1 for A/B runs
+        self.rt4_res3_edges = os.environ.get("NOPESAC_RES3_EDGES_UNFUSED", "0") == "1"
 
     def output_shape(self):
         full = {"res2": ShapeSpec(256, stride=4), "res3": ShapeSpec(512, stride=8), "res4": ShapeSpec(1024, stride=16),
@@ -104,32 +107,44 @@ class HipResNet50(ParamModule):
             self._q8[p] = q
         return q
 
-    def forward(self, x: torch.Tensor, raw=None) -> dict:
+    def forward(self, x: torch.Tensor, raw=None, stop_after: str = None, resume=None) -> dict:
         """x: NHWC [B,H,W,4] (normalised, channel-padded) in the compute dtype -> {res2..res5} NHWC.
         bf16 mode only: `raw` = (images f32 NCHW [B,3,H,W], mean f32[3], std f32[3]) may be given INSTEAD of x - the fused stem then
-        normalises while it stages its input patches (no NHWC copy of the batch is made)."""
+        normalises while it stages its input patches (no NHWC copy of the batch is made).
+        Diagnostics (scripts/bf16_attribution.py): `stop_after` = "stem" / "res2" ... returns {"x": the activation after that stage}
+        as soon as it exists; `resume` = (stage name, x) continues behind that stage (x in this model's compute dtype)."""
         P = self.packed
         dt = x.dtype if x is not None else torch.bfloat16
-        assert x is not None or (raw is not None and self.fused_stem), "backbone: raw images need the fused bf16 stem"
+        assert x is not None or resume is not None or (raw is not None and self.fused_stem), "backbone: raw images need the fused bf16 stem"
         assert not self.fp8_conv2 or (dt == torch.bfloat16 and self.fused_tail), "MODEL.AMD.BACKBONE_FP8 needs MODEL.AMD.COMPUTE_DTYPE bfloat16"
 
         def cv(t, key, stride=1, pad=0, act=ops.ACT_RELU, residual=None):
             c = P[key]
             return ops.conv2d(t, c.w(dt), c.scale, c.bias, residual, stride=stride, pad=pad, act=act)
 
-        if x is None:
+        stages = ["stem"] + [name for name, _, _, _ in RES_STAGES]
+        skip_until = None
+        if resume is not None:
+            skip_until, x = resume
+            dt = x.dtype
+        elif x is None:
             x = ops.stem_fused_raw(raw[0], raw[1], raw[2], P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         elif dt == torch.bfloat16 and self.fused_stem:
             x = ops.stem_fused(x, P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         else:
             x = cv(x, "stem", 2, 3)
             x = ops.maxpool(x, 3, 2, 1)
+        if stop_after == "stem":
+            return {"x": x}
         out = {}
         cin = 64
         fuse = dt == torch.bfloat16 and self.fused_tail
         blocks = [(name, i, n, cmid, cout) for name, n, cmid, cout in RES_STAGES for i in range(n)]
         a_pre = None                                  # conv1 output of the current block, when the previous tail produced it
         for bi, (name, i, n, cmid, cout) in enumerate(blocks):
+            if skip_until is not None and stages.index(name) <= stages.index(skip_until):
+                cin = cout
+                continue
             p = f"{name}.{i}"
             stride = 2 if (i == 0 and name != "res2") else 1
             proj = cin != cout
@@ -169,7 +184,17 @@ class HipResNet50(ParamModule):
                 # conv3 + shortcut + ReLU (+ the next block's conv1) in one launch (csrc/pwchain.hip)
                 use_next = cfg_next in ops.BOTTLENECK_TAIL_CONFIGS and nxt is not None
                 kw = {}
-                if proj:
+                # res3's edge blocks on the 128-pixel identity tail (csrc/pwchain.hip: pw_chain_rt4_kernel, round 3): the projection
+                # shortcut of res3.0 (K = 256, stride 2) runs as its own launch and enters the tail as a plain residual (the fused
+                # projection form needs a 68 KB second operand tile: one workgroup per CU, 32 pixels per weight pass); res3.3 leaves the
+                # 256-wide conv1 of res4.0 to the conv kernel (three 32-channel column tiles x four row tiles of accumulators per wave
+                # do not fit next to the tail's own).  Off by default (see __init__)
+                rt4_edges = self.rt4_res3_edges and cmid == 128 and not self.fp8_conv2
+                if rt4_edges and use_next and nxt.cout > 128:
+                    use_next = False
+                if proj and rt4_edges:
+                    kw.update(residual=cv(x, p + ".shortcut", stride, 0, ops.ACT_NONE))
+                elif proj:
                     sc = P[p + ".shortcut"]
                     kw.update(x2=x, wsc=sc.wfrag(dt), ssc=sc.scale, bsc=sc.bias, stride=stride)
                 else:
@@ -186,6 +211,8 @@ class HipResNet50(ParamModule):
             cin = cout
             if i == n - 1 and name in self.out_features:
                 out[name] = x
+            if i == n - 1 and stop_after == name:
+                return {"x": x}
         return out
 
 

@@ -29,6 +29,7 @@ from nopesac_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=32)
 ap.add_argument("--k", type=int, default=32)
+ap.add_argument("--only", default="", help="substring filter on the variant names")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bf16_attribution.json"))
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -42,9 +43,19 @@ head = m16.camera_head_list[0]
 orig_backbone_forward = m16.backbone.forward
 
 
-def fp32_backbone(x, raw=None):
+def fp32_backbone(x, raw=None, until="res5"):
+    """ResNet-50 in fp32 up to and including stage `until` ("stem", "res2" .. "res5"), bf16 kernels behind it."""
     xin = ops.preprocess(raw[0], m32.pixel_mean, m32.pixel_std, m32.backbone.STEM_CIN_PAD, torch.float32) if x is None else x.float()
-    return {k: v.to(torch.bfloat16) for k, v in m32.backbone(xin).items()}
+    if until == "res5":
+        return {k: v.to(torch.bfloat16) for k, v in m32.backbone(xin).items()}
+    mid = m32.backbone(xin, stop_after=until)["x"].to(torch.bfloat16)
+    feats = orig_backbone_forward(None, resume=(until, mid))
+    if until in ("res2", "res3", "res4"):            # the stages' own outputs that were computed in fp32
+        full = m32.backbone(xin)
+        for k in ("res2", "res3", "res4"):
+            if k in full and ["res2", "res3", "res4"].index(k) <= ["res2", "res3", "res4"].index(until):
+                feats[k] = full[k].to(torch.bfloat16)
+    return feats
 
 
 def ms_per_step(m, n=3):
@@ -60,14 +71,18 @@ def ms_per_step(m, n=3):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+import functools  # noqa: E402
 variants = [("bf16 (as timed)", (), False)] + [(p, (p,), False) for p in ("decoder", "branches", "fc", "aim", "refine")] + \
            [("backbone", (), True), ("decoder+branches+fc", ("decoder", "branches", "fc"), False), ("fc+aim+refine", ("fc", "aim", "refine"), False),
             ("branches+fc", ("branches", "fc"), False), ("all head parts", ("decoder", "branches", "fc", "aim", "refine"), False),
-            ("all head parts + backbone", ("decoder", "branches", "fc", "aim", "refine"), True)]
+            ("all head parts + backbone", ("decoder", "branches", "fc", "aim", "refine"), True)] + \
+           [("backbone fp32 through " + st, (), st) for st in ("stem", "res2", "res3", "res4")]
 table = {}
 for name, parts, bb in variants:
+    if args.only and args.only not in name and name != "bf16 (as timed)":
+        continue
     head.fp32_parts = frozenset(parts)
-    m16.backbone.forward = fp32_backbone if bb else orig_backbone_forward
+    m16.backbone.forward = (functools.partial(fp32_backbone, until=bb) if isinstance(bb, str) else fp32_backbone) if bb else orig_backbone_forward
     err = bench.bench_workload_pose_error(m16, m32, dev, B, K, nq, raw=raw, forced=forced)
     row = {k: {kk: err[k][kk] for kk in ("T_err_mean", "T_err_max", "R_err_deg_mean", "R_err_deg_max")} for k in ("camera_init", "camera_initRec", "camera")}
     row["ms_per_step_single_stream"] = round(ms_per_step(m16), 2)
