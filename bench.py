@@ -272,7 +272,9 @@ def main():
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight (HIP streams) per GPU")
     ap.add_argument("--no-autotune", dest="autotune", action="store_false", help="skip the load-time conv kernel autotuning")
-    ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward in a hipGraph and replay it")
+    ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward once and replay it through the launch tape "
+                    "(nopesac_amd/tape.py: the captured kernel nodes re-issued as plain launches by a C loop)")
+    ap.add_argument("--whole-graph", action="store_true", help="with --graph: hipGraphLaunch of the whole graph instead of the launch tape")
     ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
     ap.add_argument("--single-stream", action="store_true", help="ANALYSIS: pose net on the main stream (clean per-stage times)")
     ap.add_argument("--ablate", default="", choices=["", "backbone", "head", "nocam"],
@@ -390,10 +392,18 @@ def main():
     use_graph = False
     if args.graph:
         try:
+            from nopesac_amd.tape import LaunchTape, TapeUnsupported
             for slot in range(n_slots):
-                g = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph(keep_graph=not args.whole_graph)
                 with torch.no_grad(), torch.cuda.graph(g, stream=streams[slot]):
                     _, graph_rows[slot] = device_step(slot)
+                if not args.whole_graph:                       # replay = the graph's kernel nodes as plain launches on the slot's stream
+                    try:
+                        g = LaunchTape(g)
+                        last["tape_counts"] = dict(g.counts)
+                    except TapeUnsupported as e:
+                        print("launch tape unavailable (%s): whole-graph replay" % (e,), file=sys.stderr)
+                        g.instantiate()
                 graphs[slot] = g
             use_graph = True
             barrier()
@@ -549,7 +559,9 @@ def main():
                                   % (B, args.dtype, "bf16 operands with f32 accumulate / residual stream / LayerNorm / softmax" if args.dtype == "bfloat16"
                                      else "f32", K, m_mean, nq),
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
-                      "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph, "autotuned_shapes": tuned,
+                      "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph,
+                      "replay": None if not use_graph else ("whole hipGraph" if args.whole_graph or "tape_counts" not in last else "launch tape"),
+                      "tape_nodes": last.get("tape_counts"), "autotuned_shapes": tuned,
                       "routing_file": os.path.relpath(args.routing, ROOT) if args.routing else None, "routing_entries_loaded": routing_loaded,
                       "routing_entries_measured_now": routing_new, "host_launch_ms_per_step": round(host_launch_ms, 2),
                       "gflop_per_pair_algorithmic": GFLOP_PER_PAIR.get(K), "nonfinite_outputs": nonfinite},

@@ -365,6 +365,19 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
                                 const int32_t* n1, const int32_t* n2, const float* rot, const float* trans,
                                 int B, int nq, float* assignment_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch tape (csrc/tape.hip): the host-side executor of a captured forward.  The reference submits its ~1700 kernels per pair from
+ * the Python interpreter (inference_on_dataset, test_NopeSAC.py:157-179: one model(inputs) call per pair); here a static-shape
+ * forward is captured once into a hipGraph, `nopesac_tape_create` reads the graph's nodes back (kernel function / grid / block /
+ * dynamic LDS / argument block, memset and memcpy parameters) into a flat list in a dependency-respecting order, and
+ * `nopesac_tape_replay` issues them as plain launches on `stream` - what the eager path enqueues, without Python (4-5 ms -> ~1 ms
+ * per 32-pair forward) and without the whole-graph launch that serialises batches in flight.  `hip_graph` is a hipGraph_t that must
+ * outlive the tape (its nodes own the argument blocks).  counts4 (optional) receives {kernels, memsets, memcpys, dropped ordering
+ * nodes}.  Unsupported node kinds (host callbacks, child graphs, memory nodes, module launches with packed arguments) -> NPS_E_ARG. */
+int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* counts4);
+int nopesac_tape_replay(void* tape, void* stream);
+int nopesac_tape_destroy(void* tape);
+
 /* BENCHMARK-ONLY K control (not part of the reference: it has no such knob - the reference benchmark would need
  * trained weights to keep K planes per view).  Per pair b: the K highest-scoring queries of view 1 (score = logits[b,q,0] -
  * logits[b,q,1], logits f32 [>=B, nq, n_cls]) in ascending query order become rows 0..K-1 of feats[b] (query_feat f32 [>=B,nq,D]);

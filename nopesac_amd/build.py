@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnopesac_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv_p8.hip", "stem.hip", "conv3x3_c64.hip", "conv3x3_halo.hip", "pwchain.hip", "gnn_layer.hip", "enc_tail.hip", "mask_head.hip", "resize.hip", "rle.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
-           "ransac.hip", "mlp_chain.hip"]
+           "ransac.hip", "mlp_chain.hip", "tape.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 

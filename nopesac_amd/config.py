@@ -265,7 +265,11 @@ def add_amd_defaults(cfg) -> CfgNode:
         COMPUTE_DTYPE="float32",      # "float32" (parity path) or "bfloat16" (dense convs on bf16 MFMA)
         OUTPUT_MASKS=True,            # decode pred_plane_masks [n,H,W] from the winner map for every image
         OUTPUT_RLE=True,              # COCO RLE "segmentation" + "bbox" in every `instances` entry (siamese_planeTR.py:703-720)
-        USE_HIP_GRAPH=False,          # capture the static-shape forward in a hipGraph
+        USE_HIP_GRAPH=False,          # capture the static-shape forward of a batch once and replay it (no Python per launch)
+        GRAPH_REPLAY="launches",      # how a captured forward is replayed: "launches" = the launch tape (csrc/tape.hip: the graph's
+                                      # kernel nodes re-issued as plain launches on the caller's stream - batches in flight overlap
+                                      # like eager ones); "graph" = hipGraphLaunch of the whole graph.  "launches" falls back to
+                                      # "graph" (with a warning) if the runtime cannot read the captured graph back
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
         CHECK_FINITE=True,            # count Inf / NaN in the returned poses / plane parameters on the device; `model(...)` raises
                                       # FloatingPointError when the results are fetched (the reference drops into pdb instead)

@@ -1,0 +1,183 @@
+// Launch tape: the kernel launches of one captured forward, replayed as PLAIN launches on a caller-chosen stream.
+//
+// Why: one 32-pair forward is ~270 launches; issued from Python (wrapper + ctypes + torch allocations) they cost 4-5 ms of host
+// time per step - more than half of the 9 ms the GPU needs, and the reason the drop-in boundary (H2D + forward + package() on one
+// Python thread) ran host-bound.  A hipGraph of the forward (MODEL.AMD.USE_HIP_GRAPH, round 2) cuts the submit time to < 1 ms but
+// measured SLOWER end to end with several batches in flight (2199 vs 2790 pairs/s): whole-graph launches of different slots
+// overlap less than eagerly launched streams.  The tape keeps both properties: the forward is captured ONCE into a hipGraph (which
+// also gives every intermediate tensor a fixed address in the capture's private memory pool), the graph's nodes are read back with
+// the graph-introspection API (kernel function, grid, block, dynamic LDS, argument block; memset / memcpy parameters), and a replay
+// is a C loop of hipLaunchKernel calls on the slot's own stream - exactly what the eager path enqueues, minus Python.
+//
+// Order: nodes are replayed in a topological order of the captured graph that prefers the capture's creation order; on ONE stream
+// that order satisfies every dependency edge (the capture's side-stream fork / join edges included), so event-record / event-wait /
+// empty nodes are dropped.  The argument blocks stay owned by the graph nodes: the graph must outlive the tape (the Python side
+// keeps the torch.cuda.CUDAGraph object - created with keep_graph=True - next to the tape).
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+
+namespace nps {
+
+enum { TAPE_KERNEL = 0, TAPE_MEMSET = 1, TAPE_MEMCPY = 2 };
+
+struct TapeOp {
+    int kind;
+    hipKernelNodeParams k;
+    hipMemsetParams ms;
+    hipMemcpy3DParms cp;
+};
+
+struct Tape {
+    std::vector<TapeOp> ops;
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_dropped = 0;
+};
+
+}  // namespace nps
+
+#define TAPE_HIP(call, what)                                                                          \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            nps::set_error("launch tape: %s failed: %s", what, hipGetErrorString(e__));               \
+            return (int)e__;                                                                          \
+        }                                                                                             \
+    } while (0)
+
+extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* counts4) {
+    using namespace nps;
+    NPS_CHECK_ARG(hip_graph && tape_out, "tape_create: null pointer");
+    hipGraph_t graph = (hipGraph_t)hip_graph;
+    size_t n = 0;
+    TAPE_HIP(hipGraphGetNodes(graph, nullptr, &n), "hipGraphGetNodes(count)");
+    NPS_CHECK_ARG(n > 0, "tape_create: the graph has no nodes");
+    std::vector<hipGraphNode_t> nodes(n);
+    TAPE_HIP(hipGraphGetNodes(graph, nodes.data(), &n), "hipGraphGetNodes");
+    size_t ne = 0;
+    TAPE_HIP(hipGraphGetEdges(graph, nullptr, nullptr, &ne), "hipGraphGetEdges(count)");
+    std::vector<hipGraphNode_t> from(ne ? ne : 1), to(ne ? ne : 1);
+    if (ne) TAPE_HIP(hipGraphGetEdges(graph, from.data(), to.data(), &ne), "hipGraphGetEdges");
+    // node handle -> index (sorted lookup table)
+    std::vector<std::pair<hipGraphNode_t, int>> idx(n);
+    for (size_t i = 0; i < n; ++i) idx[i] = {nodes[i], (int)i};
+    std::sort(idx.begin(), idx.end());
+    auto find = [&](hipGraphNode_t h) -> int {
+        auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(h, -1));
+        return (it != idx.end() && it->first == h) ? it->second : -1;
+    };
+    std::vector<std::vector<int>> succ(n);
+    std::vector<int> indeg(n, 0);
+    for (size_t e = 0; e < ne; ++e) {
+        const int a = find(from[e]), b = find(to[e]);
+        NPS_CHECK_ARG(a >= 0 && b >= 0, "tape_create: an edge names a node the graph does not list");
+        succ[a].push_back(b);
+        ++indeg[b];
+    }
+    // Kahn's algorithm with a min-heap on the creation index: the capture's own order whenever it is a valid one
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (size_t i = 0; i < n; ++i)
+        if (indeg[i] == 0) ready.push((int)i);
+    std::vector<int> order;
+    order.reserve(n);
+    while (!ready.empty()) {
+        const int u = ready.top();
+        ready.pop();
+        order.push_back(u);
+        for (int v : succ[u])
+            if (--indeg[v] == 0) ready.push(v);
+    }
+    NPS_CHECK_ARG(order.size() == n, "tape_create: the captured graph has a cycle (%zu of %zu nodes ordered)", order.size(), n);
+
+    Tape* t = new Tape();
+    for (int u : order) {
+        hipGraphNodeType ty;
+        hipError_t e = hipGraphNodeGetType(nodes[u], &ty);
+        if (e != hipSuccess) {
+            delete t;
+            set_error("launch tape: hipGraphNodeGetType failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        TapeOp op;
+        memset(&op, 0, sizeof(op));
+        if (ty == hipGraphNodeTypeKernel) {
+            e = hipGraphKernelNodeGetParams(nodes[u], &op.k);
+            if (e != hipSuccess || !op.k.func || (!op.k.kernelParams && !op.k.extra)) {
+                delete t;
+                set_error("launch tape: kernel node %d: parameters not readable (%s)", u, hipGetErrorString(e));
+                return e != hipSuccess ? (int)e : NPS_E_ARG;
+            }
+            if (!op.k.kernelParams) {          // launched with a packed HIP_LAUNCH_PARAM_BUFFER: hipLaunchKernel cannot replay it
+                delete t;
+                set_error("launch tape: kernel node %d was launched with `extra` arguments (module launch): unsupported", u);
+                return NPS_E_ARG;
+            }
+            op.kind = TAPE_KERNEL;
+            ++t->n_kernel;
+        } else if (ty == hipGraphNodeTypeMemset) {
+            e = hipGraphMemsetNodeGetParams(nodes[u], &op.ms);
+            if (e != hipSuccess || !op.ms.dst || op.ms.width == 0 || (op.ms.elementSize != 1 && op.ms.elementSize != 2 && op.ms.elementSize != 4)) {
+                delete t;
+                set_error("launch tape: memset node %d: parameters not readable / unsupported (%s)", u, hipGetErrorString(e));
+                return e != hipSuccess ? (int)e : NPS_E_ARG;
+            }
+            op.kind = TAPE_MEMSET;
+            ++t->n_memset;
+        } else if (ty == hipGraphNodeTypeMemcpy) {
+            e = hipGraphMemcpyNodeGetParams(nodes[u], &op.cp);
+            const bool ok = e == hipSuccess && op.cp.extent.width > 0 && op.cp.extent.height > 0 && op.cp.extent.depth > 0 &&
+                            op.cp.srcPtr.ptr && op.cp.dstPtr.ptr && !op.cp.srcArray && !op.cp.dstArray;
+            if (!ok) {                          // (1-D copy nodes do not expose 3-D parameters on every runtime)
+                delete t;
+                set_error("launch tape: memcpy node %d: parameters not readable as a 3-D copy (%s; extent %zu x %zu x %zu)", u,
+                          hipGetErrorString(e), op.cp.extent.width, op.cp.extent.height, op.cp.extent.depth);
+                return e != hipSuccess ? (int)e : NPS_E_ARG;
+            }
+            op.kind = TAPE_MEMCPY;
+            ++t->n_memcpy;
+        } else if (ty == hipGraphNodeTypeEmpty || ty == hipGraphNodeTypeEventRecord || ty == hipGraphNodeTypeWaitEvent) {
+            ++t->n_dropped;                     // ordering-only nodes: one stream already serialises the tape
+            continue;
+        } else {
+            delete t;
+            set_error("launch tape: node %d has type %d (host / child graph / memory node): unsupported", u, (int)ty);
+            return NPS_E_ARG;
+        }
+        t->ops.push_back(op);
+    }
+    if (counts4) { counts4[0] = t->n_kernel; counts4[1] = t->n_memset; counts4[2] = t->n_memcpy; counts4[3] = t->n_dropped; }
+    *tape_out = t;
+    return 0;
+}
+
+extern "C" int nopesac_tape_replay(void* tape, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(tape, "tape_replay: null tape");
+    const Tape* t = (const Tape*)tape;
+    hipStream_t st = (hipStream_t)stream;
+    for (const TapeOp& op : t->ops) {
+        hipError_t e;
+        if (op.kind == TAPE_KERNEL) {
+            e = hipLaunchKernel(op.k.func, op.k.gridDim, op.k.blockDim, op.k.kernelParams, op.k.sharedMemBytes, st);
+        } else if (op.kind == TAPE_MEMSET) {
+            if (op.ms.height > 1) e = hipMemset2DAsync(op.ms.dst, op.ms.pitch, (int)op.ms.value, op.ms.width * op.ms.elementSize, op.ms.height, st);
+            else if (op.ms.elementSize == 4) e = hipMemsetD32Async((hipDeviceptr_t)op.ms.dst, (int)op.ms.value, op.ms.width, st);
+            else if (op.ms.elementSize == 2) e = hipMemsetD16Async((hipDeviceptr_t)op.ms.dst, (unsigned short)op.ms.value, op.ms.width, st);
+            else e = hipMemsetAsync(op.ms.dst, (int)op.ms.value, op.ms.width, st);
+        } else {
+            e = hipMemcpy3DAsync(&op.cp, st);
+        }
+        if (e != hipSuccess) {
+            set_error("launch tape: replay of a %s failed: %s", op.kind == TAPE_KERNEL ? "kernel launch" : op.kind == TAPE_MEMSET ? "memset" : "memcpy",
+                      hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    return 0;
+}
+
+extern "C" int nopesac_tape_destroy(void* tape) {
+    delete (nps::Tape*)tape;
+    return 0;
+}

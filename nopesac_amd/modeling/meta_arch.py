@@ -58,6 +58,8 @@ class PlaneTR_NopeSAC(nn.Module):
         # ctypes launch time per 32-pair batch -> < 1 ms).  GRAPH_SLOTS independent captures (own input buffer, own outputs) are
         # used round-robin, so a caller may keep GRAPH_SLOTS - 1 earlier results un-packaged while it submits the next batch.
         self.use_hip_graph = bool(amd.USE_HIP_GRAPH)
+        self.graph_replay = str(amd.GRAPH_REPLAY)
+        assert self.graph_replay in ("launches", "graph"), self.graph_replay
         self.graph_slots = 2
         self._graphs = {}
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
@@ -212,12 +214,19 @@ class PlaneTR_NopeSAC(nn.Module):
         if st.get("clone_done") is not None:                   # the previous results of this slot are still being copied out
             torch.cuda.current_stream().wait_event(st.pop("clone_done"))
         if st["graph"] is not None:
-            st["graph"].replay()
+            if st.get("tape") is not None:
+                st["tape"].replay()                            # the recorded launches, on the caller's current stream
+            else:
+                st["graph"].replay()
             return st["out"]
         if st["calls"] == 1:                                   # warm-up pass, eager
             return self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
         cur = torch.cuda.current_stream()
-        g = torch.cuda.CUDAGraph()
+        want_tape = self.graph_replay == "launches"
+        try:
+            g = torch.cuda.CUDAGraph(keep_graph=True) if want_tape else torch.cuda.CUDAGraph()
+        except TypeError:                                      # a torch without keep_graph: whole-graph replay only
+            g, want_tape = torch.cuda.CUDAGraph(), False
         cap = torch.cuda.Stream(device=self.device)
         cap.wait_stream(cur)
         with torch.cuda.graph(g, stream=cap):
@@ -225,8 +234,22 @@ class PlaneTR_NopeSAC(nn.Module):
         cur.wait_stream(cap)
         out["static_outputs"] = True                           # package() must not hand out views of graph-owned memory
         out["_owner"] = st
-        st["graph"], st["out"] = g, out
-        g.replay()                                             # capture does not execute: run this batch
+        st["graph"], st["out"], st["tape"] = g, out, None
+        if want_tape:
+            from ..tape import LaunchTape, TapeUnsupported
+            try:
+                st["tape"] = LaunchTape(g)
+                self.__dict__["tape_counts"] = dict(st["tape"].counts)
+            except TapeUnsupported as e:
+                import warnings
+                warnings.warn("nopesac_amd: launch tape unavailable, replaying the whole hipGraph instead: %s" % (e,))
+                self.__dict__["tape_error"] = str(e)
+        if st["tape"] is not None:
+            st["tape"].replay()                                # capture does not execute: run this batch
+        else:
+            if hasattr(g, "instantiate") and want_tape:
+                g.instantiate()                                # (keep_graph=True defers the instantiation)
+            g.replay()
         return out
 
     def calibrate_fp8(self, batched_inputs: List[dict]) -> dict:

@@ -189,7 +189,8 @@ def test_bf16_backbone_pose_error(device):
         assert np.isfinite(y["camera"]["tran"]).all() and np.isfinite(y["camera"]["rot"]).all()
 
 
-def test_hip_graph_mode_reproduces_the_eager_results(device):
+@pytest.mark.parametrize("replay", ["launches", "graph"])
+def test_hip_graph_mode_reproduces_the_eager_results(device, replay):
     """MODEL.AMD.USE_HIP_GRAPH: the forward of a batch as one hipGraph replay (warm-up call eager, capture on a slot's second
     call, replays afterwards; two slots round-robin).  Every call must return exactly what the eager bf16 model returns for the
     same inputs (same kernels, same order), for changing inputs, and results handed out earlier must not change when the
@@ -197,8 +198,8 @@ def test_hip_graph_mode_reproduces_the_eager_results(device):
     import copy
     from nopesac_amd.synth import synth_pair
     eager = make_model(device, dtype="bfloat16")
-    graph = make_model(device, ["MODEL.AMD.USE_HIP_GRAPH", True], dtype="bfloat16")
-    assert graph.use_hip_graph and not eager.use_hip_graph
+    graph = make_model(device, ["MODEL.AMD.USE_HIP_GRAPH", True, "MODEL.AMD.GRAPH_REPLAY", replay], dtype="bfloat16")
+    assert graph.use_hip_graph and not eager.use_hip_graph and graph.graph_replay == replay
     kept = []
     for it in range(7):                                   # slots 1, 0, 1, 0, ...: eager, eager, capture, capture, replay x 3
         inp = [synth_pair(3 * it + i) for i in range(2)]
@@ -213,6 +214,13 @@ def test_hip_graph_mode_reproduces_the_eager_results(device):
                 assert [i["segmentation"] for i in x[v]["instances"]] == [i["segmentation"] for i in y[v]["instances"]]
         kept.append((b, [{v: (r[v]["pred_plane_feats"].clone(), r[v]["winner_map"].clone()) for v in "01"} for r in b]))
     assert len(graph._graphs) == 2 and all(st["graph"] is not None for st in graph._graphs.values())
+    if replay == "launches":
+        # the launch tape must be what replayed (csrc/tape.hip): every slot has one, it holds the forward's ~270 kernel launches
+        assert getattr(graph, "tape_error", None) is None, graph.tape_error
+        assert all(st["tape"] is not None for st in graph._graphs.values())
+        assert graph.tape_counts["kernels"] > 150, graph.tape_counts
+    else:
+        assert all(st["tape"] is None for st in graph._graphs.values())
     for b, snap in kept:                                  # earlier results are untouched by the later replays
         for r, s0 in zip(b, snap):
             for v in "01":

@@ -590,12 +590,14 @@ def test_conv2d_generic_and_tail_fp8_outputs(device):
     assert torch.equal(ob.float(), _q8(oa).float().to(device))         # converted from the same bf16 staging values: bit-identical
 
 
-def test_stem_fused_raw_equals_preprocess_plus_stem(device):
+@pytest.mark.parametrize("H,W", [(100, 172), (100, 170), (480, 640)])
+def test_stem_fused_raw_equals_preprocess_plus_stem(device, H, W):
     """The raw-input stem (f32 NCHW images, normalisation while staging) is bit-identical to preprocess + fused stem, including
-    image borders and a height / width that are not multiples of the tile."""
+    image borders and a height / width that are not multiples of the tile; W % 4 == 0 takes the 16-byte-load staging path (whole
+    float4 groups inside / outside the image), W = 170 the scalar one."""
     from nopesac_amd import ops
     g = torch.Generator().manual_seed(21)
-    img = torch.randint(0, 256, (3, 3, 100, 172), generator=g).float().to(device)
+    img = torch.randint(0, 256, (3, 3, H, W), generator=g).float().to(device)
     mean = torch.tensor([123.675, 116.28, 103.53], device=device)
     std = torch.tensor([58.395, 57.12, 57.375], device=device)
     w = (torch.randn(64, 224, generator=g) / 12).to(device, torch.bfloat16)
