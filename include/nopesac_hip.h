@@ -372,9 +372,11 @@ int nopesac_refilter_assignment(const float* assignment_in, const float* planes1
  * dynamic LDS / argument block, memset and memcpy parameters) into a flat list in a dependency-respecting order, and
  * `nopesac_tape_replay` issues them as plain launches on `stream` - what the eager path enqueues, without Python (4-5 ms -> ~1 ms
  * per 32-pair forward) and without the whole-graph launch that serialises batches in flight.  `hip_graph` is a hipGraph_t that must
- * outlive the tape (its nodes own the argument blocks).  counts4 (optional) receives {kernels, memsets, memcpys, dropped ordering
- * nodes}.  Unsupported node kinds (host callbacks, child graphs, memory nodes, module launches with packed arguments) -> NPS_E_ARG. */
+ * outlive the tape (its nodes own the argument blocks).  counts4 (optional) receives {kernels, memsets, memcpys, streams used}.  Unsupported node kinds (host callbacks, child graphs, memory nodes, module launches with packed arguments) -> NPS_E_ARG. */
 int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* counts4);
+/* the same with a cap on the number of streams the tape may use (1 = everything on the caller's stream; default 4): parallel branches
+ * of the captured graph (the capture's side streams) are issued on the tape's own side streams, joined by events. */
+int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** tape_out, int32_t* counts4);
 int nopesac_tape_replay(void* tape, void* stream);
 int nopesac_tape_destroy(void* tape);
 

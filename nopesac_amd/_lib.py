@@ -63,6 +63,7 @@ SIGNATURES = {
     "nopesac_ransac_soft_vote": [P] * 21 + [I, I, I] + [P] * 6 + [P],
     "nopesac_refilter_assignment": [P, P, P, P, P, P, P, I, I, P, P],
     "nopesac_tape_create": [P, ctypes.POINTER(c_void_p), P],
+    "nopesac_tape_create_ex": [P, I, ctypes.POINTER(c_void_p), P],
     "nopesac_tape_replay": [P, P],
     "nopesac_tape_destroy": [P],
     "nopesac_force_k_select": [P, I, P, P, P, I, I, I, I, P, P, P],

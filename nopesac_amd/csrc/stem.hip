@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
                                                          const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
-                                                         bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW, int vec4) {
+                                                         bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
     unsigned char* patch = lds;
     bf16_t* wl = reinterpret_cast<bf16_t*>(lds + ST_PATCH_BYTES);
@@ -55,51 +55,10 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     if constexpr (RAW) {
         const float* xr = xraw + (long long)b * 3 * H * W;
         const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
-      if (vec4) {
-        // 16-byte loads (round 3): the patch starts at column ix0 = 80 bx - 5, so the aligned window [ix0 - 3, ix0 + 89) is 23 float4
-        // groups per row and channel; a group lies completely inside or outside the image (W % 4 == 0).  529 items of 3 float4 per
-        // workgroup instead of 2024 items of 3 scalar loads: a third of the load instructions, 4x the bytes each.
-        constexpr int GPR = (ST_IW + 3 + 3) / 4, NV = ST_IH * GPR, NITV = (NV + 255) / 256;      // 23 groups, 529 items, 3 per thread
-        static_assert(4 * GPR - 3 >= ST_IW, "the aligned window covers the patch row");
-        const int ax0 = ix0 - 3;
-        const long long hw = (long long)H * W;
-        float4 v0[NITV], v1[NITV], v2[NITV];
-#pragma unroll
-        for (int it = 0; it < NITV; ++it) {
-            const int i = tid + it * 256;
-            const int r = i / GPR, g = i % GPR;
-            const int iy = iy0 + r, gx = ax0 + 4 * g;
-            v0[it] = v1[it] = v2[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < NV && (unsigned)iy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                const float* q = xr + (long long)iy * W + gx;
-                v0[it] = *reinterpret_cast<const float4*>(q);
-                v1[it] = *reinterpret_cast<const float4*>(q + hw);
-                v2[it] = *reinterpret_cast<const float4*>(q + 2 * hw);
-            }
-        }
-        if (tid < 8) *reinterpret_cast<uint2*>(patch + (size_t)(ST_IH * ST_IW + tid) * 8) = make_uint2(0u, 0u);   // slack of the padded tap
-#pragma unroll
-        for (int it = 0; it < NITV; ++it) {
-            const int i = tid + it * 256;
-            const int r = i / GPR, g = i % GPR;
-            const int iy = iy0 + r, gx = ax0 + 4 * g;
-            const bool in = (unsigned)iy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const float a0[4] = {v0[it].x, v0[it].y, v0[it].z, v0[it].w}, a1[4] = {v1[it].x, v1[it].y, v1[it].z, v1[it].w},
-                        a2[4] = {v2[it].x, v2[it].y, v2[it].z, v2[it].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 4 * g + e - 3;
-                uint2 v = make_uint2(0u, 0u);
-                if (in) {
-                    v.x = f32x2_to_bf16x2((a0[e] - m0) / s0, (a1[e] - m1) / s1);
-                    v.y = f32x2_to_bf16x2((a2[e] - m2) / s2, 0.f);
-                }
-                if (i < NV && c >= 0 && c < ST_IW) *reinterpret_cast<uint2*>(patch + (size_t)(r * ST_IW + c) * 8) = v;
-            }
-        }
-      } else {
         // every load of the patch goes out BEFORE the first one is consumed: the rolled loop (load, divide, ds_write, next) exposed
-        // one HBM round trip per iteration - 8 in a row per workgroup; the stem ran at 1.1 TB/s (0.33 ms for 393 MB)
+        // one HBM round trip per iteration - 8 in a row per workgroup; the stem ran at 1.1 TB/s (0.33 ms for 393 MB).
+        // (Round 3: 16-byte loads of the image rows - 529 float4 groups per channel instead of 2024 scalar loads - were built and
+        //  measured: 322 vs 315 us, no gain; the staging is not bound by the number of load instructions.  Reverted.)
         constexpr int NIT = (ST_IH * ST_IW + 8 + 255) / 256;
         float r0[NIT], r1[NIT], r2[NIT];
         const long long hw = (long long)H * W;
@@ -126,7 +85,6 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             }
             if (i < ST_IH * ST_IW + 8) *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
         }
-      }
     } else {
         const bf16_t* xb = x + (long long)b * H * W * 4;
         for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
@@ -247,7 +205,7 @@ extern "C" int nopesac_stem_fused_bf16(const void* x, const void* w, const float
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
     hipLaunchKernelGGL(stem_fused_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW, 0);
+                       (const float*)nullptr, (const float*)nullptr, (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
     NPS_LAUNCH_RET();
 }
 
@@ -260,9 +218,7 @@ extern "C" int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mea
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    static const bool no_vec = getenv("NOPESAC_STEM_SCALAR_LOADS") != nullptr;          // A/B switch
-    const int vec4 = (!no_vec && W % 4 == 0 && ((uintptr_t)x_nchw % 16 == 0)) ? 1 : 0;   // 16-byte loads of the f32 image rows
     hipLaunchKernelGGL(stem_fused_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, mean, stdv,
-                       (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW, vec4);
+                       (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
     NPS_LAUNCH_RET();
 }

@@ -9,10 +9,15 @@
 // the graph-introspection API (kernel function, grid, block, dynamic LDS, argument block; memset / memcpy parameters), and a replay
 // is a C loop of hipLaunchKernel calls on the slot's own stream - exactly what the eager path enqueues, minus Python.
 //
-// Order: nodes are replayed in a topological order of the captured graph that prefers the capture's creation order; on ONE stream
-// that order satisfies every dependency edge (the capture's side-stream fork / join edges included), so event-record / event-wait /
-// empty nodes are dropped.  The argument blocks stay owned by the graph nodes: the graph must outlive the tape (the Python side
-// keeps the torch.cuda.CUDAGraph object - created with keep_graph=True - next to the tape).
+// Order and streams: nodes are issued in a topological order of the captured graph that prefers the capture's creation order.  The
+// capture's fork / join structure (the pixel pose net runs on a side stream next to the plane head: + 13 % throughput with four
+// batches in flight, - 1 ms of latency at one pair per call) is kept: the DAG is cut into CHAINS (a node continues the chain of a
+// predecessor that is still that chain's tail, otherwise it opens a new one); chain 0 is issued on the caller's stream, chain k > 0
+// on the tape's own k-th side stream, and every edge between chains becomes an event record behind the producer and a stream wait
+// in front of the consumer.  A replay starts by making the side streams wait for the caller's stream and ends by making the caller's
+// stream wait for every side chain, so to the caller a replay behaves like work enqueued on its stream.  The argument blocks stay
+// owned by the graph nodes: the graph must outlive the tape (the Python side keeps the torch.cuda.CUDAGraph object - created with
+// keep_graph=True - next to the tape).
 #include <algorithm>
 #include <queue>
 #include <vector>
@@ -21,18 +26,31 @@
 
 namespace nps {
 
-enum { TAPE_KERNEL = 0, TAPE_MEMSET = 1, TAPE_MEMCPY = 2 };
+enum { TAPE_KERNEL = 0, TAPE_MEMSET = 1, TAPE_MEMCPY = 2, TAPE_NOP = 3 };
 
 struct TapeOp {
     int kind;
     hipKernelNodeParams k;
     hipMemsetParams ms;
     hipMemcpy3DParms cp;
+    int chain = 0;                 // 0 = the caller's stream, k > 0 = side stream k - 1
+    int record = -1;               // event recorded behind this op (it has a successor on another chain)
+    std::vector<int> waits;        // events the op's stream waits for first (predecessors on other chains)
 };
 
 struct Tape {
     std::vector<TapeOp> ops;
-    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_dropped = 0;
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> events;
+    hipEvent_t start_ev = nullptr;
+    std::vector<hipEvent_t> end_ev;      // one per side chain
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_dropped = 0, n_chains = 1, max_chains = 1;
+    ~Tape() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : end_ev) (void)hipEventDestroy(e);
+        if (start_ev) (void)hipEventDestroy(start_ev);
+        for (hipStream_t q : side) (void)hipStreamDestroy(q);
+    }
 };
 
 }  // namespace nps
@@ -47,8 +65,12 @@ struct Tape {
     } while (0)
 
 extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* counts4) {
+    return nopesac_tape_create_ex(hip_graph, 4, tape_out, counts4);
+}
+
+extern "C" int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** tape_out, int32_t* counts4) {
     using namespace nps;
-    NPS_CHECK_ARG(hip_graph && tape_out, "tape_create: null pointer");
+    NPS_CHECK_ARG(hip_graph && tape_out && max_streams >= 1, "tape_create: bad arguments");
     hipGraph_t graph = (hipGraph_t)hip_graph;
     size_t n = 0;
     TAPE_HIP(hipGraphGetNodes(graph, nullptr, &n), "hipGraphGetNodes(count)");
@@ -67,12 +89,13 @@ extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* co
         auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(h, -1));
         return (it != idx.end() && it->first == h) ? it->second : -1;
     };
-    std::vector<std::vector<int>> succ(n);
+    std::vector<std::vector<int>> succ(n), pred(n);
     std::vector<int> indeg(n, 0);
     for (size_t e = 0; e < ne; ++e) {
         const int a = find(from[e]), b = find(to[e]);
         NPS_CHECK_ARG(a >= 0 && b >= 0, "tape_create: an edge names a node the graph does not list");
         succ[a].push_back(b);
+        pred[b].push_back(a);
         ++indeg[b];
     }
     // Kahn's algorithm with a min-heap on the creation index: the capture's own order whenever it is a valid one
@@ -90,7 +113,22 @@ extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* co
     }
     NPS_CHECK_ARG(order.size() == n, "tape_create: the captured graph has a cycle (%zu of %zu nodes ordered)", order.size(), n);
 
+    // ---- chains: a node continues the chain of a predecessor that is still the tail of its chain (lowest chain id first)
+    std::vector<int> chain(n, -1), tail;                    // tail[c] = last node of chain c so far
+    for (int u : order) {
+        int best = -1;
+        for (int q : pred[u])
+            if (tail[chain[q]] == q && (best < 0 || chain[q] < best)) best = chain[q];
+        if (best < 0) {
+            if ((int)tail.size() < max_streams) { best = (int)tail.size(); tail.push_back(u); }
+            else best = 0;                                   // out of streams: serialise onto the caller's stream (waits still apply)
+        }
+        chain[u] = best;
+        tail[best] = u;
+    }
     Tape* t = new Tape();
+    t->n_chains = (int)tail.size();
+    std::vector<int> op_of(n, -1);                           // node index -> position in t->ops
     for (int u : order) {
         hipGraphNodeType ty;
         hipError_t e = hipGraphNodeGetType(nodes[u], &ty);
@@ -99,8 +137,11 @@ extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* co
             set_error("launch tape: hipGraphNodeGetType failed: %s", hipGetErrorString(e));
             return (int)e;
         }
-        TapeOp op;
-        memset(&op, 0, sizeof(op));
+        TapeOp op;                                           // (record = -1, no waits)
+        op.kind = TAPE_NOP;
+        memset(&op.k, 0, sizeof(op.k));
+        memset(&op.ms, 0, sizeof(op.ms));
+        memset(&op.cp, 0, sizeof(op.cp));
         if (ty == hipGraphNodeTypeKernel) {
             e = hipGraphKernelNodeGetParams(nodes[u], &op.k);
             if (e != hipSuccess || !op.k.func || (!op.k.kernelParams && !op.k.extra)) {
@@ -137,16 +178,51 @@ extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* co
             op.kind = TAPE_MEMCPY;
             ++t->n_memcpy;
         } else if (ty == hipGraphNodeTypeEmpty || ty == hipGraphNodeTypeEventRecord || ty == hipGraphNodeTypeWaitEvent) {
-            ++t->n_dropped;                     // ordering-only nodes: one stream already serialises the tape
-            continue;
+            op.kind = TAPE_NOP;                 // ordering-only node: nothing is launched, its edges still order its neighbours
+            ++t->n_dropped;
         } else {
             delete t;
             set_error("launch tape: node %d has type %d (host / child graph / memory node): unsupported", u, (int)ty);
             return NPS_E_ARG;
         }
+        op.chain = chain[u];
+        op_of[u] = (int)t->ops.size();
         t->ops.push_back(op);
     }
-    if (counts4) { counts4[0] = t->n_kernel; counts4[1] = t->n_memset; counts4[2] = t->n_memcpy; counts4[3] = t->n_dropped; }
+    // ---- edges between chains -> events (one per producer), created now, re-recorded by every replay
+    auto fail = [&](hipError_t e, const char* what) {
+        set_error("launch tape: %s failed: %s", what, hipGetErrorString(e));
+        delete t;
+        return (int)e;
+    };
+    for (int u : order)
+        for (int v : succ[u])
+            if (chain[u] != chain[v]) {
+                TapeOp& a = t->ops[op_of[u]];
+                if (a.record < 0) {
+                    hipEvent_t ev;
+                    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                    if (e != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+                    a.record = (int)t->events.size();
+                    t->events.push_back(ev);
+                }
+                t->ops[op_of[v]].waits.push_back(a.record);
+            }
+    if (t->n_chains > 1) {
+        hipError_t e = hipEventCreateWithFlags(&t->start_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+        for (int c = 1; c < t->n_chains; ++c) {
+            hipStream_t q;
+            e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+            if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags");
+            t->side.push_back(q);
+            hipEvent_t ev;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return fail(e, "hipEventCreateWithFlags");
+            t->end_ev.push_back(ev);
+        }
+    }
+    if (counts4) { counts4[0] = t->n_kernel; counts4[1] = t->n_memset; counts4[2] = t->n_memcpy; counts4[3] = t->n_chains; }
     *tape_out = t;
     return 0;
 }
@@ -155,10 +231,17 @@ extern "C" int nopesac_tape_replay(void* tape, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(tape, "tape_replay: null tape");
     const Tape* t = (const Tape*)tape;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
+    if (t->n_chains > 1) {                                   // the side streams start behind everything the caller has enqueued
+        TAPE_HIP(hipEventRecord(t->start_ev, caller), "hipEventRecord(start)");
+        for (hipStream_t q : t->side) TAPE_HIP(hipStreamWaitEvent(q, t->start_ev, 0), "hipStreamWaitEvent(start)");
+    }
     for (const TapeOp& op : t->ops) {
-        hipError_t e;
-        if (op.kind == TAPE_KERNEL) {
+        hipStream_t st = op.chain == 0 ? caller : t->side[op.chain - 1];
+        for (int w : op.waits) TAPE_HIP(hipStreamWaitEvent(st, t->events[w], 0), "hipStreamWaitEvent");
+        hipError_t e = hipSuccess;
+        if (op.kind == TAPE_NOP) {
+        } else if (op.kind == TAPE_KERNEL) {
             e = hipLaunchKernel(op.k.func, op.k.gridDim, op.k.blockDim, op.k.kernelParams, op.k.sharedMemBytes, st);
         } else if (op.kind == TAPE_MEMSET) {
             if (op.ms.height > 1) e = hipMemset2DAsync(op.ms.dst, op.ms.pitch, (int)op.ms.value, op.ms.width * op.ms.elementSize, op.ms.height, st);
@@ -173,6 +256,11 @@ extern "C" int nopesac_tape_replay(void* tape, void* stream) {
                       hipGetErrorString(e));
             return (int)e;
         }
+        if (op.record >= 0) TAPE_HIP(hipEventRecord(t->events[op.record], st), "hipEventRecord");
+    }
+    for (size_t c = 0; c < t->side.size(); ++c) {            // the caller's stream continues behind every side chain
+        TAPE_HIP(hipEventRecord(t->end_ev[c], t->side[c]), "hipEventRecord(end)");
+        TAPE_HIP(hipStreamWaitEvent(caller, t->end_ev[c], 0), "hipStreamWaitEvent(end)");
     }
     return 0;
 }

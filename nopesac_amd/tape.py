@@ -21,7 +21,7 @@ class TapeUnsupported(RuntimeError):
 
 
 class LaunchTape:
-    def __init__(self, graph: "torch.cuda.CUDAGraph"):
+    def __init__(self, graph: "torch.cuda.CUDAGraph", max_streams: int = 4):
         if not hasattr(graph, "raw_cuda_graph"):
             raise TapeUnsupported("this torch build does not expose CUDAGraph.raw_cuda_graph()")
         try:
@@ -31,12 +31,12 @@ class LaunchTape:
         lib = _lib.load()
         handle = ctypes.c_void_p()
         counts = (ctypes.c_int32 * 4)()
-        rc = lib.nopesac_tape_create(ctypes.c_void_p(int(raw)), ctypes.byref(handle), counts)
+        rc = lib.nopesac_tape_create_ex(ctypes.c_void_p(int(raw)), int(max_streams), ctypes.byref(handle), counts)
         if rc != 0:
             msg = lib.nopesac_last_error()
             raise TapeUnsupported("nopesac_tape_create failed (rc=%d): %s" % (rc, msg.decode() if msg else ""))
         self._lib, self._h, self._graph = lib, handle, graph     # the graph's nodes own the argument blocks the tape points at
-        self.counts = {"kernels": counts[0], "memsets": counts[1], "memcpys": counts[2], "dropped_ordering_nodes": counts[3]}
+        self.counts = {"kernels": counts[0], "memsets": counts[1], "memcpys": counts[2], "streams": counts[3]}
         self._get_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     def replay(self, stream: int = None):

@@ -218,7 +218,7 @@ def test_hip_graph_mode_reproduces_the_eager_results(device, replay):
         # the launch tape must be what replayed (csrc/tape.hip): every slot has one, it holds the forward's ~270 kernel launches
         assert getattr(graph, "tape_error", None) is None, graph.tape_error
         assert all(st["tape"] is not None for st in graph._graphs.values())
-        assert graph.tape_counts["kernels"] > 150, graph.tape_counts
+        assert graph.tape_counts["kernels"] > 150 and graph.tape_counts["streams"] >= 2, graph.tape_counts   # (the pose net's side stream is kept)
     else:
         assert all(st["tape"] is None for st in graph._graphs.values())
     for b, snap in kept:                                  # earlier results are untouched by the later replays

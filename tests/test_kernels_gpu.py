@@ -593,8 +593,7 @@ def test_conv2d_generic_and_tail_fp8_outputs(device):
 @pytest.mark.parametrize("H,W", [(100, 172), (100, 170), (480, 640)])
 def test_stem_fused_raw_equals_preprocess_plus_stem(device, H, W):
     """The raw-input stem (f32 NCHW images, normalisation while staging) is bit-identical to preprocess + fused stem, including
-    image borders and a height / width that are not multiples of the tile; W % 4 == 0 takes the 16-byte-load staging path (whole
-    float4 groups inside / outside the image), W = 170 the scalar one."""
+    image borders, heights / widths that are not multiples of the tile, and the real 480 x 640 size."""
     from nopesac_amd import ops
     g = torch.Generator().manual_seed(21)
     img = torch.randint(0, 256, (3, 3, H, W), generator=g).float().to(device)
