@@ -417,7 +417,12 @@ def main():
                 step(i)
             barrier()
             if not all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(eager_rows, host_bufs)):
-                raise RuntimeError("graph replay does not reproduce the eager results")
+                diff = [[round(float(x), 6) for x in (a - b).abs().amax(dim=0)[:7]] for a, b in zip(eager_rows, host_bufs)]
+                # (every slot holds the same images: which side is the odd one out?)
+                e_vs_e0 = [round(float((a - eager_rows[-1]).abs().max()), 6) for a in eager_rows]
+                r_vs_r0 = [round(float((b - host_bufs[-1]).abs().max()), 6) for b in host_bufs]
+                raise RuntimeError("graph replay does not reproduce the eager results; max |diff| per slot, columns t, q: %r; eager slots vs the "
+                                   "last eager slot: %r; replayed slots vs the last replayed slot: %r" % (diff, e_vs_e0, r_vs_r0))
             return True
         except Exception as e:                                 # keep the eager path if capture is not possible
             print("hipGraph capture failed, staying eager: %r" % (e,), file=sys.stderr)

@@ -963,6 +963,259 @@ static int pw_launch_rt4(const PwArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Eight-wave form of the 128-pixel chunked tail for the EDGE blocks of res3, which the four-wave kernel cannot hold:
+//   * res3.3 -> res4.0 (CN = 256): the next conv1 has eight 32-channel column tiles - with four waves that is 2 x 4 accumulators of
+//     16 registers per wave next to everything else;
+//   * res3.0 (projection shortcut, K = C2 = 256, from the stride-2 sampled res2 output): a second operand tile of 68 KB and sixteen
+//     more weight fragments per column tile.
+// One 512-thread workgroup per CU (137 KB of LDS in the projection form), two waves per SIMD.  GEMM 1 of a chunk: wave w owns column
+// tile w & 3 and the 64-pixel half w >> 2, one 32-pixel row tile at a time (the weight fragments stay in registers for both; the two
+// waves that share a column tile read the same fragments: L1 hits).  GEMM 2: CN = 256: column tile w, all four row tiles; CN = 128:
+// column tile w & 3, pixel half w >> 2.  Otherwise pw_chain_rt4_kernel's scheme: y chunk in place over its residual (identity form),
+// bn scale / shift in LDS, full tiles only, fully unrolled chunk loop, same arithmetic and rounding points as pw_chain_kernel.
+template <int C, int C4, int CN, int C2>
+struct PwRt8 {
+    static constexpr int BM = 128, CH = 128, NCH = C4 / CH;
+    static constexpr int A_LD = C + 8, A2_LD = C2 + 8, Y_LD = CH + 8, O_LD = CN + 8;
+    static constexpr int KF1 = C / 16, KF1S = C2 / 16, KF2 = CH / 16;
+    static constexpr int NR2 = CN >= 256 ? 4 : 2;
+    static constexpr int OPER = BM * A_LD + (C2 ? BM * A2_LD : 0) + BM * Y_LD;      // bf16 elements of the operand tiles
+    static constexpr size_t BYTES = 2 * (size_t)OPER + (C2 ? 4 : 2) * C4 * sizeof(float);
+    static_assert(C % 16 == 0 && C4 % CH == 0 && (CN == 128 || CN == 256) && C2 % 16 == 0, "rt8 tail: shapes");
+    static_assert(BM * O_LD <= (C2 ? BM * Y_LD : BM * A_LD + BM * Y_LD), "the a' staging tile aliases dead operand tiles");
+    static_assert(BYTES <= 160 * 1024, "LDS");
+};
+
+template <int C, int C4, int CN, int C2>
+__global__ __launch_bounds__(512, 2) void pw_chain_rt8_kernel(const PwArgs p) {
+    typedef PwRt8<C, C4, CN, C2> S;
+    constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, A_LD = S::A_LD, A2_LD = S::A2_LD, Y_LD = S::Y_LD, O_LD = S::O_LD;
+    constexpr int KF1 = S::KF1, KF1S = S::KF1S, KF2 = S::KF2, NR2 = S::NR2;
+    constexpr int RCH = BM * (CH / 8) / 512;                 // 16-byte chunks per thread of one [BM][CH] tile (4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* A2 = A1 + BM * A_LD;
+    bf16_t* Y = A2 + (C2 ? BM * A2_LD : 0);
+    bf16_t* O = C2 ? Y : A1;                                 // a' staging: over the y chunk (CN = 128) or over b tile + y chunk (CN = 256)
+    float* S3 = reinterpret_cast<float*>(A1 + S::OPER);
+    float* B3 = S3 + C4;
+    float* SSC = B3 + C4;
+    float* BSC = SSC + C4;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int ct = wave & 3, rh = wave >> 2;                 // GEMM 1: column tile of the chunk, 64-pixel half
+    const int nt2 = CN >= 256 ? wave : (wave & 3);           // GEMM 2: column tile of a'
+    const int r2 = CN >= 256 ? 0 : 2 * (wave >> 2);          //         first row tile
+
+    bf16x8 wa[KF1], wb[KF2], ws[C2 ? KF1S : 1];
+    auto load_wa = [&](int c) {
+        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + ct) * KF1) * 64 + lane) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+        if constexpr (C2 > 0) {
+            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + ct) * KF1S) * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KF1S; ++kk) ws[kk] = *reinterpret_cast<const bf16x8*>(v + kk * 512);
+        }
+    };
+    auto load_wb = [&](int c) {
+        const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + lane) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KF2; ++kk) wb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+    };
+    const int trow = tid >> 4;                               // 32 rows per pass of the 512 threads, 16-byte column tid & 15
+    const unsigned toff = (unsigned)(trow * C4 + (tid & 15) * 8) * 2u;
+    const char* res_b = reinterpret_cast<const char*>(C2 ? p.y : p.res) + m0 * C4 * 2;       // (never read in the projection form)
+    char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
+    us8 rres[RCH];
+    auto fetch_res = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) rres[i] = *reinterpret_cast<const us8*>(res_b + c * (CH * 2) + (toff + (unsigned)(i * 32 * C4 * 2)));
+    };
+    auto park_res = [&]() {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) *reinterpret_cast<us8*>(Y + (trow + 32 * i) * Y_LD + (tid & 15) * 8) = rres[i];
+    };
+    // ---- prologue
+    {
+        constexpr int CPR = C / 8, NB = BM * CPR / 512;
+        us8 rb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 512, row = ch / CPR, col = (ch % CPR) * 8;
+            rb[i] = *reinterpret_cast<const us8*>(p.a1 + (m0 + row) * C + col);
+        }
+        constexpr int CPR2 = C2 ? C2 / 8 : 1, NB2 = C2 ? BM * CPR2 / 512 : 1;
+        us8 rb2[NB2];
+        if constexpr (C2 > 0) {
+            // projection source: pixel m = (b, oy, ox) reads x2[b][oy * s][ox * s] (a 2 C2-byte row each)
+            const int per = p.OH * p.OW;
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const int ch = tid + i * 512, row = ch / CPR2, col = (ch % CPR2) * 8;
+                const long long m = m0 + row;
+                const int b = (int)(m / per), rem = (int)(m % per), oy = rem / p.OW, ox = rem % p.OW;
+                const long long pix = ((long long)b * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
+                rb2[i] = *reinterpret_cast<const us8*>(p.a2 + pix * C2 + col);
+            }
+        } else {
+            fetch_res(0);
+        }
+        load_wa(0);
+        for (int i = tid; i < C4 / 4; i += 512) {
+            *reinterpret_cast<f32x4*>(S3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
+            *reinterpret_cast<f32x4*>(B3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+            if constexpr (C2 > 0) {
+                *reinterpret_cast<f32x4*>(SSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
+                *reinterpret_cast<f32x4*>(BSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 512, row = ch / CPR, col = (ch % CPR) * 8;
+            *reinterpret_cast<us8*>(A1 + row * A_LD + col) = rb[i];
+        }
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const int ch = tid + i * 512, row = ch / CPR2, col = (ch % CPR2) * 8;
+                *reinterpret_cast<us8*>(A2 + row * A2_LD + col) = rb2[i];
+            }
+        } else {
+            park_res();
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc2[NR2];
+#pragma unroll
+    for (int r = 0; r < NR2; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[r][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load_wb(c);
+        // ---- GEMM 1: this wave's 32 channels x 64 pixels of y chunk c, one 32-pixel row tile at a time
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rt = 2 * rh + r;
+            f32x16 acc, accs;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KF1; ++kk) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(A1 + (rt * 32 + l31) * A_LD + kk * 16 + half * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk], af, acc, 0, 0, 0);
+                if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (C2 > 0) {
+#pragma unroll
+                for (int kk = 0; kk < KF1S; ++kk) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(A2 + (rt * 32 + l31) * A2_LD + kk * 16 + half * 8);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[kk], af, accs, 0, 0, 0);
+                    if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = ct * 32 + 8 * q + 4 * half, n = c * CH + nl;
+                const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n), b3 = *reinterpret_cast<const f32x4*>(B3 + n);
+                f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n); bs = *reinterpret_cast<const f32x4*>(BSC + n); }
+                bf16_t* yp = Y + (rt * 32 + l31) * Y_LD + nl;
+                us4 r4 = {0, 0, 0, 0};
+                if constexpr (C2 == 0) r4 = *reinterpret_cast<const us4*>(yp);
+                us4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[4 * q + e] * s3[e];
+                    v += b3[e];
+                    if constexpr (C2 > 0) {
+                        float sc = accs[4 * q + e] * ss[e];
+                        sc += bs[e];
+                        v += sc;
+                    } else {
+                        v += bf16_to_f32(r4[e]);
+                    }
+                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(yp) = o4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                     // y chunk complete
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {
+            const us8 v = *reinterpret_cast<const us8*>(Y + (trow + 32 * i) * Y_LD + (tid & 15) * 8);
+            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (toff + (unsigned)(i * 32 * C4 * 2))) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) {
+            load_wa(c + 1);
+            if (C2 == 0) fetch_res(c + 1);
+        }
+        // ---- GEMM 2: a' += y_c W1'[:, chunk c]^T
+#pragma unroll
+        for (int kk = 0; kk < KF2; ++kk)
+#pragma unroll
+            for (int r = 0; r < NR2; ++r) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(Y + ((r2 + r) * 32 + l31) * Y_LD + kk * 16 + half * 8);
+                acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk], af, acc2[r], 0, 0, 0);
+                if (r == NR2 - 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();                                     // every wave is done with chunk c
+        if (C2 == 0 && c + 1 < NCH) {
+            park_res();
+            __syncthreads();
+        }
+    }
+    // ---- a' = relu(bn1(acc2)) -> LDS -> whole rows
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = nt2 * 32 + 8 * q + 4 * half;
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+#pragma unroll
+        for (int r = 0; r < NR2; ++r) {
+            us4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc2[r][4 * q + e] * s1[e];
+                v += b1[e];
+                o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+            }
+            *reinterpret_cast<us4*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o4;
+        }
+    }
+    __syncthreads();
+    constexpr int CPRO = CN / 8, RPI = 512 / CPRO;
+    static_assert(BM * CPRO % 512 == 0, "a' tile chunking");
+    const int orow = tid / CPRO, ocol = tid % CPRO;
+    unsigned char* o_b = reinterpret_cast<unsigned char*>(p.o) + m0 * CN * (p.o_fp8 ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < BM * CPRO / 512; ++i) {
+        const int row = orow + i * RPI;
+        const us8 v = *reinterpret_cast<const us8*>(O + row * O_LD + ocol * 8);
+        if (p.o_fp8) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+            *reinterpret_cast<uint2*>(o_b + (unsigned)(row * CN + ocol * 8)) = f32x8_to_fp8(f);
+        } else {
+            *reinterpret_cast<us8*>(o_b + (unsigned)(row * CN + ocol * 8) * 2u) = v;
+        }
+    }
+}
+
+template <int C, int C4, int CN, int C2>
+static int pw_launch_rt8(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwRt8<C, C4, CN, C2>::BYTES;
+    NPS_ENSURE_LDS((int)lds, pw_chain_rt8_kernel<C, C4, CN, C2>);
+    hipLaunchKernelGGL((pw_chain_rt8_kernel<C, C4, CN, C2>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, stream, a);
+    return 0;
+}
+
 template <int C, int C4, int CN, int C2, int BM>
 static int pw_launch(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwLds<C, C4, CN, C2, BM>::BYTES;
@@ -1012,6 +1265,12 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
 #define PW_RT4(c, c4, cn) if (C == c && C4 == c4 && CN == cn) { pw_launch_rt4<c, c4, cn>(a, st); NPS_LAUNCH_RET(); }
         PW_RT4(128, 512, 128) PW_RT4(128, 512, 0) PW_RT4(64, 256, 64) PW_RT4(64, 256, 128) PW_RT4(64, 256, 0)
 #undef PW_RT4
+    }
+    // res3's edge blocks (CN = 256 into res4; the stride-2 projection of res3.0): the eight-wave form
+    static const bool no_rt8 = getenv("NOPESAC_TAIL_NO_RT8") != nullptr;
+    if (!no_rt4 && !no_rt8 && a.M % 128 == 0 && C == 128 && C4 == 512) {
+        if (!x2 && CN == 256) { pw_launch_rt8<128, 512, 256, 0>(a, st); NPS_LAUNCH_RET(); }
+        if (x2 && CN == 128 && c2 == 256) { pw_launch_rt8<128, 512, 128, 256>(a, st); NPS_LAUNCH_RET(); }
     }
     // res2.0: projection shortcut from a same-resolution source (the stem output), in the same 128-pixel form
     if (x2 && !no_rt4 && a.M % 128 == 0 && x2_stride == 1 && x2_H == OH && x2_W == OW) {

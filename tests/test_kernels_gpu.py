@@ -271,6 +271,7 @@ def test_decode_masks_all_views_in_one_launch(device, V, H, W, nq):
 @pytest.mark.parametrize("C,proj,CN,stride,M_odd", [
     (64, False, 64, 1, False), (64, False, 128, 1, True), (64, True, 64, 1, False), (64, False, 0, 1, False), (64, True, 0, 1, True),
     (128, False, 128, 1, True), (128, False, 256, 1, False), (128, True, 128, 2, True), (128, True, 0, 2, False), (128, False, 0, 1, False),
+    (128, False, 128, 1, False), (128, True, 128, 2, False), (128, False, 256, 1, True), (64, True, 64, 1, True),     # full 128-pixel tiles -> rt4 / rt8 forms; ragged -> 32/64-pixel forms
     (256, False, 256, 1, True), (256, False, 512, 1, False), (256, True, 256, 2, True), (256, True, 0, 2, False), (256, False, 0, 1, True)])
 def test_bottleneck_tail(device, C, proj, CN, stride, M_odd):
     """Fused conv3 + shortcut + ReLU (+ next conv1) vs the per-layer bf16 kernels: identity blocks bit-exact, projection
