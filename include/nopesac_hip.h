@@ -380,6 +380,12 @@ int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** tape_out, in
 int nopesac_tape_replay(void* tape, void* stream);
 int nopesac_tape_destroy(void* tape);
 
+/* Diagnostic: `workgroups` x 256 threads fill `lds_bytes` of their LDS with a pattern, spin `spin_cycles`, verify, `rounds` times.
+ * *count (uint32, zeroed by the caller) += mismatching dwords; log4 (optional, log_cap x 4 uint32) = {workgroup, dword, expected, found}
+ * of the first mismatches.  Run on one stream while other kernels run on others (scripts/lds_victim.py). */
+int nopesac_lds_canary(int workgroups, int lds_bytes, int64_t spin_cycles, int rounds, uint32_t* count, uint32_t* log4, int log_cap,
+                       void* stream);
+
 /* BENCHMARK-ONLY K control (not part of the reference: it has no such knob - the reference benchmark would need
  * trained weights to keep K planes per view).  Per pair b: the K highest-scoring queries of view 1 (score = logits[b,q,0] -
  * logits[b,q,1], logits f32 [>=B, nq, n_cls]) in ascending query order become rows 0..K-1 of feats[b] (query_feat f32 [>=B,nq,D]);

@@ -614,6 +614,44 @@ extern "C" int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* st
 }
 
 
+// ---- LDS canary (diagnostic, round 3): a workgroup fills `words` dwords of LDS with an address-derived pattern, spins, and checks it
+// again - while other kernels run on other streams.  Every mismatch is counted; the first few are logged as {workgroup, dword index,
+// expected, found}.  Found with it: see DESIGN.md section 6 (round 3, "a workgroup's LDS is not private ...").
+namespace nps {
+__global__ __launch_bounds__(256) void lds_canary_kernel(int words, unsigned long long spin_cycles, int rounds, unsigned* __restrict__ count,
+                                                         unsigned* __restrict__ log4, int log_cap) {
+    extern __shared__ unsigned canary_lds[];
+    const unsigned salt = 0x9E3779B9u * (blockIdx.x + 1);
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) canary_lds[i] = (unsigned)i * 2654435761u ^ salt ^ (unsigned)r;
+        __syncthreads();
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - c0 < spin_cycles) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < words; i0 += blockDim.x) {
+            const int i = (i0 + 67) % words;                 // (dwords another wave wrote)
+            const unsigned want = (unsigned)i * 2654435761u ^ salt ^ (unsigned)r, got = canary_lds[i];
+            if (got != want) {
+                const unsigned k = atomicAdd(count, 1u);
+                if ((int)k < log_cap) { log4[4 * k] = blockIdx.x; log4[4 * k + 1] = (unsigned)i; log4[4 * k + 2] = want; log4[4 * k + 3] = got; }
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace nps
+
+extern "C" int nopesac_lds_canary(int workgroups, int lds_bytes, int64_t spin_cycles, int rounds, uint32_t* count, uint32_t* log4, int log_cap,
+                                  void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(workgroups > 0 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && lds_bytes % 4 == 0 && spin_cycles >= 0 && rounds > 0 && count &&
+                  (log_cap == 0 || log4), "lds_canary: bad args");
+    NPS_ENSURE_LDS(160 * 1024, lds_canary_kernel);
+    hipLaunchKernelGGL(lds_canary_kernel, dim3(workgroups), dim3(256), lds_bytes, (hipStream_t)stream, lds_bytes / 4, (unsigned long long)spin_cycles, rounds,
+                       count, log4, log_cap);
+    NPS_LAUNCH_RET();
+}
+
 // ---- uint8 image planes -> f32 (exact): lets the boundary take the decoder's 8-bit images over PCIe (a quarter of the bytes of the
 // reference mapper's float32 tensors, data/planercnn_transforms.py:225-227) and widen them on the device
 namespace nps {

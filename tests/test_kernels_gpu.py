@@ -759,7 +759,7 @@ def test_mlp_chain_rejects_bad_chains(device):
         ops.mlp_chain(x, [l1], [0], [None])
 
 
-@pytest.mark.parametrize("B,nq,K", [(3, 50, 32), (2, 64, 64), (2, 128, 128), (1, 50, 1)])
+@pytest.mark.parametrize("B,nq,K", [(3, 50, 32), (2, 64, 64), (2, 128, 128), (1, 50, 1), (4, 128, 77), (3, 100, 64)])
 def test_force_k_select_matches_the_torch_formulation(device, B, nq, K):
     """The benchmark-only K control as one launch vs the torch formulation the oracle uses (topk -> sorted indices -> gathers):
     identical feats / n_kept, including rows >= K zeroed and a larger leading dimension of the inputs (2B views)."""
