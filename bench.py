@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 (NOT the headline line): the backbone's 3x3 convs on the fp8 "
                     "(e4m3fn) MFMA, static activation scales calibrated on the synthetic pairs; the JSON line says dtype fp8+bf16")
     ap.add_argument("--config", default="mp3d", choices=sorted(CONFIG_FILES), help="configs/inference_<name>.yaml (BASELINE configs[2] = scannet, --k 64)")
-    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r2.json"),
+    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r3.json"),
                     help="kernel routing file (autotuner decisions per conv/GEMM shape): loaded when it exists so that every run - "
                          "driver, PMC, rocprofv3 - launches identical kernels; shapes it does not list are tuned and added")
     ap.add_argument("--retune", action="store_true", help="ignore the routing file's contents, tune every shape again and rewrite it")

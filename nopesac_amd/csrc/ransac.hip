@@ -7,8 +7,6 @@
 // One workgroup per image pair; hypotheses x planes are spread over lanes, reductions over hypotheses /
 // feature dims use wave shuffles + a 4-entry LDS exchange.  The MLP stacks between these kernels are
 // MFMA GEMMs (conv_igemm.hip).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace nps {
@@ -99,7 +97,6 @@ __device__ __forceinline__ PairDist hyp_plane_dist(const float* gl, const float*
     return r;
 }
 
-template <int VARIANT>
 __global__ __launch_bounds__(256) void ransac_score_maps_kernel(
     const float* __restrict__ geo_local, const float* __restrict__ rot_raw, const float* __restrict__ trans_raw,
     const float* __restrict__ init_rot, const float* __restrict__ init_trans, const int* __restrict__ mp, int nq,
@@ -127,36 +124,10 @@ __global__ __launch_bounds__(256) void ransac_score_maps_kernel(
         for (int d = 0; d < 3; ++d) trans_all[((long long)b * NH + h) * 3 + d] = t[d];
     }
     for (int e = tid; e < nq * 6; e += 256) sG[e] = geo_local[(long long)b * nq * 6 + e];
-    if (VARIANT == 1) __threadfence_block();
     __syncthreads();
-    if (VARIANT == 1) __threadfence_block();
-    if (VARIANT == 2) __syncthreads();
-    if (VARIANT == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier\n s_nop 7\n s_barrier" ::: "memory"); }
     for (int e = tid; e < NH * nq; e += 256) {
         const int h = e / nq, j = e % nq;
-        PairDist d;
-        if (VARIANT == 4 || VARIANT == 6) {                  // diagnostic: hypothesis h's R / t rebuilt by this thread from global memory
-            float q[4], t[3], Rm[9];
-            if (h == 0) {
-                for (int c = 0; c < 4; ++c) q[c] = init_rot[4 * b + c];
-                for (int c = 0; c < 3; ++c) t[c] = init_trans[3 * b + c];
-            } else {
-                const float* rr = rot_raw + ((long long)b * nq + h - 1) * 4;
-                const float nn = fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3]), 1e-12f);
-                for (int c = 0; c < 4; ++c) q[c] = rr[c] / nn;
-                for (int c = 0; c < 3; ++c) t[c] = trans_raw[((long long)b * nq + h - 1) * 3 + c];
-            }
-            quat_to_rot(q, Rm);
-            float gl[6];
-            for (int c = 0; c < 6; ++c) gl[c] = VARIANT == 6 ? geo_local[((long long)b * nq + j) * 6 + c] : sG[6 * j + c];
-            d = hyp_plane_dist(gl, Rm, t);
-        } else if (VARIANT == 5) {                           // diagnostic: plane j's geometry from global memory
-            float gl[6];
-            for (int c = 0; c < 6; ++c) gl[c] = geo_local[((long long)b * nq + j) * 6 + c];
-            d = hyp_plane_dist(gl, sR + 9 * h, sT + 3 * h);
-        } else {
-            d = hyp_plane_dist(sG + 6 * j, sR + 9 * h, sT + 3 * h);
-        }
+        const PairDist d = hyp_plane_dist(sG + 6 * j, sR + 9 * h, sT + 3 * h);
         const float mask = (h <= m && j < m) ? 1.f : 0.f;
         const long long o = (long long)b * NH * nq + e;
         normal_score[o] = expf(-(d.dn * mask)) * mask;
@@ -369,13 +340,9 @@ extern "C" int nopesac_ransac_score_maps(const float* geo_local, const float* ro
     NPS_CHECK_ARG(geo_local && rot_raw && trans_raw && init_rot && init_trans && m && rots_all && trans_all && normal_score && param_score,
                   "ransac_score_maps: null pointer");
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "ransac_score_maps: bad dims (nq<=128)");
-    static const int variant = getenv("NOPESAC_SCOREMAP_VARIANT") ? atoi(getenv("NOPESAC_SCOREMAP_VARIANT")) : 0;     // diagnostic builds
-#define SM_LAUNCH(V) hipLaunchKernelGGL(ransac_score_maps_kernel<V>, dim3(B), dim3(256), 0, (hipStream_t)stream, geo_local, rot_raw, trans_raw, \
-                       init_rot, init_trans, m, nq, rots_all, trans_all, normal_score, param_score, l2_dist, normal_angle,              \
-                       offset_dist, dn_sum, dl2_sum)
-    if (variant == 1) SM_LAUNCH(1); else if (variant == 2) SM_LAUNCH(2); else if (variant == 3) SM_LAUNCH(3); else if (variant == 4) SM_LAUNCH(4);
-    else if (variant == 5) SM_LAUNCH(5); else if (variant == 6) SM_LAUNCH(6); else SM_LAUNCH(0);
-#undef SM_LAUNCH
+    hipLaunchKernelGGL(ransac_score_maps_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, geo_local, rot_raw, trans_raw,
+                       init_rot, init_trans, m, nq, rots_all, trans_all, normal_score, param_score, l2_dist, normal_angle,
+                       offset_dist, dn_sum, dl2_sum);
     NPS_LAUNCH_RET();
 }
 

@@ -13,7 +13,7 @@ from nopesac_amd import ops, rle  # noqa: E402
 dev = torch.device("cuda:0")
 B, K = 32, 32
 model = bench.build_model(dev, 50, "bfloat16")
-ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r2.json"))
+ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
 forced = bench.make_forced(B, K, 50, dev, 7)
 g = torch.Generator().manual_seed(0)
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float().to(dev)

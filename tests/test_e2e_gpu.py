@@ -490,3 +490,40 @@ def test_bench_two_gpus_rccl():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["config"]["nonfinite_outputs"] == 0
+
+
+def test_steps_in_flight_are_bit_identical(device):
+    """Round-3 regression (profiles/r3_packed_fp32_hazard.txt): with four batches in flight on their own HIP streams (+ the pose net's
+    side streams) every step of the benchmark loop must return the SAME rows when every slot holds the same images.  Before the library
+    was built without packed-f32 VALU instructions, 40-50 % of such steps deviated (1e-4 .. 3e-2 on the refined pose of a few pairs):
+    ransac_score_maps_kernel's v_pk_*_f32 results were corrupted in lanes 48-63 whenever another batch's MFMA kernels shared its SIMD."""
+    import bench
+    from nopesac_amd import runner
+    B, K, nq, slots, steps = 16, 32, 50, 4, 40
+    model = bench.build_model(device, nq, "bfloat16")
+    raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=torch.Generator().manual_seed(1000)).float().to(device)
+    raws = [raw] + [raw.clone() for _ in range(slots - 1)]
+    forced = bench.make_forced(B, K, nq, device, 7)
+    loop = runner.InflightLoop(slots, B, device, 1)
+
+    def device_step(slot):
+        cam = model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=raws[slot])["cam"]
+        rows = runner.metric_rows(cam["cameras"]["camera"][0], cam["cameras"]["camera"][1], cam["n1"], cam["n2"], cam["m"], 0)
+        rows[:, 10:13] = cam["cameras"]["camera_init"][0]
+        rows[:, 13:16] = cam["refine"]["maps"]["normal_score"].sum((1, 2)).view(-1, 1)
+        return None, rows
+
+    blocks, hist = [], []
+    with torch.no_grad():
+        for i in range(steps):
+            slot = i % slots
+            if loop.done[slot] is not None and len(hist) >= slots:
+                loop.done[slot].synchronize()
+                blocks.append(loop.host_bufs[slot].clone())
+            loop.step(i, device_step)
+            hist.append(slot)
+        loop.barrier()
+    blocks += [loop.host_bufs[s].clone() for s in hist[-slots:]]
+    assert len(blocks) == steps
+    off = [i for i, b in enumerate(blocks) if not torch.equal(b, blocks[0])]
+    assert not off, "steps whose rows differ from step 0: %s" % off

@@ -224,3 +224,12 @@ def test_tuner_key_and_eligibility_fallback():
     assert t.choose("k", None, (ops.CFG_BFRAG3, ops.CFG_HALO16)) == ops.CFG_HALO16
     assert t.choose("k", None, (ops.CFG_BFRAG3,)) == 0
     assert t.choose("unknown", None, ()) == 0
+
+
+def test_library_is_built_without_packed_fp32_instructions():
+    """Round-3 finding (profiles/r3_packed_fp32_hazard.txt): v_pk_*_f32 results are corrupted next to another wave's MFMAs on the same
+    SIMD, so the build must keep the `packed-fp32-ops` target feature off for every kernel file."""
+    from nopesac_amd import build
+    flags = " ".join(build.FLAGS)
+    assert "-target-feature -Xclang -packed-fp32-ops" in flags, flags
+    assert all("packed-fp32" not in " ".join(v) or "-packed-fp32-ops" in " ".join(v) for v in build.EXTRA_FLAGS.values())

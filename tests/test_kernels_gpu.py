@@ -778,3 +778,34 @@ def test_force_k_select_matches_the_torch_formulation(device, B, nq, K):
     want[:B, :K], want[B:, :K] = f1, f2
     assert torch.equal(feats, want)
     assert n_kept.tolist() == [K] * (2 * B)
+
+
+def test_score_maps_reproducible_next_to_mfma_kernels(device):
+    """nopesac_ransac_score_maps on constant inputs while ANOTHER stream loops the res3 bottleneck tail (an MFMA kernel that leaves room
+    for co-resident waves): every launch must reproduce the result of an idle GPU.  With packed-f32 VALU instructions in the kernel
+    (the SLP vectoriser's default) 60 % of the launches had lanes 48-63 of some waves wrong (profiles/r3_packed_fp32_hazard.txt)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g).to(device)
+    B, nq = 32, 50
+    geo, rot_raw, trans_raw = rn(B, nq, 6), rn(B, nq, 4), rn(B, nq, 3)
+    init_rot, init_trans = F.normalize(rn(B, 4), dim=-1), rn(B, 3)
+    m = torch.full((B,), 32, device=device, dtype=torch.int32)
+    victim = lambda: ops.ransac_score_maps(geo, rot_raw, trans_raw, init_rot, init_trans, m, diagnostics=False)
+    ref = victim()
+    torch.cuda.synchronize()
+    bf = lambda *s: (torch.randn(*s, device=device) * 0.1).bfloat16()
+    xb, res = bf(64, 60, 80, 128), bf(64, 60, 80, 512)
+    w3, w1 = ops.mfma_fragment_major(bf(512, 128)), ops.mfma_fragment_major(bf(128, 512))
+    s512, b512, s128, b128 = torch.ones(512, device=device), torch.zeros(512, device=device), torch.ones(128, device=device), torch.zeros(128, device=device)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for it in range(12):
+        with torch.cuda.stream(sb):
+            for _ in range(2):
+                ops.bottleneck_tail(xb, w3, s512, b512, residual=res, w1=w1, s1=s128, b1=b128)
+        with torch.cuda.stream(sa):
+            outs = [victim() for _ in range(8)]
+        torch.cuda.synchronize()
+        bad += sum(1 for o in outs if not (torch.equal(o["normal_score"], ref["normal_score"]) and torch.equal(o["param_score"], ref["param_score"])))
+    assert bad == 0, "%d of 96 launches differ from the idle-GPU result" % bad
