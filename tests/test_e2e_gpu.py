@@ -142,9 +142,13 @@ def test_bench_configuration_bf16_forced_k32_b32(device):
     err = bench.bench_workload_pose_error(m16, m32, device, B, K, nq)
     assert err["m_bf16"] == [K] * B and err["m_fp32"] == [K] * B
     assert err["finite"] and err["max_quat_norm_dev"] < 1e-3
-    cam, ini = err["camera"], err["camera_init"]
-    assert cam["R_err_deg_max"] < 2.0 and cam["T_err_max"] < 0.02 * cam["mean_abs_t"], cam
-    assert ini["R_err_deg_max"] < 8.0 and ini["T_err_max"] < 0.03, ini
+    cam, ini, rec = err["camera"], err["camera_init"], err["camera_initRec"]
+    # bounds = 1.5 x the maxima measured on MI355X in round 3 (BENCH line `pose_err_vs_fp32_path.bench_workload`, profiles/r3_e_bench_full.json:
+    # camera R 0.62 deg / T 0.070-0.078 at |t| = 11.1; camera_init R 3.44-3.59 deg / T 0.0075; camera_initRec R 6.2-7.1 deg).  Where the error
+    # comes from: profiles/r3_a_bf16_attribution.json (the backbone's accumulated bf16 rounding; no single head stage dominates).
+    assert cam["R_err_deg_max"] < 0.95 and cam["T_err_max"] < 0.0105 * cam["mean_abs_t"], cam
+    assert ini["R_err_deg_max"] < 5.4 and ini["T_err_max"] < 0.0115, ini
+    assert rec["R_err_deg_max"] < 10.7, rec
 
 
 def test_e2e_scannet_config_nq64(device):
