@@ -238,7 +238,7 @@ class PlaneTR_NopeSAC(nn.Module):
         if want_tape:
             from ..tape import LaunchTape, TapeUnsupported
             try:
-                st["tape"] = LaunchTape(g)
+                st["tape"] = LaunchTape(g, max_streams=int(self.__dict__.get("tape_streams", 4)))
                 self.__dict__["tape_counts"] = dict(st["tape"].counts)
             except TapeUnsupported as e:
                 import warnings
