@@ -415,29 +415,25 @@ def test_graft_entry_build_then_smoke_in_one_process():
 
 
 def test_config5_fp8_backbone_k128(device):
-    """BASELINE config 5 on one GPU: fp8 3x3 backbone convs (MODEL.AMD.BACKBONE_FP8) + K = 128 forced hypotheses, nq = 128,
-    against the fp32 HIP path on the same inputs and K control: all 128 hypotheses take part, the initial pose stays close
-    (the refined pose goes through discrete decisions that reduced precision may flip: finite + unit quaternion only)."""
+    """BASELINE config 5 on one GPU: fp8 3x3 backbone convs (MODEL.AMD.BACKBONE_FP8) + K = 128 forced hypotheses, nq = 128, on the
+    bench workload (8 pairs) against the fp32 HIP path under the same K control (scripts/fp8_error.py, same seeds).  Measured in
+    round 3 (fp8 / plain bf16): camera_init R max 4.32 / 1.37 deg, T max 0.0246 / 0.0067 (|t| = 0.36); camera_initRec R max 12.9 / 3.2;
+    refined camera R max 0.34 / 0.34 deg, T max 0.21 / 0.06 (|t| = 11.2).  Gates = 2x the measured fp8 maxima."""
     import bench
-    from nopesac_amd.synth import synth_pair
-    B, K, nq = 2, 128, 128
-    m8 = make_model(device, ("MODEL.AMD.BACKBONE_FP8", True), nq=nq, dtype="bfloat16")
-    m32 = make_model(device, nq=nq)
-    inp = [synth_pair(40 + i) for i in range(B)]
-    m8.calibrate_fp8(inp)
-    forced = bench.make_forced(B, K, nq, device, 9)
+    from nopesac_amd import ops
+    B, K, nq = 8, 128, 128
+    m8 = bench.build_model(device, nq, "bfloat16", ["MODEL.AMD.BACKBONE_FP8", True])
+    m32 = bench.build_model(device, nq, "float32")
+    g = torch.Generator().manual_seed(1000)
+    raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g).float().to(device)
+    forced = bench.make_forced(B, K, nq, device, 7)
     with torch.no_grad():
-        a = m8.forward_tensors(m8.preprocess_image(inp), B, 480, 640, forced=forced)["cam"]
-        b = m32.forward_tensors(m32.preprocess_image(inp), B, 480, 640, forced=forced)["cam"]
-    assert a["m"].tolist() == [K] * B == b["m"].tolist()
-    t8, q8 = a["cameras"]["camera_init"]
-    t32, q32 = b["cameras"]["camera_init"]
-    for i in range(B):
-        t_err = float((t8[i] - t32[i]).norm())
-        dot = abs(float((q8[i] * q32[i]).sum()))
-        assert t_err < 0.1 * (1 + float(t32[i].norm())) and 2 * np.degrees(np.arccos(min(dot, 1.0))) < 15.0, (t_err, dot)
-    t, q = a["cameras"]["camera"]
-    assert torch.isfinite(t).all() and torch.isfinite(q).all() and float((q.norm(dim=-1) - 1).abs().max()) < 1e-3
+        m8.backbone.calibrate_fp8(ops.preprocess(raw[:4], m8.pixel_mean, m8.pixel_std, m8.backbone.STEM_CIN_PAD, m8.compute_dtype))
+    e = bench.bench_workload_pose_error(m8, m32, device, B, K, nq, raw=raw, forced=forced)
+    assert e["m_bf16"] == [K] * B == e["m_fp32"] and e["finite"] and e["max_quat_norm_dev"] < 1e-3
+    assert e["camera_init"]["R_err_deg_max"] < 8.7 and e["camera_init"]["T_err_max"] < 0.05, e["camera_init"]
+    assert e["camera_initRec"]["R_err_deg_max"] < 26.0, e["camera_initRec"]
+    assert e["camera"]["R_err_deg_max"] < 0.7 and e["camera"]["T_err_max"] < 0.43, e["camera"]
 
 
 def test_other_resolutions_are_rejected_like_the_reference(device):
