@@ -484,6 +484,11 @@ int nopesac_rle_compress_host(const uint32_t* positions, int n_pos, int H, int W
  * strings are written at out + out_off[i] (the caller's exclusive prefix sums of lens). */
 int nopesac_rle_compress_device(const uint32_t* positions, const int64_t* offsets, const int32_t* counts, int n_masks, int H, int W,
                                 int32_t* lens, double* bbox4, char* out, const int64_t* out_off, void* stream);
+/* Pass 2 of nopesac_rle_compress_device into a buffer of fixed capacity `cap` bytes, so that the caller needs no host round trip for
+ * the total string length: string i is written at out + out_off[i] only when out_off[i] + lens[i] <= cap (lens: pass 1's output).
+ * The strings' consumer (siamese_planeTR.py:703-720, instances[k]["segmentation"]) gets the same bytes as from the unbounded form. */
+int nopesac_rle_compress_device_capped(const uint32_t* positions, const int64_t* offsets, const int32_t* counts, int n_masks, int H, int W,
+                                       const int32_t* lens, char* out, const int64_t* out_off, int64_t cap, void* stream);
 /* Batch form of nopesac_rle_compress_host: mask i owns positions[offsets[i] .. +counts[i]); strings are packed back to back into
  * `out` (mask i at out + out_off[i], out_off[n_masks] = total), boxes at bbox4 + 4 i.  Returns the total length or < 0. */
 long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long long* offsets, const int* counts, int n_masks,

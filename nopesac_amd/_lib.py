@@ -40,6 +40,7 @@ SIGNATURES = {
     "nopesac_rle_transitions": [P, P, P, P, P, I, I, I, P],
     "nopesac_rle_compress_host": [P, I, I, I, P, I, P],
     "nopesac_rle_compress_device": [P, P, P, I, I, I, P, P, P, P, P],
+    "nopesac_rle_compress_device_capped": [P, P, P, I, I, I, P, P, P, L, P],
     "nopesac_decode_masks": [P, P, P, P, P, P, I, I, I, I, P],
     "nopesac_rle_compress_batch_host": [P, P, P, I, I, I, P, L, P, P],
     "nopesac_preprocess_nchw_to_nhwc": [P, P, P, P, I, I, I, I, I, I, P],

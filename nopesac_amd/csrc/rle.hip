@@ -210,11 +210,12 @@ __device__ __forceinline__ int rle_chars(long long x, char (&c)[8]) {
 __global__ __launch_bounds__(256) void rle_compress_kernel(const uint32_t* __restrict__ positions, const long long* __restrict__ offsets,
                                                            const int* __restrict__ counts, int H, int W, int* __restrict__ lens,
                                                            double* __restrict__ bbox4, char* __restrict__ out,
-                                                           const long long* __restrict__ out_off) {
+                                                           const long long* __restrict__ out_off, long long cap) {
     __shared__ int wave_tot[4];
     __shared__ long long red[4][4];
     __shared__ int red_full[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (out && cap >= 0 && out_off[i] + lens[i] > cap) return;   // capped pass 2: a string that does not fit is left out (the host sees it in out_off / lens)
     const int n_pos = counts[i];
     const uint32_t* pos = positions + offsets[i];
     const long long N = (long long)H * W;
@@ -302,7 +303,18 @@ extern "C" int nopesac_rle_compress_device(const uint32_t* positions, const int6
     NPS_CHECK_ARG(offsets && counts && n_masks > 0 && H > 0 && W > 0, "rle_compress_device: bad args");
     NPS_CHECK_ARG(out ? (out_off != nullptr) : (lens && bbox4), "rle_compress_device: pass 1 needs lens + bbox4, pass 2 needs out + out_off");
     hipLaunchKernelGGL(rle_compress_kernel, dim3(n_masks), dim3(256), 0, (hipStream_t)stream, positions, (const long long*)offsets, counts, H, W,
-                       lens, bbox4, out, (const long long*)out_off);
+                       lens, bbox4, out, (const long long*)out_off, -1LL);
+    NPS_LAUNCH_RET();
+}
+
+// Pass 2 into a buffer of FIXED capacity (no host round trip for the total length): string i is written at out + out_off[i] only
+// if out_off[i] + lens[i] <= cap; lens = pass 1's output (read here).  The caller compares out_off / lens with cap afterwards.
+extern "C" int nopesac_rle_compress_device_capped(const uint32_t* positions, const int64_t* offsets, const int32_t* counts, int n_masks, int H,
+                                                  int W, const int32_t* lens, char* out, const int64_t* out_off, int64_t cap, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(offsets && counts && lens && out && out_off && n_masks > 0 && H > 0 && W > 0 && cap >= 0, "rle_compress_device_capped: bad args");
+    hipLaunchKernelGGL(rle_compress_kernel, dim3(n_masks), dim3(256), 0, (hipStream_t)stream, positions, (const long long*)offsets, counts, H, W,
+                       const_cast<int32_t*>(lens), (double*)nullptr, out, (const long long*)out_off, (long long)cap);
     NPS_LAUNCH_RET();
 }
 

@@ -586,30 +586,48 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
     return counter
 
 
-def gather_to_host(tensors: dict) -> dict:
-    """{name: tensor} -> {name: host tensor of the same dtype / shape}.  Device tensors travel together: their bytes are concatenated
-    on the device (8-byte aligned segments), copied once into a fresh pinned host buffer and waited for once; the returned tensors
-    are views of that buffer (it lives as long as any of them)."""
-    dev = [(k, t.detach().contiguous()) for k, t in tensors.items() if t.is_cuda]
-    out = {k: t.detach() for k, t in tensors.items() if not t.is_cuda}
-    if not dev:
+class HostFetch:
+    """A batch of device tensors on its way to the host: their bytes were concatenated on the device (8-byte aligned segments) and
+    are being copied into ONE pinned host buffer on the stream that was current at construction.  `views()` hands out host tensors
+    of the original dtype / shape (views of that buffer) once the caller knows the copy has completed - after `wait()`, or after
+    an event it recorded behind the fetch on the same stream."""
+
+    def __init__(self, tensors: dict):
+        dev = [(k, t.detach().contiguous()) for k, t in tensors.items() if t.is_cuda]
+        self.passthrough = {k: t.detach() for k, t in tensors.items() if not t.is_cuda}
+        self.spans, self.host, self.stream = {}, None, None
+        if not dev:
+            return
+        parts, off = [], 0
+        for k, t in dev:
+            b = t.view(-1).view(torch.uint8) if t.numel() else t.new_empty(0, dtype=torch.uint8)
+            pad = (-b.numel()) % 8
+            self.spans[k] = (off, b.numel(), t.dtype, tuple(t.shape))
+            parts.append(b)
+            if pad:
+                parts.append(b.new_zeros(pad))
+            off += b.numel() + pad
+        flat = torch.cat(parts)
+        self.host = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
+        self.host.copy_(flat, non_blocking=True)
+        self.stream = torch.cuda.current_stream()
+
+    def wait(self) -> "HostFetch":
+        if self.stream is not None:
+            self.stream.synchronize()
+        return self
+
+    def views(self) -> dict:
+        out = dict(self.passthrough)
+        for k, (o, n, dt, shape) in self.spans.items():
+            out[k] = self.host[o:o + n].view(dt).view(shape)
         return out
-    parts, spans, off = [], {}, 0
-    for k, t in dev:
-        b = t.view(-1).view(torch.uint8) if t.numel() else t.new_empty(0, dtype=torch.uint8)
-        pad = (-b.numel()) % 8
-        spans[k] = (off, b.numel(), t.dtype, tuple(t.shape))
-        parts.append(b)
-        if pad:
-            parts.append(b.new_zeros(pad))
-        off += b.numel() + pad
-    flat = torch.cat(parts)
-    host = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
-    host.copy_(flat, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    for k, (o, n, dt, shape) in spans.items():
-        out[k] = host[o:o + n].view(dt).view(shape)
-    return out
+
+
+def gather_to_host(tensors: dict) -> dict:
+    """{name: tensor} -> {name: host tensor of the same dtype / shape}.  Device tensors travel together: one concatenation on the
+    device, one copy into a fresh pinned host buffer, one wait; the returned tensors are views of that buffer."""
+    return HostFetch(tensors).wait().views()
 
 
 def u8_to_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -813,6 +831,26 @@ def rle_compress(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.T
     _lib.check(L.nopesac_rle_compress_device(_p(positions), _p(offsets), _p(counts), n, H, W, None, None, _p(out), _p(out_off), _stream()),
                "nopesac_rle_compress_device")
     return out[:total], out_off, lens, bbox
+
+
+def rle_compress_capped(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.Tensor, H: int, W: int, cap: int):
+    """rle_compress without the host sync: the strings go into a byte buffer of FIXED capacity `cap`; a string that would cross it
+    is not written.  Returns (bytes uint8 [cap], out_off int64 [n], lens int32 [n], bbox float64 [n,4]) - device tensors; the
+    caller checks out_off[-1] + lens[-1] <= cap once those have reached the host."""
+    _chk(positions, torch.int32); _chk(offsets, torch.int64); _chk(counts, torch.int32)
+    n = counts.numel()
+    dev = counts.device
+    lens = torch.empty(n, device=dev, dtype=torch.int32)
+    bbox = torch.empty(n, 4, device=dev, dtype=torch.float64)
+    L = _L()
+    _lib.check(L.nopesac_rle_compress_device(_p(positions), _p(offsets), _p(counts), n, H, W, _p(lens), _p(bbox), None, None, _stream()),
+               "nopesac_rle_compress_device")
+    ends = torch.cumsum(lens.to(torch.int64), 0)
+    out_off = (ends - lens).contiguous()
+    out = torch.empty(int(cap), device=dev, dtype=torch.uint8)
+    _lib.check(L.nopesac_rle_compress_device_capped(_p(positions), _p(offsets), _p(counts), n, H, W, _p(lens), _p(out), _p(out_off), int(cap),
+                                                    _stream()), "nopesac_rle_compress_device_capped")
+    return out, out_off, lens, bbox
 
 
 def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict):

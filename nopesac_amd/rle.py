@@ -100,6 +100,49 @@ def encode_views(winner: torch.Tensor, kept_idx: torch.Tensor, n_kept: torch.Ten
     return out
 
 
+class PendingRLE:
+    """encode_views split in two so that a caller with several batches in flight never issues device work when it FETCHES results
+    (a kernel enqueued behind other batches' launches waits for them; measured 6.8 ms per 32-pair step at the drop-in boundary):
+    the constructor enqueues everything on the current stream - labels, flip positions (worst-case sized buffer: at most 2 flips
+    per pixel and view), compressed strings into a byte buffer of fixed capacity, and the copy of the first `host_cap` bytes plus
+    the offset / length / box tables into pinned host memory; `finish()` (after the stream has passed the fetch) only slices.
+    Totals beyond `host_cap` cost one more copy, beyond `cap` the synchronous encode_views."""
+
+    def __init__(self, winner, kept_idx, n_kept, flags, cap: int = 64 << 20, host_cap: int = 6 << 20):
+        V, H, W = winner.shape
+        nq = kept_idx.shape[1]
+        self.args, self.shape, self.cap, self.host_cap = (winner, kept_idx, n_kept, flags), (V, H, W, nq), int(cap), int(min(host_cap, cap))
+        labels = ops.rle_labels(winner, kept_idx, n_kept, flags)
+        counts = ops.rle_transitions(labels, n_kept, nq)
+        c64 = counts.view(-1).to(torch.int64)
+        ends = torch.cumsum(c64, 0)
+        offsets = (ends - c64).contiguous()
+        pos = torch.empty(V * 2 * H * W, device=winner.device, dtype=torch.int32)       # upper bound of the flips; only the used part is touched
+        ops.rle_transitions(labels, n_kept, nq, offsets=offsets.view(V, nq), positions=pos)
+        self.data, out_off, lens, bbox = ops.rle_compress_capped(pos, offsets, counts.view(-1).contiguous(), H, W, self.cap)
+        self.fetch = ops.HostFetch({"head": self.data[:self.host_cap], "out_off": out_off, "lens": lens, "bbox": bbox})
+
+    def finish(self, n_kept_host) -> List[List[dict]]:
+        """Only after the stream the constructor ran on has passed the fetch (event / synchronize)."""
+        V, H, W, nq = self.shape
+        h = self.fetch.views()
+        out_off, lens, bbox = h["out_off"].tolist(), h["lens"].tolist(), h["bbox"].tolist()
+        total = out_off[-1] + lens[-1]
+        if total > self.cap:                                   # (never seen: 64 MB of run-length strings in one batch)
+            return encode_views(*self.args, n_kept_host=n_kept_host)
+        raw = h["head"].numpy()[:min(total, self.host_cap)].tobytes()
+        if total > self.host_cap:
+            raw += self.data[self.host_cap:total].cpu().numpy().tobytes()
+        out = []
+        for v in range(V):
+            row = []
+            for p in range(n_kept_host[v]):
+                k = v * nq + p
+                row.append({"segmentation": {"size": [H, W], "counts": raw[out_off[k]:out_off[k] + lens[k]]}, "bbox": bbox[k]})
+            out.append(row)
+        return out
+
+
 # ---- reading side (evaluation): what pycocotools.mask.iou does for the matching evaluator (mp3d_evaluation.py:806-812)
 def counts_of(rle: dict) -> np.ndarray:
     """Run lengths of a COCO RLE dict: `counts` is either the list of an uncompressed RLE or the compressed bytes / str

@@ -14,11 +14,14 @@ import bench  # noqa: E402
 from nopesac_amd import ops  # noqa: E402
 
 pad, prio = int(sys.argv[1]), int(sys.argv[2])
-use_tape = len(sys.argv) > 3 and sys.argv[3] == "tape"
+use_tape = "tape" in sys.argv[3:]
+mimic = [a for a in sys.argv[3:] if a.startswith("mimic")]
 B = 32
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 50, "bfloat16")
 ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
+if "mimic_autotune" in mimic:
+    model.autotune(B)
 streams = [torch.cuda.Stream() for _ in range(4)]
 dummies = [torch.cuda.Stream() for _ in range(pad)]
 sides = [torch.cuda.Stream(priority=prio) for _ in range(4)]
@@ -28,25 +31,59 @@ host = raw.pin_memory()
 inputs = [{"0": {"image": host[i], "image_id": "a%d" % i, "file_name": ""}, "1": {"image": host[B + i], "image_id": "b%d" % i, "file_name": ""}}
           for i in range(B)]
 forced = bench.make_forced(B, 32, 50, dev, 7)
+if "mimic_resident" in mimic:                       # what bench.py's timed loop does first: forwards on resident inputs
+    rawd = raw.to(dev)
+    for i in range(12):
+        with torch.no_grad(), torch.cuda.stream(streams[i % 4]):
+            model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=rawd)
+    torch.cuda.synchronize()
 model.output_rle = True
 model.use_hip_graph = use_tape
 model.graph_slots = 4
 gc.collect(); gc.freeze()
 
 
+T = {"submit": 0.0, "wait": 0.0, "enqueue_fetch": 0.0, "package": 0.0, "gpu_ms": 0.0}
+
+
+def _timed(name, f):
+    def w(*a, **k):
+        t = time.perf_counter()
+        r = f(*a, **k)
+        T[name] += time.perf_counter() - t
+        return r
+    return w
+
+
+model._enqueue_fetch = _timed("enqueue_fetch", model._enqueue_fetch)
+
+
 def run(n, depth=4):
+    for k in T:
+        T[k] = 0.0
+
     def submit(slot):
+        t = time.perf_counter()
         with torch.no_grad(), torch.cuda.stream(streams[slot]):
             model.infer_iter += 1
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
             d = model.forward_device(inputs, forced=forced)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            return slot, d, ev
+        T["submit"] += time.perf_counter() - t
+        return slot, d, ev, e0
 
     def finish(h):
+        t = time.perf_counter()
         h[2].synchronize()
+        T["wait"] += time.perf_counter() - t
+        T["gpu_ms"] += h[3].elapsed_time(h[2])
+        t = time.perf_counter()
         with torch.no_grad(), torch.cuda.stream(streams[h[0]]):
-            return model.package(inputs, h[1])
+            r = model.package(inputs, h[1])
+        T["package"] += time.perf_counter() - t
+        return r
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pending = []
@@ -63,4 +100,5 @@ def run(n, depth=4):
 model.infer_iter = 0
 run(12)
 best = min(run(24) for _ in range(3))
-print("pad %d side_priority %d tape %d: %.2f ms/step = %.0f pairs/s  %s" % (pad, prio, use_tape, 1e3 * best, B / best, getattr(model, "tape_counts", "")), flush=True)
+print("   per step (last run): " + "  ".join("%s %.2f" % (k, (1e3 if k != "gpu_ms" else 1.0) * v / 24) for k, v in T.items()), flush=True)
+print("pad %d side_priority %d tape %d %s: %.2f ms/step = %.0f pairs/s  %s" % (pad, prio, use_tape, mimic, 1e3 * best, B / best, getattr(model, "tape_counts", "")), flush=True)

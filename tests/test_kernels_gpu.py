@@ -240,6 +240,13 @@ def test_rle_from_winner_map(device, V, H, W, nq, seed):
             ref = R.encode(m.numpy())
             assert out[v][p]["segmentation"] == {"size": [H, W], "counts": ref["counts"]}, (v, p)
             assert out[v][p]["bbox"] == R.to_bbox(ref).tolist()
+    # the enqueue-now / slice-later form (rle.PendingRLE, what forward_device + package use): identical strings and boxes whether the
+    # bytes fit the pinned head copy, need the second copy (host_cap small) or overflow the device buffer (cap tiny -> encode_views)
+    total = sum(len(r["segmentation"]["counts"]) for row in out for r in row)
+    for cap, host_cap in ((64 << 20, 6 << 20), (64 << 20, max(total // 2, 1)), (max(total - 1, 1), 1 << 20)):
+        pend = rle.PendingRLE(winner.to(device), kept.to(device), n_kept.to(device), flags.to(device), cap=cap, host_cap=host_cap)
+        torch.cuda.synchronize()
+        assert pend.finish(n_kept.tolist()) == out, (cap, host_cap)
 
 
 @pytest.mark.parametrize("V,H,W,nq", [(3, 48, 64, 50), (2, 37, 53, 50), (2, 480, 640, 128), (1, 5, 3, 50)])
