@@ -276,6 +276,9 @@ def main():
                     "(nopesac_amd/tape.py: the captured kernel nodes re-issued as plain launches by a C loop)")
     ap.add_argument("--no-tape", action="store_true", help="skip the second timed run through the launch tape (`launch_tape` in the JSON line)")
     ap.add_argument("--whole-graph", action="store_true", help="with --graph: hipGraphLaunch of the whole graph instead of the launch tape")
+    ap.add_argument("--streams", default="own", help="hardware-queue placement of the in-flight streams (nopesac_amd/streams.py): own = every "
+                    "batch stream on its own queue, its pose-net side stream on the same one; shiftN = the side stream on the queue of "
+                    "batch (i + N) % slots; none = plain torch streams (whatever the runtime hands out)")
     ap.add_argument("--stages", action="store_true", help="add per-stage GPU times (one extra instrumented step)")
     ap.add_argument("--single-stream", action="store_true", help="ANALYSIS: pose net on the main stream (clean per-stage times)")
     ap.add_argument("--ablate", default="", choices=["", "backbone", "head", "nocam"],
@@ -339,7 +342,11 @@ def main():
         return bool(t and t.enabled) or getattr(model, "stage_events", None) is not None
 
     n_slots = max(1, args.inflight)
-    loop = runner.InflightLoop(n_slots, B, device, world)      # streams, pinned row buffers and events of the in-flight slots
+    # streams, pinned row buffers and events of the in-flight slots; the streams are picked by hardware queue (nopesac_amd/streams.py)
+    shift = {"own": 0, "none": None}.get(args.streams, None if not args.streams.startswith("shift") else int(args.streams[5:]))
+    loop = runner.InflightLoop(n_slots, B, device, world, side_shift=shift)
+    if loop.stream_set is not None:
+        loop.stream_set.bind(model)
     streams, host_bufs, done = loop.streams, loop.host_bufs, loop.done
     raws = [raw] + [raw.clone() for _ in range(n_slots - 1)]
     last = {}
@@ -376,7 +383,11 @@ def main():
 
     def slot_step(slot):
         if graphs[slot] is not None and not timer_enabled():
-            graphs[slot].replay()
+            g = graphs[slot]
+            if loop.stream_set is not None and hasattr(g, "counts"):         # a launch tape: its side chain on the slot's side stream
+                g.replay(sides=[loop.stream_set.sides[slot]])
+            else:
+                g.replay()
             return None, graph_rows[slot]
         return device_step(slot)
 
@@ -592,6 +603,7 @@ def main():
                                      else "f32", K, m_mean, nq),
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
                       "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph,
+                      "streams": dict(loop.stream_set.describe(), policy=args.streams) if loop.stream_set is not None else {"policy": "none"},
                       "replay": None if not use_graph else ("whole hipGraph" if args.whole_graph or "tape_counts" not in last else "launch tape"),
                       "tape_nodes": last.get("tape_counts"), "autotuned_shapes": tuned,
                       "routing_file": os.path.relpath(args.routing, ROOT) if args.routing else None, "routing_entries_loaded": routing_loaded,

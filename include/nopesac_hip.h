@@ -378,6 +378,10 @@ int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* counts4);
  * of the captured graph (the capture's side streams) are issued on the tape's own side streams, joined by events. */
 int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** tape_out, int32_t* counts4);
 int nopesac_tape_replay(void* tape, void* stream);
+/* nopesac_tape_replay with the side chains on the caller's streams: side_streams[k] (hipStream_t) runs chain k + 1, a null / missing
+ * entry falls back to the tape's own stream.  Two streams that share a hardware queue execute in submission order, so the placement
+ * of the side chains decides how well replays of several tapes overlap (nopesac_amd/streams.py picks streams by queue). */
+int nopesac_tape_replay_on(void* tape, void* stream, void* const* side_streams, int n_side);
 int nopesac_tape_destroy(void* tape);
 
 /* Diagnostic: `workgroups` x 256 threads fill `lds_bytes` of their LDS with a pattern, spin `spin_cycles`, verify, `rounds` times.

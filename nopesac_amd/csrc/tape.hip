@@ -227,17 +227,24 @@ extern "C" int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** t
     return 0;
 }
 
-extern "C" int nopesac_tape_replay(void* tape, void* stream) {
+// Replay with the side chains on streams of the CALLER's choosing (side_streams[k] runs chain k + 1; missing / null entries fall back
+// to the tape's own streams): which hardware queue a side chain shares decides how well several replays overlap
+// (nopesac_amd/streams.py), and only the caller knows the queues of its streams.
+extern "C" int nopesac_tape_replay_on(void* tape, void* stream, void* const* side_streams, int n_side) {
     using namespace nps;
-    NPS_CHECK_ARG(tape, "tape_replay: null tape");
+    NPS_CHECK_ARG(tape && n_side >= 0 && (n_side == 0 || side_streams), "tape_replay: bad arguments");
     const Tape* t = (const Tape*)tape;
     hipStream_t caller = (hipStream_t)stream;
+    hipStream_t side[16];
+    const size_t ns = t->side.size();
+    NPS_CHECK_ARG(ns <= 16, "tape_replay: more than 16 side chains");
+    for (size_t c = 0; c < ns; ++c) side[c] = ((int)c < n_side && side_streams[c]) ? (hipStream_t)side_streams[c] : t->side[c];
     if (t->n_chains > 1) {                                   // the side streams start behind everything the caller has enqueued
         TAPE_HIP(hipEventRecord(t->start_ev, caller), "hipEventRecord(start)");
-        for (hipStream_t q : t->side) TAPE_HIP(hipStreamWaitEvent(q, t->start_ev, 0), "hipStreamWaitEvent(start)");
+        for (size_t c = 0; c < ns; ++c) TAPE_HIP(hipStreamWaitEvent(side[c], t->start_ev, 0), "hipStreamWaitEvent(start)");
     }
     for (const TapeOp& op : t->ops) {
-        hipStream_t st = op.chain == 0 ? caller : t->side[op.chain - 1];
+        hipStream_t st = op.chain == 0 ? caller : side[op.chain - 1];
         for (int w : op.waits) TAPE_HIP(hipStreamWaitEvent(st, t->events[w], 0), "hipStreamWaitEvent");
         hipError_t e = hipSuccess;
         if (op.kind == TAPE_NOP) {
@@ -258,12 +265,14 @@ extern "C" int nopesac_tape_replay(void* tape, void* stream) {
         }
         if (op.record >= 0) TAPE_HIP(hipEventRecord(t->events[op.record], st), "hipEventRecord");
     }
-    for (size_t c = 0; c < t->side.size(); ++c) {            // the caller's stream continues behind every side chain
-        TAPE_HIP(hipEventRecord(t->end_ev[c], t->side[c]), "hipEventRecord(end)");
+    for (size_t c = 0; c < ns; ++c) {                        // the caller's stream continues behind every side chain
+        TAPE_HIP(hipEventRecord(t->end_ev[c], side[c]), "hipEventRecord(end)");
         TAPE_HIP(hipStreamWaitEvent(caller, t->end_ev[c], 0), "hipStreamWaitEvent(end)");
     }
     return 0;
 }
+
+extern "C" int nopesac_tape_replay(void* tape, void* stream) { return nopesac_tape_replay_on(tape, stream, nullptr, 0); }
 
 extern "C" int nopesac_tape_destroy(void* tape) {
     delete (nps::Tape*)tape;

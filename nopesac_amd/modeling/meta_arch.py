@@ -248,7 +248,7 @@ class PlaneTR_NopeSAC(nn.Module):
             torch.cuda.current_stream().wait_event(st.pop("clone_done"))
         if st["graph"] is not None:
             if st.get("tape") is not None:
-                st["tape"].replay()                            # the recorded launches, on the caller's current stream
+                st["tape"].replay(sides=self._tape_sides())   # the recorded launches, on the caller's current stream
             else:
                 st["graph"].replay()
             return st["out"]
@@ -278,12 +278,18 @@ class PlaneTR_NopeSAC(nn.Module):
                 warnings.warn("nopesac_amd: launch tape unavailable, replaying the whole hipGraph instead: %s" % (e,))
                 self.__dict__["tape_error"] = str(e)
         if st["tape"] is not None:
-            st["tape"].replay()                                # capture does not execute: run this batch
+            st["tape"].replay(sides=self._tape_sides())       # capture does not execute: run this batch
         else:
             if hasattr(g, "instantiate") and want_tape:
                 g.instantiate()                                # (keep_graph=True defers the instantiation)
             g.replay()
         return out
+
+    def _tape_sides(self):
+        """The side stream this model would use for a batch on the current stream (bound by streams.StreamSet.bind or created by an
+        earlier eager call): the tape's side chain runs there, on a hardware queue the caller chose."""
+        side = (self._side_stream or {}).get(torch.cuda.current_stream().cuda_stream)
+        return [side] if side is not None else None
 
     def calibrate_fp8(self, batched_inputs: List[dict]) -> dict:
         """Static activation scales of the fp8 backbone mode (MODEL.AMD.BACKBONE_FP8) from representative pairs; returns them."""

@@ -107,7 +107,12 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
     t0, n_done, t_compute = time.perf_counter(), 0, 0.0
     on_gpu = torch.cuda.is_available() and next(model.parameters()).is_cuda
     depth = max(1, inflight) if on_gpu else 1
-    streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else []
+    streams = []
+    if depth > 1:
+        # one hardware queue per batch stream, the pose-net side stream on its batch's queue (streams.py: two batch streams on one
+        # queue - what a fresh process gets for streams 3 and 4 - serialise those batches: 2560 instead of 3240 pairs/s)
+        from .streams import stream_set
+        streams = stream_set(depth, next(model.parameters()).device, 0).bind(model).mains
     if depth > 1 and getattr(model, "use_hip_graph", False):
         model.graph_slots = max(model.graph_slots, depth)      # a graph slot's outputs must outlive the batches submitted after it
     pending = []

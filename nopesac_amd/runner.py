@@ -130,10 +130,18 @@ class InflightLoop:
     complete when its event has fired (checked before the slot is reused and by `drain`).  On a CPU (the gloo tests) the same
     control flow runs without streams / events."""
 
-    def __init__(self, n_slots: int, rows_per_rank: int, device=None, world: int = 1):
+    def __init__(self, n_slots: int, rows_per_rank: int, device=None, world: int = 1, side_shift: Optional[int] = 0):
+        """side_shift: see streams.StreamSet (which hardware queue a batch's pose-net side stream shares); None = plain
+        torch.cuda.Stream()s, whatever queues the runtime hands out."""
         self.n_slots = max(1, int(n_slots))
         self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_slots)] if self.cuda else [None] * self.n_slots
+        self.stream_set = None
+        if self.cuda and side_shift is not None:
+            from .streams import stream_set
+            self.stream_set = stream_set(self.n_slots, device, side_shift)
+            self.streams = self.stream_set.mains
+        else:
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_slots)] if self.cuda else [None] * self.n_slots
         self.host_bufs = [torch.empty(world * rows_per_rank, METRIC_WIDTH, dtype=torch.float32) for _ in range(self.n_slots)]
         if self.cuda:
             self.host_bufs = [b.pin_memory() for b in self.host_bufs]

@@ -39,12 +39,18 @@ class LaunchTape:
         self.counts = {"kernels": counts[0], "memsets": counts[1], "memcpys": counts[2], "streams": counts[3]}
         self._get_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
-    def replay(self, stream: int = None):
-        """Enqueue the recorded launches on `stream` (a raw hipStream_t as int; default: torch's current stream)."""
+    def replay(self, stream: int = None, sides=None):
+        """Enqueue the recorded launches on `stream` (a raw hipStream_t as int; default: torch's current stream).  `sides`: streams
+        (torch.cuda.Stream or raw ints) for the tape's side chains instead of its own ones - see streams.StreamSet."""
         if stream is None:
             stream = (self._get_stream(torch._C._cuda_getDevice()) if self._get_stream is not None
                       else torch.cuda.current_stream().cuda_stream)
-        rc = self._lib.nopesac_tape_replay(self._h, stream)
+        if sides:
+            raw = [int(getattr(s, "cuda_stream", s)) for s in sides]
+            arr = (ctypes.c_void_p * len(raw))(*raw)
+            rc = self._lib.nopesac_tape_replay_on(self._h, stream, arr, len(raw))
+        else:
+            rc = self._lib.nopesac_tape_replay(self._h, stream)
         if rc != 0:
             _lib.check(rc, "nopesac_tape_replay")
 

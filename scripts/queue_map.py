@@ -22,18 +22,27 @@ model = bench.build_model(dev, 50, "bfloat16")
 ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
 if "mimic_autotune" in mimic:
     model.autotune(B)
-streams = [torch.cuda.Stream() for _ in range(4)]
-dummies = [torch.cuda.Stream() for _ in range(pad)]
-sides = [torch.cuda.Stream(priority=prio) for _ in range(4)]
-model._side_stream = {s.cuda_stream: e for s, e in zip(streams, sides)}
+policy = [a for a in sys.argv[3:] if a.startswith("shift")]
+if policy:
+    from nopesac_amd.streams import StreamSet
+    model.autotune(1)                                   # (library loaded, kernels resident before the probe)
+    ss = StreamSet(4, dev, side_shift=int(policy[0][5:])).bind(model)
+    streams = ss.mains
+    print("stream set:", ss.describe(), flush=True)
+else:
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    dummies = [torch.cuda.Stream() for _ in range(pad)]
+    sides = [torch.cuda.Stream(priority=prio) for _ in range(4)]
+    model._side_stream = {s.cuda_stream: e for s, e in zip(streams, sides)}
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640)).float()
 host = raw.pin_memory()
 inputs = [{"0": {"image": host[i], "image_id": "a%d" % i, "file_name": ""}, "1": {"image": host[B + i], "image_id": "b%d" % i, "file_name": ""}}
           for i in range(B)]
 forced = bench.make_forced(B, 32, 50, dev, 7)
-if "mimic_resident" in mimic:                       # what bench.py's timed loop does first: forwards on resident inputs
+heat = [int(a[4:]) for a in sys.argv[3:] if a.startswith("heat")]
+if "mimic_resident" in mimic or heat:               # what bench.py's timed loop does first: forwards on resident inputs
     rawd = raw.to(dev)
-    for i in range(12):
+    for i in range(heat[0] if heat else 12):
         with torch.no_grad(), torch.cuda.stream(streams[i % 4]):
             model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=rawd)
     torch.cuda.synchronize()
@@ -97,8 +106,17 @@ def run(n, depth=4):
     return (time.perf_counter() - t0) / n
 
 
+def mhz():
+    t = ops.clock_probe(400000)
+    torch.cuda.synchronize()
+    t = t.tolist()
+    return 100.0 * t[0] / max(t[1], 1)
+
+
 model.infer_iter = 0
+print("engine clock before the loop: %.0f MHz" % mhz(), flush=True)
 run(12)
 best = min(run(24) for _ in range(3))
 print("   per step (last run): " + "  ".join("%s %.2f" % (k, (1e3 if k != "gpu_ms" else 1.0) * v / 24) for k, v in T.items()), flush=True)
+print("engine clock after the loop: %.0f MHz" % mhz(), flush=True)
 print("pad %d side_priority %d tape %d %s: %.2f ms/step = %.0f pairs/s  %s" % (pad, prio, use_tape, mimic, 1e3 * best, B / best, getattr(model, "tape_counts", "")), flush=True)

@@ -8,7 +8,7 @@ from nopesac_amd.config import get_cfg  # noqa: E402
 from nopesac_amd.evaluation import PoseEvaluator  # noqa: E402
 from nopesac_amd.registry import build_model  # noqa: E402
 from nopesac_amd.synth import synth_pair, synth_state_dict  # noqa: E402
-B, N = int(os.environ.get("B", "32")), int(os.environ.get("N", "256"))
+B, N = int(os.environ.get("B", "32")), int(os.environ.get("N", "1024"))
 cfg = get_cfg()
 cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
 cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r3.json")])
