@@ -816,3 +816,25 @@ def test_score_maps_reproducible_next_to_mfma_kernels(device):
         torch.cuda.synchronize()
         bad += sum(1 for o in outs if not (torch.equal(o["normal_score"], ref["normal_score"]) and torch.equal(o["param_score"], ref["param_score"])))
     assert bad == 0, "%d of 96 launches differ from the idle-GPU result" % bad
+
+
+def test_stream_set_places_streams_by_hardware_queue(device):
+    """streams.StreamSet: the probe (a tiny kernel behind another stream's spin kernel) sorts candidate streams into hardware-queue
+    classes; the batch streams it hands out are pairwise on DIFFERENT queues (as long as there are queues left), side stream i shares
+    the queue of batch stream (i + side_shift) % n."""
+    from nopesac_amd.streams import StreamSet, shares_queue
+    for shift in (0, 1):
+        ss = StreamSet(4, device, side_shift=shift)
+        d = ss.describe()
+        assert 2 <= d["queue_classes"] <= 16 and sum(d["class_sizes"]) == len(ss.pool)
+        n_distinct = min(4, d["queue_classes"])
+        assert len(set(d["batch_stream_class"][:n_distinct])) == n_distinct
+        scratch = torch.zeros(4, device=device, dtype=torch.int64)
+        torch.cuda.synchronize()
+        for i in range(n_distinct):
+            for j in range(i + 1, n_distinct):
+                assert not shares_queue(ss.mains[i], ss.mains[j], scratch), (i, j)
+        if d["queue_classes"] >= 4:
+            for i in range(4):
+                assert d["side_stream_class"][i] == d["batch_stream_class"][(i + shift) % 4]
+                assert shares_queue(ss.mains[(i + shift) % 4], ss.sides[i], scratch)
