@@ -463,12 +463,18 @@ def main():
         # the same K steps again, submitted through the launch tape instead of ~270 Python-issued launches per step (outside the
         # headline's timed region; single-process runs only: a rank whose capture failed would leave the others in a barrier)
         if capture_slots():
+            # a replay submits a batch in < 1 ms: keep two submissions as far apart as eager launching does (0.45 of the eager step
+            # time), or the slots re-submit together and run in lockstep (runner.InflightLoop.step)
+            loop.pace_s = 0.45 * elapsed / args.steps
             el_t, host_t, _ = timed(args.steps)
             tape_record = {"value": round(world * B * args.steps / el_t, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * el_t / args.steps, 3),
                            "steps": args.steps, "host_launch_ms_per_step": round(host_t, 2), "nodes": last.get("tape_counts"),
+                           "min_ms_between_submissions": round(1e3 * loop.pace_s, 2),
                            "replay": "launch tape" if "tape_counts" in last else "whole hipGraph",
                            "note": "the headline's K steps repeated with every slot's forward captured once and re-issued by "
-                                   "nopesac_tape_replay (csrc/tape.hip): same kernels, same streams, no Python between launches"}
+                                   "nopesac_tape_replay_on (csrc/tape.hip): same kernels, same streams, no Python between launches; the host "
+                                   "thread sleeps between submissions"}
+            loop.pace_s = 0.0
         graphs = [None] * n_slots
         barrier()
     ms_per_step = 1e3 * elapsed / args.steps
@@ -778,8 +784,16 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
         t0 = time.perf_counter()
         pending = []
         ts, tf = 0.0, 0.0
+        period, last = 0.0, 0.0
         for i in range(n):
+            if model.use_hip_graph and period > 0.0:                            # tape mode: pace the submissions (run.inference_on_dataset does the same)
+                rest = 0.45 * period - (time.perf_counter() - last)
+                if rest > 0.0:
+                    time.sleep(rest)
             a = time.perf_counter()
+            if i > 0:
+                period = (a - last) if period == 0.0 else 0.8 * period + 0.2 * (a - last)
+            last = a
             pending.append(submit(i % depth))
             bq = time.perf_counter()
             ts += bq - a

@@ -116,6 +116,7 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
     if depth > 1 and getattr(model, "use_hip_graph", False):
         model.graph_slots = max(model.graph_slots, depth)      # a graph slot's outputs must outlive the batches submitted after it
     pending = []
+    pace, period, last_submit = bool(getattr(model, "use_hip_graph", False)), 0.0, 0.0
 
     def consume(batch, outputs):
         nonlocal n_done
@@ -140,6 +141,16 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
             t1 = time.perf_counter()
             if depth > 1:
                 st = streams[bi % depth]
+                if pace and period > 0.0:
+                    # graph / tape mode submits a batch in ~1 ms: keep submissions 0.45 of a batch period apart, as eager launching
+                    # does by itself, or batches that finish together restart together and run in lockstep (runner.InflightLoop.step)
+                    rest = 0.45 * period - (time.perf_counter() - last_submit)
+                    if rest > 0.0:
+                        time.sleep(rest)
+                now = time.perf_counter()
+                if bi > 0:
+                    period = (now - last_submit) if period == 0.0 else 0.8 * period + 0.2 * (now - last_submit)
+                last_submit = now
                 with torch.cuda.stream(st):
                     model.infer_iter += 1
                     dev_out = model.forward_device(batch)
