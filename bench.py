@@ -767,6 +767,8 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
     def pipelined(n, depth=2):
         # `depth` batches in flight: batch i's copies and forward are enqueued (their own HIP stream) before the results of batch
         # i - depth + 1 are fetched and packaged - what a prefetching evaluation loop does; results are still complete per-pair dicts
+        from nopesac_amd.streams import stream_set
+        streams = stream_set(depth, model.device, 0).bind(model).mains       # streams picked by hardware queue, as run.inference_on_dataset does
         def submit(slot):
             with torch.no_grad(), torch.cuda.stream(streams[slot]):
                 model.infer_iter += 1

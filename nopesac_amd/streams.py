@@ -11,8 +11,11 @@ another stream finishes early iff the two streams are on different queues.  `Str
 queue classes with that probe and picks the batch / side streams by class:
 
     batch stream i      : its own queue class, for every i (so never behind another batch's launches)
-    side stream of i    : a stream in the class of batch stream (i + side_shift) % n   (side_shift = 1: the pose net of batch i
-                          queues behind the batch that was submitted BEFORE it - the one furthest along; 0 = behind its own batch)
+    side stream of i    : a queue no batch stream uses while there is one (fewer slots than queues: the pose net then overlaps with
+                          its own batch), else a stream in the class of batch stream (i + side_shift) % n.  side_shift = 0 (behind
+                          its own batch: the four queues stay independent) is the default; measured at the drop-in boundary with 4
+                          slots: shift 0 / 1 / 2 / 3 = 3240 / 2340 / 2960 / 2990 pairs/s, queues as the runtime hands them out 2530
+                          (profiles/r3_o_stream_policy.txt); resident-input loop 3640 / - / 3700 / 3450, runtime's choice 3590
 
 Unused candidates stay alive (destroying one would change the reference counts the runtime balances by)."""
 from __future__ import annotations
@@ -75,18 +78,18 @@ class StreamSet:
             used[id(c)] += 1
         self.sides: List[Optional[torch.cuda.Stream]] = [None] * self.n
         if with_sides:
+            free = [c for c in order[self.n:]]                          # queues no batch stream sits on (fewer slots than queues)
             for i in range(self.n):
-                c = order[(i + side_shift) % self.n % len(order)]
+                if free:                                                # an otherwise idle queue: the pose net overlaps with its own batch
+                    c = free.pop(0)
+                else:
+                    c = order[(i + side_shift) % self.n % len(order)]
                 k = used[id(c)]
                 if k < len(c):
                     self.sides[i] = c[k]
                     used[id(c)] += 1
-                else:                                                   # class exhausted: any unused candidate
-                    rest = [s for cc in order for s in cc[used[id(cc)]:]]
-                    self.sides[i] = rest[0] if rest else torch.cuda.Stream(device=self.device)
-                    for cc in order:
-                        if rest and rest[0] in cc:
-                            used[id(cc)] += 1
+                else:                                                   # class exhausted: a new stream, wherever the runtime puts it
+                    self.sides[i] = torch.cuda.Stream(device=self.device)
         self.queue_classes = len(self.classes)
 
     def bind(self, model) -> "StreamSet":

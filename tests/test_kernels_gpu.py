@@ -834,7 +834,11 @@ def test_stream_set_places_streams_by_hardware_queue(device):
         for i in range(n_distinct):
             for j in range(i + 1, n_distinct):
                 assert not shares_queue(ss.mains[i], ss.mains[j], scratch), (i, j)
-        if d["queue_classes"] >= 4:
+        if d["queue_classes"] == 4:                                  # as many slots as queues: side i behind batch (i + shift) % 4
             for i in range(4):
                 assert d["side_stream_class"][i] == d["batch_stream_class"][(i + shift) % 4]
                 assert shares_queue(ss.mains[(i + shift) % 4], ss.sides[i], scratch)
+    two = StreamSet(2, device)                                        # fewer slots than queues: the side streams get the idle queues
+    d = two.describe()
+    if d["queue_classes"] >= 4:
+        assert len(set(d["batch_stream_class"] + d["side_stream_class"])) == 4
