@@ -38,6 +38,15 @@ template <> struct VecT<float, 4> { typedef f32x4 type; };
 template <> struct VecT<float, 1> { typedef float type; };
 
 // Shared epilogue (see the comment inside): acc -> LDS (f32) -> 8-channel chunks -> scale/shift/residual/act -> store.
+// LDS-only workgroup barrier: orders this wave's LDS accesses and synchronises WITHOUT the vmcnt(0) that __syncthreads() carries -
+// between the passes of an epilogue that would wait for the previous pass's global STORES to be acknowledged (microseconds under load).
+#define NPS_LDS_SYNC()                                         \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    } while (0)
+
 template <int BM, int BN, int TM, int TN, int WAVES_M = 2, int WAVES_N = 2>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi, int lds_bytes, const ConvParams& p, int m0, int n0,
                                               int bz, int wm, int wn, int lane, int tid) {
@@ -68,7 +77,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                         *(f32x4*)(epi + row * ELD + c) = v;
                     }
         }
-        __syncthreads();
+        NPS_LDS_SYNC();                                  // staged tile visible (the K loop ended with a full barrier: no DMA in flight)
         for (int idx = tid; idx < BM * (EN / 8); idx += NTHREADS) {
             const int row = idx / (EN / 8), ch = (idx % (EN / 8)) * 8;
             const int m = m0 + row, n = n0 + pass * EN + ch;
@@ -126,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* epi,
                 }
             }
         }
-        if (pass + 1 < NPASS) __syncthreads();
+        if (pass + 1 < NPASS) NPS_LDS_SYNC();            // every wave is done reading the staging rows; the stores stay in flight
     }
 }
 

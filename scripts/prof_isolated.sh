@@ -4,7 +4,7 @@
 TAG=${1:-iso}; shift
 R=$PWD; export TMPDIR=/tmp; cd /tmp
 STEPS=6
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG} -o bench -- python $R/bench.py --steps $STEPS --warmup 2 --inflight 1 --single-stream --no-cpu-baseline --no-accuracy "$@" > $R/gpurun_out/prof_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG} -o bench -- python $R/bench.py --steps $STEPS --warmup 2 --inflight 1 --single-stream --no-cpu-baseline --no-accuracy --no-boundary --no-other-configs --no-tape --no-fp32-path "$@" > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd $R
 tail -1 gpurun_out/prof_${TAG}.log | cut -c1-200
 python - <<PY
