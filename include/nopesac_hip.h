@@ -235,9 +235,17 @@ int nopesac_layernorm_ex(const float* x, const float* res, const float* gamma, c
 /* out = a + b (b row index = row % b_rows); f32. */
 int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream);
 
+/* a and a + b as bf16 (a_bf16, ab_bf16: [rows, D], D % 4 == 0): the operands of the first encoder layer's v and q|k projections
+ * (src and src + pos, transformer.py: TransformerEncoderLayer.forward_post) in one pass over the f32 rows. */
+int nopesac_add_rows_bf16(const float* a, const float* b, void* a_bf16, void* ab_bf16, int rows, int D, int b_rows, void* stream);
+
 /* row softmax over the last dim (<= 1024); camera_head.py:1131 (after the NHWC re-layout the 300
  * view-2 positions are the channel dim). f32. */
 int nopesac_softmax_rows(const float* x, float* y, int rows, int D, void* stream);
+
+/* The same softmax written into rows of out_ld >= D elements (columns D .. out_ld-1 = 0), f32 or bf16 (out_dt = NPS_DT_F32 /
+ * NPS_DT_BF16): the affinity volume in the channel-padded layout and the type the branch convs read (camera_head.py:1131-1133). */
+int nopesac_softmax_rows_pad(const float* x, void* y, int rows, int D, int out_ld, int out_dt, void* stream);
 
 /* Multi-head softmax attention for short sequences (<= 512 keys), head dim 32.
  *   o[b,i,h,:] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] ) v[b,j,h,:]

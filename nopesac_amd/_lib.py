@@ -52,6 +52,8 @@ SIGNATURES = {
     "nopesac_layernorm_ex": [P, P, P, P, P, P, I, P, P, P, I, I, F, P],
     "nopesac_add_rows": [P, P, P, I, I, I, P],
     "nopesac_softmax_rows": [P, P, I, I, P],
+    "nopesac_softmax_rows_pad": [P, P, I, I, I, I, P],
+    "nopesac_add_rows_bf16": [P, P, P, P, I, I, I, P],
     "nopesac_attention_small": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16io": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],

@@ -326,6 +326,23 @@ __global__ void add_rows_kernel(const float* __restrict__ a, const float* __rest
     }
 }
 
+// a and a + b (b row index = row % b_rows) as bf16: the two operand tensors of the first encoder layer's q|k and v GEMMs in one pass
+// over the f32 rows (was: a cast, an add and another cast); 4 elements per thread, D % 4 == 0.
+__global__ void add_rows_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ a16,
+                                     bf16_t* __restrict__ ab16, long long total4, int D, int b_rows) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 4, row = e / D;
+        const int d = (int)(e - row * D);
+        const float4 av = *reinterpret_cast<const float4*>(a + e);
+        const float4 bv = *reinterpret_cast<const float4*>(b + (row % b_rows) * D + d);
+        ushort4 o, o2;
+        o.x = f32_to_bf16(av.x); o.y = f32_to_bf16(av.y); o.z = f32_to_bf16(av.z); o.w = f32_to_bf16(av.w);
+        o2.x = f32_to_bf16(av.x + bv.x); o2.y = f32_to_bf16(av.y + bv.y); o2.z = f32_to_bf16(av.z + bv.z); o2.w = f32_to_bf16(av.w + bv.w);
+        *reinterpret_cast<ushort4*>(a16 + e) = o;
+        *reinterpret_cast<ushort4*>(ab16 + e) = o2;
+    }
+}
+
 // row softmax, one wave per row, D <= 1024
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            int rows, int D) {
@@ -350,6 +367,38 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int i = 0; i < per; ++i) {
         const int d = lane + i * 64;
         if (d < D) y[(long long)row * D + d] = v[i] / s;
+    }
+}
+
+// the same softmax written into rows of `out_ld` >= D elements, f32 or bf16, columns D .. out_ld-1 zero: the affinity volume in the
+// layout and type the branch convs read (was: softmax, a zero fill of the padded tensor and a strided cast copy)
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_pad_kernel(const float* __restrict__ x, TO* __restrict__ y, int rows, int D, int out_ld) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[16];
+    float m = -INFINITY;
+    const int per = (D + 63) / 64;
+    for (int i = 0; i < per; ++i) {
+        const int d = lane + i * 64;
+        v[i] = d < D ? x[(long long)row * D + d] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = expf(v[i] - m);
+        s += v[i];
+    }
+    s = wave_sum(s);
+    const int per_o = (out_ld + 63) / 64;
+    for (int i = 0; i < per_o; ++i) {
+        const int d = lane + i * 64;
+        if (d >= out_ld) continue;
+        const float r = (d < D && i < per) ? v[i] / s : 0.f;
+        if constexpr (sizeof(TO) == 2) y[(long long)row * out_ld + d] = f32_to_bf16(r);
+        else y[(long long)row * out_ld + d] = r;
     }
 }
 
@@ -512,6 +561,25 @@ extern "C" int nopesac_layernorm_ex(const float* x, const float* res, const floa
 extern "C" int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream) {
     NPS_CHECK_ARG(a && b && out && rows > 0 && D > 0 && b_rows > 0, "add_rows: bad args");
     hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for((long long)rows * D)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long long)rows * D, D, b_rows);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_add_rows_bf16(const float* a, const float* b, void* a_bf16, void* ab_bf16, int rows, int D, int b_rows, void* stream) {
+    NPS_CHECK_ARG(a && b && a_bf16 && ab_bf16 && rows > 0 && D > 0 && D % 4 == 0 && b_rows > 0, "add_rows_bf16: bad args (D %% 4 == 0)");
+    NPS_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0 && (((uintptr_t)a_bf16 | (uintptr_t)ab_bf16) & 7) == 0, "add_rows_bf16: alignment");
+    const long long total4 = (long long)rows * D / 4;
+    hipLaunchKernelGGL(add_rows_bf16_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, a, b, (bf16_t*)a_bf16, (bf16_t*)ab_bf16, total4, D,
+                       b_rows);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_softmax_rows_pad(const float* x, void* y, int rows, int D, int out_ld, int out_dt, void* stream) {
+    NPS_CHECK_ARG(x && y && rows > 0 && D > 0 && D <= 1024 && out_ld >= D && out_ld <= 1024, "softmax_rows_pad: bad args");
+    NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16, "softmax_rows_pad: out_dt");
+    if (out_dt == NPS_DT_BF16)
+        hipLaunchKernelGGL(softmax_rows_pad_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, rows, D, out_ld);
+    else
+        hipLaunchKernelGGL(softmax_rows_pad_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (float*)y, rows, D, out_ld);
     NPS_LAUNCH_RET();
 }
 

@@ -111,16 +111,13 @@ class PlaneCameraHead(ParamModule):
         # correlation volume (:1117-1133): channel = view-2 position in (w,h) order, softmax over channels
         x2t = ops.transpose_hw_rows(x2.reshape(B, h * w, 256), h, w)
         corr = ops.conv2d(x1, x2t.view(B, h * w, 1, 1, 256), batched_weights=True)          # [B,h,w,h*w]
-        aff = ops.softmax_rows(corr)
         # bf16 GEMM mode: the branch convs round their f32 activations to bf16 while staging them anyway, so the affinity volume and
         # the activations between the branch convs are STORED as bf16 (the same values) - the twelve convs then run on the bf16
         # conv kernels instead of the register-staged mixed-precision one (0.43 -> 0.2 ms per step) and move half the bytes
         gd = self._gd("branches")
-        act_dt = torch.bfloat16 if gd == torch.bfloat16 else aff.dtype
-        if (h * w) % 8 or act_dt != aff.dtype:           # zero-padded channels (see pack): 300 -> 304
-            aff_p = torch.zeros(B, h, w, self.CORR_PAD if (h * w) % 8 else h * w, device=aff.device, dtype=act_dt)
-            aff_p[..., :h * w] = aff
-            aff = aff_p
+        act_dt = torch.bfloat16 if gd == torch.bfloat16 else torch.float32
+        # softmax over the channels, written in the conv operand type with zero-padded channels (see pack): 300 -> 304
+        aff = ops.softmax_rows(corr, out_dtype=act_dt, pad_to=self.CORR_PAD if (h * w) % 8 else h * w)
 
         def branch(name, fc, reg):
             t = aff

@@ -233,8 +233,7 @@ class PlaneTRHead(ParamModule):
         def ln(x, prefix, addend=None, want=("y",)):
             return ops.layernorm_ex(x, self.raw(prefix + ".weight"), self.raw(prefix + ".bias"), addend=addend, want=want)
 
-        src16 = src.to(bf)
-        q_in16 = ops.add_rows(src, pos).to(bf)
+        src16, q_in16 = ops.add_rows_bf16(src, pos)            # src and src + pos as bf16 GEMM operands, one launch
         for i in range(6):
             p = f"context_SA.layers.{i}"
             W = P[p]
@@ -258,7 +257,10 @@ class PlaneTRHead(ParamModule):
         k_all = lin(memk16, P["cross_k_all"].w2d(bf), P["cross_k_all"].bias, out_dtype=bf)          # [B*L, 6*256]
         v_all = lin(mem16, P["cross_v_all"].w2d(bf), P["cross_v_all"].bias, out_dtype=bf)
         qpos = self.raw("query_embed.weight")
-        tgt = torch.zeros(B * nq, 256, device=src.device, dtype=f32)
+        zc = self.__dict__.setdefault("_zero_tgt", {})          # the decoder's all-zero start (read-only: every layer writes a new tensor)
+        tgt = zc.get((B * nq, src.device))
+        if tgt is None:
+            tgt = zc[(B * nq, src.device)] = torch.zeros(B * nq, 256, device=src.device, dtype=f32)
         nin = ln(tgt, "context2plane_decoder.layers.0.norm1", addend=qpos, want=("y16", "y2_16"))
         n16, npos16, hs = nin["y16"], nin["y2_16"], None
         for i in range(6):

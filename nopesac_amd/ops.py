@@ -539,12 +539,30 @@ def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+def softmax_rows(x: torch.Tensor, out_dtype=None, pad_to: int = 0) -> torch.Tensor:
+    """softmax over the last dim; with out_dtype (float32 / bfloat16) and / or pad_to > D the result is written into rows of
+    max(D, pad_to) elements of that type, zero beyond D (one launch instead of softmax + zero fill + strided cast copy)."""
     _chk(x, torch.float32)
     D = x.shape[-1]
-    y = torch.empty_like(x)
-    _lib.check(_L().nopesac_softmax_rows(_p(x), _p(y), x.numel() // D, D, _stream()), "nopesac_softmax_rows")
+    out_dtype = out_dtype or torch.float32
+    if out_dtype == torch.float32 and pad_to <= D:
+        y = torch.empty_like(x)
+        _lib.check(_L().nopesac_softmax_rows(_p(x), _p(y), x.numel() // D, D, _stream()), "nopesac_softmax_rows")
+        return y
+    ld = max(D, pad_to)
+    y = torch.empty(x.shape[:-1] + (ld,), device=x.device, dtype=out_dtype)
+    _lib.check(_L().nopesac_softmax_rows_pad(_p(x), _p(y), x.numel() // D, D, ld, _DT[out_dtype], _stream()), "nopesac_softmax_rows_pad")
     return y
+
+
+def add_rows_bf16(a: torch.Tensor, b: torch.Tensor):
+    """(a as bf16, a + b as bf16), b broadcast over blocks of b.shape[0] rows; one launch."""
+    _chk(a, torch.float32); _chk(b, torch.float32)
+    D = a.shape[-1]
+    a16 = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    ab16 = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    _lib.check(_L().nopesac_add_rows_bf16(_p(a), _p(b), _p(a16), _p(ab16), a.numel() // D, D, b.numel() // D, _stream()), "nopesac_add_rows_bf16")
+    return a16, ab16
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Lq: int, Lk: int, heads: int, scale: float,
