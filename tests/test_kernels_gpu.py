@@ -842,3 +842,31 @@ def test_stream_set_places_streams_by_hardware_queue(device):
     d = two.describe()
     if d["queue_classes"] >= 4:
         assert len(set(d["batch_stream_class"] + d["side_stream_class"])) == 4
+
+
+@pytest.mark.parametrize("rows,D,pad_to,dt", [(7, 300, 304, torch.bfloat16), (5, 300, 304, torch.float32), (9, 64, 64, torch.bfloat16),
+                                              (3, 129, 192, torch.bfloat16), (4, 300, 0, torch.float32)])
+def test_softmax_rows_padded_output(device, rows, D, pad_to, dt):
+    """nopesac_softmax_rows_pad: the plain kernel's f32 values, rounded to the requested type, in rows of max(D, pad_to) elements
+    with zeros behind column D (what camera_head.pixel_pose_net used to build with a zero fill and a strided cast copy)."""
+    from nopesac_amd import ops
+    torch.manual_seed(rows * D)
+    x = torch.randn(rows, D, device=device) * 4
+    ref = ops.softmax_rows(x)
+    y = ops.softmax_rows(x, out_dtype=dt, pad_to=pad_to)
+    ld = max(D, pad_to)
+    assert y.shape == (rows, ld) and y.dtype == dt
+    assert torch.equal(y[:, :D], ref.to(dt))
+    assert ld == D or float(y[:, D:].float().abs().max()) == 0.0
+    assert float((ref - torch.softmax(x, -1)).abs().max()) < 1e-6
+
+
+def test_add_rows_bf16(device):
+    """nopesac_add_rows_bf16 = (a.to(bf16), (a + b broadcast over row blocks).to(bf16)) exactly."""
+    from nopesac_amd import ops
+    torch.manual_seed(3)
+    a = torch.randn(6 * 300, 256, device=device)
+    b = torch.randn(300, 256, device=device)
+    a16, ab16 = ops.add_rows_bf16(a, b)
+    assert torch.equal(a16, a.to(torch.bfloat16))
+    assert torch.equal(ab16, (a.view(6, 300, 256) + b).view(-1, 256).to(torch.bfloat16))
