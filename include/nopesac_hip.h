@@ -235,6 +235,9 @@ int nopesac_layernorm_ex(const float* x, const float* res, const float* gamma, c
 /* out = a + b (b row index = row % b_rows); f32. */
 int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream);
 
+/* out[r] = [a[r] | b[r]] (f32 rows of Da and Db elements): the 7-vector (t, q) the matcher takes (camera_head.py:455). */
+int nopesac_concat_cols(const float* a, int Da, const float* b, int Db, float* out, int rows, void* stream);
+
 /* a and a + b as bf16 (a_bf16, ab_bf16: [rows, D], D % 4 == 0): the operands of the first encoder layer's v and q|k projections
  * (src and src + pos, transformer.py: TransformerEncoderLayer.forward_post) in one pass over the f32 rows. */
 int nopesac_add_rows_bf16(const float* a, const float* b, void* a_bf16, void* ab_bf16, int rows, int D, int b_rows, void* stream);
@@ -447,6 +450,11 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
 int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                            const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
                            int apply_sigmoid, void* stream);
+
+/* The two per-image operands of nopesac_mask_head_bf16 from the folded plane embeddings (fold f32 [B * nq][ld]: columns 0..255 mask
+ * weights, column 256 mask bias - the pixel-embedding conv folded into the plane-embedding MLP, planeTR_head.py:170-188): mask_w bf16
+ * in the kernel's per-image MFMA fragment order for nqp = 64 / 128 planes (planes >= nq zero), mask_b f32 [B][nqp].  One launch. */
+int nopesac_mask_operands(const float* fold, int ld, void* mask_w, float* mask_b, int B, int nq, int nqp, void* stream);
 
 /* Tail of one post-norm transformer encoder layer (transformer/transformer.py:183-199) for M tokens of width 256, FFN 1024:
  *   y1 = LN1(src + attn . wo^T + bo);  y2 = LN2(y1 + relu(y1 . w1^T + b1) . w2^T + b2)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "nopesac_encoder_tail_bf16": [P] * 13 + [I] + [P] * 3 + [I, P],
     "nopesac_resize_bilinear_u8": [P, I, I, I, P, I, I, P],
     "nopesac_mask_head_bf16": [P] * 9 + [I] * 5 + [P],
+    "nopesac_mask_operands": [P, I, P, P, I, I, I, P],
     "nopesac_decoder_tail_bf16": [P] * 13 + [I] + [P] * 4 + [I, P],
     "nopesac_conv3x3_c64_bf16": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_conv3x3_halo_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -54,6 +55,7 @@ SIGNATURES = {
     "nopesac_softmax_rows": [P, P, I, I, P],
     "nopesac_softmax_rows_pad": [P, P, I, I, I, I, P],
     "nopesac_add_rows_bf16": [P, P, P, P, I, I, I, P],
+    "nopesac_concat_cols": [P, I, P, I, P, I, P],
     "nopesac_attention_small": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16io": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],

@@ -564,6 +564,22 @@ extern "C" int nopesac_add_rows(const float* a, const float* b, float* out, int 
     NPS_LAUNCH_RET();
 }
 
+namespace nps {
+__global__ void concat_cols_kernel(const float* __restrict__ a, int Da, const float* __restrict__ b, int Db, float* __restrict__ out, int rows) {
+    const int D = Da + Db, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int r = i / D, c = i % D;
+    out[i] = c < Da ? a[r * Da + c] : b[r * Db + (c - Da)];
+}
+}  // namespace nps
+
+extern "C" int nopesac_concat_cols(const float* a, int Da, const float* b, int Db, float* out, int rows, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(a && b && out && rows > 0 && Da > 0 && Db > 0 && (long long)rows * (Da + Db) < (1ll << 31), "concat_cols: bad args");
+    hipLaunchKernelGGL(concat_cols_kernel, dim3((rows * (Da + Db) + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, Da, b, Db, out, rows);
+    NPS_LAUNCH_RET();
+}
+
 extern "C" int nopesac_add_rows_bf16(const float* a, const float* b, void* a_bf16, void* ab_bf16, int rows, int D, int b_rows, void* stream) {
     NPS_CHECK_ARG(a && b && a_bf16 && ab_bf16 && rows > 0 && D > 0 && D % 4 == 0 && b_rows > 0, "add_rows_bf16: bad args (D %% 4 == 0)");
     NPS_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0 && (((uintptr_t)a_bf16 | (uintptr_t)ab_bf16) & 7) == 0, "add_rows_bf16: alignment");

@@ -201,6 +201,39 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
 
 }  // namespace nps
 
+// The mask GEMM's per-image operands from the folded plane embeddings (plane_head.py: `fold` f32 [B * nq][ld], columns 0..255 = mask
+// weights, column 256 = mask bias): mw bf16 [B][nqp / 32][16 k-steps][2 halves][32 planes][8] (the MFMA fragment order this kernel
+// reads: lane = half * 32 + plane), mb f32 [B][nqp]; planes >= nq are zero.  One launch (was: two zero fills, two strided copies and
+// a permuting copy in torch).
+namespace nps {
+__global__ void mask_operands_kernel(const float* __restrict__ fold, int ld, bf16_t* __restrict__ mw, float* __restrict__ mb, int B, int nq,
+                                     int nqp) {
+    const long long total = (long long)B * nqp * 32;                        // 8-element groups
+    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(g & 31), h = (int)((g >> 5) & 1), kk = (int)((g >> 6) & 15);
+        const long long bt = g >> 10;                                        // b * (nqp / 32) + t
+        const int nt = nqp / 32, b = (int)(bt / nt), t = (int)(bt % nt), q = t * 32 + r;
+        us8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float* row = fold + ((long long)b * nq + q) * ld;
+        if (q < nq) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(row[kk * 16 + h * 8 + e]);
+        }
+        *reinterpret_cast<us8*>(mw + g * 8) = o;
+        if (kk == 0 && h == 0) mb[(long long)b * nqp + q] = q < nq ? row[256] : 0.f;
+    }
+}
+}  // namespace nps
+
+extern "C" int nopesac_mask_operands(const float* fold, int ld, void* mw, float* mb, int B, int nq, int nqp, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(fold && mw && mb && B > 0 && nq > 0 && nq <= nqp && (nqp == 64 || nqp == 128) && ld >= 257, "mask_operands: bad args");
+    NPS_CHECK_ARG(((uintptr_t)mw & 15) == 0, "mask_operands: mw must be 16-byte aligned");
+    const long long total = (long long)B * nqp * 32;
+    hipLaunchKernelGGL(mask_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fold, ld, (bf16_t*)mw, mb, B, nq, nqp);
+    NPS_LAUNCH_RET();
+}
+
 extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                                       const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
                                       int apply_sigmoid, void* stream) {

@@ -136,7 +136,10 @@ class PlaneCameraHead(ParamModule):
         P, gd = self.packed, self._gd("aim")
         rot_feat, rot_raw = run_stacks(rot0, [(P["rot_emb_proj"], ops.ACT_RELU, True), ([P["rots"]], ops.ACT_NONE, True)], gd)  # rot0 has w >= 0 (:695-696)
         rec_rot = ops.normalize_rows(rot_raw)
-        trans_feat, rec_trans = run_stacks(trans0 + 1e-10, [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
+        eps = self.__dict__.setdefault("_eps_row", {})
+        if trans0.device not in eps:
+            eps[trans0.device] = torch.full((1, trans0.shape[-1]), 1e-10, device=trans0.device, dtype=torch.float32)
+        trans_feat, rec_trans = run_stacks(ops.add_rows(trans0, eps[trans0.device]), [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
         return rec_trans, rec_rot, trans_feat, rot_feat
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
@@ -186,16 +189,19 @@ class PlaneCameraHead(ParamModule):
         n_all = sel["n_kept"]
         n1, n2 = n_all[:B].contiguous(), n_all[B:].contiguous()
         planes1, planes2 = sel["planes"][:B], sel["planes"][B:]
-        cam7 = torch.cat([rec_t, rec_r], dim=-1)                                             # :455
+        cam7 = ops.concat_cols(rec_t, rec_r) if rec_t.is_cuda else torch.cat([rec_t, rec_r], dim=-1)   # :455
         log_scores, A0 = matching_net(sel["feats"], n_all, cam7, planes1, planes2, self.matching_score_threshold)
         if forced_assignment is not None:       # benchmark-only K control, see PlaneTR_NopeSAC._force_k
             A0 = forced_assignment
         mark("matcher")
         ref = self.refine(A0, planes1, planes2, n1, n2, rec_t, rec_r, rec_tf, rec_rf, diagnostics)
         A1 = ops.refilter_assignment(A0, planes1, planes2, n1, n2, ref["pred_rot"], ref["pred_trans"])
-        zero_t = torch.zeros_like(trans0)
-        zero_r = torch.zeros_like(rot0)
-        zero_r[:, 0] = 1.0
+        zc = self.__dict__.setdefault("_zero_cam", {})          # the constant "camera_zero" pose (never written to)
+        if (B, trans0.device) not in zc:
+            zero_r = torch.zeros_like(rot0)
+            zero_r[:, 0] = 1.0
+            zc[(B, trans0.device)] = (torch.zeros_like(trans0), zero_r)
+        zero_t, zero_r = zc[(B, trans0.device)]
         cams = {"camera_zero": (zero_t, zero_r), "camera_init": (trans0, rot0), "camera_initRec": (rec_t, rec_r),
                 "camera_avgRef0": (ref["avg_trans"], ref["avg_rot"]), "camera_softRef0": (ref["pred_trans"], ref["pred_rot"]),
                 "camera": (ref["pred_trans"], ref["pred_rot"])}                             # sign NOT canonicalised (:596-601)

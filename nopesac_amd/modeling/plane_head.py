@@ -344,8 +344,7 @@ class PlaneTRHead(ParamModule):
             mark("ph.top_down")
             # (a planar [B,nq,h,w] output + valid-planes-only fetch in the post-selection is implemented and tested, but measured
             # slower - 581 vs 437 us: that kernel is bound by its per-(pixel, valid query) instruction stream, not by bytes)
-            heads["mask_prob"] = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, fold[:, :256].view(B, nq, 256),
-                                               fold[:, 256].contiguous().view(B, nq))
+            heads["mask_prob"] = ops.mask_head(c1, t1, l.wfrag(cd), l.scale, l.bias, None, None, fold=fold)
             return heads, hs.view(B, nq, 256)
         p1 = up_stage(p2, "up_conv1", cbr(c1, "c1_conv"))
         mark("ph.top_down")

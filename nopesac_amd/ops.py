@@ -555,6 +555,16 @@ def softmax_rows(x: torch.Tensor, out_dtype=None, pad_to: int = 0) -> torch.Tens
     return y
 
 
+def concat_cols(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[a | b] along the last dim of two contiguous f32 row tensors."""
+    _chk(a, torch.float32); _chk(b, torch.float32)
+    rows, Da, Db = a.shape[0], a.shape[-1], b.shape[-1]
+    _require(a.dim() == 2 and b.dim() == 2 and b.shape[0] == rows, "concat_cols: [rows, Da], [rows, Db]")
+    out = torch.empty(rows, Da + Db, device=a.device, dtype=torch.float32)
+    _lib.check(_L().nopesac_concat_cols(_p(a), Da, _p(b), Db, _p(out), rows, _stream()), "nopesac_concat_cols")
+    return out
+
+
 def add_rows_bf16(a: torch.Tensor, b: torch.Tensor):
     """(a as bf16, a + b as bf16), b broadcast over blocks of b.shape[0] rows; one launch."""
     _chk(a, torch.float32); _chk(b, torch.float32)
@@ -915,20 +925,27 @@ def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tenso
 
 
 def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scale, bias, mask_w: torch.Tensor, mask_b: torch.Tensor,
-              sigmoid: bool = True, want_p1: bool = False, planar: bool = False):
+              sigmoid: bool = True, want_p1: bool = False, planar: bool = False, fold: Optional[torch.Tensor] = None):
     """Fused lateral conv + bilinear add + per-image mask GEMM (csrc/mask_head.hip).  c1 [B,H,W,256] / t1 [B,H/2,W/2,256] bf16;
     mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] ([B,nq,H,W] when `planar`) (and p1 bf16 if asked)."""
     _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
     B, H, W, C = c1.shape
-    nq = mask_w.shape[1]
+    nq = mask_w.shape[1] if fold is None else fold.shape[0] // B
     _require(C == 256 and t1.shape == (B, H // 2, W // 2, 256) and nq <= 128 and nq % 2 == 0 and (H * W) % 128 == 0,
              'mask_head: C == 256, t1 at half resolution, nq even and <= 128, H * W a multiple of 128')
     nqp = 64 if nq <= 64 else 128                                                       # planes padded to whole pairs of 32-wide MFMA tiles
-    mw = torch.zeros(B, nqp, 256, device=c1.device, dtype=torch.bfloat16)
-    mw[:, :nq] = mask_w
-    mw = mw.view(B, nqp // 32, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()    # per-image MFMA fragment-major
-    mb = torch.zeros(B, nqp, device=c1.device, dtype=torch.float32)
-    mb[:, :nq] = mask_b
+    if fold is not None:          # both operands straight from the folded plane embeddings [B * nq, >= 257] f32, one launch
+        _chk(fold, torch.float32)
+        _require(fold.dim() == 2 and fold.shape[0] == B * nq and fold.shape[1] >= 257 and fold.is_contiguous(), "mask_head: fold [B * nq, >= 257]")
+        mw = torch.empty(B, nqp // 32, 16, 2, 32, 8, device=c1.device, dtype=torch.bfloat16)
+        mb = torch.empty(B, nqp, device=c1.device, dtype=torch.float32)
+        _lib.check(_L().nopesac_mask_operands(_p(fold), fold.shape[1], _p(mw), _p(mb), B, nq, nqp, _stream()), "nopesac_mask_operands")
+    else:
+        mw = torch.zeros(B, nqp, 256, device=c1.device, dtype=torch.bfloat16)
+        mw[:, :nq] = mask_w
+        mw = mw.view(B, nqp // 32, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()    # per-image MFMA fragment-major
+        mb = torch.zeros(B, nqp, device=c1.device, dtype=torch.float32)
+        mb[:, :nq] = mask_b
     prob = torch.empty((B, nq, H, W) if planar else (B, H, W, nq), device=c1.device, dtype=torch.float32)
     p1 = torch.empty(B, H, W, 256, device=c1.device, dtype=torch.bfloat16) if want_p1 else None
     rc = _L().nopesac_mask_head_bf16(_p(c1), _p(t1), _p(w_lat_frag), _p(scale), _p(bias), _p(mw), _p(mb), _p(prob), _p(p1), B, H, W, nq,

@@ -1,15 +1,35 @@
-"""Which torch (ATen) kernels still run inside one forward of the bench workload, and from which source lines: torch.profiler with
-stacks over one eager step.  usage: torch_ops_on_path.py"""
+"""Which torch (ATen) ops that launch a kernel still run inside one forward of the bench workload, and from which source lines
+(TorchDispatchMode + the Python stack).  usage: torch_ops_on_path.py"""
+import collections
 import os
 import sys
+import traceback
 
 import torch
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from nopesac_amd import ops  # noqa: E402
+
+QUIET = ("aten.empty", "aten.view", "aten.as_strided", "aten.slice", "aten.select", "aten.reshape", "aten._unsafe_view", "aten.expand",
+         "aten.permute", "aten.transpose", "aten.unsqueeze", "aten.squeeze", "aten.detach", "aten.alias", "aten.t.", "aten.unbind",
+         "aten.split", "aten.narrow", "aten.lift_fresh", "aten._local_scalar_dense", "aten.is_pinned", "aten.record_stream", "aten.unflatten",
+         "aten.flatten", "aten.chunk", "aten._reshape_alias", "aten.empty_like", "aten.empty_strided", "aten.new_empty")
+seen = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(QUIET):
+            fr = [f for f in traceback.extract_stack() if "/root/repo/" in f.filename or "nopesac_amd" in f.filename]
+            fr = [f for f in fr if "torch_ops_on_path" not in f.filename]
+            where = "%s:%d" % (fr[-1].filename.split("/root/repo/")[-1], fr[-1].lineno) if fr else "?"
+            seen[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+
 
 B = 32
 dev = torch.device("cuda:0")
@@ -21,19 +41,8 @@ with torch.no_grad():
     for _ in range(2):
         model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=raw)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with Log():
         model.forward_tensors(None, B, 480, 640, forced=forced, raw_images=raw)
-        torch.cuda.synchronize()
-import collections
-c = collections.Counter()
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or not getattr(ev, "kernels", None):
-        continue
-    if ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::") and getattr(ev.cpu_parent, "kernels", None):
-        continue                                              # count the outermost op that launched something
-    st = [f for f in (ev.stack or []) if "/root/repo" in f or "nopesac_amd" in f or "bench.py" in f]
-    where = st[0].split("/root/repo/")[-1] if st else (ev.stack[0] if ev.stack else "?")
-    c[(ev.name, where, len(ev.kernels))] += 1
-for (name, where, nk), n in sorted(c.items(), key=lambda kv: (kv[0][1], kv[0][0])):
-    print("%3d x %-20s (%d kernel%s)  %s" % (n, name, nk, "" if nk == 1 else "s", where))
-print("total torch launches:", sum(n * k[2] for k, n in c.items()))
+    torch.cuda.synchronize()
+for (name, where), n in sorted(seen.items(), key=lambda kv: kv[0][1]):
+    print("%3d x %-34s %s" % (n, name, where))

@@ -870,3 +870,22 @@ def test_add_rows_bf16(device):
     a16, ab16 = ops.add_rows_bf16(a, b)
     assert torch.equal(a16, a.to(torch.bfloat16))
     assert torch.equal(ab16, (a.view(6, 300, 256) + b).view(-1, 256).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,nq", [(3, 50), (2, 64), (2, 100), (1, 128), (2, 6)])
+def test_mask_operands_from_the_folded_embeddings(device, B, nq):
+    """nopesac_mask_operands (the mask head's per-image weights in MFMA fragment order + bias, zero-padded planes) equals the torch
+    formulation ops.mask_head used before (zero fill, strided cast copy, permuting copy)."""
+    from nopesac_amd import _lib, ops
+    torch.manual_seed(B * 1000 + nq)
+    fold = torch.randn(B * nq, 264, device=device)
+    nqp = 64 if nq <= 64 else 128
+    mw = torch.empty(B, nqp // 32, 16, 2, 32, 8, device=device, dtype=torch.bfloat16)
+    mb = torch.empty(B, nqp, device=device, dtype=torch.float32)
+    _lib.check(_lib.load().nopesac_mask_operands(fold.data_ptr(), 264, mw.data_ptr(), mb.data_ptr(), B, nq, nqp, ops._stream()), "nopesac_mask_operands")
+    ref_w = torch.zeros(B, nqp, 256, device=device, dtype=torch.bfloat16)
+    ref_w[:, :nq] = fold[:, :256].view(B, nq, 256)
+    ref_w = ref_w.view(B, nqp // 32, 32, 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+    ref_b = torch.zeros(B, nqp, device=device)
+    ref_b[:, :nq] = fold[:, 256].view(B, nq)
+    assert torch.equal(mw, ref_w) and torch.equal(mb, ref_b)
