@@ -136,10 +136,9 @@ class PlaneCameraHead(ParamModule):
         P, gd = self.packed, self._gd("aim")
         rot_feat, rot_raw = run_stacks(rot0, [(P["rot_emb_proj"], ops.ACT_RELU, True), ([P["rots"]], ops.ACT_NONE, True)], gd)  # rot0 has w >= 0 (:695-696)
         rec_rot = ops.normalize_rows(rot_raw)
-        eps = self.__dict__.setdefault("_eps_row", {})
-        if trans0.device not in eps:
-            eps[trans0.device] = torch.full((1, trans0.shape[-1]), 1e-10, device=trans0.device, dtype=torch.float32)
-        trans_feat, rec_trans = run_stacks(ops.add_rows(trans0, eps[trans0.device]), [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
+        eps = ops.cached_constant(self.__dict__.setdefault("_eps_row", {}), trans0.device,
+                                  lambda: torch.full((1, trans0.shape[-1]), 1e-10, device=trans0.device, dtype=torch.float32))
+        trans_feat, rec_trans = run_stacks(ops.add_rows(trans0, eps), [(P["trans_emb_proj"], ops.ACT_RELU, True), ([P["trans"]], ops.ACT_NONE, True)], gd)  # :718
         return rec_trans, rec_rot, trans_feat, rot_feat
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
@@ -196,12 +195,13 @@ class PlaneCameraHead(ParamModule):
         mark("matcher")
         ref = self.refine(A0, planes1, planes2, n1, n2, rec_t, rec_r, rec_tf, rec_rf, diagnostics)
         A1 = ops.refilter_assignment(A0, planes1, planes2, n1, n2, ref["pred_rot"], ref["pred_trans"])
-        zc = self.__dict__.setdefault("_zero_cam", {})          # the constant "camera_zero" pose (never written to)
-        if (B, trans0.device) not in zc:
-            zero_r = torch.zeros_like(rot0)
-            zero_r[:, 0] = 1.0
-            zc[(B, trans0.device)] = (torch.zeros_like(trans0), zero_r)
-        zero_t, zero_r = zc[(B, trans0.device)]
+        def make_zero_pose():
+            zr = torch.zeros_like(rot0)
+            zr[:, 0] = 1.0
+            return torch.zeros_like(trans0), zr
+
+        # the constant "camera_zero" pose (never written to)
+        zero_t, zero_r = ops.cached_constant(self.__dict__.setdefault("_zero_cam", {}), (B, trans0.device), make_zero_pose)
         cams = {"camera_zero": (zero_t, zero_r), "camera_init": (trans0, rot0), "camera_initRec": (rec_t, rec_r),
                 "camera_avgRef0": (ref["avg_trans"], ref["avg_rot"]), "camera_softRef0": (ref["pred_trans"], ref["pred_rot"]),
                 "camera": (ref["pred_trans"], ref["pred_rot"])}                             # sign NOT canonicalised (:596-601)

@@ -257,10 +257,9 @@ class PlaneTRHead(ParamModule):
         k_all = lin(memk16, P["cross_k_all"].w2d(bf), P["cross_k_all"].bias, out_dtype=bf)          # [B*L, 6*256]
         v_all = lin(mem16, P["cross_v_all"].w2d(bf), P["cross_v_all"].bias, out_dtype=bf)
         qpos = self.raw("query_embed.weight")
-        zc = self.__dict__.setdefault("_zero_tgt", {})          # the decoder's all-zero start (read-only: every layer writes a new tensor)
-        tgt = zc.get((B * nq, src.device))
-        if tgt is None:
-            tgt = zc[(B * nq, src.device)] = torch.zeros(B * nq, 256, device=src.device, dtype=f32)
+        # the decoder's all-zero start (read-only: every layer writes a new tensor)
+        tgt = ops.cached_constant(self.__dict__.setdefault("_zero_tgt", {}), (B * nq, src.device),
+                                  lambda: torch.zeros(B * nq, 256, device=src.device, dtype=f32))
         nin = ln(tgt, "context2plane_decoder.layers.0.norm1", addend=qpos, want=("y16", "y2_16"))
         n16, npos16, hs = nin["y16"], nin["y2_16"], None
         for i in range(6):

@@ -555,6 +555,20 @@ def softmax_rows(x: torch.Tensor, out_dtype=None, pad_to: int = 0) -> torch.Tens
     return y
 
 
+def cached_constant(cache: dict, key, make):
+    """A read-only device tensor built once per key and shared by every later call ON ANY STREAM: the stream that builds it is waited
+    for before the tensor is published, so that a batch on another stream can never read it half-written (the kernels that fill it
+    are not ordered against other streams by anything else)."""
+    t = cache.get(key)
+    if t is None:
+        t = make()
+        first = t[0] if isinstance(t, tuple) else t
+        if first.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(first.device).synchronize()
+        cache[key] = t
+    return t
+
+
 def concat_cols(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[a | b] along the last dim of two contiguous f32 row tensors."""
     _chk(a, torch.float32); _chk(b, torch.float32)
