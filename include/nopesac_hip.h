@@ -478,6 +478,20 @@ int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, const void* wo
                               const float* lnn_g, const float* lnn_b, const float* pos, int pos_rows, float* y, void* y_bf16,
                               void* ypos_bf16, float* yn, int M, void* stream);
 
+/* General form of the two tails above, followed by the input projections of the NEXT attention - one launch:
+ *   pre_norm = 0 (encoder layer, transformer.py:183-199):  n = LN_b(y1 + FFN(y1)), y1 = LN_a(src + out_proj(attn));  y = n
+ *   pre_norm = 1 (decoder layer after the cross-attention, :308-322):  u = s + FFN(LN_a(s)), s = src + out_proj(attn); n = LN_b(u); y = u
+ *   skip_ffn = 1 (decoder layer after the SELF-attention, :300-306):  s = src + out_proj(attn), n = LN_a(s), y = s (w1 / w2 / ln_b unused)
+ *   proj_pos [M][n_pos] = bf16((n + pos) Wpos^T + bpos),  proj [M][n_proj] = bf16(n Wp^T + bp): the next self-attention's q|k and v, or
+ *   the cross-attention's q (nn.MultiheadAttention in_proj slices); weights in mfma_fragment_major order (K = 256), widths multiples of 32.
+ * Outputs y / y_bf16 / ypos_bf16 / yn as in the two entries above; every output is optional (at least one). */
+int nopesac_transformer_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
+                                  const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                  const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                  void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
+                                  void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
+                                  void* stream);
+
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----
  * labels: winner uint8[V,H,W] (+ kept_idx int32[V,nq], n_kept int32[V], flags int32[V] from nopesac_postselect_planes)

@@ -11,6 +11,7 @@
 // sit in LDS as the bf16 A tile, every GEMM is "LDS tile x fragment-major weights streamed from L2" (pwchain.hip /
 // gnn_layer.hip), LayerNorm reduces across the waves through LDS, y1 stays in registers (f32) for the second residual
 // and in LDS (bf16) as the FFN operand, the 32 x 1024 hidden tile never leaves the CU.
+#include <type_traits>
 #include "common.h"
 
 namespace nps {
@@ -35,6 +36,11 @@ struct EncTailArgs {
     float* y; bf16_t* y16; bf16_t* ypos16;                // outputs [M][256] (each nullable)
     float* yn;                                            // pre-norm only: f32 copy of the normalised result (nullable)
     int M, pre_norm;
+    // chained projections of the NEXT attention (nullable): pa = bf16((n + pos) Wpa^T + bpa) [M][npa], pb = bf16(n Wpb^T + bpb) [M][npb]
+    // with n = the normalised result; fragment-major weights, npa / npb multiples of 32
+    const bf16_t* wpa; const float* bpa; bf16_t* pa; int npa;
+    const bf16_t* wpb; const float* bpb; bf16_t* pb; int npb;
+    int skip_ffn;                                         // decoder self-attention half: s = src + out_proj(attn), n = LN(s), no FFN
 };
 
 struct EtRing {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     __syncthreads();
 
     // ---- y1 = LN1(src + out_proj(attn)); wave owns channels wave*32 .. +32
-    et_issue(ring, 1, p.w1, 16, 0, 4 * wave, lane);                               // step 1: linear1 tile 4w
+    if (!p.skip_ffn) et_issue(ring, 1, p.w1, 16, 0, 4 * wave, lane);              // step 1: linear1 tile 4w
     f32x16 y1;
     et_zero(y1);
     et_gemm(ring, 0, At, ET_LD, y1, lane);
@@ -141,6 +147,12 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     }
     __syncthreads();
 
+    f32x16 y2;
+    f32x16 u;
+    if (p.skip_ffn) {                                         // (wave-uniform) the residual stream leaves as s, its norm feeds the projections
+        u = resid;
+        y2 = y1;
+    } else {
     // ---- hidden = relu(linear1(y1)): tiles 4w .. 4w+3 of 32
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -166,7 +178,6 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     __syncthreads();
 
     // ---- y2 = LN2(y1 + linear2(hidden)): K = 1024 in four ring steps
-    f32x16 y2;
     et_zero(y2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -181,8 +192,9 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y2[4 * q + e] = (y2[4 * q + e] + b[e]) + resid[4 * q + e];
     }
-    const f32x16 u = y2;                                      // pre-norm: the residual stream leaves un-normalised
+    u = y2;                                                   // pre-norm: the residual stream leaves un-normalised
     et_layernorm(y2, p.g2, p.be2, red, wave, lane);           // its barriers also retire every read of Ht / Yt
+    }
 
     // ---- outputs through LDS so that they leave as whole rows: f32 tile(s) in the hidden region, bf16 tiles in At / Yt
     float* Yf = reinterpret_cast<float*>(Ht);                 // [32][256] f32: the residual-stream output
@@ -229,6 +241,46 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
             if (p.ypos16) *reinterpret_cast<us8*>(p.ypos16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(At + r * ET_LD + col);
         }
     }
+    // ---- the next attention's input projections, straight from the two bf16 tiles that are still in LDS (At = n + pos, Yt = n):
+    //      column tile nt = round * 8 + wave of [Wpa ; Wpb]; K = 256 = one ring step per tile
+    const int ta = p.wpa ? p.npa / 32 : 0, tb = p.wpb ? p.npb / 32 : 0, tt = ta + tb;     // (at most 32 tiles: four rounds)
+    if (tt > 0) {
+        auto issue_tile = [&](auto BUF, int nt) {
+            constexpr int buf = decltype(BUF)::value;
+            if (nt < ta) et_issue(ring, buf, p.wpa, 16, 0, nt, lane);
+            else et_issue(ring, buf, p.wpb, 16, 0, nt - ta, lane);
+        };
+        auto do_tile = [&](auto BUF, int nt) {
+            constexpr int buf = decltype(BUF)::value;
+            const bool is_a = nt < ta;
+            const int ct = is_a ? nt : nt - ta, ldo = is_a ? p.npa : p.npb;
+            f32x16 acc;
+            et_zero(acc);
+            et_gemm(ring, buf, is_a ? At : Yt, ET_LD, acc, lane);
+            const float* bias = is_a ? p.bpa : p.bpb;
+            bf16_t* outp = (is_a ? p.pa : p.pb) + row * ldo + ct * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 8 * q + 4 * half;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[4 * q + e] + b[e]);
+                if (row_ok) *reinterpret_cast<us4*>(outp + n) = o;
+            }
+        };
+        typedef std::integral_constant<int, 0> B0;
+        typedef std::integral_constant<int, 1> B1;
+        if (wave < tt) issue_tile(B0{}, wave);
+        if (wave + 8 < tt) issue_tile(B1{}, wave + 8);
+        if (wave < tt) do_tile(B0{}, wave);
+        if (wave + 16 < tt) issue_tile(B0{}, wave + 16);
+        if (wave + 8 < tt) do_tile(B1{}, wave + 8);
+        if (wave + 24 < tt) issue_tile(B1{}, wave + 24);
+        if (wave + 16 < tt) do_tile(B0{}, wave + 16);
+        if (wave + 24 < tt) do_tile(B1{}, wave + 24);
+    }
 }
 
 }  // namespace nps
@@ -248,6 +300,7 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = ln2_g; a.be2 = ln2_b;
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = nullptr; a.pre_norm = 0;
+    a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
     NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
     hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
@@ -272,6 +325,42 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
     a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = lnn_g; a.be2 = lnn_b;
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = yn; a.pre_norm = 1;
+    a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
+    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
+    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    NPS_LAUNCH_RET();
+}
+
+// General form: the tail of a transformer layer followed by the input projections of the NEXT attention, one launch.
+//   pre_norm = 0 (encoder, transformer.py:183-199): n = LN2(y1 + FFN(y1)), y1 = LN1(src + out_proj(attn)); y = n
+//   pre_norm = 1 (decoder, :293-322): u = s + FFN(LN_a(s)), s = src + out_proj(attn); n = LN_b(u); y = u
+//   skip_ffn = 1 (the decoder's self-attention half, :300-306): s = src + out_proj(attn), n = LN_a(s), y = s  (w1 / w2 / ln_b unused)
+//   proj_pos [M][n_pos] = bf16((n + pos) Wpos^T + bpos), proj [M][n_proj] = bf16(n Wp^T + bp): e.g. the next layer's q|k and v
+//   (encoder / decoder self-attention) or the cross-attention's q; fragment-major weights (K = 256), n_pos / n_proj multiples of 32.
+extern "C" int nopesac_transformer_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
+                                             const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                             const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                             void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
+                                             void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
+                                             void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(attn && src && wo && bo && lna_g && lna_b && M > 0, "transformer_tail: null pointer");
+    NPS_CHECK_ARG(skip_ffn || (w1 && b1 && w2 && b2 && lnb_g && lnb_b), "transformer_tail: FFN / second norm parameters missing");
+    NPS_CHECK_ARG(!skip_ffn || pre_norm, "transformer_tail: skip_ffn is the pre-norm (decoder) form");
+    NPS_CHECK_ARG(y || y_bf16 || ypos_bf16 || yn || proj_pos || proj, "transformer_tail: no output requested");
+    NPS_CHECK_ARG((!ypos_bf16 && !proj_pos) || (pos && pos_rows > 0), "transformer_tail: ypos / proj_pos need pos");
+    NPS_CHECK_ARG((!proj_pos || (w_pos && n_pos > 0 && n_pos % 32 == 0)) && (!proj || (w_proj && n_proj > 0 && n_proj % 32 == 0)),
+                  "transformer_tail: projection weights / widths (multiples of 32)");
+    const void* ptrs[] = {attn, src, wo, bo, lna_g, lna_b, w1, b1, w2, b2, lnb_g, lnb_b, pos, y, y_bf16, ypos_bf16, yn, w_pos, b_pos, proj_pos,
+                          w_proj, b_proj, proj};
+    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "transformer_tail: pointers must be 16-byte aligned");
+    EncTailArgs a;
+    a.attn = (const bf16_t*)attn; a.src = src; a.wo = (const bf16_t*)wo; a.bo = bo; a.g1 = lna_g; a.be1 = lna_b;
+    a.w1 = (const bf16_t*)w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.g2 = lnb_g; a.be2 = lnb_b;
+    a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
+    a.yn = yn; a.pre_norm = pre_norm ? 1 : 0; a.skip_ffn = skip_ffn ? 1 : 0;
+    a.wpa = proj_pos ? (const bf16_t*)w_pos : nullptr; a.bpa = b_pos; a.pa = (bf16_t*)proj_pos; a.npa = n_pos;
+    a.wpb = proj ? (const bf16_t*)w_proj : nullptr; a.bpb = b_proj; a.pb = (bf16_t*)proj; a.npb = n_proj;
     NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
     hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();

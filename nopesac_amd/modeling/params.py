@@ -61,7 +61,7 @@ class ParamModule(nn.Module):
 
     # packed-weight cache invalidation: `_packed` and every derived-weight cache a subclass keeps in its __dict__
     # (fragment-major bf16 copies for the fused kernels) are dropped whenever the raw tensors can have changed
-    _DERIVED_CACHES = ("_fused_w", "_enc_tail_w", "_dec_tail_w", "_mlp_chain_w")
+    _DERIVED_CACHES = ("_fused_w", "_enc_tail_w", "_dec_tail_w", "_tail_w", "_mlp_chain_w")
 
     def _drop_derived(self):
         DERIVED_EPOCH[0] += 1          # anything that holds addresses of packed tensors (captured hipGraphs) is stale now

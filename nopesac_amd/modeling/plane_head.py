@@ -97,6 +97,7 @@ class PlaneTRHead(ParamModule):
         self.fused_encoder_tail = True
         self.fused_mask_head = True
         self.fused_decoder_tail = True
+        self.chain_projections = True           # the tails also compute the next attention's input projections (one launch per half layer)
 
     # ---------------------------------------------------------------- packing
     def _mha(self, prefix: str, fuse_qk: bool):
@@ -234,12 +235,25 @@ class PlaneTRHead(ParamModule):
             return ops.layernorm_ex(x, self.raw(prefix + ".weight"), self.raw(prefix + ".bias"), addend=addend, want=want)
 
         src16, q_in16 = ops.add_rows_bf16(src, pos)            # src and src + pos as bf16 GEMM operands, one launch
+        chain = self.fused_encoder_tail and self.fused_decoder_tail and self.chain_projections
+        qk = v = None
         for i in range(6):
             p = f"context_SA.layers.{i}"
             W = P[p]
-            qk = lin(q_in16, W["attn"]["qk"].w2d(bf), W["attn"]["qk"].bias, out_dtype=bf)
-            v = lin(src16, W["attn"]["v"].w2d(bf), W["attn"]["v"].bias, out_dtype=bf)
+            if qk is None:
+                qk = lin(q_in16, W["attn"]["qk"].w2d(bf), W["attn"]["qk"].bias, out_dtype=bf)
+                v = lin(src16, W["attn"]["v"].w2d(bf), W["attn"]["v"].bias, out_dtype=bf)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, L, L, nh, scale, mfma_bf16=True)
+            qk = v = None
+            if chain:      # ... + the NEXT layer's q|k and v projections from the tiles that are still on the chip (one launch per layer)
+                Wn = P[f"context_SA.layers.{i + 1}"]["attn"] if i < 5 else None
+                r = ops.transformer_tail(o, src, self._tail_weights("enc", i), pre_norm=False, pos=pos, want=("y",),
+                                         proj_pos=(Wn["qk"].wfrag(bf), Wn["qk"].bias, 512) if Wn else None,
+                                         proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256) if Wn else None)
+                src = r["y"]
+                if Wn:
+                    qk, v = r["proj_pos"], r["proj"]
+                continue
             if self.fused_encoder_tail:      # out-proj + LN1 + FFN + LN2 in one launch (csrc/enc_tail.hip)
                 r = ops.encoder_tail(o, src, self._enc_tail_weights(i), pos=pos)
                 src, src16, q_in16 = r["y"], r["y16"], r["ypos16"]
@@ -262,17 +276,31 @@ class PlaneTRHead(ParamModule):
                                   lambda: torch.zeros(B * nq, 256, device=src.device, dtype=f32))
         nin = ln(tgt, "context2plane_decoder.layers.0.norm1", addend=qpos, want=("y16", "y2_16"))
         n16, npos16, hs = nin["y16"], nin["y2_16"], None
+        qk = v = None
         for i in range(6):
             p = f"context2plane_decoder.layers.{i}"
             W = P[p]
-            qk = lin(npos16, W["self"]["qk"].w2d(bf), W["self"]["qk"].bias, out_dtype=bf)
-            v = lin(n16, W["self"]["v"].w2d(bf), W["self"]["v"].bias, out_dtype=bf)
+            if qk is None:
+                qk = lin(npos16, W["self"]["qk"].w2d(bf), W["self"]["qk"].bias, out_dtype=bf)
+                v = lin(n16, W["self"]["v"].w2d(bf), W["self"]["v"].bias, out_dtype=bf)
             o = ops.attention(qk[:, :256], qk[:, 256:], v, B, nq, nq, nh, scale, mfma_bf16=True)
-            tgt = lin(o, W["self"]["o"].w2d(bf), W["self"]["o"].bias, residual=tgt, out_dtype=f32)
-            r = ln(tgt, p + ".norm2", addend=qpos, want=("y2_16",))
-            q = lin(r["y2_16"], W["cross"]["q"].w2d(bf), W["cross"]["q"].bias, out_dtype=bf)
+            qk = v = None
+            if chain:      # self out-proj + residual + norm2 + the cross-attention's q projection: one launch
+                r = ops.transformer_tail(o, tgt, self._tail_weights("dec_self", i), pre_norm=True, skip_ffn=True, pos=qpos, want=("y",),
+                                         proj_pos=(W["cross"]["q"].wfrag(bf), W["cross"]["q"].bias, 256))
+                tgt, q = r["y"], r["proj_pos"]
+            else:
+                tgt = lin(o, W["self"]["o"].w2d(bf), W["self"]["o"].bias, residual=tgt, out_dtype=f32)
+                r = ln(tgt, p + ".norm2", addend=qpos, want=("y2_16",))
+                q = lin(r["y2_16"], W["cross"]["q"].w2d(bf), W["cross"]["q"].bias, out_dtype=bf)
             o = ops.attention(q, k_all[:, 256 * i:256 * (i + 1)], v_all[:, 256 * i:256 * (i + 1)], B, nq, L, nh, scale, mfma_bf16=True)
             nxt = f"context2plane_decoder.layers.{i + 1}.norm1" if i < 5 else "context2plane_decoder.norm"
+            if chain and i < 5:      # cross out-proj + LN3 + FFN + the next norm + the next layer's self q|k and v projections
+                Wn = P[f"context2plane_decoder.layers.{i + 1}"]["self"]
+                r = ops.transformer_tail(o, tgt, self._tail_weights("dec", i), pre_norm=True, pos=qpos, want=("y",),
+                                         proj_pos=(Wn["qk"].wfrag(bf), Wn["qk"].bias, 512), proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256))
+                tgt, qk, v = r["y"], r["proj_pos"], r["proj"]
+                continue
             if self.fused_decoder_tail:      # cross out-proj + LN3 + FFN + the next norm in one launch (csrc/enc_tail.hip)
                 r = ops.decoder_tail(o, tgt, self._dec_tail_weights(i, nxt), pos=qpos,
                                      want=("y", "y16", "ypos16") if i < 5 else ("yn",))
@@ -291,6 +319,24 @@ class PlaneTRHead(ParamModule):
         if hs is None:
             hs = self._ln(tgt, "context2plane_decoder.norm")
         return hs, memory
+
+    def _tail_weights(self, kind: str, i: int) -> dict:
+        """Operands of ops.transformer_tail: "enc" = encoder layer i, "dec" = decoder layer i after the cross-attention (second norm = the
+        next layer's norm1), "dec_self" = decoder layer i after the self-attention (out-proj + norm2 only)."""
+        cache = self.__dict__.setdefault("_tail_w", {})
+        if (kind, i) not in cache:
+            bf = torch.bfloat16
+            f = lambda k: self.raw(k).float().contiguous()
+            if kind == "enc":
+                e = self._enc_tail_weights(i)
+                cache[(kind, i)] = dict(e, ga=e["g1"], bea=e["be1"], gb=e["g2"], beb=e["be2"])
+            elif kind == "dec":
+                d = self._dec_tail_weights(i, f"context2plane_decoder.layers.{i + 1}.norm1" if i < 5 else "context2plane_decoder.norm")
+                cache[(kind, i)] = dict(d, ga=d["g3"], bea=d["be3"], gb=d["gn"], beb=d["ben"])
+            else:
+                p, W = f"context2plane_decoder.layers.{i}", self.packed[f"context2plane_decoder.layers.{i}"]
+                cache[(kind, i)] = {"wo": W["self"]["o"].wfrag(bf), "bo": W["self"]["o"].bias, "ga": f(p + ".norm2.weight"), "bea": f(p + ".norm2.bias")}
+        return cache[(kind, i)]
 
     def _dec_tail_weights(self, i: int, next_norm: str) -> dict:
         cache = self.__dict__.setdefault("_dec_tail_w", {})

@@ -985,6 +985,34 @@ def decoder_tail(attn: torch.Tensor, tgt: torch.Tensor, W: dict, pos=None, want=
     return out
 
 
+def transformer_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, *, pre_norm: bool, skip_ffn: bool = False, pos=None,
+                     want=("y",), proj_pos=None, proj=None) -> dict:
+    """The tail of a transformer layer + the input projections of the next attention in one launch (nopesac_transformer_tail_bf16).
+    W: "wo", "bo", "ga", "bea" (first norm) and - unless skip_ffn - "w1", "b1", "w2", "b2", "gb", "beb" (second norm); fragment-major
+    bf16 matrices, f32 vectors.  proj_pos / proj = (fragment-major weight, f32 bias or None, width): projections of the normalised
+    result + pos / of the normalised result, returned as "proj_pos" / "proj" (bf16 [M, width]).  want: any of "y", "y16", "ypos16", "yn"."""
+    _chk(attn, torch.bfloat16); _chk(src, torch.float32)
+    M = src.shape[0]
+    _require(attn.shape == (M, 256) and src.shape == (M, 256), "transformer_tail: attn / src [M, 256]")
+    out = {k: torch.empty(M, 256, device=src.device, dtype=torch.float32 if k in ("y", "yn") else torch.bfloat16) for k in want}
+    if pos is not None:
+        _chk(pos, torch.float32)
+    wa, ba, na = proj_pos if proj_pos is not None else (None, None, 0)
+    wb, bb, nb = proj if proj is not None else (None, None, 0)
+    if na:
+        out["proj_pos"] = torch.empty(M, na, device=src.device, dtype=torch.bfloat16)
+    if nb:
+        out["proj"] = torch.empty(M, nb, device=src.device, dtype=torch.bfloat16)
+    g = W.get
+    rc = _L().nopesac_transformer_tail_bf16(
+        _p(attn), _p(src), _p(W["wo"]), _p(W["bo"]), _p(W["ga"]), _p(W["bea"]), _p(g("w1")), _p(g("b1")), _p(g("w2")), _p(g("b2")),
+        _p(g("gb")), _p(g("beb")), _p(pos), 0 if pos is None else pos.shape[0], _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")),
+        _p(out.get("yn")), int(pre_norm), int(skip_ffn), _p(wa), _p(ba), _p(out.get("proj_pos")), na, _p(wb), _p(bb), _p(out.get("proj")), nb, M,
+        _stream())
+    _lib.check(rc, "nopesac_transformer_tail_bf16")
+    return out
+
+
 def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, act: int = ACT_RELU) -> torch.Tensor:
     """bf16 3x3/s1/p1 conv 64 -> 64 + BN + act from an LDS halo tile (csrc/conv3x3_c64.hip).  x [B,H,W,64], w [64,3,3,64]."""
     _chk(x, torch.bfloat16); _chk(w, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)

@@ -889,3 +889,45 @@ def test_mask_operands_from_the_folded_embeddings(device, B, nq):
     ref_b = torch.zeros(B, nqp, device=device)
     ref_b[:, :nq] = fold[:, 256].view(B, nq)
     assert torch.equal(mw, ref_w) and torch.equal(mb, ref_b)
+
+
+@pytest.mark.parametrize("M", [19200 // 8, 333])
+def test_transformer_tail_with_chained_projections(device, M):
+    """nopesac_transformer_tail_bf16: (a) its tail equals the encoder / decoder tail entries bit for bit, (b) the chained projections
+    equal ops.linear on the tail's bf16 outputs (same bf16 operands, same MFMA k order: bit for bit), (c) skip_ffn = the decoder's
+    self-attention half (out-proj + residual, norm, cross-q projection) against the per-op kernels."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(M + 7)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    bf = torch.bfloat16
+    attn, src, pos = rn(M, 256).bfloat16(), rn(M, 256), rn(300, 256)
+    wo, w1, w2 = rn(256, 256, k=1 / 16).bfloat16(), rn(1024, 256, k=1 / 16).bfloat16(), rn(256, 1024, k=1 / 32).bfloat16()
+    bo, b1, b2 = rn(256, k=0.1), rn(1024, k=0.1), rn(256, k=0.1)
+    ga, bea, gb, beb = 1 + rn(256, k=0.1), rn(256, k=0.1), 1 + rn(256, k=0.1), rn(256, k=0.1)
+    wqk, bqk, wv, bv = rn(512, 256, k=1 / 16).bfloat16(), rn(512, k=0.1), rn(256, 256, k=1 / 16).bfloat16(), rn(256, k=0.1)
+    fm = ops.mfma_fragment_major
+    W = {"wo": fm(wo), "w1": fm(w1), "w2": fm(w2), "bo": bo, "b1": b1, "b2": b2, "ga": ga, "bea": bea, "gb": gb, "beb": beb}
+    # (a) + (b), encoder form
+    ref = ops.encoder_tail(attn, src, dict(W, g1=ga, be1=bea, g2=gb, be2=beb), pos=pos)
+    out = ops.transformer_tail(attn, src, W, pre_norm=False, pos=pos, want=("y", "y16", "ypos16"),
+                               proj_pos=(fm(wqk), bqk, 512), proj=(fm(wv), bv, 256))
+    assert torch.equal(out["y"], ref["y"]) and torch.equal(out["y16"], ref["y16"]) and torch.equal(out["ypos16"], ref["ypos16"])
+    qk = ops.linear(ref["ypos16"], wqk, bqk, out_dtype=bf)
+    v = ops.linear(ref["y16"], wv, bv, out_dtype=bf)
+    assert _rel(out["proj_pos"].float(), qk.float()) < 1e-2 and _rel(out["proj"].float(), v.float()) < 1e-2
+    assert float((out["proj_pos"].float() - qk.float()).abs().mean()) < 1e-3 * float(qk.float().abs().mean() + 1)
+    # decoder form (pre-norm), projections only (no y16 / ypos16 written)
+    ref = ops.decoder_tail(attn, src, dict(W, g3=ga, be3=bea, gn=gb, ben=beb), pos=pos, want=("y", "y16", "ypos16", "yn"))
+    out = ops.transformer_tail(attn, src, W, pre_norm=True, pos=pos, want=("y", "yn"), proj_pos=(fm(wqk), bqk, 512), proj=(fm(wv), None, 256))
+    assert torch.equal(out["y"], ref["y"]) and torch.equal(out["yn"], ref["yn"])
+    assert _rel(out["proj_pos"].float(), ops.linear(ref["ypos16"], wqk, bqk, out_dtype=bf).float()) < 1e-2
+    assert _rel(out["proj"].float(), ops.linear(ref["y16"], wv, None, out_dtype=bf).float()) < 1e-2
+    # (c) the self-attention half: s = src + out_proj(attn), n = LN(s), q = (n + pos) Wq
+    out = ops.transformer_tail(attn, src, {"wo": fm(wo), "bo": bo, "ga": ga, "bea": bea}, pre_norm=True, skip_ffn=True, pos=pos,
+                               want=("y",), proj_pos=(fm(wv), bv, 256))
+    s = ops.linear(attn, wo, bo, residual=src, out_dtype=torch.float32)
+    r = ops.layernorm_ex(s, ga, bea, addend=pos, want=("y2_16",))
+    q = ops.linear(r["y2_16"], wv, bv, out_dtype=bf)
+    assert _rel(out["y"], s) < 1e-5
+    assert _rel(out["proj_pos"].float(), q.float()) < 1e-2
+    assert float((out["proj_pos"].float() - q.float()).abs().mean()) < 2e-3 * float(q.float().abs().mean() + 1)
