@@ -235,6 +235,12 @@ int nopesac_layernorm_ex(const float* x, const float* res, const float* gamma, c
 /* out = a + b (b row index = row % b_rows); f32. */
 int nopesac_add_rows(const float* a, const float* b, float* out, int rows, int D, int b_rows, void* stream);
 
+/* rows[b] = [t(3) | q(4) | n1 | n2 | m | t_err | r_err | pair_idx0 + b | nonfinite[0] | 0 | 0] as f32 [B][16]: the per-pair result rows
+ * the runner all-gathers (the reference gathers the same numbers as python objects over Gloo, mp3d_evaluation.py:316-319).  t_err, r_err
+ * and nonfinite (device int32[1]) may be NULL.  One launch, no host synchronisation. */
+int nopesac_metric_rows(const float* trans, const float* rot, const int32_t* n1, const int32_t* n2, const int32_t* m,
+                        const float* t_err, const float* r_err, const int32_t* nonfinite, int pair_idx0, float* rows, int B, void* stream);
+
 /* out[r] = [a[r] | b[r]] (f32 rows of Da and Db elements): the 7-vector (t, q) the matcher takes (camera_head.py:455). */
 int nopesac_concat_cols(const float* a, int Da, const float* b, int Db, float* out, int rows, void* stream);
 

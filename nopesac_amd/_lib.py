@@ -57,6 +57,7 @@ SIGNATURES = {
     "nopesac_softmax_rows_pad": [P, P, I, I, I, I, P],
     "nopesac_add_rows_bf16": [P, P, P, P, I, I, I, P],
     "nopesac_concat_cols": [P, I, P, I, P, I, P],
+    "nopesac_metric_rows": [P, P, P, P, P, P, P, P, I, P, I, P],
     "nopesac_attention_small": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],
     "nopesac_attention_small_bf16io": [P, L, P, L, P, L, P, L, I, I, I, I, F, P, P, P],

@@ -564,6 +564,35 @@ extern "C" int nopesac_add_rows(const float* a, const float* b, float* out, int 
     NPS_LAUNCH_RET();
 }
 
+// The per-pair result row of the runner: [t(3) | q(4) | n1 | n2 | m | t_err | r_err | pair index | non-finite count | 0 | 0] as f32
+// (nopesac_amd/runner.py METRIC_WIDTH = 16; the reference gathers the same numbers as python objects, mp3d_evaluation.py:316-319).
+namespace nps {
+__global__ void metric_rows_kernel(const float* __restrict__ t, const float* __restrict__ q, const int* __restrict__ n1, const int* __restrict__ n2,
+                                   const int* __restrict__ m, const float* __restrict__ t_err, const float* __restrict__ r_err,
+                                   const int* __restrict__ nonfinite, int pair_idx0, float* __restrict__ rows, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* r = rows + (long long)b * 16;
+    r[0] = t[3 * b]; r[1] = t[3 * b + 1]; r[2] = t[3 * b + 2];
+    r[3] = q[4 * b]; r[4] = q[4 * b + 1]; r[5] = q[4 * b + 2]; r[6] = q[4 * b + 3];
+    r[7] = (float)n1[b]; r[8] = (float)n2[b]; r[9] = (float)m[b];
+    r[10] = t_err ? t_err[b] : 0.f; r[11] = r_err ? r_err[b] : 0.f;
+    r[12] = (float)(pair_idx0 + b);
+    r[13] = nonfinite ? (float)nonfinite[0] : 0.f;
+    r[14] = 0.f; r[15] = 0.f;
+}
+}  // namespace nps
+
+extern "C" int nopesac_metric_rows(const float* trans, const float* rot, const int32_t* n1, const int32_t* n2, const int32_t* m,
+                                   const float* t_err, const float* r_err, const int32_t* nonfinite, int pair_idx0, float* rows, int B,
+                                   void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(trans && rot && n1 && n2 && m && rows && B > 0, "metric_rows: bad args");
+    hipLaunchKernelGGL(metric_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, trans, rot, n1, n2, m, t_err, r_err, nonfinite,
+                       pair_idx0, rows, B);
+    NPS_LAUNCH_RET();
+}
+
 namespace nps {
 __global__ void concat_cols_kernel(const float* __restrict__ a, int Da, const float* __restrict__ b, int Db, float* __restrict__ out, int rows) {
     const int D = Da + Db, i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -569,6 +569,22 @@ def cached_constant(cache: dict, key, make):
     return t
 
 
+def metric_rows(trans, rot, n1, n2, m, pair_idx0: int, t_err=None, r_err=None, nonfinite=None) -> torch.Tensor:
+    """[B,16] f32 result rows of the runner (runner.metric_rows on a GPU): one launch."""
+    _chk(trans, torch.float32); _chk(rot, torch.float32); _chk(n1, torch.int32); _chk(n2, torch.int32); _chk(m, torch.int32)
+    B = trans.shape[0]
+    _require(trans.shape == (B, 3) and rot.shape == (B, 4) and n1.numel() == B and n2.numel() == B and m.numel() == B, "metric_rows: shapes")
+    for v in (t_err, r_err):
+        if v is not None:
+            _chk(v, torch.float32)
+    if nonfinite is not None:
+        _chk(nonfinite, torch.int32)
+    rows = torch.empty(B, 16, device=trans.device, dtype=torch.float32)
+    _lib.check(_L().nopesac_metric_rows(_p(trans), _p(rot), _p(n1), _p(n2), _p(m), _p(t_err), _p(r_err), _p(nonfinite), int(pair_idx0), _p(rows),
+                                        B, _stream()), "nopesac_metric_rows")
+    return rows
+
+
 def concat_cols(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[a | b] along the last dim of two contiguous f32 row tensors."""
     _chk(a, torch.float32); _chk(b, torch.float32)

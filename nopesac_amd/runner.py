@@ -89,6 +89,12 @@ def metric_rows(trans: torch.Tensor, rot: torch.Tensor, n1: torch.Tensor, n2: to
                 nonfinite: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Pack per-pair results into [B, 16] fp32 rows on the tensors' device (no host sync)."""
     B = trans.shape[0]
+    if (trans.is_cuda and trans.dtype == torch.float32 and rot.dtype == torch.float32 and trans.is_contiguous() and rot.is_contiguous()
+            and all(v.dtype == torch.int32 and v.is_contiguous() for v in (n1, n2, m))
+            and all(v is None or (v.dtype == torch.float32 and v.is_contiguous() and v.is_cuda) for v in (t_err, r_err))
+            and (nonfinite is None or nonfinite.dtype == torch.int32)):
+        from . import ops
+        return ops.metric_rows(trans, rot, n1, n2, m, pair_idx0, t_err, r_err, nonfinite)     # one launch instead of a dozen torch ones
     rows = torch.zeros(B, METRIC_WIDTH, device=trans.device, dtype=torch.float32)
     rows[:, 0:3], rows[:, 3:7] = trans, rot
     rows[:, 7], rows[:, 8], rows[:, 9] = n1.float(), n2.float(), m.float()

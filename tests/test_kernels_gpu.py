@@ -931,3 +931,18 @@ def test_transformer_tail_with_chained_projections(device, M):
     assert _rel(out["y"], s) < 1e-5
     assert _rel(out["proj_pos"].float(), q.float()) < 1e-2
     assert float((out["proj_pos"].float() - q.float()).abs().mean()) < 2e-3 * float(q.float().abs().mean() + 1)
+
+
+def test_metric_rows_kernel_equals_the_torch_formulation(device):
+    """runner.metric_rows on the GPU (nopesac_metric_rows, one launch) = the torch formulation the CPU / gloo tests use."""
+    from nopesac_amd import runner
+    torch.manual_seed(5)
+    B = 37
+    t, q = torch.randn(B, 3, device=device), torch.randn(B, 4, device=device)
+    n1, n2, m = (torch.randint(0, 50, (B,), device=device, dtype=torch.int32) for _ in range(3))
+    te, re = torch.rand(B, device=device), torch.rand(B, device=device)
+    nf = torch.tensor([3], device=device, dtype=torch.int32)
+    for kw in ({}, {"t_err": te, "r_err": re}, {"nonfinite": nf}, {"t_err": te, "r_err": re, "nonfinite": nf}):
+        got = runner.metric_rows(t, q, n1, n2, m, 96, **kw)
+        ref = runner.metric_rows(t.cpu(), q.cpu(), n1.cpu(), n2.cpu(), m.cpu(), 96, **{k: v.cpu() for k, v in kw.items()})
+        assert got.is_cuda and torch.equal(got.cpu(), ref)
