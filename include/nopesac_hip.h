@@ -119,6 +119,9 @@ int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, con
 #define NOPESAC_MLP_MAX_IN 1280
 #define NOPESAC_MLP_MAX_WIDTH 1024
 #define NOPESAC_MLP_MAX_LAYERS 12
+#define NOPESAC_MLP_RESTART 1   /* nopesac_mlp_layer.reserved: this layer reads the chain INPUT again instead of the previous layer's
+                                 * output - several stacks over the same rows (e.g. the plane head's embedding / prob / param / center
+                                 * MLPs, planeTR_head.py:170-188) run in one launch */
 typedef struct nopesac_mlp_layer {
     const void* w;
     const float* bias;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
     auto layer_at = [&](int l) {
         nopesac_mlp_layer L;
         L.w = pc->layers[l].w; L.bias = pc->layers[l].bias; L.out = pc->layers[l].out; L.out_ld = pc->layers[l].out_ld;
-        L.K = pc->layers[l].K; L.N = pc->layers[l].N; L.act = pc->layers[l].act; L.reserved = 0;
+        L.K = pc->layers[l].K; L.N = pc->layers[l].N; L.act = pc->layers[l].act; L.reserved = pc->layers[l].reserved;
         return L;
     };
     struct {
@@ -197,8 +197,13 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
     // ---- LDS: zeros everywhere (padding columns meet zero weights, but must not be NaN patterns), then the input rows
     for (int i = tid; i < (int)(MC_LDS_BYTES / 16); i += 512) reinterpret_cast<uint4*>(mc_smem)[i] = make_uint4(0u, 0u, 0u, 0u);
     MC_LDS_SYNC();
-    {
+    // the chain input rows (f32 in HBM) as a bf16 tile in region R (row stride ld); columns [K0, kzero) are zeroed
+    auto stage_input = [&](bf16_t* R, int ld, int kzero) {
         const int K0 = p.xb_width + p.x_width;
+        for (int i = tid; i < MC_BM * (kzero - K0); i += 512) {
+            const int r = i / (kzero - K0), c = K0 + i - r * (kzero - K0);
+            R[r * ld + c] = 0;
+        }
         const bool vec = ((p.xb_width | p.x_width) & 3) == 0 && (p.x_ld & 3) == 0 && (p.xb_ld & 3) == 0 &&
                          (((uintptr_t)p.x | (uintptr_t)p.xb) & 15) == 0;
         if (vec) {
@@ -206,24 +211,26 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
             for (int i = tid; i < MC_BM * q4; i += 512) {
                 const int r = i / q4, c = (i - r * q4) * 4;
                 const long long row = row0 + r;
-                if (row >= p.rows) continue;
-                const float* s = c < p.xb_width ? p.xb + (row / p.xb_rows_per) * p.xb_ld + c : p.x + row * p.x_ld + (c - p.xb_width);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(s);
-                us4 o;
+                us4 o = {0, 0, 0, 0};
+                if (row < p.rows) {
+                    const float* s = c < p.xb_width ? p.xb + (row / p.xb_rows_per) * p.xb_ld + c : p.x + row * p.x_ld + (c - p.xb_width);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(s);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
-                *reinterpret_cast<us4*>(R0 + r * MC_LD0 + c) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
+                }
+                *reinterpret_cast<us4*>(R + r * ld + c) = o;
             }
         } else {
             for (int i = tid; i < MC_BM * K0; i += 512) {
                 const int r = i / K0, c = i - r * K0;
                 const long long row = row0 + r;
-                if (row >= p.rows) continue;
-                const float v = c < p.xb_width ? p.xb[(row / p.xb_rows_per) * p.xb_ld + c] : p.x[row * p.x_ld + (c - p.xb_width)];
-                R0[r * MC_LD0 + c] = f32_to_bf16(v);
+                float v = 0.f;
+                if (row < p.rows) v = c < p.xb_width ? p.xb[(row / p.xb_rows_per) * p.xb_ld + c] : p.x[row * p.x_ld + (c - p.xb_width)];
+                R[r * ld + c] = f32_to_bf16(v);
             }
         }
-    }
+    };
+    stage_input(R0, MC_LD0, p.xb_width + p.x_width);
     MC_LDS_SYNC();
     for (int l = 0; l < p.n_layers; ++l) {
         const nopesac_mlp_layer L = layer_at(l);
@@ -231,6 +238,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(const nopesac_mlp_chain 
         const bf16_t* src = (l & 1) ? R1 : R0;
         bf16_t* dst = (l & 1) ? R0 : R1;
         const int sld = (l & 1) ? MC_LD1 : MC_LD0, dld = (l & 1) ? MC_LD0 : MC_LD1;
+        if (L.reserved & NOPESAC_MLP_RESTART) {               // this layer reads the chain INPUT again (a parallel stack over the same rows):
+            stage_input(const_cast<bf16_t*>(src), sld, mc_kpad(L.K, L.N));   // the previous layer's output in this region is dead (its
+            MC_LDS_SYNC();                                                   // consumers, if any, got it through L.out)
+        }
         mc_layer(L, shape, next, src, sld, dst, dld, row0, p.rows, wave, lane, ring);
         shape = next;
         MC_LDS_SYNC();
@@ -256,6 +267,8 @@ extern "C" int nopesac_mlp_chain_bf16(const nopesac_mlp_chain* chain, void* stre
     NPS_CHECK_ARG(width <= MC_W0, "mlp_chain: input wider than NOPESAC_MLP_MAX_IN");
     for (int l = 0; l < chain->n_layers; ++l) {
         const nopesac_mlp_layer& L = chain->layers[l];
+        if (L.reserved & NOPESAC_MLP_RESTART) width = chain->xb_width + chain->x_width;      // a parallel stack: back to the chain input
+        NPS_CHECK_ARG((L.reserved & ~NOPESAC_MLP_RESTART) == 0 && (l > 0 || L.reserved == 0), "mlp_chain: layer flags");
         NPS_CHECK_ARG(L.w && L.K == width && L.N > 0 && L.N <= MC_W1, "mlp_chain: layer K must equal the previous width, N <= NOPESAC_MLP_MAX_WIDTH");
         NPS_CHECK_ARG(mc_kpad(L.K, L.N) <= ((l & 1) ? MC_W1 : MC_W0), "mlp_chain: padded K exceeds the LDS region");
         NPS_CHECK_ARG(((uintptr_t)L.w & 15) == 0 && ((uintptr_t)L.bias & 15) == 0 && ((uintptr_t)L.out & 3) == 0, "mlp_chain: w / bias must be 16-byte aligned");

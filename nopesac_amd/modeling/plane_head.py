@@ -43,21 +43,27 @@ def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE, gd=torch.float32):
     return x
 
 
-def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1):
+def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1, parallel=False):
     """Consecutive MLP stacks (each: ReLU between its layers, `final_act` after its last one) applied to the rows of x [rows, K] f32;
     stacks = [(layers: [ConvW], final_act, out)], out = an f32 [rows, N] tensor (may be a column slice) that receives the stack's
     output, True to allocate one, None if only the next stack consumes it (the last stack always returns its output).
     x_bcast [P, Kb]: optional input prefix shared by `rows_per` consecutive rows.  Returns one entry per stack (tensor or None).
+    parallel = True, or a list with one flag per stack: a flagged stack reads x instead of the previous stack's output (independent
+    stacks over the same rows; still one launch in bf16 GEMM mode: NOPESAC_MLP_RESTART).
     bf16 GEMM mode: ONE launch for everything (csrc/mlp_chain.hip, activations stay in LDS); fp32 mode: one launch per layer."""
     rows = x.shape[0]
-    flat, last_of = [], []
+    par = list(parallel) if isinstance(parallel, (list, tuple)) else [bool(parallel)] * len(stacks)
+    flat, last_of, restarts = [], [], []
     for si, (layers, final_act, out) in enumerate(stacks):
         for i, l in enumerate(layers):
             last = i == len(layers) - 1
             flat.append((l, final_act if last else ops.ACT_RELU))
             last_of.append(si if last else -1)
+            restarts.append(par[si] and si > 0 and i == 0)
     want = [o for (_, _, o) in stacks]
-    want[-1] = True if want[-1] is None else want[-1]
+    for si in range(len(stacks)):                             # a stack nothing in the chain consumes always returns its output
+        if want[si] is None and (si == len(stacks) - 1 or par[si + 1]):
+            want[si] = True
     results = [None] * len(stacks)
     for si, o in enumerate(want):
         if o is True:
@@ -68,7 +74,7 @@ def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1):
     if (gd == torch.bfloat16 and x.dtype == torch.float32 and len(flat) <= _lib.MLP_MAX_LAYERS and k0 <= _lib.MLP_MAX_IN
             and all(l.cout <= _lib.MLP_MAX_WIDTH for l, _ in flat)):
         ops.mlp_chain(x, [l.chain() for l, _ in flat], [a for _, a in flat], [results[si] if si >= 0 else None for si in last_of],
-                      x_bcast=x_bcast, rows_per=rows_per)
+                      x_bcast=x_bcast, rows_per=rows_per, restarts=restarts)
         return results
     if x_bcast is not None:                       # per-layer path: materialise the concatenated input once
         assert rows == x_bcast.shape[0] * rows_per, "run_stacks: x_bcast rows x rows_per must equal the rows of x"
@@ -76,8 +82,9 @@ def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1):
         full.view(-1, rows_per, k0)[:, :, :x_bcast.shape[1]] = x_bcast[:, None, :]
         full[:, x_bcast.shape[1]:] = x
         x = full
-    for (l, a), si in zip(flat, last_of):
-        x = ops.linear(x, l.w2d(gd), l.bias, act=a, out=results[si] if si >= 0 else None)
+    x_in = x
+    for (l, a), si, rs in zip(flat, last_of, restarts):
+        x = ops.linear(x_in if rs else x, l.w2d(gd), l.bias, act=a, out=results[si] if si >= 0 else None)
     return results
 
 
@@ -374,12 +381,20 @@ class PlaneTRHead(ParamModule):
         p3 = up_stage(p4, "up_conv3", cbr(c3, "c3_conv"))
         p2 = up_stage(p3, "up_conv2", cbr(c2, "c2_conv"))
         # plane embedding MLP [B*nq, 256] -> folded mask-head operands [B*nq, 264]: mask weights | bias | pad
-        fold = run_stacks(hs, [(P["plane_embedding"], ops.ACT_NONE, None), ([P["pe_fold"]], ops.ACT_NONE, True)], gd)[1]
-        heads = {
-            "pred_logits": run_mlp(hs, [P["plane_prob"]], gd=gd).view(B, nq, 2),
-            "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
-            "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
-        }
+        # ... and the three small heads on the same rows: five stacks, one launch in bf16 GEMM mode
+        if gd == torch.bfloat16 and hs.dtype == torch.float32:
+            r = run_stacks(hs, [(P["plane_embedding"], ops.ACT_NONE, None), ([P["pe_fold"]], ops.ACT_NONE, True),
+                                ([P["plane_prob"]], ops.ACT_NONE, True), (P["plane_param"], ops.ACT_NONE, True),
+                                (P["plane_center"], ops.ACT_SIGMOID, True)], gd, parallel=[False, False, True, True, True])
+            fold = r[1]
+            heads = {"pred_logits": r[2].view(B, nq, 2), "pred_params": r[3].view(B, nq, 3), "pred_centers": r[4].view(B, nq, 2)}
+        else:
+            fold = run_stacks(hs, [(P["plane_embedding"], ops.ACT_NONE, None), ([P["pe_fold"]], ops.ACT_NONE, True)], gd)[1]
+            heads = {
+                "pred_logits": run_mlp(hs, [P["plane_prob"]], gd=gd).view(B, nq, 2),
+                "pred_params": run_mlp(hs, P["plane_param"], gd=gd).view(B, nq, 3),
+                "pred_centers": run_mlp(hs, P["plane_center"], final_act=ops.ACT_SIGMOID, gd=gd).view(B, nq, 2),
+            }
         h1, w1 = c1.shape[1], c1.shape[2]
         if (self.fused_mask_head and cd == torch.bfloat16 and not want_logits and nq <= 128 and nq % 2 == 0 and (h1 * w1) % 128 == 0):
             # finest lateral conv + bilinear add + mask GEMM in one launch: p1 never goes to HBM (csrc/mask_head.hip)

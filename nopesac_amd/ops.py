@@ -358,12 +358,12 @@ class MlpLayer:
         self.N, self.K = N, K
 
 
-def mlp_chain(x: torch.Tensor, layers, acts, outs, x_bcast: Optional[torch.Tensor] = None, rows_per: int = 1):
+def mlp_chain(x: torch.Tensor, layers, acts, outs, x_bcast: Optional[torch.Tensor] = None, rows_per: int = 1, restarts=None):
     """A stack of Linear(+bias)(+act) layers over the rows of x in ONE launch (bf16 MFMA operands, f32 activations: the rounding
     points of one ops.linear per layer).  x [rows, Kx] f32 (may be a column slice of a wider row-major buffer); x_bcast [P, Kb]:
     optional prefix columns shared by `rows_per` consecutive rows (row r reads x_bcast[r // rows_per]); layers: [MlpLayer];
     acts: [ACT_*] per layer; outs: per layer None or an f32 [rows, N] tensor (may be a column slice) that receives the layer's
-    output - the last one is required."""
+    output - the last one is required.  restarts: per layer True if the layer starts a new stack over the SAME input rows."""
     _require(len(layers) == len(acts) == len(outs) and 1 <= len(layers) <= _lib.MLP_MAX_LAYERS, "mlp_chain: layers / acts / outs")
     _require(x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "mlp_chain: x must be f32 [rows, K] with unit column stride")
     rows = x.shape[0]
@@ -378,6 +378,7 @@ def mlp_chain(x: torch.Tensor, layers, acts, outs, x_bcast: Optional[torch.Tenso
     for i, (l, a, o) in enumerate(zip(layers, acts, outs)):
         e = c.layers[i]
         e.w, e.bias, e.K, e.N, e.act = _p(l.w), _p(l.bias), l.K, l.N, a
+        e.reserved = 1 if (restarts is not None and restarts[i]) else 0        # NOPESAC_MLP_RESTART: reads the chain input again
         e.out, e.out_ld = None, 0
         if o is not None:
             _require(o.dtype == torch.float32 and o.dim() == 2 and o.shape == (rows, l.N) and o.stride(1) == 1, "mlp_chain: out tensor")

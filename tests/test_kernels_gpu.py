@@ -946,3 +946,31 @@ def test_metric_rows_kernel_equals_the_torch_formulation(device):
         got = runner.metric_rows(t, q, n1, n2, m, 96, **kw)
         ref = runner.metric_rows(t.cpu(), q.cpu(), n1.cpu(), n2.cpu(), m.cpu(), 96, **{k: v.cpu() for k, v in kw.items()})
         assert got.is_cuda and torch.equal(got.cpu(), ref)
+
+
+def test_mlp_chain_parallel_stacks_over_the_same_rows(device):
+    """NOPESAC_MLP_RESTART: stacks that all read the chain input run in ONE launch and give exactly what one launch per stack gives
+    (the plane head's embedding -> fold chain plus its prob / param / center heads; odd and even restart positions, a ragged row tile)."""
+    from nopesac_amd import ops
+    from nopesac_amd.modeling.params import ConvW
+    from nopesac_amd.modeling.plane_head import run_mlp, run_stacks
+    torch.manual_seed(11)
+    rows, bf = 50 * 7 + 3, torch.bfloat16
+    x = torch.randn(rows, 256, device=device)
+    mk = lambda n, k: ConvW((torch.randn(n, k, device=device) / k ** 0.5), None, torch.randn(n, device=device) * 0.1)
+    emb = [mk(256, 256), mk(256, 256), mk(256, 256)]
+    fold = [mk(264, 256)]
+    prob = [mk(2, 256)]
+    param = [mk(256, 256), mk(256, 256), mk(3, 256)]
+    center = [mk(256, 256), mk(2, 256)]
+    r = run_stacks(x, [(emb, ops.ACT_NONE, None), (fold, ops.ACT_NONE, True), (prob, ops.ACT_NONE, True), (param, ops.ACT_NONE, True),
+                       (center, ops.ACT_SIGMOID, True)], bf, parallel=[False, False, True, True, True])
+    ref_fold = run_stacks(x, [(emb, ops.ACT_NONE, None), (fold, ops.ACT_NONE, True)], bf)[1]
+    assert r[0] is None and torch.equal(r[1], ref_fold)
+    assert torch.equal(r[2], run_mlp(x, prob, gd=bf))
+    assert torch.equal(r[3], run_mlp(x, param, gd=bf))
+    assert torch.equal(r[4], run_mlp(x, center, final_act=ops.ACT_SIGMOID, gd=bf))
+    # every stack parallel (restart on an odd layer index too)
+    r = run_stacks(x, [(prob, ops.ACT_NONE, True), (param, ops.ACT_NONE, True), (center, ops.ACT_SIGMOID, True)], bf, parallel=True)
+    assert torch.equal(r[0], run_mlp(x, prob, gd=bf)) and torch.equal(r[1], run_mlp(x, param, gd=bf))
+    assert torch.equal(r[2], run_mlp(x, center, final_act=ops.ACT_SIGMOID, gd=bf))
