@@ -139,9 +139,50 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = qlen ? min(qlen[b], Lq) : Lq;
     const int nk = klen ? min(klen[b], Lk) : Lk;
+    // ---- this wave's 32 query rows; lane l: row = l&31, k-half = l>>5 (requested first: in flight while K / V are staged)
+    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool row_ok = row < nq;
+    const int half = lane >> 5;
+    float tq[2][8];
+    {
+        const TIO* qp = q + ((long long)b * Lq + (row_ok ? row : 0)) * q_stride + h * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) att_load8<TIO>(qp + ks * 16 + half * 8, tq[ks]);
+    }
     // ---- stage K (row-major) and V^T as bf16; rows >= nk are zero
     const TIO* kb = k + (long long)b * Lk * k_stride + h * HD;
     const TIO* vb = v + (long long)b * Lk * v_stride + h * HD;
+    if constexpr (sizeof(TIO) == 2) {
+        // bf16 in memory: the 16-byte pieces of up to five passes are requested back to back (unconditional, row clamped) and only then
+        // consumed - one memory round trip for the whole K / V of a (batch, head) instead of one per pass (300 keys = 5 passes: the
+        // staging was ~10 us of the kernel's 15-20 us per workgroup)
+        constexpr int UB = 5;
+        const int nkc = max(nk, 1) - 1;
+        for (int base = 0; base < Lk_pad * 4; base += 256 * UB) {
+            u32x4 kr[UB], vr[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid, j = min(idx >> 2, nkc), c = (idx & 3) * 8;
+                kr[u] = *(const u32x4*)(kb + (long long)j * k_stride + c);
+                vr[u] = *(const u32x4*)(vb + (long long)j * v_stride + c);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid, j = idx >> 2, c = (idx & 3) * 8;
+                if (idx >= Lk_pad * 4) continue;
+                const bool live = j < nk;
+                u32x4 pk = kr[u];
+                if (!live) pk = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(Ks + j * ATT_KSTRIDE + c) = pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int w2 = live ? vr[u][e] : 0u;
+                    Vt[(c + 2 * e) * vt_stride + j] = (bf16_t)(w2 & 0xffffu);
+                    Vt[(c + 2 * e + 1) * vt_stride + j] = (bf16_t)(w2 >> 16);
+                }
+            }
+        }
+    } else
     for (int idx = tid; idx < Lk_pad * 4; idx += 256) {                  // 8 floats per chunk
         const int j = idx >> 2, c = (idx & 3) * 8;
         float kv[8], vv[8];
@@ -157,23 +198,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
         for (int e = 0; e < 8; ++e) Vt[(c + e) * vt_stride + j] = f32_to_bf16(vv[e]);
     }
     __syncthreads();
-    // ---- this wave's 32 query rows; lane l: row = l&31, k-half = l>>5
-    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
-    const bool row_ok = row < nq;
-    const int half = lane >> 5;
     bf16x8 qf[2];
-    {
-        const TIO* qp = q + ((long long)b * Lq + (row_ok ? row : 0)) * q_stride + h * HD;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            float t[8];
-            att_load8<TIO>(qp + ks * 16 + half * 8, t);
-            // scores are kept in the log2 domain (scale * log2(e) folded into q): the soft-max then needs bare v_exp_f32's
-            const float sc2 = scale * 1.4426950408889634f;
-            u32x4 pk = {pack_bf16x2(t[0] * sc2, t[1] * sc2), pack_bf16x2(t[2] * sc2, t[3] * sc2),
-                        pack_bf16x2(t[4] * sc2, t[5] * sc2), pack_bf16x2(t[6] * sc2, t[7] * sc2)};
-            qf[ks] = __builtin_bit_cast(bf16x8, pk);
-        }
+    for (int ks = 0; ks < 2; ++ks) {
+        // scores are kept in the log2 domain (scale * log2(e) folded into q): the soft-max then needs bare v_exp_f32's
+        const float sc2 = scale * 1.4426950408889634f;
+        const float* t = tq[ks];
+        u32x4 pk = {pack_bf16x2(t[0] * sc2, t[1] * sc2), pack_bf16x2(t[2] * sc2, t[3] * sc2),
+                    pack_bf16x2(t[4] * sc2, t[5] * sc2), pack_bf16x2(t[6] * sc2, t[7] * sc2)};
+        qf[ks] = __builtin_bit_cast(bf16x8, pk);
     }
     f32x16 oacc;
 #pragma unroll
