@@ -68,6 +68,15 @@ class StreamSet:
                 else:
                     self.classes.append([s])
             torch.cuda.synchronize()
+        self.queue_classes = len(self.classes)
+        self.inconclusive = self.n > 1 and len(self.classes) == 1
+        if self.inconclusive:
+            # every pair looked shared: either the process really has one hardware queue, or the probe was disturbed (a GPU busy with
+            # someone else's work delays the tiny kernel like a shared queue would).  Forcing all batch streams into "the" class
+            # would serialise them for certain - hand out the streams as the runtime placed them instead.
+            self.mains = self.pool[:self.n]
+            self.sides = list(self.pool[self.n:2 * self.n]) if with_sides else [None] * self.n
+            return
         # batch streams: one per class while classes last (then round robin: more slots than queues must share)
         self.mains: List[torch.cuda.Stream] = []
         order = sorted(self.classes, key=len, reverse=True)
@@ -90,7 +99,6 @@ class StreamSet:
                     used[id(c)] += 1
                 else:                                                   # class exhausted: a new stream, wherever the runtime puts it
                     self.sides[i] = torch.cuda.Stream(device=self.device)
-        self.queue_classes = len(self.classes)
 
     def bind(self, model) -> "StreamSet":
         """Make `model` (PlaneTR_NopeSAC) run the pose net of a batch submitted on mains[i] on sides[i]."""
@@ -103,7 +111,7 @@ class StreamSet:
 
     def describe(self) -> dict:
         idx = {id(s): k for k, c in enumerate(self.classes) for s in c}
-        return {"queue_classes": self.queue_classes, "class_sizes": [len(c) for c in self.classes],
+        return {"queue_classes": self.queue_classes, "probe_inconclusive": self.inconclusive, "class_sizes": [len(c) for c in self.classes],
                 "batch_stream_class": [idx[id(s)] for s in self.mains],
                 "side_stream_class": [idx.get(id(s)) if s is not None else None for s in self.sides]}
 
