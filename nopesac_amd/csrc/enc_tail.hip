@@ -11,6 +11,7 @@
 // sit in LDS as the bf16 A tile, every GEMM is "LDS tile x fragment-major weights streamed from L2" (pwchain.hip /
 // gnn_layer.hip), LayerNorm reduces across the waves through LDS, y1 stays in registers (f32) for the second residual
 // and in LDS (bf16) as the FFN operand, the 32 x 1024 hidden tile never leaves the CU.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -283,6 +284,276 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 64-token form of the ENCODER tail (post-norm, with the optional chained projections).  The 32-token kernel above is bound by the
+// latency of its weight steps - every step a wave multiplies 16 fragments it waited ~1.5 us for - and its 167-250 VGPRs allow one
+// workgroup per CU: 600 workgroups x 30 us for the 19200 encoder tokens.  Here a workgroup owns 64 tokens and every fragment feeds TWO
+// MFMAs (row tiles 0 and 1), so the same latency chain covers twice the tokens: half the workgroups, each a little longer.  What
+// makes it fit: weight steps of K = 128 (8 fragments x 2 buffers = 64 VGPRs instead of 128) and the 1024-wide hidden tile in two
+// halves of 512 (66 KB of LDS), linear2 accumulating across the halves in registers.  Same arithmetic in the same order as the
+// 32-token kernel (ascending K inside every accumulator, the same LayerNorm reduction order): bit-identical results.
+constexpr int E6_BM = 64, E6_HW = 512, E6_HLD = E6_HW + 8;
+constexpr int E6_A = E6_BM * ET_LD;
+constexpr size_t E6_LDS_BYTES = 2 * (size_t)(2 * E6_A + E6_BM * E6_HLD) + 2 * 8 * 64 * sizeof(float);
+static_assert((size_t)E6_BM * ET_D * 4 <= 2 * (size_t)E6_BM * E6_HLD, "the f32 staging tile must fit the hidden region");
+
+struct E6Ring {
+    bf16x8 f[2][8];
+};
+template <int BUF>
+__device__ __forceinline__ void e6_issue(E6Ring& ring, const bf16_t* __restrict__ w, int kf_total, int kf_off, int nt, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+        ring.f[BUF][kk] = *reinterpret_cast<const bf16x8*>(w + ((long long)(nt * kf_total + kf_off + kk) * 64 + lane) * 8);
+}
+// acc[r] += A[r*32 + row][koff*16 ..] * W over the 8 k-steps held in ring.f[BUF]
+template <int BUF>
+__device__ __forceinline__ void e6_gemm(const E6Ring& ring, const bf16_t* A, int lda, int koff, f32x16 (&acc)[2], int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + (r * 32 + l31) * lda + (koff + kk) * 16 + half * 8);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[BUF][kk], af, acc[r], 0, 0, 0);
+        }
+}
+__device__ __forceinline__ void e6_layernorm(f32x16 (&acc)[2], const float* __restrict__ gamma, const float* __restrict__ beta, float* red,
+                                             int wave, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* rp = red + pass * 8 * 64;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = pass == 0 ? acc[r][e] : acc[r][e] - mean[r];
+                s += pass == 0 ? d : d * d;
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (half == 0) rp[wave * 64 + r * 32 + l31] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += rp[w * 64 + r * 32 + l31];
+            if (pass == 0) mean[r] = t / ET_D;
+            else rstd[r] = rsqrtf(t / ET_D + 1e-5f);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n), b = *reinterpret_cast<const f32x4*>(beta + n);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][4 * q + e] = (acc[r][4 * q + e] - mean[r]) * rstd[r] * g[e] + b[e];
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char et_smem[];
+    bf16_t* At = reinterpret_cast<bf16_t*>(et_smem);         // attention rows [64][264]; later bf16(y + pos)
+    bf16_t* Yt = At + E6_A;                                  // bf16(y1) [64][264]; later bf16(y)
+    bf16_t* Ht = Yt + E6_A;                                  // hidden half [64][520]; later the f32 output staging
+    float* red = reinterpret_cast<float*>(Ht + E6_BM * E6_HLD);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * E6_BM;
+    E6Ring ring;
+    typedef std::integral_constant<int, 0> B0;
+    (void)sizeof(B0);
+
+    e6_issue<0>(ring, p.wo, 16, 0, wave, lane);                                   // out-proj tile `wave`, K 0..127
+#pragma unroll
+    for (int i = 0; i < E6_BM * 32 / 512; ++i) {                                  // attention rows -> LDS
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        us8 v = us8{};
+        if (m0 + r < p.M) v = *reinterpret_cast<const us8*>(p.attn + (m0 + r) * ET_D + col);
+        *reinterpret_cast<us8*>(At + r * ET_LD + col) = v;
+    }
+    __syncthreads();
+    // ---- y1 = LN1(src + out_proj(attn))
+    f32x16 y1[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) et_zero(y1[r]);
+    e6_issue<1>(ring, p.wo, 16, 8, wave, lane);
+    e6_gemm<0>(ring, At, ET_LD, 0, y1, lane);
+    e6_issue<0>(ring, p.w1, 16, 0, 2 * wave, lane);                               // linear1, half 0, tile 2w, K 0..127
+    e6_gemm<1>(ring, At, ET_LD, 8, y1, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + n);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long row = m0 + r * 32 + l31;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (row < p.M) s = *reinterpret_cast<const f32x4*>(p.src + row * ET_D + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y1[r][4 * q + e] = (y1[r][4 * q + e] + b[e]) + s[e];
+        }
+    }
+    e6_layernorm(y1, p.g1, p.be1, red, wave, lane);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            us4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y1[r][4 * q + e]);
+            *reinterpret_cast<us4*>(Yt + (r * 32 + l31) * ET_LD + wave * 32 + 8 * q + 4 * half) = o;
+        }
+    __syncthreads();
+    // ---- FFN in two halves of 512 hidden channels: hidden_h = relu(linear1 tiles 16h .. 16h+15), y2 += hidden_h W2[:, 512h ..]
+    f32x16 y2[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) et_zero(y2[r]);
+    auto hidden_tile = [&](auto H, auto J) {                 // on entry ring buffer 0 holds K 0..127 of tile 16h + 2w + j
+        constexpr int h = decltype(H)::value, j = decltype(J)::value;
+        const int nt = 16 * h + 2 * wave + j;
+        f32x16 hd[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) et_zero(hd[r]);
+        e6_issue<1>(ring, p.w1, 16, 8, nt, lane);
+        e6_gemm<0>(ring, Yt, ET_LD, 0, hd, lane);
+        if constexpr (j == 0) e6_issue<0>(ring, p.w1, 16, 0, nt + 1, lane);      // the wave's second tile of this half
+        else e6_issue<0>(ring, p.w2, 64, 32 * h, wave, lane);                     // linear2, K 512h .. +127
+        e6_gemm<1>(ring, Yt, ET_LD, 8, hd, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = (2 * wave + j) * 32 + 8 * q + 4 * half;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + 512 * h + nl);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = hd[r][4 * q + e] + b[e];
+                    o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(Ht + (r * 32 + l31) * E6_HLD + nl) = o;
+            }
+        }
+    };
+    auto linear2_half = [&](auto H) {                         // on entry ring buffer 0 holds K 512h .. +127 of tile `wave`
+        constexpr int h = decltype(H)::value;
+        e6_issue<1>(ring, p.w2, 64, 32 * h + 8, wave, lane);
+        e6_gemm<0>(ring, Ht, E6_HLD, 0, y2, lane);
+        e6_issue<0>(ring, p.w2, 64, 32 * h + 16, wave, lane);
+        e6_gemm<1>(ring, Ht, E6_HLD, 8, y2, lane);
+        e6_issue<1>(ring, p.w2, 64, 32 * h + 24, wave, lane);
+        e6_gemm<0>(ring, Ht, E6_HLD, 16, y2, lane);
+        if constexpr (h == 0) e6_issue<0>(ring, p.w1, 16, 0, 16 + 2 * wave, lane);          // half 1, first tile
+        e6_gemm<1>(ring, Ht, E6_HLD, 24, y2, lane);
+    };
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 0> I0;
+    hidden_tile(I0{}, I0{});
+    hidden_tile(I0{}, I1{});
+    __syncthreads();
+    linear2_half(I0{});
+    __syncthreads();                                          // every wave is done reading hidden half 0
+    hidden_tile(I1{}, I0{});
+    hidden_tile(I1{}, I1{});
+    __syncthreads();
+    // the first projection tile (if any) while linear2's second half runs
+    const int ta = p.wpa ? p.npa / 32 : 0, tb = p.wpb ? p.npb / 32 : 0, tt = ta + tb;
+    auto tile_w = [&](int nt) { return nt < ta ? p.wpa : p.wpb; };
+    linear2_half(I1{});
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y2[r][4 * q + e] = (y2[r][4 * q + e] + b[e]) + y1[r][4 * q + e];
+    }
+    e6_layernorm(y2, p.g2, p.be2, red, wave, lane);           // its barriers also retire every read of Ht / Yt
+    // ---- outputs through LDS (whole rows): f32 tile in the hidden region, bf16 tiles in Yt (y) / At (y + pos)
+    float* Yf = reinterpret_cast<float*>(Ht);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = wave * 32 + 8 * q + 4 * half, rl = r * 32 + l31;
+            const long long row = m0 + rl;
+            const f32x4 v = {y2[r][4 * q], y2[r][4 * q + 1], y2[r][4 * q + 2], y2[r][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(Yf + rl * ET_D + n) = v;
+            f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+            if (p.pos && row < p.M) pv = *reinterpret_cast<const f32x4*>(p.pos + (row % p.pos_rows) * ET_D + n);
+            us4 o, op;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = f32_to_bf16(v[e]); op[e] = f32_to_bf16(v[e] + pv[e]); }
+            *reinterpret_cast<us4*>(Yt + rl * ET_LD + n) = o;
+            *reinterpret_cast<us4*>(At + rl * ET_LD + n) = op;
+        }
+    __syncthreads();
+    if (p.y) {
+#pragma unroll
+        for (int i = 0; i < E6_BM * 64 / 512; ++i) {
+            const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_D + col);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < E6_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        if (m0 + r < p.M) {
+            if (p.y16) *reinterpret_cast<us8*>(p.y16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(Yt + r * ET_LD + col);
+            if (p.ypos16) *reinterpret_cast<us8*>(p.ypos16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(At + r * ET_LD + col);
+        }
+    }
+    // ---- the next attention's input projections from the two bf16 tiles (At = y + pos, Yt = y): tile nt = round * 8 + wave, K = 256
+    if (tt > 0) {
+        for (int nt = wave; nt < tt; nt += 8) {
+            const bool is_a = nt < ta;
+            const int ct = is_a ? nt : nt - ta, ldo = is_a ? p.npa : p.npb;
+            f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) et_zero(acc[r]);
+            e6_issue<0>(ring, tile_w(nt), 16, 0, ct, lane);
+            e6_issue<1>(ring, tile_w(nt), 16, 8, ct, lane);
+            e6_gemm<0>(ring, is_a ? At : Yt, ET_LD, 0, acc, lane);
+            e6_gemm<1>(ring, is_a ? At : Yt, ET_LD, 8, acc, lane);
+            const float* bias = is_a ? p.bpa : p.bpb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 8 * q + 4 * half;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const long long row = m0 + r * 32 + l31;
+                    us4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[r][4 * q + e] + b[e]);
+                    if (row < p.M) *reinterpret_cast<us4*>((is_a ? p.pa : p.pb) + row * ldo + ct * 32 + n) = o;
+                }
+            }
+        }
+    }
+}
+
+static int et_launch(const EncTailArgs& a, hipStream_t stream) {
+    // the encoder (post-norm, thousands of tokens) on the 64-token kernel; decoder forms and small inputs on the 32-token one
+    if (!a.pre_norm && !a.skip_ffn && a.M >= 2048 && !getenv("NOPESAC_ENC_TAIL_32")) {
+        NPS_ENSURE_LDS((int)E6_LDS_BYTES, enc_tail64_kernel);
+        hipLaunchKernelGGL(enc_tail64_kernel, dim3((a.M + E6_BM - 1) / E6_BM), dim3(512), E6_LDS_BYTES, stream, a);
+    } else {
+        NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
+        hipLaunchKernelGGL(enc_tail_kernel, dim3((a.M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, stream, a);
+    }
+    return 0;
+}
+
 }  // namespace nps
 
 extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* ln1_g,
@@ -301,8 +572,7 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = nullptr; a.pre_norm = 0;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
-    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
-    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    et_launch(a, (hipStream_t)stream);
     NPS_LAUNCH_RET();
 }
 
@@ -326,8 +596,7 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = yn; a.pre_norm = 1;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
-    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
-    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    et_launch(a, (hipStream_t)stream);
     NPS_LAUNCH_RET();
 }
 
@@ -361,7 +630,6 @@ extern "C" int nopesac_transformer_tail_bf16(const void* attn, const float* src,
     a.yn = yn; a.pre_norm = pre_norm ? 1 : 0; a.skip_ffn = skip_ffn ? 1 : 0;
     a.wpa = proj_pos ? (const bf16_t*)w_pos : nullptr; a.bpa = b_pos; a.pa = (bf16_t*)proj_pos; a.npa = n_pos;
     a.wpb = proj ? (const bf16_t*)w_proj : nullptr; a.bpb = b_proj; a.pb = (bf16_t*)proj; a.npb = n_proj;
-    NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
-    hipLaunchKernelGGL(enc_tail_kernel, dim3((M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, (hipStream_t)stream, a);
+    et_launch(a, (hipStream_t)stream);
     NPS_LAUNCH_RET();
 }

@@ -974,3 +974,26 @@ def test_mlp_chain_parallel_stacks_over_the_same_rows(device):
     r = run_stacks(x, [(prob, ops.ACT_NONE, True), (param, ops.ACT_NONE, True), (center, ops.ACT_SIGMOID, True)], bf, parallel=True)
     assert torch.equal(r[0], run_mlp(x, prob, gd=bf)) and torch.equal(r[1], run_mlp(x, param, gd=bf))
     assert torch.equal(r[2], run_mlp(x, center, final_act=ops.ACT_SIGMOID, gd=bf))
+
+
+@pytest.mark.parametrize("M", [2048, 19200 // 4 + 17])
+def test_encoder_tail_64_token_kernel_equals_the_32_token_one(device, M, monkeypatch):
+    """enc_tail64_kernel (64 tokens per workgroup, K = 128 weight steps, hidden tile in two halves) computes the same sums in the same
+    order as enc_tail_kernel: bit-identical outputs and chained projections (ragged last tile included)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    attn, src, pos = rn(M, 256).bfloat16(), rn(M, 256), rn(300, 256)
+    fm = ops.mfma_fragment_major
+    W = {"wo": fm(rn(256, 256, k=1 / 16).bfloat16()), "w1": fm(rn(1024, 256, k=1 / 16).bfloat16()), "w2": fm(rn(256, 1024, k=1 / 32).bfloat16()),
+         "bo": rn(256, k=0.1), "b1": rn(1024, k=0.1), "b2": rn(256, k=0.1), "ga": 1 + rn(256, k=0.1), "bea": rn(256, k=0.1),
+         "gb": 1 + rn(256, k=0.1), "beb": rn(256, k=0.1)}
+    pp = (fm(rn(512, 256, k=1 / 16).bfloat16()), rn(512, k=0.1), 512)
+    pj = (fm(rn(256, 256, k=1 / 16).bfloat16()), None, 256)
+    run = lambda: ops.transformer_tail(attn, src, W, pre_norm=False, pos=pos, want=("y", "y16", "ypos16"), proj_pos=pp, proj=pj)
+    new = run()
+    monkeypatch.setenv("NOPESAC_ENC_TAIL_32", "1")
+    old = run()
+    torch.cuda.synchronize()
+    for k in ("y", "y16", "ypos16", "proj_pos", "proj"):
+        assert torch.equal(new[k], old[k]), k
