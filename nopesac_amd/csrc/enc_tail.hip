@@ -467,6 +467,10 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
     const int ta = p.wpa ? p.npa / 32 : 0, tb = p.wpb ? p.npb / 32 : 0, tt = ta + tb;
     auto tile_w = [&](int nt) { return nt < ta ? p.wpa : p.wpb; };
     linear2_half(I1{});
+    if (wave < tt) {                                          // first projection tile: in flight during LN2 and the output staging
+        e6_issue<0>(ring, tile_w(wave), 16, 0, wave < ta ? wave : wave - ta, lane);
+        e6_issue<1>(ring, tile_w(wave), 16, 8, wave < ta ? wave : wave - ta, lane);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = wave * 32 + 8 * q + 4 * half;
@@ -519,10 +523,11 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
             f32x16 acc[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) et_zero(acc[r]);
-            e6_issue<0>(ring, tile_w(nt), 16, 0, ct, lane);
-            e6_issue<1>(ring, tile_w(nt), 16, 8, ct, lane);
+            const int nn = nt + 8, cn = nn < ta ? nn : nn - ta;       // the next tile's fragments replace this one's as they are consumed
             e6_gemm<0>(ring, is_a ? At : Yt, ET_LD, 0, acc, lane);
+            if (nn < tt) e6_issue<0>(ring, tile_w(nn), 16, 0, cn, lane);
             e6_gemm<1>(ring, is_a ? At : Yt, ET_LD, 8, acc, lane);
+            if (nn < tt) e6_issue<1>(ring, tile_w(nn), 16, 8, cn, lane);
             const float* bias = is_a ? p.bpa : p.bpb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
