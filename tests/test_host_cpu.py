@@ -233,3 +233,19 @@ def test_library_is_built_without_packed_fp32_instructions():
     flags = " ".join(build.FLAGS)
     assert "-target-feature -Xclang -packed-fp32-ops" in flags, flags
     assert all("packed-fp32" not in " ".join(v) or "-packed-fp32-ops" in " ".join(v) for v in build.EXTRA_FLAGS.values())
+
+
+def test_host_fetch_and_cached_constant_on_cpu_tensors():
+    """ops.HostFetch passes host tensors through untouched (no device, no copy) and ops.cached_constant builds a key once."""
+    import torch
+    from nopesac_amd import ops
+    a, b = torch.arange(6.0).view(2, 3), torch.tensor([1, 2, 3], dtype=torch.int32)
+    f = ops.HostFetch({"a": a, "b": b})
+    v = f.wait().views()
+    assert v["a"] is not None and torch.equal(v["a"], a) and torch.equal(v["b"], b) and f.host is None
+    assert ops.gather_to_host({"a": a})["a"].data_ptr() == a.data_ptr()
+    calls, cache = [], {}
+    make = lambda: (calls.append(1), torch.zeros(3))[1]
+    t1 = ops.cached_constant(cache, "k", make)
+    t2 = ops.cached_constant(cache, "k", make)
+    assert t1 is t2 and len(calls) == 1
