@@ -249,3 +249,20 @@ def test_host_fetch_and_cached_constant_on_cpu_tensors():
     t1 = ops.cached_constant(cache, "k", make)
     t2 = ops.cached_constant(cache, "k", make)
     assert t1 is t2 and len(calls) == 1
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks of the round-3 entry points run before any HIP call: wrong arguments come back as an error code + message on a
+    machine without a GPU (no compute is attempted)."""
+    from nopesac_amd import _lib
+    lib = _lib.load()
+    err = lambda: lib.nopesac_last_error().decode()
+    assert lib.nopesac_transformer_tail_bf16(*([None] * 13), 0, *([None] * 4), 0, 0, None, None, None, 0, None, None, None, 0, 64, None) != 0
+    assert "transformer_tail" in err()
+    assert lib.nopesac_mask_operands(None, 264, None, None, 1, 50, 64, None) != 0 and "mask_operands" in err()
+    assert lib.nopesac_rle_compress_device_capped(None, None, None, 4, 8, 8, None, None, None, -1, None) != 0 and "rle_compress_device_capped" in err()
+    assert lib.nopesac_tape_replay_on(None, None, None, 0) != 0 and "tape_replay" in err()
+    assert lib.nopesac_metric_rows(None, None, None, None, None, None, None, None, 0, None, 4, None) != 0 and "metric_rows" in err()
+    assert lib.nopesac_add_rows_bf16(None, None, None, None, 4, 6, 1, None) != 0 and "add_rows_bf16" in err()
+    assert lib.nopesac_softmax_rows_pad(None, None, 4, 300, 304, 1, None) != 0 and "softmax_rows_pad" in err()
+    assert lib.nopesac_concat_cols(None, 3, None, 4, None, 2, None) != 0 and "concat_cols" in err()
