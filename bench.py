@@ -2,7 +2,8 @@
 """bench.py — image-pairs/s of the NopeSAC inference hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W              # single GPU
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W              # N ranks spawned by this file (runner.launch), one per GPU, RCCL
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     # or joined from a torchrun environment
 
 A "step" = one pass of the whole hot path (preprocess -> ResNet-50 -> PlaneTR head -> plane post-selection
 -> pixel pose net -> matcher (GNN + 200-iter Sinkhorn) -> neural one-plane RANSAC -> results fetched) over
@@ -248,7 +249,7 @@ def cpu_baseline(budget_s=15.0):
             "sample": f"{n} synthetic 480x640 pairs, fp32, batch 1, K={K} matched planes forced as on the GPU, {el:.1f}s"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -285,13 +286,91 @@ def main():
                     help="ANALYSIS ONLY (the JSON line is marked invalid): time a truncated pipeline - backbone only / "
                          "backbone + plane head + post-selection / everything but the camera head - to see what each stage "
                          "costs once batches overlap")
-    args = ap.parse_args()
+    ap.add_argument("--stub-model", action="store_true",
+                    help="TEST ONLY (the JSON line is marked invalid): the launcher, the in-flight loop, the per-step gather and the timed region "
+                         "of this file around a stub that fabricates result rows instead of running the model - what the gloo CPU tests drive")
+    return ap.parse_args(argv)
 
+
+def timed_region(loop, step, steps, world, device=None):
+    """EXACTLY `steps` steps between two (drain + process barrier + device synchronize) brackets (the caller's warmup ends with
+    loop.barrier()); the elapsed time is the MAX over the ranks.  -> (seconds, host ms per step, last step's gathered rows)."""
+    loop.host_seconds = 0.0
+    host = None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _, host = step(i)
+    host_ms = 1e3 * loop.host_seconds / max(steps, 1)
+    loop.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device if device is not None else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    return el, host_ms, host
+
+
+def main(argv=None):
+    """`--gpus N` with no torchrun environment: start the N ranks HERE (runner.launch = detectron2's `launch` for one machine,
+    test_NopeSAC.py:209-216), one process per GPU; under torchrun (WORLD_SIZE set) join that world, which must have N ranks."""
+    args = parse_args(argv)
+    from nopesac_amd import runner
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s" % (args.gpus, os.environ["WORLD_SIZE"]))
+    elif args.gpus > 1 and not args.stub_model:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible (one rank per GPU; no oversubscription)" % (args.gpus, n_dev))
+    return runner.launch(rank_main, args.gpus, (args,))
+
+
+def stub_rank_main(args, rank, world, local):
+    """--stub-model: this file's launcher, InflightLoop, one gather per step and timed region with fabricated rows (CPU + gloo in
+    the tests, or GPUs + RCCL to check a node's plumbing without the model).  Never a measurement."""
+    from nopesac_amd import runner
+    cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local) if cuda else None
+    B = args.pairs
+    loop = runner.InflightLoop(max(1, args.inflight), B, device, world, side_shift=None)
+
+    def slot_step(slot):
+        idx = torch.arange(B, dtype=torch.float32, device=device)
+        t = torch.stack([idx, idx + 0.5 * rank, torch.full_like(idx, float(slot))], dim=1)
+        q = torch.nn.functional.normalize(torch.ones(B, 4, device=device), dim=-1)
+        k = torch.full((B,), args.k, dtype=torch.int32, device=device)
+        return None, runner.metric_rows(t, q, k, k, k, rank * B)
+
+    for i in range(args.warmup):
+        loop.step(i, slot_step)
+    loop.barrier()
+    elapsed, host_ms, host = timed_region(loop, lambda i: loop.step(i, slot_step), args.steps, world, device)
+    ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    ok = host.shape[0] == world * B and host[:, 12].tolist() == [float(v) for v in range(world * B)]
+    if rank == 0:
+        print(json.dumps({"INVALID_stub_model": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 4), "rows_gathered": int(host.shape[0]), "rows_in_rank_order": bool(ok),
+                          "config": {"rccl_ranks": ranks, "backend": torch.distributed.get_backend() if ranks > 1 else None,
+                                     "pairs_per_gpu": B, "global_batch": world * B, "device": str(device) if cuda else "cpu"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if not ok:
+        sys.exit("bench.py --stub-model: gathered rows are not the rank-major pair indices")
+
+
+def rank_main(args):
     from nopesac_amd import runner
     rank, world, local = runner.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but this process is rank %d of %d" % (args.gpus, rank, world))
+    if args.stub_model:
+        return stub_rank_main(args, rank, world, local)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (nopesac_amd has no CPU path)")
+    if local >= torch.cuda.device_count():
+        sys.exit("bench.py: LOCAL_RANK %d but only %d GPU(s) are visible" % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     B, K = args.pairs, args.k
@@ -441,19 +520,7 @@ def main():
             return False
 
     def timed(steps):
-        """EXACTLY `steps` steps between two (drain + process barrier + device synchronize) brackets; max over the ranks."""
-        loop.host_seconds = 0.0
-        t0 = time.perf_counter()
-        for i in range(steps):
-            d, host = step(i)
-        host_ms = 1e3 * loop.host_seconds / steps
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t.item())
-        return el, host_ms, host
+        return timed_region(loop, step, steps, world, device)
 
     if args.graph:
         use_graph = capture_slots()
@@ -608,6 +675,8 @@ def main():
                                   % (B, args.dtype, "bf16 operands with f32 accumulate / residual stream / LayerNorm / softmax" if args.dtype == "bfloat16"
                                      else "f32", K, m_mean, nq),
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
+                      "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                      "pairs_per_s_per_gpu": round(pairs_per_s / world, 3),
                       "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph,
                       "streams": dict(loop.stream_set.describe(), policy=args.streams) if loop.stream_set is not None else {"policy": "none"},
                       "replay": None if not use_graph else ("whole hipGraph" if args.whole_graph or "tape_counts" not in last else "launch tape"),

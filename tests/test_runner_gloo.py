@@ -145,3 +145,41 @@ def test_bench_inflight_loop_world2(tmp_path):
         np.testing.assert_allclose(a[i, :B, 0], i + np.arange(B) / 100, rtol=1e-6)           # rank 0's rows of step i
         np.testing.assert_allclose(a[i, B:, 0], 1000 + i + np.arange(B) / 100, rtol=1e-6)    # rank 1's rows of step i
         assert (a[i, :, 9] == 32).all()
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment must start two ranks by itself (runner.launch) - not run one rank and
+    report n_gpus 1.  Stub model (fabricated rows) on CPU over gloo: the launcher, InflightLoop, the per-step all_gather, the timed
+    region's max-over-ranks and rank 0's single JSON line are bench.py's own."""
+    r, j = _run_bench(["--gpus", "2", "--stub-model", "--steps", "6", "--warmup", "2", "--pairs", "3", "--inflight", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # rank 0 only
+    assert j["n_gpus"] == 2 and j["config"]["rccl_ranks"] == 2 and j["config"]["global_batch"] == 6
+    assert j["rows_gathered"] == 6 and j["rows_in_rank_order"] and j["steps"] == 6 and j["warmup"] == 2
+    assert j["INVALID_stub_model"] is True
+
+
+def test_bench_gpus_mismatch_fails_loudly():
+    """A torchrun world of another size than --gpus, or more GPUs asked for than visible, is an error - never a silent 1-rank run."""
+    r, j = _run_bench(["--gpus", "4", "--stub-model", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and j is None and "WORLD_SIZE" in r.stderr
+    r, j = _run_bench(["--gpus", "64", "--steps", "1", "--warmup", "0"])              # the real model path: no node has 64 GPUs
+    assert r.returncode != 0 and j is None and "visible" in r.stderr
+
+
+def test_bench_single_rank_stub():
+    r, j = _run_bench(["--gpus", "1", "--stub-model", "--steps", "3", "--warmup", "1", "--pairs", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["n_gpus"] == 1 and j["config"]["rccl_ranks"] == 1 and j["rows_gathered"] == 4
