@@ -260,7 +260,7 @@ def parse_args(argv=None):
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 (NOT the headline line): the backbone's 3x3 convs on the fp8 "
                     "(e4m3fn) MFMA, static activation scales calibrated on the synthetic pairs; the JSON line says dtype fp8+bf16")
     ap.add_argument("--config", default="mp3d", choices=sorted(CONFIG_FILES), help="configs/inference_<name>.yaml (BASELINE configs[2] = scannet, --k 64)")
-    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r3.json"),
+    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r4.json"),
                     help="kernel routing file (autotuner decisions per conv/GEMM shape): loaded when it exists so that every run - "
                          "driver, PMC, rocprofv3 - launches identical kernels; shapes it does not list are tuned and added")
     ap.add_argument("--retune", action="store_true", help="ignore the routing file's contents, tune every shape again and rewrite it")
@@ -737,7 +737,7 @@ def other_configs(args, steps=12, warmup=4):
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--pairs", str(args.pairs),
                "--inflight", str(args.inflight), "--no-cpu-baseline", "--no-accuracy", "--no-fp32-path", "--no-boundary", "--no-other-configs", "--no-tape",
-               "--routing", os.path.join(ROOT, "profiles", "routing_r3_%s.json" % name)] + extra
+               "--routing", os.path.join(ROOT, "profiles", "routing_r4_%s.json" % name)] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)

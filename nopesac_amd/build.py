@@ -23,6 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 if os.environ.get("NOPESAC_ALLOW_PACKED_FP32"):           # A/B builds only
     FLAGS = FLAGS[:5]
 EXTRA_FLAGS = {}                                          # per-file additions
+if os.environ.get("NOPESAC_HIPCC_EXTRA"):                 # A/B builds only (e.g. -DSOME_TUNING_MACRO=1): part of the digest, so a rebuild follows
+    FLAGS = FLAGS + os.environ["NOPESAC_HIPCC_EXTRA"].split()
 
 
 def _hipcc() -> str:

@@ -70,6 +70,8 @@ constexpr int P8_LDS = P8_TAB_OFF + P8_BM * 8;                     // 131 KB
 // owns, for its pixel row, the 32 channels wc*64 + j*32 + 8q + 4*(lane >> 5) + e: their scale / bias values sit in 64 registers
 // (loaded once per tile, before the next tile's DMAs), the staged tile is bf16 (half the LDS bytes of the f32 staging) and the
 // second stage is a pure 16-byte LDS -> global copy.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct P8EpiRegs16 {
     float sc[2][4][4], bs[2][4][4];
 };
@@ -91,8 +93,8 @@ __device__ __forceinline__ void p8_epilogue16_prefetch(P8EpiRegs16& R, const Con
 constexpr int P8_ELD16 = P8_BN + 8;                             // bf16 elements per staged row (528 bytes)
 
 template <int EPI>
-__device__ __forceinline__ void p8_epilogue16(f32x16 (&acc)[4][2], unsigned char* lds, const ConvParams& p, int m0, int n0, int wr, int wc,
-                                              int lane, int tid, bool drain_dma, const P8EpiRegs16& R) {
+__device__ __forceinline__ void p8_epilogue16(f32x16 (&acc)[4][2], unsigned char* lds, const ConvParams& p, const __amdgpu_buffer_rsrc_t& ry,
+                                              int m0, int n0, int wr, int wc, int lane, int tid, bool drain_dma, const P8EpiRegs16& R) {
     bf16_t* epi = reinterpret_cast<bf16_t*>(lds + P8_EPI_OFF);
     const int c8 = tid & 31, rg = tid >> 5;
     constexpr int act = EPI == 1 ? NPS_ACT_RELU : (EPI == 2 ? NPS_ACT_NONE : NPS_ACT_LEAKY);
@@ -115,18 +117,21 @@ __device__ __forceinline__ void p8_epilogue16(f32x16 (&acc)[4][2], unsigned char
                 const uint2 o = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
                 *(uint2*)(epi + (wr * 32 + (lane & 31)) * P8_ELD16 + wc * 64 + j * 32 + 8 * q + 4 * (lane >> 5)) = o;
             }
-        if constexpr (pass == 3) {                              // as late as possible: the DMAs had the whole epilogue to land
-            if (drain_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (pass == 3) {
+            // the next tile's first DMAs must have landed before its K loop reads buffer 0.  They are the OLDEST operations in flight
+            // (issued before pass 0); younger are exactly the 12 stores of passes 0-2 (unconditional: rows >= M are dropped by the
+            // descriptor's bounds check) - a counted wait, the stores are never waited for (round 4; was vmcnt(0))
+            if (drain_dma) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         }
         P8_LDS_SYNC();
-        uint4 o[4];
+        u32x4 o[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) o[it] = *(const uint4*)(epi + (it * 16 + rg) * P8_ELD16 + c8 * 8);
+        for (int it = 0; it < 4; ++it) o[it] = *(const u32x4*)(epi + (it * 16 + rg) * P8_ELD16 + c8 * 8);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rs = it * 16 + rg;
-            const int m = m0 + (rs >> 5) * 128 + pass * 32 + (rs & 31);
-            if (m < p.M) *(uint4*)((bf16_t*)p.y + (long long)m * p.y_cs + n0 + c8 * 8) = o[it];
+            const unsigned m = (unsigned)(m0 + (rs >> 5) * 128 + pass * 32 + (rs & 31));
+            __builtin_amdgcn_raw_buffer_store_b128(o[it], ry, (int)((m * (unsigned)p.y_cs + (unsigned)(n0 + c8 * 8)) * 2u), 0, 0);
         }
         P8_LDS_SYNC();
     };
@@ -304,6 +309,113 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[4][2], unsigned char* 
     do_pass(IC<3>{});
 }
 
+// EPI 4 (bf16 residual added before a ReLU, bf16 output: the expand conv of a bottleneck - K = Cin <= 512, four K-tiles, so the
+// tile IS its epilogue: 128 KB of residual in, 128 KB out per 9 k cycles of MFMAs).  Round 4: the generic form above issued the
+// residual loads of pass q at the START of pass q, i.e. BEHIND the stores of pass q-1 - and vmcnt retires in issue order, so the
+// wait for the residual was a wait for the previous pass's store acknowledgements plus one exposed HBM round trip, four times per
+// tile (PMC: waves parked 56 % of their cycles, 3.5 TB/s).  Here:
+//   * residual and output go through buffer descriptors: rows >= M read zeros / are dropped by the bounds check, so the epilogue
+//     is branch-free straight-line code and every s_waitcnt vmcnt is a COUNTED one;
+//   * the residual rows of pass q+1 are requested in the middle of pass q (after the staging read-back, before pass q's own
+//     arithmetic and stores): they have a whole pass (staging writes, barrier, read-back) to arrive and the wait for them leaves
+//     the 4 stores of pass q in flight (vmcnt(4) / vmcnt(8)) - stores are never waited for inside the epilogue.  (Two passes of
+//     rows in flight - 16 more registers - measured slower on the same box: 90.0 / 90.9 vs 87.5 / 86.6 us on res4's expand conv,
+//     profiles/r4_e_epi4_prefetch_depth_ab.txt: the pass is not waiting for its residual any more);
+//   * the next tile's first DMAs (issued before pass 0, older than every residual load) have landed once pass 3's residual has:
+//     no vmcnt(0) at the end either.
+struct P8Epi4Regs {
+    float sc[8], bs[8];
+    u32x4 r0[4];                    // residual rows of pass 0 (requested BEFORE the next tile's DMAs)
+};
+
+__device__ __forceinline__ unsigned p8_epi4_row(int m0, int it, int rg, int pass) {
+    const int rs = it * 16 + rg;
+    return (unsigned)(m0 + (rs >> 5) * 128 + pass * 32 + (rs & 31));
+}
+
+__device__ __forceinline__ void p8_epilogue4_prefetch(P8Epi4Regs& R, const ConvParams& p, const __amdgpu_buffer_rsrc_t& rres, int m0, int n0,
+                                                      int tid) {
+    const int c8 = tid & 31, rg = tid >> 5;
+    const int n = n0 + c8 * 8;
+    *(f32x4*)(R.sc) = *(const f32x4*)(p.scale + n);
+    *(f32x4*)(R.sc + 4) = *(const f32x4*)(p.scale + n + 4);
+    *(f32x4*)(R.bs) = *(const f32x4*)(p.bias + n);
+    *(f32x4*)(R.bs + 4) = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        R.r0[it] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)((p8_epi4_row(m0, it, rg, 0) * (unsigned)p.r_cs + (unsigned)n) * 2u), 0, 0);
+}
+
+__device__ __forceinline__ void p8_epilogue4(f32x16 (&acc)[4][2], unsigned char* lds, const ConvParams& p, const __amdgpu_buffer_rsrc_t& rres,
+                                             const __amdgpu_buffer_rsrc_t& ry, int m0, int n0, int wr, int wc, int lane, int tid,
+                                             const P8Epi4Regs& R) {
+    float* epi = reinterpret_cast<float*>(lds + P8_EPI_OFF);
+    const int c8 = tid & 31, rg = tid >> 5;
+    const int n = n0 + c8 * 8;
+    u32x4 rc[4], rn[4];                                         // residual rows of this pass / of the next (in flight)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rc[it] = R.r0[it];
+    auto do_pass = [&](auto PASSC) {
+        constexpr int pass = decltype(PASSC)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rs = wr * 32 + (lane & 31);
+                const int c = wc * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+                const f32x16& a = acc[pass][j];
+                const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                *(f32x4*)(epi + rs * P8_ELD + c) = v;
+            }
+        P8_LDS_SYNC();
+        float v[4][8];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rs = it * 16 + rg;
+            *(f32x4*)(v[it]) = *(const f32x4*)(epi + rs * P8_ELD + c8 * 8);
+            *(f32x4*)(v[it] + 4) = *(const f32x4*)(epi + rs * P8_ELD + c8 * 8 + 4);
+        }
+        if constexpr (pass < 3) {                               // the NEXT pass's residual rows: in front of this pass's stores
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                rn[it] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)((p8_epi4_row(m0, it, rg, pass + 1) * (unsigned)p.r_cs + (unsigned)n) * 2u), 0, 0);
+        } else {
+            // pass 3: younger than its residual are only pass 2's four stores; everything older - the next tile's first DMAs
+            // included - has then landed (vmcnt retires in issue order)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[it][e] *= R.sc[e]; v[it][e] += R.bs[e]; }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const us8 r8 = __builtin_bit_cast(us8, rc[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = v[it][e] + bf16_to_f32(r8[e]);
+                v[it][e] = t > 0.f ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            u32x4 o;
+            o.x = f32x2_to_bf16x2(v[it][0], v[it][1]); o.y = f32x2_to_bf16x2(v[it][2], v[it][3]);
+            o.z = f32x2_to_bf16x2(v[it][4], v[it][5]); o.w = f32x2_to_bf16x2(v[it][6], v[it][7]);
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, (int)((p8_epi4_row(m0, it, rg, pass) * (unsigned)p.y_cs + (unsigned)n) * 2u), 0, 0);
+        }
+        if constexpr (pass < 3) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rc[it] = rn[it];
+        }
+        P8_LDS_SYNC();                                          // staging rows free for the next pass / for the DMAs of buffer 1
+    };
+    do_pass(IC<0>{});
+    do_pass(IC<1>{});
+    do_pass(IC<2>{});
+    do_pass(IC<3>{});
+}
+
 // STAMP: tuning build - per (workgroup, wave) cycle stamps of the first tile into p.dbg (prologue / K loop / epilogue split).
 template <bool STAMP, int EPI>
 __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) {
@@ -336,6 +448,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.x - padb), 0, (int)(((long long)p.B * p.H * p.W * p.x_cs) * 2 + padb), 0x00020000);
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+    // EPI 1-4: output (EPI 4: and residual) through descriptors that end with row M - 1 (rows >= M of the last tile: zeros in, dropped out)
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.res, 0, EPI == 4 ? (int)((((long long)p.M - 1) * p.r_cs + p.N) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        p.y, 0, EPI >= 1 ? (int)((((long long)p.M - 1) * p.y_cs + p.N) * 2) : 0, 0x00020000);
     unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
     int m0 = 0, n0 = 0;
     // wave-uniform K-tile cursor of the NEXT tile to stage (tiles are staged strictly in order)
@@ -598,12 +715,28 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         constexpr bool EPI16 = EPI >= 1 && EPI <= 3;             // arithmetic in the accumulator layout + bf16 staging
         P8EpiRegs epr;
         P8EpiRegs16 epr16;
+        P8Epi4Regs epr4;
         if constexpr (EPI16) p8_epilogue16_prefetch(epr16, p, cur_n0, wc, lane);
+        else if constexpr (EPI == 4) p8_epilogue4_prefetch(epr4, p, rres, cur_m0, cur_n0, tid);
         else p8_epilogue_prefetch<EPI>(epr, p, cur_m0, cur_n0, tid);  // BEFORE the DMAs (in-order vmcnt)
         if constexpr (STAMP) {
             if (stamp_now) est[9] = __builtin_readcyclecounter();
         }
-        if (more) {
+        if constexpr (EPI == 4) {
+            // straight-line form: the four DMA pieces are ALWAYS issued (after the last tile with every row out of bounds: zeros
+            // into buffer 0, nobody reads them), so the compiler counts every vmcnt of the epilogue exactly - the residual rows of
+            // pass 0 are waited for with the 8 DMAs (and the next pass's rows) still in flight
+            if (more) {
+                set_tile(next);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { a_mask[h][j] = 0u; b_voff[h][j] = OOB; }
+                cur_tap = 0; cur_kw = 0; cur_c0 = 0; cur_tapoff = 0u; cur_k0b = 0u;
+            }
+            stage_first();
+        } else if (more) {
             set_tile(next);                                      // ALU work under the latency of the prefetch loads
             if constexpr (STAMP) {
                 if (stamp_now) est[10] = __builtin_readcyclecounter();
@@ -621,7 +754,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(epr.sc[e]), "v"(epr.bs[e]));
             }
-            if (EPI == 4 || (EPI == 0 && p.res && p.out_dt != NPS_DT_F32)) {
+            if (EPI == 0 && p.res && p.out_dt != NPS_DT_F32) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(epr.r0[it]));
             }
@@ -630,7 +763,8 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 if (stamp_now) est[11] = __builtin_readcyclecounter();
             }
         }
-        if constexpr (EPI16) p8_epilogue16<EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr16);
+        if constexpr (EPI16) p8_epilogue16<EPI>(acc, lds, p, ry, cur_m0, cur_n0, wr, wc, lane, tid, more, epr16);
+        else if constexpr (EPI == 4) p8_epilogue4(acc, lds, p, rres, ry, cur_m0, cur_n0, wr, wc, lane, tid, epr4);
         else p8_epilogue<STAMP, EPI>(acc, lds, p, cur_m0, cur_n0, wr, wc, lane, tid, more, epr, est);
         if constexpr (STAMP) {
             if (stamp_now) {
@@ -730,8 +864,10 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     const dim3 grid(nwg);
     // epilogue specialisation (code size, see p8_epilogue): the common no-residual / bf16-output forms get their own build
     int epi = 0;
-    if (!residual && out_dt == NPS_DT_BF16 && !res_after) epi = act == NPS_ACT_RELU ? 1 : act == NPS_ACT_NONE ? 2 : act == NPS_ACT_LEAKY ? 3 : 0;
-    if (residual && out_dt == NPS_DT_BF16 && !res_after && act == NPS_ACT_RELU) epi = 4;
+    // (the specialised builds address the output / residual rows with 32-bit buffer offsets)
+    const bool off32 = ((long long)p.M + 256) * y_cstride * 2 < (1ll << 31) && (!residual || ((long long)p.M + 256) * r_cstride * 2 < (1ll << 31));
+    if (!residual && out_dt == NPS_DT_BF16 && !res_after && off32) epi = act == NPS_ACT_RELU ? 1 : act == NPS_ACT_NONE ? 2 : act == NPS_ACT_LEAKY ? 3 : 0;
+    if (residual && out_dt == NPS_DT_BF16 && !res_after && act == NPS_ACT_RELU && scale && bias && off32) epi = 4;
     if (generic_epi) epi = 0;
     const hipStream_t st = (hipStream_t)stream;
     if (variant == 24) {

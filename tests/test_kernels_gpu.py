@@ -693,6 +693,62 @@ def test_conv2d_p8_specialised_epilogues_match_the_generic_build(device, act):
     assert _rel(outs[0].float(), ref.float()) < 1e-2
 
 
+@pytest.mark.parametrize("case", [(3, 30, 40, 256, 1024, 1, 1, 0, 0),     # res4's expand conv: four K-tiles, 14.06 row tiles x 4 channel tiles
+                                  (2, 9, 7, 64, 256, 1, 1, 0, 0),          # one K-tile, 126 rows: half of the only tile is out of bounds
+                                  (2, 15, 20, 512, 512, 3, 1, 1, 0),       # 3x3, 72 K-tiles
+                                  (5, 23, 31, 128, 512, 1, 1, 0, 64)])     # M tail + y / residual as channel slices of wider buffers
+def test_conv2d_p8_residual_relu_epilogue_matches_the_generic_build(device, case):
+    """EPI 4 (bf16 residual + ReLU, bf16 output; round 4: residual rows of pass q+1 requested inside pass q, buffer-descriptor bounds
+    instead of row tests) must give bit for bit what the generic epilogue build (variant + 64) gives: whole grids, grids capped at
+    3 / 1 persistent workgroups (several tiles per workgroup: the residual prefetch crosses the next tile's DMAs), M tails, strided
+    output / residual views; bytes outside the output view stay untouched."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p, extra = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    cs = Cout + extra
+    res = torch.randn(B, OH, OW, cs, generator=g).to(device, torch.bfloat16)
+    outs = []
+    for variant in (0, 64, 0 | (3 << 8), 32 | (1 << 8), 32 | 64 | (1 << 8)):
+        y = torch.full((B, OH, OW, cs), 7.0, device=device, dtype=torch.bfloat16)
+        rc = _lib.load().nopesac_conv2d_nhwc_p8(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), res.data_ptr(), y.data_ptr(), B, H, W, Cin,
+                                                 Cout, k, k, s, p, Cin, cs, cs, ops.ACT_RELU, 1, variant, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[3], outs[4])                                    # channel-major K order: specialised vs generic
+    if extra:
+        assert bool((outs[0][..., Cout:] == 7.0).all())
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, s, p) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+                 + res[..., :Cout].float().permute(0, 3, 1, 2))
+    assert _rel(outs[0][..., :Cout].float().permute(0, 3, 1, 2), ref) < 1e-2
+    assert _rel(outs[3][..., :Cout].float().permute(0, 3, 1, 2), ref) < 1e-2
+
+
+def test_conv2d_p8_bf16_epilogue_into_a_channel_slice_with_a_row_tail(device):
+    """EPI 1 (bf16 staging, stores through a buffer descriptor that ends with the last row: round 4) writing a channel slice of a
+    wider buffer, M = 2.46 tiles: the other channels and nothing beyond the last row may be touched."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, pad_c = 1, 21, 30, 64, 256, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) / 8).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    buf = torch.full((B * H * W + 300, Cout + pad_c), 7.0, device=device, dtype=torch.bfloat16)      # 300 guard rows behind the tensor
+    y = buf[:B * H * W].view(B, H, W, Cout + pad_c)
+    rc = _lib.load().nopesac_conv2d_nhwc_p8(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout,
+                                             1, 1, 1, 0, Cin, Cout + pad_c, 0, ops.ACT_RELU, 1, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = ops.conv2d(x, w, sc, bi, act=ops.ACT_RELU)
+    assert _rel(y[..., :Cout].float(), ref.float()) < 1e-2
+    assert bool((y[..., Cout:] == 7.0).all()) and bool((buf[B * H * W:] == 7.0).all())
+
+
 MLP_CHAIN_CASES = {
     # name: (rows, x_width, bcast_width, rows_per, [(N, act, tapped)])
     "geo_encoder+proj": (100, 8, 0, 1, [(1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (256, "ACT_NONE", True)]),
