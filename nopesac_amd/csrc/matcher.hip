@@ -25,32 +25,44 @@ __device__ __forceinline__ float group_sum(float v, int tg) {
 // <1024, 36> nq = 128 (tg = 4, 33 entries; 148 B of spills at the 128-VGPR cap).  The first version ran 256 threads: nq = 64
 // (BASELINE configs[2]) and above fell to an LDS loop with one or two LANES per row - 1.77 ms per launch at nq = 64, 6.9 ms at
 // nq = 128 (configs[4]); now 0.72 / 2.77 ms; nq = 50: 0.88 -> 0.63 ms (32 pairs, full plane sets, 200 iterations; scripts/sinkhorn_one.py).
-template <int NT, int ZREG>
-__global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
-    const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
-    const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
-    const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
-    float* __restrict__ log_scores, float* __restrict__ assignment) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int R = nq + 1;
-    const int LD = (R & 1) ? R : R + 1;            // odd leading dimension: column walks hit distinct banks
-    float* Z = smem;                               // R*LD
-    float* u = Z + R * LD;                         // R
-    float* v = u + R;                              // R
-    float* lmu = v + R;                            // R
-    float* lnu = lmu + R;                          // R
-    float* g1r = lnu + R;                          // nq*3 normals of view-1 planes warped by (R,0)
-    float* g1rt = g1r + 3 * nq;                    // nq*3 normals warped by (R,t)
-    float* o1 = g1rt + 3 * nq;                     // nq offsets (R,t)
-    float* g2 = o1 + nq;                           // nq*3 flipped view-2 normals
-    float* o2 = g2 + 3 * nq;                       // nq
-    float* max0 = o2 + nq;                         // R
-    int* idx0 = (int*)(max0 + R);                  // R
-    int* idx1 = idx0 + R;                          // R
+struct SinkLds {
+    float *Z, *u, *v, *lmu, *lnu, *g1r, *g1rt, *o1, *g2, *o2, *max0;
+    int *idx0, *idx1;
+    float* xch;                                    // 4-wave kernel only: [2 phases][64 lanes][4 waves][m, s]
+    int R, LD;
+};
 
-    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
-    const int R1 = n1 + 1, C1 = n2 + 1;
+__device__ __forceinline__ SinkLds sink_lds(float* smem, int nq) {
+    SinkLds L;
+    L.R = nq + 1;
+    L.LD = (L.R & 1) ? L.R : L.R + 1;              // odd leading dimension: column walks hit distinct banks
+    const int R = L.R;
+    L.Z = smem;                                    // R*LD
+    L.u = L.Z + R * L.LD;                          // R
+    L.v = L.u + R;                                 // R
+    L.lmu = L.v + R;                               // R
+    L.lnu = L.lmu + R;                             // R
+    L.g1r = L.lnu + R;                             // nq*3 normals of view-1 planes warped by (R,0)
+    L.g1rt = L.g1r + 3 * nq;                       // nq*3 normals warped by (R,t)
+    L.o1 = L.g1rt + 3 * nq;                        // nq offsets (R,t)
+    L.g2 = L.o1 + nq;                              // nq*3 flipped view-2 normals
+    L.o2 = L.g2 + 3 * nq;                          // nq
+    L.max0 = L.o2 + nq;                            // R
+    L.idx0 = (int*)(L.max0 + R);                   // R
+    L.idx1 = L.idx0 + R;                           // R
+    L.xch = (float*)(L.idx1 + R);
+    return L;
+}
+__host__ __device__ constexpr size_t sink_lds_floats(int nq) {
+    return (size_t)(nq + 1) * (((nq + 1) & 1) ? (nq + 1) : (nq + 2)) + 4 * (nq + 1) + 11 * nq + 3 * (nq + 1);
+}
+
+// geometric priors + couplings + marginals (u = v = 0) into LDS; ends with a workgroup barrier
+template <int NT>
+__device__ __forceinline__ float sink_setup(const SinkLds& L, int b, int tid, int nq, int n1, int n2, const float* __restrict__ desc_dot,
+                                            const float* __restrict__ planes1, const float* __restrict__ planes2, const float* __restrict__ cam7,
+                                            const float* __restrict__ bin_score, float offset_mult, float normal_mult) {
+    const int R = L.R, LD = L.LD, R1 = n1 + 1, C1 = n2 + 1;
     const float* cam = cam7 + 7 * b;
     // ---- per-plane geometry
     if (tid < nq) {
@@ -65,15 +77,15 @@ __global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
             warp_plane(p, Rm, t, wrt);
             normalize3(wr, nr);
             normalize3(wrt, nrt);
-            for (int d = 0; d < 3; ++d) { g1r[3 * i + d] = nr[d]; g1rt[3 * i + d] = nrt[d]; }
-            o1[i] = norm3(wrt);
+            for (int d = 0; d < 3; ++d) { L.g1r[3 * i + d] = nr[d]; L.g1rt[3 * i + d] = nrt[d]; }
+            L.o1[i] = norm3(wrt);
         }
         if (i < n2) {
             float p[3] = {planes2[((long long)b * nq + i) * 3], -planes2[((long long)b * nq + i) * 3 + 1], -planes2[((long long)b * nq + i) * 3 + 2]};
             float nn[3];
             normalize3(p, nn);
-            for (int d = 0; d < 3; ++d) g2[3 * i + d] = nn[d];
-            o2[i] = norm3(p);
+            for (int d = 0; d < 3; ++d) L.g2[3 * i + d] = nn[d];
+            L.o2[i] = norm3(p);
         }
     }
     __syncthreads();
@@ -84,22 +96,80 @@ __global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
         const int i = e / C1, j = e % C1;
         float val = bin;
         if (i < n1 && j < n2) {
-            const float ntn_r = g1r[3 * i] * g2[3 * j] + g1r[3 * i + 1] * g2[3 * j + 1] + g1r[3 * i + 2] * g2[3 * j + 2];
+            const float* a = L.g1r + 3 * i;
+            const float* c = L.g2 + 3 * j;
+            const float* at = L.g1rt + 3 * i;
+            const float ntn_r = a[0] * c[0] + a[1] * c[1] + a[2] * c[2];
             const float ang = acosf(fminf(fmaxf(ntn_r, -1.f), 1.f)) / 3.14159265358979323846f * 180.f;
-            const float ntn_rt = g1rt[3 * i] * g2[3 * j] + g1rt[3 * i + 1] * g2[3 * j + 1] + g1rt[3 * i + 2] * g2[3 * j + 2];
-            float off = ntn_rt < 0.f ? fabsf(o1[i] + o2[j]) : fabsf(o1[i] - o2[j]);
+            const float ntn_rt = at[0] * c[0] + at[1] * c[1] + at[2] * c[2];
+            float off = ntn_rt < 0.f ? fabsf(L.o1[i] + L.o2[j]) : fabsf(L.o1[i] - L.o2[j]);
             off = fminf(fmaxf(off, 1e-10f), 5.f);
             val = dd[i * nq + j] - off / offset_mult - ang / normal_mult;
         }
-        Z[i * LD + j] = val;
+        L.Z[i * LD + j] = val;
     }
     const float norm = -logf((float)(n1 + n2));
     for (int i = tid; i < R; i += NT) {
-        u[i] = 0.f; v[i] = 0.f;
-        lmu[i] = i < n1 ? norm : logf((float)n2) + norm;
-        lnu[i] = i < n2 ? norm : logf((float)n1) + norm;
+        L.u[i] = 0.f; L.v[i] = 0.f;
+        L.lmu[i] = i < n1 ? norm : logf((float)n2) + norm;
+        L.lnu[i] = i < n2 ? norm : logf((float)n1) + norm;
     }
     __syncthreads();
+    return norm;
+}
+
+// final scores Z + u + v - norm (kept in LDS for the assignment) + padded output + mutual nearest neighbours (u, v final in LDS)
+template <int NT>
+__device__ __forceinline__ void sink_finalize(const SinkLds& L, int b, int tid, int nq, int n1, int n2, float norm, float match_thr,
+                                              float* __restrict__ log_scores, float* __restrict__ assignment) {
+    const int R = L.R, LD = L.LD, R1 = n1 + 1, C1 = n2 + 1;
+    float* Z = L.Z;
+    for (int e = tid; e < R1 * C1; e += NT) {
+        const int i = e / C1, j = e % C1;
+        Z[i * LD + j] = Z[i * LD + j] + L.u[i] + L.v[j] - norm;
+    }
+    __syncthreads();
+    float* out = log_scores + (long long)b * R * R;
+    for (int e = tid; e < R * R; e += NT) {
+        const int i = e / R, j = e % R;
+        const int si = i < n1 ? i : (i == nq ? n1 : -1), sj = j < n2 ? j : (j == nq ? n2 : -1);
+        out[e] = (si >= 0 && sj >= 0) ? Z[si * LD + sj] : NEG_PAD;
+    }
+    // ---- mutual nearest neighbours over the plane block
+    for (int i = tid; i < n1; i += NT) {
+        float m = -INFINITY; int a = 0;
+        for (int j = 0; j < n2; ++j) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = j; } }
+        L.max0[i] = m; L.idx0[i] = a;
+    }
+    for (int j = tid; j < n2; j += NT) {
+        float m = -INFINITY; int a = 0;
+        for (int i = 0; i < n1; ++i) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = i; } }
+        L.idx1[j] = a;
+    }
+    __syncthreads();
+    float* A = assignment + (long long)b * nq * nq;
+    for (int e = tid; e < nq * nq; e += NT) {
+        const int i = e / nq, j = e % nq;
+        float a = 0.f;
+        if (i < n1 && j < n2 && n2 > 0 && L.idx0[i] == j && L.idx1[j] == i && expf(L.max0[i]) > match_thr) a = 1.f;
+        A[e] = a;
+    }
+}
+
+template <int NT, int ZREG>
+__global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
+    const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
+    const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
+    const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
+    float* __restrict__ log_scores, float* __restrict__ assignment) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SinkLds L = sink_lds(smem, nq);
+    const int LD = L.LD;
+    float *Z = L.Z, *u = L.u, *v = L.v, *lmu = L.lmu, *lnu = L.lnu;
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    const int R1 = n1 + 1, C1 = n2 + 1;
+    const float norm = sink_setup<NT>(L, b, tid, nq, n1, n2, desc_dot, planes1, planes2, cam7, bin_score, offset_mult, normal_mult);
     // ---- Sinkhorn: lane groups of tg lanes per row / column
     const int big = max(R1, C1);
     int tg = 64;
@@ -176,37 +246,76 @@ __global__ __launch_bounds__(NT) void matcher_sinkhorn_kernel(
         }
         __syncthreads();
     }
-    // ---- final scores (kept in LDS for the assignment) + padded output
-    for (int e = tid; e < R1 * C1; e += NT) {
-        const int i = e / C1, j = e % C1;
-        Z[i * LD + j] = Z[i * LD + j] + u[i] + v[j] - norm;
+    sink_finalize<NT>(L, b, tid, nq, n1, n2, norm, match_thr, log_scores, assignment);
+}
+
+// Four-wave form for nq <= 63 (round 4; the reference's nq = 50): the 1024-thread kernel above spends its 2.6 us per iteration in
+// two 16-wave barriers and two 4-step shuffle reductions per phase - the arithmetic of an iteration (2 x 51 x 51 exp) is 1 us of ONE
+// SIMD.  Here a workgroup is four waves, one per SIMD, and LANE = ROW in the row phase, LANE = COLUMN in the column phase:
+//   * wave w keeps, for every row i = lane, the KW couplings of columns w*KW .. (and, for every column j = lane, those of rows
+//     w*KW ..) in registers; u (lane = row) and v (lane = column) live in one register each in EVERY wave;
+//   * a phase: t_k = z_k + v[w*KW + k] (v_readlane with a wave-uniform index: no LDS, no shuffle), the wave's own max m_w and
+//     s_w = sum exp(t_k - m_w) over its KW entries - no cross-lane reduction at all - then ONE exchange of (m_w, s_w) through LDS
+//     and a 4-wave barrier; every wave merges the four partials the online-softmax way (M = max m_w, S = sum s_w exp(m_w - M):
+//     exactly the max-shifted log-sum-exp of the whole row) and ends the phase with u (or v) complete in its own register;
+//   * exp / log are the hardware v_exp_f32 / v_log_f32 forms (1 ulp; inputs are <= 0 after the max shift).
+// 2 barriers of 4 waves per iteration instead of 2 of 16, no shuffles: ~0.7 us per iteration.
+template <int KW>
+__global__ __launch_bounds__(256) void matcher_sinkhorn_w4_kernel(
+    const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
+    const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
+    const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
+    float* __restrict__ log_scores, float* __restrict__ assignment) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SinkLds L = sink_lds(smem, nq);
+    const int LD = L.LD;
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    const int R1 = n1 + 1, C1 = n2 + 1;
+    const float norm = sink_setup<256>(L, b, tid, nq, n1, n2, desc_dot, planes1, planes2, cam7, bin_score, offset_mult, normal_mult);
+    float zr[KW], zc[KW];
+    const bool rok = lane < R1, cok = lane < C1;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int e = w * KW + k;                  // this wave's k-th column (row phase) / row (column phase)
+        zr[k] = (rok && e < C1) ? L.Z[lane * LD + e] : -INFINITY;
+        zc[k] = (cok && e < R1) ? L.Z[e * LD + lane] : -INFINITY;
+    }
+    const float lmu_l = rok ? L.lmu[lane] : 0.f, lnu_l = cok ? L.lnu[lane] : 0.f;
+    float uu = 0.f, vv = 0.f;                      // u[lane] / v[lane]; 0 outside the valid rows / columns
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x2_t* xr = reinterpret_cast<f32x2_t*>(L.xch);                 // [64 lanes][4 waves] (m, s)
+    f32x2_t* xc = xr + 64 * 4;
+    auto phase = [&](const float (&z)[KW], float other, float marg, bool ok, f32x2_t* xch) -> float {
+        float t[KW];
+        float m = -1e30f;                          // finite floor: a wave whose KW entries are all masked contributes (floor, 0)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            t[k] = z[k] + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, other), w * KW + k));
+            m = fmaxf(m, t[k]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) s += __expf(t[k] - m);
+        xch[lane * 4 + w] = f32x2_t{m, s};
+        __syncthreads();
+        const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(xch + lane * 4), p1 = *reinterpret_cast<const f32x4_t*>(xch + lane * 4 + 2);
+        const float M = fmaxf(fmaxf(p0[0], p0[2]), fmaxf(p1[0], p1[2]));
+        const float S = p0[1] * __expf(p0[0] - M) + p0[3] * __expf(p0[2] - M) + p1[1] * __expf(p1[0] - M) + p1[3] * __expf(p1[2] - M);
+        return ok ? marg - (M + __logf(S)) : 0.f;
+    };
+    for (int it = 0; it < iters; ++it) {
+        uu = phase(zr, vv, lmu_l, rok, xr);
+        vv = phase(zc, uu, lnu_l, cok, xc);
+    }
+    if (w == 0) {
+        if (rok) L.u[lane] = uu;
+        if (cok) L.v[lane] = vv;
     }
     __syncthreads();
-    float* out = log_scores + (long long)b * R * R;
-    for (int e = tid; e < R * R; e += NT) {
-        const int i = e / R, j = e % R;
-        const int si = i < n1 ? i : (i == nq ? n1 : -1), sj = j < n2 ? j : (j == nq ? n2 : -1);
-        out[e] = (si >= 0 && sj >= 0) ? Z[si * LD + sj] : NEG_PAD;
-    }
-    // ---- mutual nearest neighbours over the plane block
-    for (int i = tid; i < n1; i += NT) {
-        float m = -INFINITY; int a = 0;
-        for (int j = 0; j < n2; ++j) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = j; } }
-        max0[i] = m; idx0[i] = a;
-    }
-    for (int j = tid; j < n2; j += NT) {
-        float m = -INFINITY; int a = 0;
-        for (int i = 0; i < n1; ++i) { const float x = Z[i * LD + j]; if (x > m) { m = x; a = i; } }
-        idx1[j] = a;
-    }
-    __syncthreads();
-    float* A = assignment + (long long)b * nq * nq;
-    for (int e = tid; e < nq * nq; e += NT) {
-        const int i = e / nq, j = e % nq;
-        float a = 0.f;
-        if (i < n1 && j < n2 && n2 > 0 && idx0[i] == j && idx1[j] == i && expf(max0[i]) > match_thr) a = 1.f;
-        A[e] = a;
-    }
+    sink_finalize<256>(L, b, tid, nq, n1, n2, norm, match_thr, log_scores, assignment);
 }
 
 // assignment re-filter under the refined pose (camera_head.py:605-629)
@@ -267,9 +376,17 @@ extern "C" int nopesac_matcher_sinkhorn(const float* desc_dot, const float* plan
     using namespace nps;
     NPS_CHECK_ARG(desc_dot && planes1 && planes2 && cam7 && n1 && n2 && bin_score && log_scores && assignment, "sinkhorn: null pointer");
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && iters >= 0, "sinkhorn: bad dims (nq<=128)");
-    const int R = nq + 1, LD = (R & 1) ? R : R + 1;
-    const size_t lds = sizeof(float) * ((size_t)R * LD + 4 * R + 11 * nq + R + 2 * R);
-    if (nq + 1 <= 128) {              // 1024 threads: lane groups of 8-64 lanes per row / column, <= 16 entries per lane (no spills)
+    const size_t lds = sizeof(float) * sink_lds_floats(nq);
+    const bool no_w4 = getenv("NOPESAC_SINKHORN_NO_W4") != nullptr;            // A/B runs and the kernel-vs-kernel test (read per call)
+    if (nq + 1 <= 64 && !no_w4) {     // four waves, lane = row / column, one exchange per phase (the reference's nq = 50)
+        const size_t lds4 = lds + sizeof(float) * 2 * 64 * 4 * 2;
+        if (nq + 1 <= 52)
+            hipLaunchKernelGGL((matcher_sinkhorn_w4_kernel<13>), dim3(B), dim3(256), lds4, (hipStream_t)stream, desc_dot, planes1, planes2, cam7,
+                               n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+        else
+            hipLaunchKernelGGL((matcher_sinkhorn_w4_kernel<16>), dim3(B), dim3(256), lds4, (hipStream_t)stream, desc_dot, planes1, planes2, cam7,
+                               n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    } else if (nq + 1 <= 128) {              // 1024 threads: lane groups of 8-64 lanes per row / column, <= 16 entries per lane (no spills)
         if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, (matcher_sinkhorn_kernel<1024, 16>));
         hipLaunchKernelGGL((matcher_sinkhorn_kernel<1024, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, desc_dot, planes1, planes2,
                            cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);

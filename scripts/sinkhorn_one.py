@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nopesac_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 B = 32
-for nq in (50, 64, 100, 128):
+for nq in (50, 63, 64, 100, 128):
     g = torch.Generator(device=dev).manual_seed(nq)
     dots = torch.randn(B, nq, nq, device=dev, generator=g)
     p1 = torch.randn(B, nq, 3, device=dev, generator=g); p2 = torch.randn(B, nq, 3, device=dev, generator=g)
