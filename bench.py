@@ -730,14 +730,16 @@ LOOSE = ["TEST.OVERLAP_THRESHOLD", 0.0, "TEST.PLANE_SCORE_THRESHOLD", 0.5, "TEST
 def other_configs(args, steps=12, warmup=4):
     """BASELINE configs[2] and configs[4] (its single-GPU half) measured by THIS file in short child runs - outside the timed region of
     the headline line, each in its own process (own model, own kernel routing: nq = 64 / 128 change the head GEMM shapes) - so that the
-    driver's record carries them: {"scannet_k64": {...}, "fp8_k128": {...}} with value / ms_per_step / roofline of each."""
+    driver's record carries them: {"scannet_k64": {...}, "fp8_k128": {...}, "bf16_k128": {...}} with value / ms_per_step / roofline of each
+    (fp8_k128 and bf16_k128 share one routing file: the fp8 convs are not routed by the tuner, every other shape is the same)."""
     import subprocess
-    runs = {"scannet_k64": ["--config", "scannet", "--k", "64"], "fp8_k128": ["--fp8", "--k", "128"]}
+    # bf16_k128 = the A/B partner of fp8_k128 (same workload, same K control, dense bf16 backbone): what the fp8 mode buys or costs
+    runs = {"scannet_k64": ["--config", "scannet", "--k", "64"], "fp8_k128": ["--fp8", "--k", "128"], "bf16_k128": ["--k", "128"]}
     res = {}
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--pairs", str(args.pairs),
                "--inflight", str(args.inflight), "--no-cpu-baseline", "--no-accuracy", "--no-fp32-path", "--no-boundary", "--no-other-configs", "--no-tape",
-               "--routing", os.path.join(ROOT, "profiles", "routing_r4_%s.json" % name)] + extra
+               "--routing", os.path.join(ROOT, "profiles", "routing_r4_%s.json" % name.replace("bf16_k128", "fp8_k128"))] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)

@@ -553,6 +553,8 @@ static int et_launch(const EncTailArgs& a, hipStream_t stream) {
         NPS_ENSURE_LDS((int)E6_LDS_BYTES, enc_tail64_kernel);
         hipLaunchKernelGGL(enc_tail64_kernel, dim3((a.M + E6_BM - 1) / E6_BM), dim3(512), E6_LDS_BYTES, stream, a);
     } else {
+        // the 32-token kernel issues its projection tiles in four unrolled rounds of 8 column tiles: 32 tiles = 1024 output columns
+        NPS_CHECK_ARG((a.wpa ? a.npa : 0) + (a.wpb ? a.npb : 0) <= 1024, "transformer_tail: n_pos + n_proj > 1024 on the 32-token kernel");
         NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
         hipLaunchKernelGGL(enc_tail_kernel, dim3((a.M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, stream, a);
     }
@@ -577,7 +579,7 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = nullptr; a.pre_norm = 0;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
-    et_launch(a, (hipStream_t)stream);
+    if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }
 
@@ -601,7 +603,7 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = yn; a.pre_norm = 1;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
-    et_launch(a, (hipStream_t)stream);
+    if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }
 
@@ -635,6 +637,6 @@ extern "C" int nopesac_transformer_tail_bf16(const void* attn, const float* src,
     a.yn = yn; a.pre_norm = pre_norm ? 1 : 0; a.skip_ffn = skip_ffn ? 1 : 0;
     a.wpa = proj_pos ? (const bf16_t*)w_pos : nullptr; a.bpa = b_pos; a.pa = (bf16_t*)proj_pos; a.npa = n_pos;
     a.wpb = proj ? (const bf16_t*)w_proj : nullptr; a.bpb = b_proj; a.pb = (bf16_t*)proj; a.npb = n_proj;
-    et_launch(a, (hipStream_t)stream);
+    if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }

@@ -70,7 +70,8 @@ extern "C" int nopesac_tape_create(void* hip_graph, void** tape_out, int32_t* co
 
 extern "C" int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** tape_out, int32_t* counts4) {
     using namespace nps;
-    NPS_CHECK_ARG(hip_graph && tape_out && max_streams >= 1, "tape_create: bad arguments");
+    NPS_CHECK_ARG(hip_graph && tape_out && max_streams >= 1 && max_streams <= 17, "tape_create: bad arguments (1 <= max_streams <= 17: the caller's "
+                  "stream + at most 16 side chains, the limit nopesac_tape_replay_on enforces)");
     hipGraph_t graph = (hipGraph_t)hip_graph;
     size_t n = 0;
     TAPE_HIP(hipGraphGetNodes(graph, nullptr, &n), "hipGraphGetNodes(count)");
@@ -154,6 +155,17 @@ extern "C" int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** t
                 set_error("launch tape: kernel node %d was launched with `extra` arguments (module launch): unsupported", u);
                 return NPS_E_ARG;
             }
+            {   // a handle hipLaunchKernel cannot resolve (a module / hiprtc function launched with kernelParams) must fail HERE, where
+                // the caller still falls back to the whole-graph replay - not at the first replay
+                hipFuncAttributes fa;
+                const hipError_t fe = hipFuncGetAttributes(&fa, op.k.func);
+                if (fe != hipSuccess) {
+                    (void)hipGetLastError();
+                    delete t;
+                    set_error("launch tape: kernel node %d: function handle not launchable through hipLaunchKernel (%s)", u, hipGetErrorString(fe));
+                    return NPS_E_ARG;
+                }
+            }
             op.kind = TAPE_KERNEL;
             ++t->n_kernel;
         } else if (ty == hipGraphNodeTypeMemset) {
@@ -162,6 +174,17 @@ extern "C" int nopesac_tape_create_ex(void* hip_graph, int max_streams, void** t
                 delete t;
                 set_error("launch tape: memset node %d: parameters not readable / unsupported (%s)", u, hipGetErrorString(e));
                 return e != hipSuccess ? (int)e : NPS_E_ARG;
+            }
+            if (op.ms.height > 1 && op.ms.elementSize != 1) {
+                // 2-D memsets are replayed with hipMemset2DAsync, a BYTE fill: only byte-uniform 16 / 32-bit patterns are the same thing
+                const unsigned v = op.ms.value, b0 = v & 0xffu;
+                const bool uniform = op.ms.elementSize == 2 ? ((v >> 8) & 0xffu) == b0
+                                                            : (((v >> 8) & 0xffu) == b0 && ((v >> 16) & 0xffu) == b0 && ((v >> 24) & 0xffu) == b0);
+                if (!uniform) {
+                    delete t;
+                    set_error("launch tape: memset node %d: 2-D memset of %u-byte elements with a non-uniform byte pattern: unsupported", u, op.ms.elementSize);
+                    return NPS_E_ARG;
+                }
             }
             op.kind = TAPE_MEMSET;
             ++t->n_memset;

@@ -165,10 +165,14 @@ class PlaneTR_NopeSAC(nn.Module):
         if "nonfinite" in cam:
             need["nonfinite"] = cam["nonfinite"]
         f = {"small": ops.HostFetch(need)}
-        if self.output_rle:
-            f["rle"] = rle.PendingRLE(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"])
         if d.get("static_outputs"):       # hipGraph mode: these device tensors are overwritten by the slot's next replay
             f["sel"] = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
+        if self.output_rle:
+            # (graph mode: the overflow fallback of PendingRLE.finish re-reads its inputs - hand it the private winner map; kept_idx /
+            #  n_kept / flags are small and cloned here for the same reason)
+            rs = f.get("sel")
+            f["rle"] = (rle.PendingRLE(rs["winner"], sel["kept_idx"].clone(), sel["n_kept"].clone(), sel["flags"].clone()) if rs is not None
+                        else rle.PendingRLE(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]))
         f["ready"] = torch.cuda.Event()
         f["ready"].record()
         if d.get("static_outputs"):       # ... which must not start before the copies above have run (whatever stream it is issued on)
@@ -242,10 +246,12 @@ class PlaneTR_NopeSAC(nn.Module):
         buf = st["in"]
         if imgs[0].dtype == torch.uint8 and "in_u8" not in st:
             st["in_u8"] = torch.empty(buf.shape, device=self.device, dtype=torch.uint8)
+        if st.get("clone_done") is not None:
+            # the slot's previous replay (its stem still reads `buf`) and the copy-out of its results must be complete before the new
+            # images overwrite the static input buffer - also when the caller rotates its slots across streams
+            torch.cuda.current_stream().wait_event(st.pop("clone_done"))
         self._copy_images(imgs, buf, st.get("in_u8"))
         st["calls"] += 1
-        if st.get("clone_done") is not None:                   # the previous results of this slot are still being copied out
-            torch.cuda.current_stream().wait_event(st.pop("clone_done"))
         if st["graph"] is not None:
             if st.get("tape") is not None:
                 st["tape"].replay(sides=self._tape_sides())   # the recorded launches, on the caller's current stream

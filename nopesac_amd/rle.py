@@ -127,6 +127,8 @@ class PendingRLE:
         V, H, W, nq = self.shape
         h = self.fetch.views()
         out_off, lens, bbox = h["out_off"].tolist(), h["lens"].tolist(), h["bbox"].tolist()
+        if not out_off:                                        # no views / no plane slots: nothing was encoded
+            return [[] for _ in range(V)]
         total = out_off[-1] + lens[-1]
         if total > self.cap:                                   # (never seen: 64 MB of run-length strings in one batch)
             return encode_views(*self.args, n_kept_host=n_kept_host)

@@ -48,7 +48,7 @@ def shares_queue(a: "torch.cuda.Stream", b: "torch.cuda.Stream", scratch: torch.
 
 
 class StreamSet:
-    def __init__(self, n_slots: int, device=None, side_shift: int = 1, candidates: int = 16, with_sides: bool = True):
+    def __init__(self, n_slots: int, device=None, side_shift: int = 0, candidates: int = 16, with_sides: bool = True):
         self.device = torch.device(device if device is not None else "cuda")
         self.n = int(n_slots)
         with torch.cuda.device(self.device):
@@ -83,6 +83,12 @@ class StreamSet:
         used = {id(c): 0 for c in order}
         for i in range(self.n):
             c = order[i % len(order)]
+            if used[id(c)] >= len(c):                                   # uneven classes (a probe disturbed under load can leave a singleton)
+                rest = [d for d in order if used[id(d)] < len(d)]
+                if not rest:                                            # every candidate handed out: a new stream, wherever the runtime puts it
+                    self.mains.append(torch.cuda.Stream(device=self.device))
+                    continue
+                c = rest[0]
             self.mains.append(c[used[id(c)]])
             used[id(c)] += 1
         self.sides: List[Optional[torch.cuda.Stream]] = [None] * self.n
@@ -112,7 +118,7 @@ class StreamSet:
     def describe(self) -> dict:
         idx = {id(s): k for k, c in enumerate(self.classes) for s in c}
         return {"queue_classes": self.queue_classes, "probe_inconclusive": self.inconclusive, "class_sizes": [len(c) for c in self.classes],
-                "batch_stream_class": [idx[id(s)] for s in self.mains],
+                "batch_stream_class": [idx.get(id(s)) for s in self.mains],
                 "side_stream_class": [idx.get(id(s)) if s is not None else None for s in self.sides]}
 
 

@@ -418,7 +418,7 @@ def test_config5_fp8_backbone_k128(device):
     """BASELINE config 5 on one GPU: fp8 3x3 backbone convs (MODEL.AMD.BACKBONE_FP8) + K = 128 forced hypotheses, nq = 128, on the
     bench workload (8 pairs) against the fp32 HIP path under the same K control (scripts/fp8_error.py, same seeds).  Measured in
     round 3 (fp8 / plain bf16): camera_init R max 4.32 / 1.37 deg, T max 0.0246 / 0.0067 (|t| = 0.36); camera_initRec R max 12.9 / 3.2;
-    refined camera R max 0.34 / 0.34 deg, T max 0.21 / 0.06 (|t| = 11.2).  Gates = 2x the measured fp8 maxima."""
+    refined camera R max 0.34 / 0.34 deg, T max 0.21 / 0.06 (|t| = 11.2).  Gates = 1.5x the measured fp8 maxima (round 4; were 2x)."""
     import bench
     from nopesac_amd import ops
     B, K, nq = 8, 128, 128
@@ -431,9 +431,9 @@ def test_config5_fp8_backbone_k128(device):
         m8.backbone.calibrate_fp8(ops.preprocess(raw[:4], m8.pixel_mean, m8.pixel_std, m8.backbone.STEM_CIN_PAD, m8.compute_dtype))
     e = bench.bench_workload_pose_error(m8, m32, device, B, K, nq, raw=raw, forced=forced)
     assert e["m_bf16"] == [K] * B == e["m_fp32"] and e["finite"] and e["max_quat_norm_dev"] < 1e-3
-    assert e["camera_init"]["R_err_deg_max"] < 8.7 and e["camera_init"]["T_err_max"] < 0.05, e["camera_init"]
-    assert e["camera_initRec"]["R_err_deg_max"] < 26.0, e["camera_initRec"]
-    assert e["camera"]["R_err_deg_max"] < 0.7 and e["camera"]["T_err_max"] < 0.43, e["camera"]
+    assert e["camera_init"]["R_err_deg_max"] < 6.5 and e["camera_init"]["T_err_max"] < 0.037, e["camera_init"]
+    assert e["camera_initRec"]["R_err_deg_max"] < 19.4, e["camera_initRec"]
+    assert e["camera"]["R_err_deg_max"] < 0.51 and e["camera"]["T_err_max"] < 0.32, e["camera"]
 
 
 def test_other_resolutions_are_rejected_like_the_reference(device):

@@ -266,3 +266,18 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.nopesac_add_rows_bf16(None, None, None, None, 4, 6, 1, None) != 0 and "add_rows_bf16" in err()
     assert lib.nopesac_softmax_rows_pad(None, None, 4, 300, 304, 1, None) != 0 and "softmax_rows_pad" in err()
     assert lib.nopesac_concat_cols(None, 3, None, 4, None, 2, None) != 0 and "concat_cols" in err()
+
+
+def test_round4_argument_checks_without_a_gpu():
+    """Round-4 argument checks (advisor findings of round 3) come back as error codes before any HIP call: a launch tape with more
+    streams than a replay accepts, the 4-wave Sinkhorn entry keeps the old
+    contract (nq <= 128)."""
+    import ctypes
+    from nopesac_amd import _lib
+    lib = _lib.load()
+    err = lambda: lib.nopesac_last_error().decode()
+    out = ctypes.c_void_p()
+    fake_graph = ctypes.c_void_p(16)                      # never dereferenced: the range check comes first
+    assert lib.nopesac_tape_create_ex(fake_graph, 18, ctypes.byref(out), None) != 0 and "max_streams" in err()
+    assert lib.nopesac_tape_create_ex(fake_graph, 0, ctypes.byref(out), None) != 0 and "tape_create" in err()
+    assert lib.nopesac_matcher_sinkhorn(*([None] * 7), 1.0, 1.0, 200, 0.2, 1, 50, None, None, None) != 0 and "sinkhorn" in err()
