@@ -468,6 +468,11 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
     }
     int cur_tap = 0, cur_kw = 0, cur_c0 = 0;
     unsigned cur_tapoff = 0u;
+    // p.force = 1: channel-major K order (as in conv_igemm_p8_kernel): the pixels a workgroup re-reads for the KH*KW taps of one channel
+    // slice are ONE 128-byte line each and stay in the XCD's L2 between the taps.  Tap-major streams all Cin channels of the tile's
+    // pixels once per tap: the 3x3 128 -> 128 layers of res3 read 291 MB from HBM for a 79 MB input (profiles/r3_s_pmc_traffic.json).
+    const bool kmajor = p.force != 0;
+    const int ntaps = p.KH * p.KW;
     auto issue_a = [&](int stage) {
         unsigned char* sbase = lds + stage * A_BYTES;
         const unsigned a_soff = cur_tapoff + (unsigned)cur_c0 * (unsigned)EB;
@@ -476,18 +481,28 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
             const unsigned vo = ((a_mask[j] >> cur_tap) & 1u) ? a_voff[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)(sbase + (wave * A_DMA + j) * 1024), 16, vo, a_soff, 0, 0);
         }
-        cur_c0 += BK;
-        if (cur_c0 >= p.Cin) {
-            cur_c0 = 0; ++cur_tap; ++cur_kw;
+        if (!kmajor) {                                       // tap-major: all channels of tap 0, then tap 1 ... (the order of the weight rows)
+            cur_c0 += BK;
+            if (cur_c0 >= p.Cin) {
+                cur_c0 = 0; ++cur_tap; ++cur_kw;
+                cur_tapoff += (unsigned)p.x_cs * (unsigned)EB;
+                if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * (unsigned)EB; }
+            }
+        } else {                                             // CHANNEL-major: the KH*KW taps of one BK-channel slice, then the next slice
+            ++cur_tap; ++cur_kw;
             cur_tapoff += (unsigned)p.x_cs * (unsigned)EB;
             if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * (unsigned)EB; }
+            if (cur_tap == ntaps) { cur_tap = 0; cur_kw = 0; cur_tapoff = 0u; cur_c0 += BK; }
         }
     };
     // this wave's weight fragments: column tile n0/32 + wave, fragment-major [N/32][K*EB/32 pieces][64][16 B]
     const int nk = p.K / BK, kf_total = p.K * EB / 32;
     const T* wfr = (const T*)p.w + ((long long)(n0 / 32 + wave) * kf_total * 64 + lane) * 8;
     bf16x8 bring[2][KF];
-    auto load_b = [&](int kt, int buf, int kk) { bring[buf][kk] = *(const bf16x8*)(wfr + (long long)(kt * KF + kk) * 512); };
+    // K-tile kt of the WALK -> K-tile of the (tap-major) weight layout.  Channel-major walk: kt = slice * ntaps + tap -> tap * slices + slice
+    const int cslices = p.Cin / BK;
+    auto wkt_of = [&](int kt) { return kmajor ? (kt % ntaps) * cslices + kt / ntaps : kt; };
+    auto load_b = [&](int wkt, int buf, int kk) { bring[buf][kk] = *(const bf16x8*)(wfr + (long long)(wkt * KF + kk) * 512); };
 
     f32x16 acc[TM][1];
 #pragma unroll
@@ -503,9 +518,12 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
     for (int t = 0; t < DA; ++t)
         if (t < nk) issue_a(t);
     if (nk > 1) {
+        const int w1 = wkt_of(1);
 #pragma unroll
-        for (int kk = 0; kk < KF; ++kk) load_b(1, 1, kk);
+        for (int kk = 0; kk < KF; ++kk) load_b(w1, 1, kk);
     }
+    // weight cursor of walk tile j + 2 (refilled while tile j is consumed): (tap, slice) advanced once per step
+    int b_tap = 2 % ntaps, b_sl = 2 / ntaps;
     // steady state per K-tile j (buf = j & 1): newer than B(j) are A(j+DA-1)?.. see the counts below
     auto step = [&](int j, int buf, int stage_j) {
         // outstanding-op budget when tile j is needed: B(j+1) (4 ops) + the A tiles issued after B(j)
@@ -523,6 +541,8 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
             issue_a(st);                                     // A(j+DA) into the stage tile j-1 just vacated
         }
         const unsigned char* sb = lds + stage_j * A_BYTES;
+        const int wk2 = kmajor ? b_tap * cslices + b_sl : j + 2;      // weight K-tile of walk tile j + 2
+        if (++b_tap == ntaps) { b_tap = 0; ++b_sl; }
         if constexpr (FP8) {
 #pragma unroll
             for (int f = 0; f < KF / 2; ++f) {                   // one K = 64 MFMA step: lane needs bytes 32*(lane>>5) .. +31 of the 64
@@ -540,7 +560,7 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
                     const i32x8 aw = {a0[i][0], a0[i][1], a0[i][2], a0[i][3], a1[i][0], a1[i][1], a1[i][2], a1[i][3]};
                     acc[i][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bw, aw, acc[i][0], 0, 0, 0, 0, 0, 0);
                 }
-                if (j + 2 < nk) { load_b(j + 2, buf, 2 * f); load_b(j + 2, buf, 2 * f + 1); }
+                if (j + 2 < nk) { load_b(wk2, buf, 2 * f); load_b(wk2, buf, 2 * f + 1); }
             }
         } else {
 #pragma unroll
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256, BKT == 32 ? 4 : (NSTAGE == 3 ? 3 : 2)) void co
                 for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sb + a_row_off + i * 32 * ROWB + so);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bring[buf][kk], af[i], acc[i][0], 0, 0, 0);
-                if (j + 2 < nk) load_b(j + 2, buf, kk);          // refill the slot that was just consumed
+                if (j + 2 < nk) load_b(wk2, buf, kk);            // refill the slot that was just consumed
             }
         }
     };
@@ -739,7 +759,9 @@ static int bfrag_launch(bool fp8, const void* x, const void* w_frag, const float
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_bfrag: bad dims");
     NPS_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 128 == 0, "conv2d_bfrag: needs Cin %% 64 == 0 and Cout %% 128 == 0");
     NPS_CHECK_ARG(out_dt == NPS_DT_F32 || out_dt == NPS_DT_BF16 || out_dt == NPS_DT_FP8, "conv2d_bfrag: bad out_dt %d", out_dt);
-    NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (4-stage ring, K-tile 32)");
+    const int kmajor = (nstage >> 8) & 1;       // + 256: channel-major K order (better L2 reuse of the taps of a KxK conv)
+    nstage &= 0xff;
+    NPS_CHECK_ARG(nstage == 3 || nstage == 32, "conv2d_bfrag: variant must be 3 (3-stage ring, K-tile 64) or 32 (4-stage ring, K-tile 32), + 256: channel-major K");
     NPS_CHECK_ARG(!(fp8 && nstage == 3) || Cin % 128 == 0, "conv2d_fp8: variant 3 (K-tile 128) needs Cin %% 128 == 0");
     NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % (16 / eb) == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w_frag % 16 == 0),
                   "conv2d_bfrag: strides / alignment");
@@ -759,7 +781,7 @@ static int bfrag_launch(bool fp8, const void* x, const void* w_frag, const float
     p.rows_per_b = p.OH * p.OW;
     p.batched = 0;
     p.M = B * p.rows_per_b; p.N = Cout; p.K = KH * KW * Cin;
-    p.act = act; p.out_dt = out_dt; p.res_after = res_after;
+    p.act = act; p.out_dt = out_dt; p.res_after = res_after; p.force = kmajor;
     NPS_CHECK_ARG((long long)B * H * W * x_cstride * eb + ((long long)pad * W + pad) * x_cstride * eb < (1ll << 31), "conv2d_bfrag: input larger than 2 GB");
     {
         const int al = out_dt == NPS_DT_F32 ? 4 : 8;

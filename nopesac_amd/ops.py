@@ -8,6 +8,7 @@ from __future__ import annotations
 from typing import Optional
 
 import ctypes
+import os
 
 import torch
 
@@ -144,6 +145,9 @@ CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
 P8_VARIANT = [32]                      # variant handed to nopesac_conv2d_nhwc_p8: 32 = channel-major K order (better L2 reuse of the taps)
+# added to nopesac_conv2d_nhwc_bfrag's variant for stride-1 KxK convs: channel-major K order (round 4: same time in isolation, 95 instead
+# of 149 MB read from HBM per launch on res3's 3x3 layers; stride 2 measured slower and stays tap-major).  NOPESAC_BFRAG_KMAJOR=0: A/B runs
+BFRAG_KMAJOR = [0 if os.environ.get("NOPESAC_BFRAG_KMAJOR") == "0" else 256]
 LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
@@ -233,8 +237,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
             return
         if cfg in (CFG_BFRAG3, CFG_BFRAG32):
             rc = _L().nopesac_conv2d_nhwc_bfrag(_p(x), _p(_frag_weights(w)), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout,
-                                                KH, KW, stride, pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], 3 if cfg == CFG_BFRAG3 else 32,
-                                                _stream())
+                                                KH, KW, stride, pad, x_cs, y_cs, r_cs, act, _DT[out_dtype],
+                                                (3 if cfg == CFG_BFRAG3 else 32) + (BFRAG_KMAJOR[0] if (KH * KW > 1 and stride == 1) else 0), _stream())
             _lib.check(rc, "nopesac_conv2d_nhwc_bfrag")
             return
         rc = _L().nopesac_conv2d_nhwc_ex(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW,

@@ -427,10 +427,11 @@ def test_scannet_mapper_resizes_on_gpu(device, tmp_path):
 
 @pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1), (3, 31, 29, 128, 128, 3, 2, 1), (2, 24, 32, 512, 256, 1, 1, 0),
                                   (1, 15, 20, 64, 384, 3, 1, 1), (2, 9, 7, 64, 128, 1, 1, 0)])
-@pytest.mark.parametrize("nstage", [3, 32])
+@pytest.mark.parametrize("nstage", [3, 32, 3 + 256, 32 + 256])
 def test_conv2d_bfrag(device, case, nstage):
     """'A through LDS, B from L2' conv kernel (fragment-major weights) vs F.conv2d on bf16-rounded operands: M tails, stride 2,
-    1x1 and 3x3, several output-channel tiles, K loops shorter than the ring."""
+    1x1 and 3x3, several output-channel tiles, K loops shorter than the ring; + 256 = channel-major K order (round 4: the taps of a
+    channel slice back to back), whose f32 output must agree with the tap-major order to summation-order accuracy."""
     from nopesac_amd import _lib, ops
     B, H, W, Cin, Cout, k, s, p = case
     g = torch.Generator().manual_seed(sum(case) + nstage)
@@ -450,6 +451,19 @@ def test_conv2d_bfrag(device, case, nstage):
     torch.cuda.synchronize()
     assert rc == 0
     assert _rel(y.float().permute(0, 3, 1, 2), ref) < 1.5e-2
+    if nstage >= 256:
+        outs = []
+        for v in (nstage, nstage - 256):
+            y32 = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device=device)
+            rc = _lib.load().nopesac_conv2d_nhwc_bfrag(xd.data_ptr(), ops._frag_weights(wd).data_ptr(), sd.data_ptr(), bd.data_ptr(), None,
+                                                        y32.data_ptr(), B, H, W, Cin, Cout, k, k, s, p, Cin, Cout, 0, ops.ACT_NONE, 0, v,
+                                                        torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            outs.append(y32)
+        torch.cuda.synchronize()
+        assert _rel(outs[0], outs[1]) < 2e-5
+        if k == 1:
+            assert torch.equal(outs[0], outs[1])                 # one tap: both orders are the same walk
 
 
 @pytest.mark.parametrize("M,last", [(3200, False), (3200, True), (77, False)])
