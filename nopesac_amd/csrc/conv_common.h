@@ -21,6 +21,7 @@ struct ConvParams {
     int rows_per_b;    // OH*OW
     int batched;       // 1: grid.y = batch index, per-batch weights
     int act, out_dt, res_after, epi_vec, use_glds, force, dense1x1, bias_bs;
+    int kmajor;        // conv_igemm_glds_kernel: 1 = channel-major K order (the KH*KW taps of one K-tile's channel slice back to back)
     int tiles_m, tiles_n;
     int dbg_tile;
     unsigned long long* dbg;   // tuning builds only: per-workgroup cycle stamps (nullptr in product launches)

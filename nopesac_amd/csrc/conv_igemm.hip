@@ -326,12 +326,27 @@ __global__ __launch_bounds__(WAVES_M * 128, (NSTAGE == 2 || WAVES_M == 4) ? (BKT
         for (int j = 0; j < B_DMA; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)(sbase + A_BYTES + (wave * B_DMA + j) * 1024), 16, b_voff[j], cur_k0b, 0, 0);
         // advance the cursor to the next K-tile (tiles are always issued in order)
-        cur_k0b += BK * 2;
-        cur_c0 += BK;
-        if (cur_c0 >= p.Cin) {
-            cur_c0 = 0; ++cur_tap; ++cur_kw;
+        if (!p.kmajor) {                                     // tap-major: the order of the weight rows
+            cur_k0b += BK * 2;
+            cur_c0 += BK;
+            if (cur_c0 >= p.Cin) {
+                cur_c0 = 0; ++cur_tap; ++cur_kw;
+                cur_tapoff += (unsigned)p.x_cs * 2u;
+                if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * 2u; }
+            }
+        } else {
+            // channel-major (round 4, as in conv_igemm_p8_kernel): the KH*KW taps of one BK-channel slice, then the next slice - the
+            // pixels re-read for the taps of a slice are one 128-byte line each and stay in L2 between the taps.  Tap-major streams
+            // all Cin channels of the tile once per tap: the 3x3 2048 -> 128 layer of the pose net read 700 MB from HBM for a 79 MB input
+            ++cur_tap; ++cur_kw;
+            cur_k0b += (unsigned)p.Cin * 2u;
             cur_tapoff += (unsigned)p.x_cs * 2u;
             if (cur_kw == p.KW) { cur_kw = 0; cur_tapoff += (unsigned)(p.W - p.KW) * (unsigned)p.x_cs * 2u; }
+            if (cur_tap == p.KH * p.KW) {
+                cur_tap = 0; cur_kw = 0; cur_tapoff = 0u;
+                cur_c0 += BK;
+                cur_k0b = (unsigned)cur_c0 * 2u;
+            }
         }
     };
 
@@ -641,6 +656,9 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
         if (dma_ok) {
             ConvParams q = p;
             q.tiles_m = (q.M + 127) / 128;
+            const char* km = getenv("NOPESAC_GLDS_KMAJOR");                               // "0": tap-major (A/B runs, the order test; read per call)
+            const bool no_kmajor = km && !strcmp(km, "0");
+            q.kmajor = (p.KH * p.KW > 1 && p.stride == 1 && !no_kmajor) ? 1 : 0;
             // few 128x128 tiles but a long K loop (e.g. 2048 -> 128, 3x3 at 15x20: 150 tiles, K = 18432): 128x64 tiles double the
             // number of workgroups
             const bool narrow = p.N <= 64 || (tiles128 < 256 && p.N % 64 == 0);

@@ -466,6 +466,27 @@ def test_conv2d_bfrag(device, case, nstage):
             assert torch.equal(outs[0], outs[1])                 # one tap: both orders are the same walk
 
 
+@pytest.mark.parametrize("case", [(4, 60, 80, 128, 256, 3, 1, 1), (3, 15, 20, 512, 128, 3, 1, 1), (2, 15, 20, 2048, 128, 3, 1, 1)])
+def test_conv2d_lds_dma_kernel_channel_major_k_order(device, case, monkeypatch):
+    """conv_igemm_glds_kernel walks K channel-major on stride-1 KxK layers (round 4: the taps of a 64-channel slice back to back, so
+    the re-read pixels stay in L2).  Same products, another summation order: the f32 output must agree with the tap-major walk
+    (NOPESAC_GLDS_KMAJOR=0) to summation-order accuracy, and with F.conv2d on the bf16-rounded operands."""
+    from nopesac_amd import ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16()
+    xd, wd = _nhwc(x.float()).to(device, torch.bfloat16), w.float().permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    y_cm = ops.conv2d(xd, wd, stride=s, pad=p, out_dtype=torch.float32)
+    monkeypatch.setenv("NOPESAC_GLDS_KMAJOR", "0")
+    y_tm = ops.conv2d(xd, wd, stride=s, pad=p, out_dtype=torch.float32)
+    monkeypatch.delenv("NOPESAC_GLDS_KMAJOR")
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), w.float(), None, s, p)
+    assert _rel(y_cm, y_tm) < 2e-5 and not torch.equal(y_cm, y_tm)          # (not equal: proves the two orders were both exercised)
+    assert _rel(y_cm.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 @pytest.mark.parametrize("M,last", [(3200, False), (3200, True), (77, False)])
 def test_decoder_tail(device, M, last):
     """Pre-norm decoder tail (enc_tail kernel, pre_norm = 1) vs the same chain through the per-op bf16-mode kernels."""
