@@ -176,6 +176,13 @@ int nopesac_stem_fused_bf16(const void* x, const void* w, const float* scale, co
  * nopesac_preprocess_nchw_to_nhwc followed by nopesac_stem_fused_bf16. */
 int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mean, const float* std, const void* w, const float* scale,
                                 const float* bias, void* y, int B, int H, int W, void* stream);
+/* Raw-image stem with the normalisation folded into its operands (round 4): the staged patch holds v - 128, exact in bf16 for the
+ * 8-bit pixel values preprocess_image receives, so the input operand carries no rounding error (the normalised image of the entry
+ * above is rounded to 8 significant bits).  The caller folds: w_folded[o][kh][kw][c] = bf16(w[o][kh][kw][c] / std[c]),
+ * bias_folded[o] = bias[o] + scale[o] * sum_{kh,kw,c} (w / std[c]) * (128 - mean[c]), pad3[c] = mean[c] - 128 (the raw value whose
+ * folded contribution is the reference's zero padding of the NORMALISED image; siamese_planeTR.py:534-542 + d2 BasicStem). */
+int nopesac_stem_fused_raw_shifted_bf16(const float* x_nchw, const float* pad3, const void* w_folded, const float* scale,
+                                        const float* bias_folded, void* y, int B, int H, int W, void* stream);
 
 /* Fused tail of a bf16 ResNet bottleneck (d2 BottleneckBlock.forward: conv3 + shortcut + ReLU) plus, optionally, the NEXT
  * block's 1x1 reduce conv, in one launch (all tensors bf16 NHWC, pixel-dense; FrozenBN as f32 scale/bias):

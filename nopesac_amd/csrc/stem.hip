@@ -32,10 +32,15 @@ constexpr int ST_W_BYTES = 64 * ST_WLD * 2;
 constexpr int ST_CONV_BYTES = ST_M * ST_CLD * 2;     // 53,136 B: three workgroups per CU (the 384-row version allowed two)
 constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH_BYTES + ST_W_BYTES) : ST_CONV_BYTES;
 
-// RAW = true: x is not read; the patch comes straight from the f32 NCHW images `xraw` [B,3,H,W], normalised per channel
+// RAW = 1: x is not read; the patch comes straight from the f32 NCHW images `xraw` [B,3,H,W], normalised per channel
 // ((v - mean[c]) / std[c], then rounded to bf16 - exactly what nopesac_preprocess_nchw_to_nhwc writes) while it is staged:
 // the 157 MB bf16 NHWC copy of the batch is never written or read.
-template <bool RAW>
+// RAW = 2 (round 4): the normalisation is FOLDED into the weights and the BN shift by the caller (w' = w / std[c], shift' = shift +
+// scale * sum w' (128 - mean[c])): the patch holds v - 128, which is EXACT in bf16 for 8-bit pixel values - the operand rounding of
+// the normalised image (the larger half of the stem's bf16 error, profiles/r4_bf16_attribution_stem.json) is gone, and so are the 24
+// f32 divisions per thread.  Positions outside the image hold `mean` = (mean[c] - 128), the value whose folded contribution is zero
+// like the reference's zero padding of the normalised image; `stdv` is not read.
+template <int RAW>
 __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ xraw,
                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
                                                          const bf16_t* __restrict__ w,
@@ -52,9 +57,10 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- stage the input patch (zero outside the image) and the weights
-    if constexpr (RAW) {
+    if constexpr (RAW != 0) {
         const float* xr = xraw + (long long)b * 3 * H * W;
-        const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = stdv[0], s1 = stdv[1], s2 = stdv[2];
+        const float m0 = mean[0], m1 = mean[1], m2 = mean[2];
+        const float s0 = RAW == 1 ? stdv[0] : 1.f, s1 = RAW == 1 ? stdv[1] : 1.f, s2 = RAW == 1 ? stdv[2] : 1.f;
         // every load of the patch goes out BEFORE the first one is consumed: the rolled loop (load, divide, ds_write, next) exposed
         // one HBM round trip per iteration - 8 in a row per workgroup; the stem ran at 1.1 TB/s (0.33 ms for 393 MB).
         // (Round 3: 16-byte loads of the image rows - 529 float4 groups per channel instead of 2024 scalar loads - were built and
@@ -79,7 +85,11 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             const int r = i / ST_IW, c = i % ST_IW;
             const int iy = iy0 + r, ix = ix0 + c;
             uint2 v = make_uint2(0u, 0u);
-            if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            if constexpr (RAW == 2) {
+                const bool in = i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                v.x = f32x2_to_bf16x2(in ? r0[it] - 128.f : m0, in ? r1[it] - 128.f : m1);
+                v.y = f32x2_to_bf16x2(in ? r2[it] - 128.f : m2, 0.f);
+            } else if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
                 v.x = f32x2_to_bf16x2((r0[it] - m0) / s0, (r1[it] - m1) / s1);
                 v.y = f32x2_to_bf16x2((r2[it] - m2) / s2, 0.f);
             }
@@ -204,7 +214,7 @@ extern "C" int nopesac_stem_fused_bf16(const void* x, const void* w, const float
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    hipLaunchKernelGGL(stem_fused_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const float*)nullptr,
+    hipLaunchKernelGGL(stem_fused_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
     NPS_LAUNCH_RET();
 }
@@ -218,7 +228,24 @@ extern "C" int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mea
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    hipLaunchKernelGGL(stem_fused_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, mean, stdv,
+    hipLaunchKernelGGL(stem_fused_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, mean, stdv,
                        (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
+    NPS_LAUNCH_RET();
+}
+
+// Raw-image stem with the normalisation folded into the operands (stem_fused_kernel<2>): x_nchw f32 [B,3,H,W] with 8-bit pixel values
+// 0..255 (other values are rounded to bf16 after subtracting 128); pad3 = mean[c] - 128 (the raw value of the reference's zero
+// padding, minus 128); w = bf16 [64][224] of w[o][kh][kw][c] / std[c]; bias = BN shift + scale * sum_k w'(128 - mean[c]).
+extern "C" int nopesac_stem_fused_raw_shifted_bf16(const float* x_nchw, const float* pad3, const void* w_folded, const float* scale,
+                                                   const float* bias_folded, void* y, int B, int H, int W, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x_nchw && pad3 && w_folded && scale && bias_folded && y && B > 0 && H >= 7 && W >= 7, "stem_fused_raw_shifted: bad args");
+    NPS_CHECK_ARG(((uintptr_t)w_folded % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)scale % 16 == 0) && ((uintptr_t)bias_folded % 16 == 0),
+                  "stem_fused_raw_shifted: alignment");
+    const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
+    const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
+    dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
+    hipLaunchKernelGGL(stem_fused_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, pad3, (const float*)nullptr,
+                       (const bf16_t*)w_folded, scale, bias_folded, (bf16_t*)y, H, W, CH, CW, PH, PW);
     NPS_LAUNCH_RET();
 }

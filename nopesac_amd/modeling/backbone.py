@@ -37,6 +37,9 @@ class HipResNet50(ParamModule):
         else:
             self.out_features = ["res2", "res3", "res4", "res5"]
         self.fused_stem = True
+        # raw-image stem with the normalisation folded into its weights (exact bf16 input operand; NOPESAC_STEM_FOLDED=0: the
+        # round-3 form that normalises while staging, bit-identical to preprocess + fused stem)
+        self.stem_folded_norm = os.environ.get("NOPESAC_STEM_FOLDED", "1") != "0"
         self.fused_tail = True
         self.halo_conv2 = not os.environ.get("NOPESAC_NO_HALO_CONV2")
         # fp8 mode (MODEL.AMD.BACKBONE_FP8): the 3x3 conv of every res3 / res4 / res5 bottleneck runs on the fp8 MFMA; its input (the block's conv1 output)
@@ -128,7 +131,16 @@ class HipResNet50(ParamModule):
             skip_until, x = resume
             dt = x.dtype
         elif x is None:
-            x = ops.stem_fused_raw(raw[0], raw[1], raw[2], P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
+            if self.stem_folded_norm:
+                # normalisation folded into the stem's weights / shift, the patch holds v - 128 (exact in bf16): no input rounding
+                key = ("stem_shift", raw[1].data_ptr(), raw[2].data_ptr())
+                if key not in P:
+                    P[key] = ops.fold_stem_normalisation(self.raw("stem.conv1.weight").float().permute(0, 2, 3, 1), P["stem"].scale,
+                                                         P["stem"].bias, raw[1], raw[2])
+                pad3, wsh, bsh = P[key]
+                x = ops.stem_fused_raw_shifted(raw[0], pad3, wsh, P["stem"].scale, bsh)
+            else:
+                x = ops.stem_fused_raw(raw[0], raw[1], raw[2], P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         elif dt == torch.bfloat16 and self.fused_stem:
             x = ops.stem_fused(x, P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         else:

@@ -324,6 +324,34 @@ def stem_fused_raw(images: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, 
     return y
 
 
+def stem_fused_raw_shifted(images: torch.Tensor, pad3: torch.Tensor, w224_folded: torch.Tensor, scale: torch.Tensor,
+                           bias_folded: torch.Tensor) -> torch.Tensor:
+    """The raw-image stem with the normalisation folded into weights / shift (see `fold_stem_normalisation`): the patch holds the
+    pixel values minus 128, exact in bf16."""
+    _chk(images, torch.float32); _chk(pad3, torch.float32); _chk(w224_folded, torch.bfloat16); _chk(scale, torch.float32); _chk(bias_folded, torch.float32)
+    B, C, H, W = images.shape
+    _require(C == 3 and pad3.numel() == 3 and w224_folded.shape == (64, 224), 'argument check failed: C == 3 and pad3.numel() == 3 and w224_folded.shape == (64, 224)')
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    y = torch.empty((B, PH, PW, 64), device=images.device, dtype=torch.bfloat16)
+    _lib.check(_L().nopesac_stem_fused_raw_shifted_bf16(_p(images), _p(pad3), _p(w224_folded), _p(scale), _p(bias_folded), _p(y), B, H, W, _stream()),
+               "nopesac_stem_fused_raw_shifted_bf16")
+    return y
+
+
+def fold_stem_normalisation(w_o773: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, mean: torch.Tensor, std: torch.Tensor):
+    """Operands of `stem_fused_raw_shifted` from the stem's f32 weights [64,7,7,3] (o, kh, kw, c), its folded-BN scale / shift and the
+    per-channel pixel mean / std:  sum_k w (v - mean) / std = sum_k (w / std) (v - 128) + sum_k (w / std) (128 - mean).
+    -> (pad3 f32[3] = mean - 128, w224 bf16 [64,224] in the fused stem's (kh, kw padded to 8, c padded to 4) order, bias' f32[64])."""
+    wd, m, s = w_o773.double(), mean.double().view(1, 1, 1, 3), std.double().view(1, 1, 1, 3)
+    wf = wd / s
+    const = (wf * (128.0 - m)).sum(dim=(1, 2, 3))
+    w8 = w_o773.new_zeros(64, 7, 8, 4, dtype=torch.float32)
+    w8[:, :, :7, :3] = wf.float()
+    return ((mean.float() - 128.0).contiguous(), w8.reshape(64, 224).to(torch.bfloat16).contiguous(),
+            (bias.double() + scale.double() * const).float().contiguous())
+
+
 BOTTLENECK_TAIL_CONFIGS = {(64, 256, 0, 0), (64, 256, 64, 0), (64, 256, 128, 0), (64, 256, 0, 64), (64, 256, 64, 64),          # (C, C4, CN, C2)
                            (128, 512, 0, 0), (128, 512, 128, 0), (128, 512, 256, 0), (128, 512, 0, 256), (128, 512, 128, 256),
                            (256, 1024, 0, 0), (256, 1024, 256, 0), (256, 1024, 512, 0), (256, 1024, 0, 512), (256, 1024, 256, 512)}

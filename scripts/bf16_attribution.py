@@ -71,18 +71,37 @@ def ms_per_step(m, n=3):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+def stem_rounding_variant(x, raw=None, round_input=False, round_weights=False):
+    """Which operand rounding of the bf16 stem matters?  (round 4)  The fp32 stem with ONLY its input or ONLY its weights rounded to
+    bf16, its output rounded to bf16 once, the bf16 kernels behind it."""
+    xin = ops.preprocess(raw[0], m32.pixel_mean, m32.pixel_std, m32.backbone.STEM_CIN_PAD, torch.float32) if x is None else x.float()
+    if round_input:
+        xin = xin.bfloat16().float()
+    c = m32.backbone.packed["stem"]
+    w = c.w(torch.float32)
+    if round_weights:
+        w = w.bfloat16().float()
+    y = ops.maxpool(ops.conv2d(xin, w, c.scale, c.bias, stride=2, pad=3, act=ops.ACT_RELU), 3, 2, 1)
+    return orig_backbone_forward(None, resume=("stem", y.to(torch.bfloat16)))
+
+
 import functools  # noqa: E402
+STEM_VARIANTS = {"stem: bf16 input, f32 weights": dict(round_input=True), "stem: f32 input, bf16 weights": dict(round_weights=True),
+                 "stem: bf16 input and weights, f32 kernel": dict(round_input=True, round_weights=True)}
 variants = [("bf16 (as timed)", (), False)] + [(p, (p,), False) for p in ("decoder", "branches", "fc", "aim", "refine")] + \
            [("backbone", (), True), ("decoder+branches+fc", ("decoder", "branches", "fc"), False), ("fc+aim+refine", ("fc", "aim", "refine"), False),
             ("branches+fc", ("branches", "fc"), False), ("all head parts", ("decoder", "branches", "fc", "aim", "refine"), False),
             ("all head parts + backbone", ("decoder", "branches", "fc", "aim", "refine"), True)] + \
-           [("backbone fp32 through " + st, (), st) for st in ("stem", "res2", "res3", "res4")]
+           [("backbone fp32 through " + st, (), st) for st in ("stem", "res2", "res3", "res4")] + [(k, (), k) for k in STEM_VARIANTS]
 table = {}
 for name, parts, bb in variants:
     if args.only and args.only not in name and name != "bf16 (as timed)":
         continue
     head.fp32_parts = frozenset(parts)
-    m16.backbone.forward = (functools.partial(fp32_backbone, until=bb) if isinstance(bb, str) else fp32_backbone) if bb else orig_backbone_forward
+    if isinstance(bb, str) and bb in STEM_VARIANTS:
+        m16.backbone.forward = functools.partial(stem_rounding_variant, **STEM_VARIANTS[bb])
+    else:
+        m16.backbone.forward = (functools.partial(fp32_backbone, until=bb) if isinstance(bb, str) else fp32_backbone) if bb else orig_backbone_forward
     err = bench.bench_workload_pose_error(m16, m32, dev, B, K, nq, raw=raw, forced=forced)
     row = {k: {kk: err[k][kk] for kk in ("T_err_mean", "T_err_max", "R_err_deg_mean", "R_err_deg_max")} for k in ("camera_init", "camera_initRec", "camera")}
     row["ms_per_step_single_stream"] = round(ms_per_step(m16), 2)

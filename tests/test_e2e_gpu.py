@@ -143,12 +143,13 @@ def test_bench_configuration_bf16_forced_k32_b32(device):
     assert err["m_bf16"] == [K] * B and err["m_fp32"] == [K] * B
     assert err["finite"] and err["max_quat_norm_dev"] < 1e-3
     cam, ini, rec = err["camera"], err["camera_init"], err["camera_initRec"]
-    # bounds = 1.5 x the maxima measured on MI355X in round 3 (BENCH line `pose_err_vs_fp32_path.bench_workload`, profiles/r3_e_bench_full.json:
-    # camera R 0.62 deg / T 0.070-0.078 at |t| = 11.1; camera_init R 3.44-3.59 deg / T 0.0075; camera_initRec R 6.2-7.1 deg).  Where the error
-    # comes from: profiles/r3_a_bf16_attribution.json (the backbone's accumulated bf16 rounding; no single head stage dominates).
-    assert cam["R_err_deg_max"] < 0.95 and cam["T_err_max"] < 0.0105 * cam["mean_abs_t"], cam
-    assert ini["R_err_deg_max"] < 5.4 and ini["T_err_max"] < 0.0115, ini
-    assert rec["R_err_deg_max"] < 10.7, rec
+    # bounds = 1.5 x the maxima measured on MI355X in round 4 with the normalisation folded into the stem (exact bf16 input operand):
+    # camera R 0.44-0.47 deg / T 0.069-0.087 at |t| = 11.1; camera_init R 1.65-2.24 deg / T 0.0066; camera_initRec R 4.1-4.7 deg (routed
+    # kernels of the bench line / the library's heuristics of this test; round 3: 0.62 / 3.6 / 7.1 deg).  Where the error comes from:
+    # profiles/r3_a_bf16_attribution.json, profiles/r4_bf16_attribution_stem.json (the stem's operand rounding carried the maxima).
+    assert cam["R_err_deg_max"] < 0.71 and cam["T_err_max"] < 0.0117 * cam["mean_abs_t"], cam
+    assert ini["R_err_deg_max"] < 3.4 and ini["T_err_max"] < 0.0105, ini
+    assert rec["R_err_deg_max"] < 7.1, rec
 
 
 def test_e2e_scannet_config_nq64(device):

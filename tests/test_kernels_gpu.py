@@ -649,6 +649,43 @@ def test_stem_fused_raw_equals_preprocess_plus_stem(device, H, W):
     assert a.shape == b.shape and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("H,W", [(100, 172), (480, 640)])
+def test_stem_fused_raw_shifted_has_no_input_rounding(device, H, W):
+    """Round 4: the raw-image stem with the normalisation folded into its weights / BN shift (the patch holds v - 128, exact in bf16
+    for 8-bit pixels) against an f64 reference of normalise -> conv7x7/s2 -> BN -> ReLU -> maxpool on the SAME bf16-rounded folded
+    weights: what is left is accumulation order + the output rounding (< 1/256 relative), at the image borders too (zero padding of
+    the normalised image = raw pad value mean - 128).  The unfolded stem (normalised image rounded to bf16) must be further away from
+    the exact-operand reference than the folded one."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(H)
+    img = torch.randint(0, 256, (2, 3, H, W), generator=g).float()
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    w = torch.randn(64, 7, 7, 3, generator=g) / 12
+    sc, bi = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    pad3, w224, bsh = ops.fold_stem_normalisation(w, sc, bi, mean, std)
+    y = ops.stem_fused_raw_shifted(img.to(device), pad3.to(device), w224.to(device), sc.to(device), bsh.to(device)).float().cpu()
+    # reference with the rounded folded weights, everything else exact: conv over v - 128 with the raw pad value, f64
+    wf = w224.view(64, 7, 8, 4)[:, :, :7, :3].double().permute(0, 3, 1, 2)
+    xs = F.pad(img.double() - 128.0, (3, 3, 3, 3))
+    pb = pad3.to(torch.bfloat16).double()                      # the kernel stores the pad value as bf16 too
+    for c in range(3):
+        xs[:, c, :3, :] = pb[c]; xs[:, c, -3:, :] = pb[c]; xs[:, c, :, :3] = pb[c]; xs[:, c, :, -3:] = pb[c]
+    ref = F.max_pool2d(F.relu(F.conv2d(xs, wf, None, 2, 0) * sc.double().view(1, -1, 1, 1) + bsh.double().view(1, -1, 1, 1)), 3, 2, 1)
+    assert _rel(y.permute(0, 3, 1, 2).double(), ref) < 3e-3                    # bf16 output rounding only
+    # exact-operand reference (f64 weights, exact normalisation) vs folded and vs unfolded stem
+    exact = F.max_pool2d(F.relu(F.conv2d((img.double() - mean.double().view(1, 3, 1, 1)) / std.double().view(1, 3, 1, 1),
+                                         w.double().permute(0, 3, 1, 2), None, 2, 3) * sc.double().view(1, -1, 1, 1)
+                                + bi.double().view(1, -1, 1, 1)), 3, 2, 1)
+    w8 = torch.zeros(64, 7, 8, 4)
+    w8[:, :, :7, :3] = w
+    old = ops.stem_fused_raw(img.to(device), mean.to(device), std.to(device), w8.reshape(64, 224).to(device, torch.bfloat16), sc.to(device),
+                             bi.to(device)).float().cpu()
+    # (the maximum error is the bf16 OUTPUT rounding in both; the root-mean-square error shows the operand rounding that is gone)
+    rms = lambda a: float(((a.permute(0, 3, 1, 2).double() - exact) ** 2).mean().sqrt())
+    e_new, e_old = rms(y), rms(old)
+    assert e_new < e_old and _rel(y.permute(0, 3, 1, 2).double(), exact) < 6e-3, (e_new, e_old)
+
+
 @pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1),      # 10 tiles, 36 K-tiles (even)
                                   (3, 31, 29, 128, 256, 3, 2, 1),      # stride 2, M tail (720 rows = 2.8 tiles), 18 K-tiles
                                   (2, 24, 32, 512, 512, 1, 1, 0),      # 1x1, two channel tiles, 8 K-tiles
