@@ -28,7 +28,7 @@ __device__ __forceinline__ float group_sum(float v, int tg) {
 struct SinkLds {
     float *Z, *u, *v, *lmu, *lnu, *g1r, *g1rt, *o1, *g2, *o2, *max0;
     int *idx0, *idx1;
-    float* xch;                                    // 4-wave kernel only: [2 phases][64 lanes][4 waves][m, s]
+    float* xch;                                    // 4-wave kernel only: [2 phases][4 waves][64 lanes][m, s]
     int R, LD;
 };
 
@@ -285,8 +285,7 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_w4_kernel(
     const float lmu_l = rok ? L.lmu[lane] : 0.f, lnu_l = cok ? L.lnu[lane] : 0.f;
     float uu = 0.f, vv = 0.f;                      // u[lane] / v[lane]; 0 outside the valid rows / columns
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    f32x2_t* xr = reinterpret_cast<f32x2_t*>(L.xch);                 // [64 lanes][4 waves] (m, s)
+    f32x2_t* xr = reinterpret_cast<f32x2_t*>(L.xch);                 // [4 waves][64 lanes] (m, s)
     f32x2_t* xc = xr + 64 * 4;
     auto phase = [&](const float (&z)[KW], float other, float marg, bool ok, f32x2_t* xch) -> float {
         float t[KW];
@@ -299,11 +298,11 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_w4_kernel(
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KW; ++k) s += __expf(t[k] - m);
-        xch[lane * 4 + w] = f32x2_t{m, s};
+        xch[w * 64 + lane] = f32x2_t{m, s};                      // [wave][lane]: 8-byte lane stride, conflict-free writes and reads
         __syncthreads();
-        const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(xch + lane * 4), p1 = *reinterpret_cast<const f32x4_t*>(xch + lane * 4 + 2);
-        const float M = fmaxf(fmaxf(p0[0], p0[2]), fmaxf(p1[0], p1[2]));
-        const float S = p0[1] * __expf(p0[0] - M) + p0[3] * __expf(p0[2] - M) + p1[1] * __expf(p1[0] - M) + p1[3] * __expf(p1[2] - M);
+        const f32x2_t q0 = xch[lane], q1 = xch[64 + lane], q2 = xch[128 + lane], q3 = xch[192 + lane];
+        const float M = fmaxf(fmaxf(q0[0], q1[0]), fmaxf(q2[0], q3[0]));
+        const float S = q0[1] * __expf(q0[0] - M) + q1[1] * __expf(q1[0] - M) + q2[1] * __expf(q2[0] - M) + q3[1] * __expf(q3[0] - M);
         return ok ? marg - (M + __logf(S)) : 0.f;
     };
     for (int it = 0; it < iters; ++it) {

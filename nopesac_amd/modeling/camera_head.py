@@ -27,6 +27,10 @@ CAM_MODES = {"soft": 0, "avg-all": 1, "min-cost": 2, "max-score": 3}
 @CAMERA_HEAD_REGISTRY.register()
 class PlaneCameraHead(ParamModule):
     CORR_PAD = 304      # 15 x 20 = 300 correlation channels at 480 x 640, padded to a multiple of 8
+    # bf16 GEMM mode (round 4): padded to a multiple of 64 instead, which makes the branches' first conv (3x3, 300 -> 128 at 15 x 20)
+    # eligible for the LDS-DMA / fragment-streaming MFMA kernels: 41 instead of 75 us per branch at 32 pairs (150 instead of 300
+    # workgroups); the 20 extra channels are zeros in both operands
+    CORR_PAD_BF16 = 320
 
     def __init__(self, cfg, input_shape=None):
         C = cfg.MODEL.CAMERA_HEAD
@@ -65,6 +69,7 @@ class PlaneCameraHead(ParamModule):
                 # the first conv reads the 300-channel correlation volume: pad Cin to 304 (zeros) so its im2col rows are
                 # 8-element aligned and the vector / MFMA-friendly staging path applies
                 P[f"{br}.{i}"] = conv_bn(self, f"{br}.{i}.0.weight", f"{br}.{i}.1", 1e-3, cin_pad=self.CORR_PAD if i == 0 else 0)
+            P[f"{br}.0.pad64"] = conv_bn(self, f"{br}.0.0.weight", f"{br}.0.1", 1e-3, cin_pad=self.CORR_PAD_BF16)
         for nm in ("fc_trans", "fc_rots"):
             # the reference flattens NCHW (128,2,3) -> index c*6+hw; our activations are NHWC -> hw*128+c
             w = self.raw(nm + ".weight").float().view(256, 128, 6).permute(0, 2, 1).reshape(256, 768)
@@ -117,12 +122,14 @@ class PlaneCameraHead(ParamModule):
         gd = self._gd("branches")
         act_dt = torch.bfloat16 if gd == torch.bfloat16 else torch.float32
         # softmax over the channels, written in the conv operand type with zero-padded channels (see pack): 300 -> 304
-        aff = ops.softmax_rows(corr, out_dtype=act_dt, pad_to=self.CORR_PAD if (h * w) % 8 else h * w)
+        wide = act_dt == torch.bfloat16 and (h * w) % 64 != 0
+        aff = ops.softmax_rows(corr, out_dtype=act_dt, pad_to=self.CORR_PAD_BF16 if wide else (self.CORR_PAD if (h * w) % 8 else h * w))
 
         def branch(name, fc, reg):
             t = aff
             for i in range(6):
-                t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY, out_dtype=torch.float32 if i == 5 else None)
+                t = cv(t, f"{name}.{i}" + (".pad64" if (i == 0 and wide) else ""), 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY,
+                       out_dtype=torch.float32 if i == 5 else None)
             # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
             feat, raw = run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], self._gd("fc"))
             return feat, raw

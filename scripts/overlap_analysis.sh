@@ -8,7 +8,7 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/prof_ovl/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if ("stem_fused_kernel<true>" in r["Kernel_Name"] or "preprocess" in r["Kernel_Name"])]
+starts = [i for i, r in enumerate(rows) if (("stem_fused_kernel<1>" in r["Kernel_Name"] or "stem_fused_kernel<2>" in r["Kernel_Name"]) or "preprocess" in r["Kernel_Name"])]
 # the last 27 step starts = 24 timed steps + 3 instrumented ones; analyse timed steps 6 .. 20
 a, b = starts[-27 + 6], starts[-27 + 20]
 sel = rows[a:b]
