@@ -260,13 +260,15 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             // first chunk: run_mx = -inf, nothing accumulated yet (scale irrelevant); a fully masked set keeps mx = -inf: msg = 0 below
-            const float scale = (c == 0 || mx == -INFINITY) ? 1.f : expf(run_mx[r] - mx);
+            // (hardware v_exp_f32 forms: the probabilities are rounded to bf16 MFMA operands right below; 64 library expf per lane and
+            //  chunk were ~2.5 k cycles of VALU on the layer's critical path)
+            const float scale = (c == 0 || mx == -INFINITY) ? 1.f : __expf(run_mx[r] - mx);
             const float sub = mx == -INFINITY ? 0.f : mx;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { s[kt][e] = expf(s[kt][e] - sub); ps += s[kt][e]; }
+                for (int e = 0; e < 16; ++e) { s[kt][e] = __expf(s[kt][e] - sub); ps += s[kt][e]; }
             ps += __shfl_xor(ps, 32, 64);
             run_ps[r] = run_ps[r] * scale + ps;
             run_mx[r] = mx;
@@ -333,6 +335,14 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
 
     // ---- out = x + LN2(hidden W2^T)
     gn_issue(ring, 1, p.w2, 32, 16, wave, lane);                           // step 9: mlp.2, last 256 hidden channels
+    // the f32 residual rows of the epilogue, requested now: their L2 / HBM round trip runs under the last GEMM + LayerNorm
+    f32x4 xres[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = min(r * 32 + l31, max(nq - row0 - 1, 0));           // (rows beyond the set are clamped: loaded, never stored)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xres[r][q] = *reinterpret_cast<const f32x4*>(xg + (long long)row * GN_D + wave * 32 + 8 * q + 4 * half);
+    }
     gn_zero(acc);
     gn_gemm<false>(ring, 0, Ht, GN_HLD, acc, lane);
     gn_gemm<false>(ring, 1, Ht + 256, GN_HLD, acc, lane);
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = wave * 32 + 8 * q + 4 * half;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + (long long)row * GN_D + n);
+            const f32x4 xv = xres[r][q];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = xv[e] + acc[r][4 * q + e];
