@@ -545,6 +545,15 @@ long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long 
                                           int H, int W, char* out, long long cap, long long* out_off, double* bbox4);
 
 
+/* Layers 1..5 of both branches of the pixel pose net (camera_net/camera_modules.py `convs_trans` / `convs_rots`: Conv3x3 + BatchNorm +
+ * LeakyReLU(0.01), strides 2,1,2,1,2 behind the stride-1 first layer; call site camera_head.py:642-735) in one launch, one workgroup per
+ * (image pair, branch), activations resident in LDS.  x_trans / x_rots: the branches' layer-0 outputs [B][15][20][128] bf16;
+ * w10 / scale10 / bias10: 10 pointers each, index = branch * 5 + (layer - 1), branch 0 = trans: bf16 weights [128][3*3*128] in
+ * nopesac MFMA fragment-major order (K index = (kh*3 + kw)*128 + c), folded-BatchNorm f32 scale / shift [128];
+ * y_trans / y_rots: [B][2][3][128] f32 (NHWC: the FC stack's input).  H, W, C must be 15, 20, 128 (the 480 x 640 geometry). */
+int nopesac_posenet_branch_tail_bf16(const void* x_trans, const void* x_rots, const void* const* w10, const float* const* scale10,
+                                     const float* const* bias10, float* y_trans, float* y_rots, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ SIGNATURES = {
     "nopesac_tape_create_ex": [P, I, ctypes.POINTER(c_void_p), P],
     "nopesac_tape_replay": [P, P],
     "nopesac_tape_replay_on": [P, P, P, I],
+    "nopesac_posenet_branch_tail_bf16": [P, P, P, P, P, P, P, I, I, I, I, P],
     "nopesac_tape_destroy": [P],
     "nopesac_lds_canary": [I, I, L, I, P, P, I, P],
     "nopesac_force_k_select": [P, I, P, P, P, I, I, I, I, P, P, P],

@@ -13,6 +13,8 @@ counts as device int32 vectors, and no stage synchronises with the host.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
@@ -42,6 +44,7 @@ class PlaneCameraHead(ParamModule):
             "implemented: the shipped inference configuration (REFINE_ON, CAM_REC_ON, plane matcher on; inference_mp3d.yaml:17-23)"
         assert not cfg.TEST.POSE_REFINEMENT_WITH_GT_MATCHERS, "GT matchers are an evaluation-only mode"
         assert self.out_cam_type in CAM_MODES
+        self.fused_branch_tail = os.environ.get("NOPESAC_BRANCH_TAIL_UNFUSED", "0") != "1"     # bf16 mode: pose-net branch layers 1..5 in one launch
         assert cfg.MODEL.SEM_SEG_HEAD.NORM == "GN" and cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM == 128
         spec = {k[len("camera_head_list.0."):]: v for k, v in state_dict_spec(self.num_queries).items()
                 if k.startswith("camera_head_list.0.")}
@@ -125,16 +128,27 @@ class PlaneCameraHead(ParamModule):
         wide = act_dt == torch.bfloat16 and (h * w) % 64 != 0
         aff = ops.softmax_rows(corr, out_dtype=act_dt, pad_to=self.CORR_PAD_BF16 if wide else (self.CORR_PAD if (h * w) % 8 else h * w))
 
-        def branch(name, fc, reg):
-            t = aff
-            for i in range(6):
-                t = cv(t, f"{name}.{i}" + (".pad64" if (i == 0 and wide) else ""), 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY,
-                       out_dtype=torch.float32 if i == 5 else None)
-            # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
-            feat, raw = run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], self._gd("fc"))
-            return feat, raw
+        def conv0(name):
+            return cv(aff, f"{name}.0" + (".pad64" if wide else ""), 1, 1, ops.ACT_LEAKY)
 
-        (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
+        def head(t, fc, reg):
+            # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
+            return run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], self._gd("fc"))
+
+        def branch(name, fc, reg):
+            t = conv0(name)
+            for i in range(1, 6):
+                t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY, out_dtype=torch.float32 if i == 5 else None)
+            return head(t, fc, reg)
+
+        if self.fused_branch_tail and act_dt == torch.bfloat16 and (h, w) == (15, 20):
+            # layers 1..5 of BOTH branches in one launch, activations resident in LDS (csrc/posenet_branch.hip): 3 launches instead of 12
+            if "branch_tail" not in P:
+                P["branch_tail"] = ops.PoseBranchTail([P[f"convs_trans.{i}"] for i in range(1, 6)], [P[f"convs_rots.{i}"] for i in range(1, 6)])
+            yt, yr = ops.posenet_branch_tail(conv0("convs_trans"), conv0("convs_rots"), P["branch_tail"])
+            (trans_feat, trans0), (rots_feat, rot_raw) = head(yt, "fc_trans", "trans"), head(yr, "fc_rots", "rots")
+        else:
+            (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
         rot0 = ops.normalize_rows(rot_raw, canonical_sign=True)                                   # :667, :436-437
         return trans0, rot0, trans_feat, rots_feat
 

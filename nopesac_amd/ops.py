@@ -1062,6 +1062,37 @@ def transformer_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, *, pre_norm
     return out
 
 
+class PoseBranchTail:
+    """Operands of nopesac_posenet_branch_tail_bf16, packed once: layers 1..5 of the two pose-net branches (ConvW objects with folded
+    BatchNorm) as fragment-major bf16 weights + pointer tables (the ctypes arrays keep the tensors alive)."""
+
+    def __init__(self, convs_trans, convs_rots):
+        import ctypes
+        self.keep = []
+        ws, ss, bs = [], [], []
+        for c in list(convs_trans) + list(convs_rots):
+            _require(c.cout == 128 and c.cin == 128 and c.kh == 3 and c.kw == 3 and c.scale is not None and c.bias is not None,
+                     "pose-net branch tail: 3x3, 128 -> 128 convs with folded BatchNorm")
+            wf = mfma_fragment_major(c.w(torch.bfloat16).reshape(128, -1))
+            self.keep += [wf, c.scale, c.bias]
+            ws.append(wf.data_ptr()); ss.append(c.scale.data_ptr()); bs.append(c.bias.data_ptr())
+        _require(len(ws) == 10, "pose-net branch tail: five layers per branch")
+        arr = ctypes.c_void_p * 10
+        self.w, self.s, self.b = arr(*ws), arr(*ss), arr(*bs)
+
+
+def posenet_branch_tail(x_trans: torch.Tensor, x_rots: torch.Tensor, packed: PoseBranchTail):
+    """Layers 1..5 of both pose-net branches in one launch.  x_*: layer-0 outputs [B,15,20,128] bf16 -> two [B,2,3,128] f32 tensors."""
+    _chk(x_trans, torch.bfloat16); _chk(x_rots, torch.bfloat16)
+    B, H, W, C = x_trans.shape
+    _require(x_rots.shape == x_trans.shape, "pose-net branch tail: the two branches have the same shape")
+    yt = torch.empty((B, 2, 3, 128), device=x_trans.device, dtype=torch.float32)
+    yr = torch.empty_like(yt)
+    _lib.check(_L().nopesac_posenet_branch_tail_bf16(_p(x_trans), _p(x_rots), packed.w, packed.s, packed.b, _p(yt), _p(yr), B, H, W, C, _stream()),
+               "nopesac_posenet_branch_tail_bf16")
+    return yt, yr
+
+
 def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, act: int = ACT_RELU) -> torch.Tensor:
     """bf16 3x3/s1/p1 conv 64 -> 64 + BN + act from an LDS halo tile (csrc/conv3x3_c64.hip).  x [B,H,W,64], w [64,3,3,64]."""
     _chk(x, torch.bfloat16); _chk(w, torch.bfloat16); _chk(scale, torch.float32); _chk(bias, torch.float32)

@@ -487,6 +487,30 @@ def test_conv2d_lds_dma_kernel_channel_major_k_order(device, case, monkeypatch):
     assert _rel(y_cm.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B", [1, 5])
+def test_posenet_branch_tail_matches_the_per_layer_convs(device, B):
+    """nopesac_posenet_branch_tail_bf16 (round 4: layers 1..5 of both pose-net branches in one launch, activations in LDS) against
+    five ops.conv2d launches per branch with the same bf16 weights, folded BatchNorm and LeakyReLU: same rounding points (bf16
+    activations between the layers, f32 out of the last one), only the f32 summation order differs."""
+    from nopesac_amd import ops
+    from nopesac_amd.modeling.params import ConvW
+    g = torch.Generator().manual_seed(40 + B)
+    convs = [[ConvW((torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(9 * 128 / 2)).to(device), (1 + 0.1 * torch.randn(128, generator=g)).to(device),
+                    (0.1 * torch.randn(128, generator=g)).to(device)) for _ in range(5)] for _ in range(2)]
+    xs = [torch.randn(B, 15, 20, 128, generator=g).to(device, torch.bfloat16) for _ in range(2)]
+    packed = ops.PoseBranchTail(convs[0], convs[1])
+    yt, yr = ops.posenet_branch_tail(xs[0], xs[1], packed)
+    for br, y in ((0, yt), (1, yr)):
+        t = xs[br]
+        for i, c in enumerate(convs[br]):
+            t = ops.conv2d(t, c.w(torch.bfloat16), c.scale, c.bias, stride=2 if i % 2 == 0 else 1, pad=1, act=ops.ACT_LEAKY,
+                           out_dtype=torch.float32 if i == 4 else None)
+        assert y.shape == t.shape == (B, 2, 3, 128)
+        assert _rel(y, t) < 1e-2, br
+    yt2, yr2 = ops.posenet_branch_tail(xs[0], xs[1], packed)
+    assert torch.equal(yt, yt2) and torch.equal(yr, yr2)
+
+
 @pytest.mark.parametrize("M,last", [(3200, False), (3200, True), (77, False)])
 def test_decoder_tail(device, M, last):
     """Pre-norm decoder tail (enc_tail kernel, pre_norm = 1) vs the same chain through the per-op bf16-mode kernels."""
