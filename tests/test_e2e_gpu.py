@@ -377,9 +377,9 @@ def test_cli_runner_autotunes_and_keeps_a_routing_file(device, tmp_path):
         opts = ["MODEL.DEVICE", str(device), "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", str(routing)]
         a = run.main(head + ["--output", str(tmp_path / "a.json")] + opts)
         doc = json.load(open(routing))
-        assert doc["format"] == "nopesac_amd.ConvTuner/1" and len(doc["routing"]) > 40
+        assert doc["format"] == "nopesac_amd.ConvTuner/1" and len(doc["routing"]) > 30     # (40 distinct shapes since the pose-net branches are one launch)
         n_measured = len(ops.TUNER.log)
-        assert n_measured > 40
+        assert n_measured > 30
         ops.TUNER.best, ops.TUNER.log = {}, []                     # a fresh process would start like this
         b = run.main(head + ["--output", str(tmp_path / "b.json")] + opts)
         assert len(ops.TUNER.log) == 0 and len(ops.TUNER.loaded) == len(doc["routing"])
