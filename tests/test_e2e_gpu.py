@@ -472,9 +472,11 @@ def test_nonfinite_outputs_raise(device):
     model(inp)
 
 
-def test_bench_two_gpus_rccl():
-    """bench.py --gpus 2 under torchrun over RCCL: skipped unless the box has two GPUs (the driver's scaling run is the 8-GPU
-    version of exactly this command).  Rank 0's line must report n_gpus = 2 and a global batch of 2 x pairs."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_gpus_rccl(launcher):
+    """bench.py --gpus 2 over RCCL, under torchrun (the driver's scaling run is the 8-GPU version of exactly this command) and with
+    bench.py starting its own two ranks (round 4): skipped unless the box has two GPUs.  Rank 0's line must report n_gpus = 2,
+    two RCCL ranks and a global batch of 2 x pairs."""
     import json
     import os
     import subprocess
@@ -482,15 +484,19 @@ def test_bench_two_gpus_rccl():
     from tests.util import ROOT
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "8", "--no-cpu-baseline", "--no-accuracy",
-           "--no-fp32-path"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    bench_cmd = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "8", "--no-cpu-baseline", "--no-accuracy",
+                 "--no-fp32-path"]
+    cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                               "29533"] if launcher == "torchrun" else []) + bench_cmd
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["config"]["nonfinite_outputs"] == 0
+    assert out["config"]["rccl_ranks"] == 2 and abs(out["config"]["pairs_per_s_per_gpu"] * 2 - out["value"]) < 1e-2 * out["value"]
 
 
 def test_steps_in_flight_are_bit_identical(device):
