@@ -183,3 +183,13 @@ def test_bench_single_rank_stub():
     r, j = _run_bench(["--gpus", "1", "--stub-model", "--steps", "3", "--warmup", "1", "--pairs", "4"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert j["n_gpus"] == 1 and j["config"]["rccl_ranks"] == 1 and j["rows_gathered"] == 4
+
+
+def test_bench_gpus8_global_batch_256_stub():
+    """BASELINE configs[3] in shape (8 ranks x 32 pairs = global batch 256, four steps in flight, one all_gather of [32,16] rows per
+    step and rank) through bench.py's own launcher on CPU / gloo with the stub model: the 8-rank rendezvous, the rank-major order
+    of the 256 gathered rows and the single JSON line are what a node without torchrun would run."""
+    r, j = _run_bench(["--gpus", "8", "--stub-model", "--steps", "6", "--warmup", "2", "--pairs", "32", "--inflight", "4"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8 and j["config"]["global_batch"] == 256
+    assert j["rows_gathered"] == 256 and j["rows_in_rank_order"]
