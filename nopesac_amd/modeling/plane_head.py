@@ -8,6 +8,8 @@ layer's heads are evaluated (the reference's deep-supervision outputs are traini
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import torch
@@ -43,6 +45,10 @@ def run_mlp(x, layers, out=None, final_act=ops.ACT_NONE, gd=torch.float32):
     return x
 
 
+CHAIN_MIN_ROWS = int(os.environ.get("NOPESAC_CHAIN_MIN_ROWS", "64"))     # up to this many rows big stacks run one launch per layer
+CHAIN_SMALL_PARAMS = 1 << 20                                              # ... when they hold at least this many weights (2 MB in bf16)
+
+
 def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1, parallel=False):
     """Consecutive MLP stacks (each: ReLU between its layers, `final_act` after its last one) applied to the rows of x [rows, K] f32;
     stacks = [(layers: [ConvW], final_act, out)], out = an f32 [rows, N] tensor (may be a column slice) that receives the stack's
@@ -71,8 +77,12 @@ def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1, parallel=False):
         elif o is not None:
             results[si] = o
     k0 = x.shape[1] + (0 if x_bcast is None else x_bcast.shape[1])
+    # One pair per call (round 4): with <= 64 rows the chained kernel is ONE or TWO workgroups streaming the whole stack's weights
+    # through one CU's L2 port (the refine stacks: 10 MB, 263 us for 33-64 rows); one launch per layer spreads every weight matrix
+    # over N / 64 workgroups (~12 us per layer).  Same rounding points (f32 activations, bf16 operands), another summation order.
+    few_rows = rows <= CHAIN_MIN_ROWS and sum(l.cout * l.cin for l, _ in flat) >= CHAIN_SMALL_PARAMS
     if (gd == torch.bfloat16 and x.dtype == torch.float32 and len(flat) <= _lib.MLP_MAX_LAYERS and k0 <= _lib.MLP_MAX_IN
-            and all(l.cout <= _lib.MLP_MAX_WIDTH for l, _ in flat)):
+            and all(l.cout <= _lib.MLP_MAX_WIDTH for l, _ in flat) and not few_rows):
         ops.mlp_chain(x, [l.chain() for l, _ in flat], [a for _, a in flat], [results[si] if si >= 0 else None for si in last_of],
                       x_bcast=x_bcast, rows_per=rows_per, restarts=restarts)
         return results
