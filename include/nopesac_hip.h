@@ -446,6 +446,17 @@ int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* stream);
 #define NOPESAC_NONFINITE_MAX_TENSORS 16
 int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n_tensors, int32_t* count, void* stream);
 
+/* Result fetch (replaces the per-tensor `.cpu()` copies of siamese_planeTR.py:384-450 at the drop-in boundary): n_segments byte
+ * ranges (HOST arrays of device pointers / sizes / destination offsets, n_segments <= NOPESAC_GATHER_MAX_SEGMENTS) are copied into
+ * `dst` by ONE kernel.  dst is device memory or device-mapped pinned host memory (hipHostMalloc / torch pin_memory): the latter is the
+ * intended use - the batch's small result tensors reach the host in one launch that a captured graph can hold.  Ranges may be
+ * unaligned (16-byte vectors are used when a segment's source and destination addresses allow it).  size_dev: NULL, or a HOST array
+ * of device pointers (entries may be NULL) to the number of VALID bytes of a segment when only the device knows it (the run-length
+ * strings of a batch: a buffer of fixed capacity, filled to a data-dependent length); min(size[i], *size_dev[i]) bytes are copied. */
+#define NOPESAC_GATHER_MAX_SEGMENTS 32
+int nopesac_gather_bytes(const void* const* src, const int64_t* size, const int64_t* const* size_dev, const int64_t* dst_off,
+                         int n_segments, void* dst, void* stream);
+
 /* One GNN layer of the plane matcher (transformer/gnn.py:73-96) for n_sets plane sets, one workgroup per set, bf16 MFMA
  * operands / f32 residual stream (csrc/gnn_layer.hip).  Feature buffers are f32 [sets][nq][256] (nq <= 64); workgroup b updates
  * set x_off + b attending to set src_off + b (same buffer and offset = 'self' layer) and writes set out_off + b of `out`

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nopesac_count_nonfinite_batch": [P, P, I, P, P],
     "nopesac_clock_probe": [P, L, P],
     "nopesac_u8_to_f32": [P, P, L, P],
+    "nopesac_gather_bytes": [P, P, P, P, I, P, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

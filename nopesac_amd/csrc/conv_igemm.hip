@@ -75,9 +75,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     const bool is1x1 = (p.KH == 1 && p.KW == 1);
 
-    vec_t a_reg[A_VECS], b_reg[B_VECS];
+    // PF2 (round 4; bf16 activations and weights, BK = 128: the small latency-bound GEMMs / one-pair convs, a handful of workgroups
+    // each): TWO tiles of global loads in flight.  With one (the other builds) a K step costs a full memory round trip minus the 256
+    // cycles of its MFMAs: ~1.2 us per step when nothing else runs on the CU.  The loads must be BRANCH-FREE for that to work - behind
+    // the im2col bounds branches the compiler can only wait with vmcnt(0), which also drains the tile requested last - so this build
+    // fetches through bounds-checked buffer descriptors: an out-of-image tap / row >= M / channel >= N gets an out-of-range voffset
+    // and reads zeros.  Offsets are relative to the first image (dense 1x1: first pixel) of the tile, so they fit 32 bits whatever the
+    // batch (the launcher checks one tile's span).
+#ifdef NPS_NO_PF2                                           // A/B builds (NOPESAC_HIPCC_EXTRA=-DNPS_NO_PF2)
+    constexpr bool PF2 = false;
+#else
+    constexpr bool PF2 = sizeof(T) == 2 && sizeof(TA) == 2 && KMUL == 4 && VEC == 8;
+#endif
+    vec_t a_regs[PF2 ? 2 : 1][A_VECS], b_regs[PF2 ? 2 : 1][B_VECS];
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    unsigned a_rel[PF2 ? A_VECS : 1], b_off[PF2 ? B_VECS : 1];
+    __amdgpu_buffer_rsrc_t xsrc, wsrc;
+    if constexpr (PF2) {
+        const long long mg0 = (long long)m0 + (long long)bz * p.rows_per_b;
+        const long long px0 = p.dense1x1 ? mg0 : mg0 / p.rows_per_b * p.H * p.W;            // first pixel the tile can touch
+        const long long left = ((long long)p.B * p.H * p.W - px0) * p.x_cs * 2;
+        xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(X + px0 * p.x_cs), 0, (int)(left < 0x7FFFFFFFll ? left : 0x7FFFFFFFll), 0x00020000);
+        wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) {
+            // a_base: pixel index of (b, 0, 0) / of the row; + the (ih0, iw0) corner (mod 2^32: a padding corner is "negative")
+            a_rel[i] = (unsigned)((a_base[i] - px0 + (long long)a_ih0[i] * p.W + a_iw0[i]) * p.x_cs * 2);
+            if (!a_ok[i]) a_ih0[i] = -(1 << 20);                // rows >= M: every tap out of the image
+        }
+#pragma unroll
+        for (int i = 0; i < B_VECS; ++i) {
+            const int v = tid + i * 256;
+            const int n = n0 + v / VPR;
+            b_off[i] = n < p.N ? (unsigned)(((long long)n * p.K + (v % VPR) * VEC) * 2) : OOB;
+        }
+    }
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, auto SETC) {
+        constexpr int SET = decltype(SETC)::value;
+        vec_t (&a_reg)[A_VECS] = a_regs[SET];
+        vec_t (&b_reg)[B_VECS] = b_regs[SET];
+        if constexpr (PF2) {                                   // K % 128 == 0 here: no k tail
+            // 256 % VPR == 0: all of a thread's vectors sit at the same k -> one tap decode per tile, no branch anywhere (a 1x1 layer
+            // has Cin == K: tap 0; the dense form has ih0 = iw0 = 0)
+            const int k = kt * BK + (tid % VPR) * VEC;
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const unsigned tapoff = (unsigned)((kh * p.W + kw) * (int)p.x_cs + c) * 2u;
+#pragma unroll
+            for (int i = 0; i < A_VECS; ++i) {
+                const bool in = (unsigned)(a_ih0[i] + kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + kw) < (unsigned)p.W;
+                const unsigned vo = in ? a_rel[i] + tapoff : OOB;       // a_rel: pixel (ih0, iw0) - may be "negative", the sum is not
+                a_reg[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)vo, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < B_VECS; ++i)
+                b_reg[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (int)b_off[i], kt * BK * 2, 0));
+            __builtin_amdgcn_sched_barrier(0);                 // the requests go out HERE, not after the MFMAs of the tile in LDS
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
             const int v = tid + i * 256;
@@ -120,7 +176,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             b_reg[i] = val;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, auto SETC) {
+        constexpr int SET = decltype(SETC)::value;
+        vec_t (&a_reg)[A_VECS] = a_regs[SET];
+        vec_t (&b_reg)[B_VECS] = b_regs[SET];
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
             const int v = tid + i * 256;
@@ -158,13 +217,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int r = 0; r < 16; ++r) acc_hi[i][j][r] = 0.f;
     }
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, PF2 ? 1 : 0> S1;
+    load_tile(0, S0{});
+    store_tile(0, S0{});
+    if constexpr (PF2) load_tile(nk > 1 ? 1 : 0, S1{});
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    auto compute_tile = [&](int kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
         const T* Ab = lds + buf * BUF_ELEMS + (wm * WM + (lane & 31)) * LDS_STRIDE;
         const T* Bb = lds + buf * BUF_ELEMS + (BM + wn * WN + (lane & 31)) * LDS_STRIDE;
         if constexpr (sizeof(T) == 2) {
@@ -214,8 +275,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         for (int r = 0; r < 16; ++r) { acc_hi[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
             }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    if constexpr (PF2) {
+        // tile kt in LDS, tile kt+1 in register set (kt+1)&1 (in flight), tile kt+2 requested into set kt&1 before tile kt's MFMAs
+        // The steady-state body is straight-line (a request past the last tile re-reads the last one; the one or two tiles left at the
+        // end are a separate tail): any branch around a load or a store makes the compiler merge wait states conservatively, and the
+        // loop top then waits for loads that were issued one half-iteration earlier.
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            load_tile(kt + 2, S0{});
+            compute_tile(kt);
+            store_tile(1, S1{});
+            __syncthreads();
+            load_tile(kt + 3 < nk ? kt + 3 : nk - 1, S1{});
+            compute_tile(kt + 1);
+            store_tile(0, S0{});
+            __syncthreads();
+        }
+        compute_tile(kt);
+        if (kt + 1 < nk) {
+            store_tile(1, S1{});
+            __syncthreads();
+            compute_tile(kt + 1);
+        }
         __syncthreads();
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1, S0{});
+            compute_tile(kt);
+            if (kt + 1 < nk) store_tile((kt & 1) ^ 1, S0{});
+            __syncthreads();
+        }
     }
     if constexpr (TWO_LEVEL) {
 #pragma unroll
@@ -614,7 +704,11 @@ static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
     constexpr int VW = Cfg<T>::VECW;
     if constexpr (sizeof(T) == 2 && BM == 64) {
         // head GEMMs (a few hundred blocks, K >= 128): BK = 128 halves/quarters the number of exposed-latency steps
-        if (vec == VW && p.K % 128 == 0 && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048) {
+        // (bf16 activations: 32-bit offsets relative to the tile's first image - see PF2 in the kernel - must cover the images one
+        //  tile of BM rows can span)
+        const long long span = ((long long)BM / p.rows_per_b + 2) * p.H * p.W * p.x_cs * 2;
+        if (vec == VW && p.K % 128 == 0 && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048 &&
+            (sizeof(TA) != 2 || span < 0x7FFFFFFFll)) {
             hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 4>), grid, dim3(256), 0, stream, p);
             return 0;
         }
@@ -651,7 +745,12 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
         // LDS-DMA kernel: bf16, every K-tile of 64 inside one tap, 16-byte aligned 8-channel chunks
         // measured (scripts/conv_microbench.py): the DMA kernel wins on 3x3 layers and on 1x1 layers with K >= 1024,
         // loses on the HBM-bound small-K 1x1 layers (2 blocks/CU keep too few bytes in flight)
-        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && (tiles128 >= 192 || p.K >= 4096) && (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
+        // few tiles but a long K loop (K >= 4096, e.g. one pair's res5 3x3 convs: 40 workgroups of 128x64 walking 72 K-tiles, 60 us): the
+        // 64x64-tile kernel with two tiles of prefetch (PF2 in conv_igemm_kernel) has twice the workgroups and half the steps and
+        // took the one-pair call from 4.04 to 3.97 ms; the DMA kernel keeps these shapes only when asked for (tuner / NOPESAC_CONV_FORCE)
+        const bool pf2_small = p.K % 128 == 0 && (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (p.batched ? p.B : 1) <= 2048;
+        const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && (tiles128 >= 192 || (p.K >= 4096 && (p.force >= 3 || !pf2_small))) &&
+                            (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
                             (long long)p.B * p.H * p.W * p.x_cs * 2 + ((long long)p.pad * p.W + p.pad) * p.x_cs * 2 < (1ll << 31) && (long long)p.N * p.K * 2 < (1ll << 31);
         if (dma_ok) {
             ConvParams q = p;

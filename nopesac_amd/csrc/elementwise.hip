@@ -793,3 +793,49 @@ extern "C" int nopesac_u8_to_f32(const uint8_t* x, float* y, int64_t n, void* st
     if (n % 16) hipLaunchKernelGGL(u8_to_f32_tail_kernel, dim3(1), dim3(16), 0, (hipStream_t)stream, x, y, n16 * 16, (long long)n);
     NPS_LAUNCH_RET();
 }
+
+// ---- result fetch: up to NOPESAC_GATHER_MAX_SEGMENTS byte ranges -> ONE destination buffer in ONE launch.  The destination is normally
+// PINNED HOST memory (device-mapped: the stores travel over PCIe): the small result tensors of a batch reach the host without the
+// torch.cat + pad fills + copy launches the fetch used to issue (12 launches per call), and - being a kernel - the fetch becomes part
+// of a captured graph / launch tape.  blockIdx.y = segment; 16-byte vectors when source and destination offsets allow it.
+namespace nps {
+struct GatherSegs {
+    const unsigned char* src[NOPESAC_GATHER_MAX_SEGMENTS];
+    long long size[NOPESAC_GATHER_MAX_SEGMENTS];
+    long long dst_off[NOPESAC_GATHER_MAX_SEGMENTS];
+    const long long* size_dev[NOPESAC_GATHER_MAX_SEGMENTS];      // optional: valid bytes of the segment, known on the device only
+};
+__global__ void gather_bytes_kernel(const GatherSegs g, unsigned char* __restrict__ dst) {
+    const unsigned char* __restrict__ s = g.src[blockIdx.y];
+    unsigned char* __restrict__ d = dst + g.dst_off[blockIdx.y];
+    long long n = g.size[blockIdx.y];
+    if (g.size_dev[blockIdx.y]) n = max(0ll, min(n, *g.size_dev[blockIdx.y]));
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const long long n16 = n >> 4;
+        for (long long i = t0; i < n16; i += step) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (long long i = (n16 << 4) + t0; i < n; i += step) d[i] = s[i];
+    } else {
+        for (long long i = t0; i < n; i += step) d[i] = s[i];
+    }
+}
+}  // namespace nps
+
+extern "C" int nopesac_gather_bytes(const void* const* src, const int64_t* size, const int64_t* const* size_dev, const int64_t* dst_off,
+                                    int n_segments, void* dst, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(src && size && dst_off && dst && n_segments > 0 && n_segments <= NOPESAC_GATHER_MAX_SEGMENTS, "gather_bytes: bad args");
+    GatherSegs g;
+    long long nmax = 0;
+    for (int i = 0; i < NOPESAC_GATHER_MAX_SEGMENTS; ++i) {
+        const int j = i < n_segments ? i : 0;
+        NPS_CHECK_ARG(src[j] && size[j] > 0 && dst_off[j] >= 0, "gather_bytes: null / empty segment %d", j);
+        g.src[i] = (const unsigned char*)src[j]; g.size[i] = size[j]; g.dst_off[i] = dst_off[j];
+        g.size_dev[i] = size_dev ? (const long long*)size_dev[j] : nullptr;
+        if (size[j] > nmax) nmax = size[j];
+    }
+    const long long want = (nmax + 256 * 16 - 1) / (256 * 16);
+    const int blocks = (int)(want > 64 ? 64 : want);
+    hipLaunchKernelGGL(gather_bytes_kernel, dim3(blocks, n_segments), dim3(256), 0, (hipStream_t)stream, g, (unsigned char*)dst);
+    NPS_LAUNCH_RET();
+}

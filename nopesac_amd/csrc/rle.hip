@@ -75,10 +75,14 @@ __device__ __forceinline__ uint32_t rle_eq16(const uint4& q, uint32_t pb) {
     return m;
 }
 
-__global__ __launch_bounds__(256) void rle_transitions_kernel(const uint8_t* __restrict__ labels, const int* __restrict__ n_kept,
-                                                              const long long* __restrict__ offsets, int* __restrict__ counts,
-                                                              uint32_t* __restrict__ positions, int N, int nq) {
-    __shared__ int wave_tot[4];
+// 16 waves per (plane, view): a wave walks its share of the image 1024 pixels at a time, and with few planes (one pair per call:
+// ~10 workgroups on the chip) the length of that walk is the kernel's time - 75 dependent steps with 4 waves (40 + 68 us for the two
+// passes), 19 with 16.
+constexpr int RLE_TW = 16;
+__global__ __launch_bounds__(RLE_TW * 64) void rle_transitions_kernel(const uint8_t* __restrict__ labels, const int* __restrict__ n_kept,
+                                                                      const long long* __restrict__ offsets, int* __restrict__ counts,
+                                                                      uint32_t* __restrict__ positions, int N, int nq) {
+    __shared__ int wave_tot[RLE_TW];
     const int p = blockIdx.x, v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p >= n_kept[v]) {
         if (tid == 0) counts[v * nq + p] = 0;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void rle_transitions_kernel(const uint8_t* __r
     const uint8_t* lv = labels + (long long)v * N;
     const bool vec_ok = (N % 16 == 0) && (((uintptr_t)lv & 15) == 0);
     const uint32_t pb = (uint32_t)p * 0x01010101u;
-    const int Q = ((N + 4 * 1024 - 1) / (4 * 1024)) * 1024;              // pixels per wave, multiple of 1024
+    const int Q = ((N + RLE_TW * 1024 - 1) / (RLE_TW * 1024)) * 1024;    // pixels per wave, multiple of 1024
     const int k_begin = wave * Q, k_end = min(N, k_begin + Q);
     // flips among the 16 pixels k .. k+15 (bit j: pixel k+j differs from pixel k+j-1 in "belongs to p"; pixel -1 counts as outside)
     auto flips = [&](int k) -> uint32_t {
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void rle_transitions_kernel(const uint8_t* __r
     __syncthreads();
     int wbase = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < RLE_TW; ++w) {
         const int t = wave_tot[w];
         if (w < wave) wbase += t;
         total += t;
@@ -155,7 +159,7 @@ extern "C" int nopesac_rle_transitions(const uint8_t* labels, const int32_t* n_k
     NPS_CHECK_ARG(labels && n_kept && counts, "rle_transitions: null pointer");
     NPS_CHECK_ARG((positions == nullptr) == (offsets == nullptr), "rle_transitions: offsets and positions go together");
     NPS_CHECK_ARG(V > 0 && N > 0 && nq > 0 && nq <= 128, "rle_transitions: bad sizes");
-    hipLaunchKernelGGL(rle_transitions_kernel, dim3(nq, V), dim3(256), 0, (hipStream_t)stream, labels, n_kept,
+    hipLaunchKernelGGL(rle_transitions_kernel, dim3(nq, V), dim3(RLE_TW * 64), 0, (hipStream_t)stream, labels, n_kept,
                        (const long long*)offsets, counts, positions, N, nq);
     NPS_LAUNCH_RET();
 }

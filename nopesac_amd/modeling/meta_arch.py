@@ -11,6 +11,7 @@ Differences by design (MI355X-first):
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import numpy as np
@@ -61,6 +62,7 @@ class PlaneTR_NopeSAC(nn.Module):
         self.graph_replay = str(amd.GRAPH_REPLAY)
         assert self.graph_replay in ("launches", "graph"), self.graph_replay
         self.graph_slots = 2
+        self.graph_fetch = os.environ.get("NOPESAC_GRAPH_FETCH", "1") != "0"      # the result fetch + RLE encode inside the captured graph
         self._graphs = {}
         # camCls k-means pickles (siamese_planeTR.py:119-128) are not needed for inference math
 
@@ -148,12 +150,11 @@ class PlaneTR_NopeSAC(nn.Module):
             d["fetch"] = self._enqueue_fetch(d)
         return d
 
-    def _enqueue_fetch(self, d: dict) -> dict:
-        """Everything `package()` needs on the host, enqueued NOW on the batch's stream behind its forward: the small result tensors
-        (one concatenation, one copy into pinned memory), the COCO RLE strings (rle.PendingRLE) and - graph mode - private copies of
-        the device tensors the result dicts hand out; then an event.  package() waits for that event and does host work only.
-        With several batches in flight this matters: device work issued at fetch time queues behind the other batches' launches
-        (6.8 ms of the 9.7 ms package() took per 32-pair step were that wait)."""
+    def _fetch_device_work(self, d: dict, static: bool = False, hosts=None, rle_args=None) -> dict:
+        """The device side of the fetch: the small result tensors -> pinned host memory (ops.HostFetch: one kernel), the COCO RLE
+        strings (rle.PendingRLE).  static = True: called INSIDE the graph capture - the fetch is replayed with the graph / tape (the
+        ~30 eager launches behind every replay were 0.3 ms of host-bound tail per one-pair call) into the pinned buffers `hosts`
+        (allocated before the capture; sizes from the slot's eager warm-up pass)."""
         sel, cam = d["sel"], d["cam"]
         need = {"n_kept": sel["n_kept"], "kept_idx": sel["kept_idx"], "planes": sel["planes"], "centers": sel["centers"],
                 "scores": sel["scores"], "areas": sel["areas"], "flags": sel["flags"], "m": cam["m"],
@@ -164,15 +165,36 @@ class PlaneTR_NopeSAC(nn.Module):
             need["ass:" + k] = cam[k]
         if "nonfinite" in cam:
             need["nonfinite"] = cam["nonfinite"]
-        f = {"small": ops.HostFetch(need)}
-        if d.get("static_outputs"):       # hipGraph mode: these device tensors are overwritten by the slot's next replay
-            f["sel"] = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
+        hosts = hosts or (None, None)
+        f = {"small": ops.HostFetch(need, private_views=static, host=hosts[0])}
         if self.output_rle:
+            f["rle"] = rle.PendingRLE(*(rle_args or (sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"])), host=hosts[1])
+        return f
+
+    def _enqueue_fetch(self, d: dict) -> dict:
+        """Everything `package()` needs on the host, enqueued NOW on the batch's stream behind its forward: the small result tensors
+        (one kernel into pinned memory), the COCO RLE strings (rle.PendingRLE) and - graph mode - private copies of
+        the device tensors the result dicts hand out; then an event.  package() waits for that event and does host work only.
+        With several batches in flight this matters: device work issued at fetch time queues behind the other batches' launches
+        (6.8 ms of the 9.7 ms package() took per 32-pair step were that wait)."""
+        sel = d["sel"]
+        sf = d.get("static_fetch")
+        if sf is not None and (("rle" in sf) or not self.output_rle):
+            f = {k: v for k, v in sf.items() if k != "rle" or self.output_rle}      # recorded in the graph: this replay has run it
+            if d.get("static_outputs"):
+                f["sel"] = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
+        else:
+            rs = None
+            if d.get("static_outputs"):       # hipGraph mode: these device tensors are overwritten by the slot's next replay
+                rs = dict(sel, feats=sel["feats"].clone(), winner=sel["winner"].clone())
             # (graph mode: the overflow fallback of PendingRLE.finish re-reads its inputs - hand it the private winner map; kept_idx /
             #  n_kept / flags are small and cloned here for the same reason)
-            rs = f.get("sel")
-            f["rle"] = (rle.PendingRLE(rs["winner"], sel["kept_idx"].clone(), sel["n_kept"].clone(), sel["flags"].clone()) if rs is not None
-                        else rle.PendingRLE(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"]))
+            f = self._fetch_device_work(d, rle_args=None if rs is None or not self.output_rle else
+                                        (rs["winner"], sel["kept_idx"].clone(), sel["n_kept"].clone(), sel["flags"].clone()))
+            if rs is not None:
+                f["sel"] = rs
+            if d.get("_warm") is not None:     # the slot's eager warm-up pass: the capture that follows allocates pinned buffers of these sizes
+                d["_warm"]["fetch_sizes"] = (f["small"].host_bytes(), f["rle"].fetch.host_bytes() if "rle" in f else None)
         f["ready"] = torch.cuda.Event()
         f["ready"].record()
         if d.get("static_outputs"):       # ... which must not start before the copies above have run (whatever stream it is issued on)
@@ -259,7 +281,9 @@ class PlaneTR_NopeSAC(nn.Module):
                 st["graph"].replay()
             return st["out"]
         if st["calls"] == 1:                                   # warm-up pass, eager
-            return self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
+            out = self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
+            out["_warm"] = st
+            return out
         cur = torch.cuda.current_stream()
         want_tape = self.graph_replay == "launches"
         try:
@@ -268,8 +292,12 @@ class PlaneTR_NopeSAC(nn.Module):
             g, want_tape = torch.cuda.CUDAGraph(), False
         cap = torch.cuda.Stream(device=self.device)
         cap.wait_stream(cur)
+        sizes = st.get("fetch_sizes") if self.graph_fetch else None
+        hosts = None if sizes is None else tuple(None if n is None else torch.empty(n, dtype=torch.uint8, pin_memory=True) for n in sizes)
         with torch.cuda.graph(g, stream=cap):
             out = self.forward_tensors(None, B, H, W, forced=forced, raw_images=buf)
+            if hosts is not None and (hosts[1] is not None or not self.output_rle):
+                out["static_fetch"] = self._fetch_device_work(out, static=True, hosts=hosts)
         cur.wait_stream(cap)
         out["static_outputs"] = True                           # package() must not hand out views of graph-owned memory
         out["_owner"] = st

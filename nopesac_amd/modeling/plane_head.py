@@ -94,7 +94,12 @@ def run_stacks(x, stacks, gd, x_bcast=None, rows_per=1, parallel=False):
         x = full
     x_in = x
     for (l, a), si, rs in zip(flat, last_of, restarts):
-        x = ops.linear(x_in if rs else x, l.w2d(gd), l.bias, act=a, out=results[si] if si >= 0 else None)
+        # bf16 GEMM mode: a layer output only the NEXT layer reads is stored as bf16 - the value the consumer's MFMA operand would be
+        # rounded to anyway (same rounding point as the chained kernel and as the f32 -> bf16 staging of the mixed GEMM kernel), half the
+        # activation traffic, and the all-bf16 small-grid kernel with two tiles of prefetch instead of the mixed one
+        inner = gd == torch.bfloat16 and (si < 0 or results[si] is None)
+        x = ops.linear(x_in if rs else x, l.w2d(gd), l.bias, act=a, out=results[si] if si >= 0 else None,
+                       out_dtype=torch.bfloat16 if inner else None)
     return results
 
 

@@ -678,40 +678,89 @@ def count_nonfinite(tensors, counter: Optional[torch.Tensor] = None) -> torch.Te
 
 
 class HostFetch:
-    """A batch of device tensors on its way to the host: their bytes were concatenated on the device (8-byte aligned segments) and
-    are being copied into ONE pinned host buffer on the stream that was current at construction.  `views()` hands out host tensors
-    of the original dtype / shape (views of that buffer) once the caller knows the copy has completed - after `wait()`, or after
-    an event it recorded behind the fetch on the same stream."""
+    """A batch of device tensors on its way to the host, on the stream that was current at construction.  Up to 16 MB: ONE kernel per
+    32 tensors (`nopesac_gather_bytes`) stores their bytes straight into one pinned, device-mapped host buffer (16-byte aligned
+    segments) - no concatenation, no pad fills, no copy node, so a captured graph / launch tape can hold the fetch.  Larger sets: one
+    torch.cat on the device + one copy.  `views()` hands out host tensors of the original dtype / shape (views of that buffer) once the caller
+    knows the fetch has completed - after `wait()`, or after an event it recorded behind the fetch on the same stream.
+    private_views = True (a fetch recorded in a graph: the buffer is written again by every replay): views() snapshots the buffer.
+    dynamic = {name: int64[1] device tensor}: only that many leading BYTES of the named tensor are valid (known on the device only); the
+    rest of its host view is undefined.  Such a tensor does not count towards the 16 MB bound of the kernel path."""
+    KERNEL_MAX_BYTES, KERNEL_MAX_SEGMENTS, ALIGN = 16 << 20, 32, 16
+    _zero_pad = {}
 
-    def __init__(self, tensors: dict):
+    def __init__(self, tensors: dict, private_views: bool = False, dynamic: Optional[dict] = None, host: Optional[torch.Tensor] = None):
+        dynamic = dynamic or {}
         dev = [(k, t.detach().contiguous()) for k, t in tensors.items() if t.is_cuda]
         self.passthrough = {k: t.detach() for k, t in tensors.items() if not t.is_cuda}
-        self.spans, self.host, self.stream = {}, None, None
+        self.spans, self.host, self.stream, self.private_views = {}, None, None, bool(private_views)
         if not dev:
             return
-        parts, off = [], 0
+        off, segs, fixed = 0, [], 0
         for k, t in dev:
-            b = t.view(-1).view(torch.uint8) if t.numel() else t.new_empty(0, dtype=torch.uint8)
-            pad = (-b.numel()) % 8
-            self.spans[k] = (off, b.numel(), t.dtype, tuple(t.shape))
-            parts.append(b)
-            if pad:
-                parts.append(b.new_zeros(pad))
-            off += b.numel() + pad
+            nb = t.numel() * t.element_size()
+            self.spans[k] = (off, nb, t.dtype, tuple(t.shape))
+            if nb:
+                segs.append((t, nb, off, dynamic.get(k)))
+                fixed += 0 if k in dynamic else nb
+            off += nb + (-nb) % self.ALIGN
+        self.stream = torch.cuda.current_stream()
+        if not segs:
+            self.host = torch.empty(0, dtype=torch.uint8)
+            return
+        if fixed <= self.KERNEL_MAX_BYTES:
+            # (the bytes between segments are never read; `host`: a pinned uint8 buffer the caller allocated - inside a stream capture
+            #  nothing may be allocated on the host)
+            if host is not None:
+                _require(host.dtype == torch.uint8 and host.is_pinned() and host.numel() >= off, "HostFetch: host buffer too small / not pinned")
+            self.host = host[:off] if host is not None else torch.empty(off, dtype=torch.uint8, pin_memory=True)
+            for i in range(0, len(segs), self.KERNEL_MAX_SEGMENTS):             # NOPESAC_GATHER_MAX_SEGMENTS per launch
+                grp = segs[i:i + self.KERNEL_MAX_SEGMENTS]
+                n = len(grp)
+                for _, _, _, dyn in grp:
+                    if dyn is not None:
+                        _chk(dyn, torch.int64)
+                ptrs = (ctypes.c_void_p * n)(*[_p(t) for t, _, _, _ in grp])
+                sizes = (ctypes.c_int64 * n)(*[nb for _, nb, _, _ in grp])
+                dyns = (ctypes.c_void_p * n)(*[_p(dyn) for _, _, _, dyn in grp])
+                offs = (ctypes.c_int64 * n)(*[o for _, _, o, _ in grp])
+                _lib.check(_L().nopesac_gather_bytes(ptrs, sizes, dyns, offs, n, self.host.data_ptr(), _stream()), "nopesac_gather_bytes")
+            self._keep = [(t, dyn) for t, _, _, dyn in segs]                     # sources stay allocated until the object goes
+            return
+        _require(host is None, "HostFetch: more than KERNEL_MAX_BYTES of fixed-size tensors cannot go into a caller-provided buffer")
+        d0 = dev[0][1].device
+        z = HostFetch._zero_pad.get(d0)
+        if z is None:
+            z = HostFetch._zero_pad[d0] = torch.zeros(self.ALIGN, device=d0, dtype=torch.uint8)
+        parts = []
+        for k, t in dev:
+            nb = t.numel() * t.element_size()
+            if nb:
+                parts.append(t.view(-1).view(torch.uint8))
+            if (-nb) % self.ALIGN:
+                parts.append(z[:(-nb) % self.ALIGN])
         flat = torch.cat(parts)
         self.host = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
         self.host.copy_(flat, non_blocking=True)
-        self.stream = torch.cuda.current_stream()
 
     def wait(self) -> "HostFetch":
         if self.stream is not None:
             self.stream.synchronize()
         return self
 
+    def host_bytes(self) -> int:
+        return 0 if self.host is None else int(self.host.numel())
+
     def views(self) -> dict:
         out = dict(self.passthrough)
+        host = self.host
+        if self.private_views and host is not None:
+            # (a plain memcpy into pageable memory: .clone() of a pinned tensor allocates PINNED memory - a hipHostMalloc of ~10 ms
+            #  whenever the results of earlier calls still hold the allocator's cached blocks - and torch's copy_ from a pinned source
+            #  measured 1-30 ms per call where numpy's copy of the same bytes takes 50 us)
+            host = torch.from_numpy(self.host.numpy().copy())
         for k, (o, n, dt, shape) in self.spans.items():
-            out[k] = self.host[o:o + n].view(dt).view(shape)
+            out[k] = host[o:o + n].view(dt).view(shape)
         return out
 
 
@@ -926,8 +975,8 @@ def rle_compress(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.T
 
 def rle_compress_capped(positions: torch.Tensor, offsets: torch.Tensor, counts: torch.Tensor, H: int, W: int, cap: int):
     """rle_compress without the host sync: the strings go into a byte buffer of FIXED capacity `cap`; a string that would cross it
-    is not written.  Returns (bytes uint8 [cap], out_off int64 [n], lens int32 [n], bbox float64 [n,4]) - device tensors; the
-    caller checks out_off[-1] + lens[-1] <= cap once those have reached the host."""
+    is not written.  Returns (bytes uint8 [cap], out_off int64 [n], lens int32 [n], bbox float64 [n,4], total int64 [1]) - device
+    tensors; the caller checks out_off[-1] + lens[-1] (= total) <= cap once those have reached the host."""
     _chk(positions, torch.int32); _chk(offsets, torch.int64); _chk(counts, torch.int32)
     n = counts.numel()
     dev = counts.device
@@ -941,7 +990,7 @@ def rle_compress_capped(positions: torch.Tensor, offsets: torch.Tensor, counts: 
     out = torch.empty(int(cap), device=dev, dtype=torch.uint8)
     _lib.check(L.nopesac_rle_compress_device_capped(_p(positions), _p(offsets), _p(counts), n, H, W, _p(lens), _p(out), _p(out_off), int(cap),
                                                     _stream()), "nopesac_rle_compress_device_capped")
-    return out, out_off, lens, bbox
+    return out, out_off, lens, bbox, ends[-1:]
 
 
 def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict):

@@ -104,11 +104,11 @@ class PendingRLE:
     """encode_views split in two so that a caller with several batches in flight never issues device work when it FETCHES results
     (a kernel enqueued behind other batches' launches waits for them; measured 6.8 ms per 32-pair step at the drop-in boundary):
     the constructor enqueues everything on the current stream - labels, flip positions (worst-case sized buffer: at most 2 flips
-    per pixel and view), compressed strings into a byte buffer of fixed capacity, and the copy of the first `host_cap` bytes plus
-    the offset / length / box tables into pinned host memory; `finish()` (after the stream has passed the fetch) only slices.
+    per pixel and view), compressed strings into a byte buffer of fixed capacity, and the fetch of its filled part (at most `host_cap`
+    bytes) plus the offset / length / box tables into pinned host memory; `finish()` (after the stream has passed the fetch) only slices.
     Totals beyond `host_cap` cost one more copy, beyond `cap` the synchronous encode_views."""
 
-    def __init__(self, winner, kept_idx, n_kept, flags, cap: int = 64 << 20, host_cap: int = 6 << 20):
+    def __init__(self, winner, kept_idx, n_kept, flags, cap: int = 64 << 20, host_cap: int = 6 << 20, host=None):
         V, H, W = winner.shape
         nq = kept_idx.shape[1]
         self.args, self.shape, self.cap, self.host_cap = (winner, kept_idx, n_kept, flags), (V, H, W, nq), int(cap), int(min(host_cap, cap))
@@ -119,8 +119,11 @@ class PendingRLE:
         offsets = (ends - c64).contiguous()
         pos = torch.empty(V * 2 * H * W, device=winner.device, dtype=torch.int32)       # upper bound of the flips; only the used part is touched
         ops.rle_transitions(labels, n_kept, nq, offsets=offsets.view(V, nq), positions=pos)
-        self.data, out_off, lens, bbox = ops.rle_compress_capped(pos, offsets, counts.view(-1).contiguous(), H, W, self.cap)
-        self.fetch = ops.HostFetch({"head": self.data[:self.host_cap], "out_off": out_off, "lens": lens, "bbox": bbox})
+        self.data, out_off, lens, bbox, total = ops.rle_compress_capped(pos, offsets, counts.view(-1).contiguous(), H, W, self.cap)
+        # only the bytes the strings fill travel (one pair: ~20 KB of the 6 MB window - 0.11 ms of PCIe time per call before)
+        # (finish() copies everything it hands out: the fetch may sit in a captured graph and be rewritten by the next replay)
+        self.fetch = ops.HostFetch({"head": self.data[:self.host_cap], "out_off": out_off, "lens": lens, "bbox": bbox},
+                                   dynamic={"head": total}, host=host)
 
     def finish(self, n_kept_host) -> List[List[dict]]:
         """Only after the stream the constructor ran on has passed the fetch (event / synchronize)."""

@@ -36,4 +36,16 @@ with open("gpurun_out/one_pair_${TAG}.tsv", "w") as out:
         line = "%-92s n/call=%6.1f us/call=%9.1f avg_us=%8.2f" % (k, c / n, us / n, us / c)
         out.write(line + "\n")
 for l in open("gpurun_out/one_pair_${TAG}.tsv").read().split("\n")[:40]: print(l)
+# ordered timeline of the LAST complete call: start offset, duration, gap since the previous kernel on the same queue ended, queue
+last = rows[starts[-2]:starts[-1]]
+t0 = int(last[0]["Start_Timestamp"])
+qend, qn = {}, {}
+with open("gpurun_out/one_pair_${TAG}_timeline.tsv", "w") as out:
+    out.write("start_us\tdur_us\tgap_same_queue_us\tqueue\tkernel\n")
+    for r in last:
+        s, e, q = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")
+        qi = qn.setdefault(q, len(qn))
+        gap = (s - qend[q]) / 1e3 if q in qend else 0.0
+        qend[q] = e
+        out.write("%.1f\t%.1f\t%.1f\t%d\t%s\n" % ((s - t0) / 1e3, (e - s) / 1e3, gap, qi, r["Kernel_Name"].split("(")[0].replace("void nps::", "").replace("nps::", "")[:80]))
 PY

@@ -217,7 +217,8 @@ def test_hip_graph_mode_reproduces_the_eager_results(device, replay):
                 assert torch.equal(x[v]["pred_plane"], y[v]["pred_plane"]) and x[v]["pred_plane_oriIdxs"] == y[v]["pred_plane_oriIdxs"]
                 assert torch.equal(x[v]["pred_plane_feats"], y[v]["pred_plane_feats"]) and torch.equal(x[v]["winner_map"], y[v]["winner_map"])
                 assert [i["segmentation"] for i in x[v]["instances"]] == [i["segmentation"] for i in y[v]["instances"]]
-        kept.append((b, [{v: (r[v]["pred_plane_feats"].clone(), r[v]["winner_map"].clone()) for v in "01"} for r in b]))
+        kept.append((b, [{v: (r[v]["pred_plane_feats"].clone(), r[v]["winner_map"].clone(), r[v]["pred_plane"].clone(),
+                              r["pred_assignment"].clone()) for v in "01"} for r in b]))
     assert len(graph._graphs) == 2 and all(st["graph"] is not None for st in graph._graphs.values())
     if replay == "launches":
         # the launch tape must be what replayed (csrc/tape.hip): every slot has one, it holds the forward's ~270 kernel launches
@@ -230,6 +231,8 @@ def test_hip_graph_mode_reproduces_the_eager_results(device, replay):
         for r, s0 in zip(b, snap):
             for v in "01":
                 assert torch.equal(r[v]["pred_plane_feats"], s0[v][0]) and torch.equal(r[v]["winner_map"], s0[v][1])
+                # (host views of the fetch buffer: the fetch is part of the graph and writes the same pinned buffer on every replay)
+                assert torch.equal(r[v]["pred_plane"], s0[v][2]) and torch.equal(r["pred_assignment"], s0[v][3])
     # a checkpoint load drops the captured graphs (they hold the addresses of the old packed weights): the new weights take effect
     sd = {k: v.clone() for k, v in eager.state_dict().items()}
     sd["camera_head_list.0.trans.weight"] = sd["camera_head_list.0.trans.weight"] * 1.5

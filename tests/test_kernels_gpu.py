@@ -36,7 +36,7 @@ CONV_CASES = [
     (6, 64, 80, 256, 64, 1, 1, 0),    # BN = 64 variant
     (4, 62, 82, 128, 192, 3, 2, 1),   # stride 2 + N tail inside a 128-wide tile
     (8, 60, 80, 64, 64, 3, 1, 1),     # BN = 64, 3x3
-    (3, 15, 20, 512, 128, 3, 1, 1),   # few tiles, K = 4608 >= 4096: DMA kernel with 128x64 tiles, two tile columns, M tail
+    (3, 15, 20, 512, 128, 3, 1, 1),   # few tiles, K = 4608: 64x64 tiles with two tiles of prefetch (the DMA kernel with 128x64 tiles when forced: see the channel-major test), M tail
 ]
 
 
@@ -85,6 +85,42 @@ def test_conv2d_batched_weights(device):
     y = ops.conv2d(x.to(device), w.to(device), batched_weights=True, act=ops.ACT_SIGMOID)
     ref = torch.sigmoid(torch.einsum("bhwc,bnc->bhwn", x, w.view(3, 50, 256)))
     assert _rel(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(3, 31, 29, 128, 128, 3, 2, 1),     # stride 2, odd sizes, M tail, tiles that straddle images
+                                  (2, 8, 10, 128, 64, 1, 1, 0),       # one K-tile (prologue + tail only)
+                                  (2, 8, 10, 256, 70, 1, 1, 0),       # two K-tiles (no steady-state iteration), N tail
+                                  (1, 8, 10, 384, 64, 1, 1, 0),       # three (one iteration, clamped second request)
+                                  (1, 15, 20, 256, 128, 3, 1, 1),     # 18 K-tiles, one pair's res5-sized 3x3
+                                  (2, 12, 16, 512, 128, 1, 2, 0)])    # strided 1x1
+def test_conv2d_small_grid_two_tile_prefetch(device, case, monkeypatch):
+    """conv_igemm.hip, bf16 / K % 128 == 0 / <= 2048 tiles of 64x64: two tiles of branch-free buffer loads in flight (PF2).  The
+    input is a channel slice of a wider buffer (x_cstride > Cin) and the output goes into one."""
+    from nopesac_amd import ops
+    monkeypatch.setenv("NOPESAC_CONV_FORCE", "t64")               # read per call by the C side: the 64x64-tile generic kernel
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    xw = torch.randn(B, H, W, Cin + 72, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    x = xw[..., 40:40 + Cin]
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    ref = F.relu(ref).permute(0, 2, 3, 1)
+    out = torch.full((B, ref.shape[1], ref.shape[2], Cout + 24), 7.0, device=device, dtype=torch.bfloat16)
+    ops.conv2d(xw.to(device)[..., 40:40 + Cin], w.permute(0, 2, 3, 1).contiguous().to(device), scale.to(device), bias.to(device),
+               stride=s, pad=p, act=ops.ACT_RELU, out=out[..., 8:8 + Cout])
+    assert _rel(out[..., 8:8 + Cout].float(), ref) < 1e-2
+    assert float((out[..., :8].float() - 7).abs().max()) == 0 and float((out[..., 8 + Cout:].float() - 7).abs().max()) == 0
+
+
+def test_conv2d_batched_weights_bf16_two_tile_prefetch(device):
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(3, 10, 12, 256, generator=g).bfloat16()
+    w = (torch.randn(3, 50, 1, 1, 256, generator=g) / 16).bfloat16()
+    y = ops.conv2d(x.to(device), w.to(device), batched_weights=True, act=ops.ACT_SIGMOID)
+    ref = torch.sigmoid(torch.einsum("bhwc,bnc->bhwn", x.float(), w.view(3, 50, 256).float()))
+    assert _rel(y.float(), ref) < 1e-2
 
 
 @pytest.mark.parametrize("K,N", [(3, 256), (8, 1024), (50, 128), (1280, 1024), (768, 256)])
@@ -477,6 +513,7 @@ def test_conv2d_lds_dma_kernel_channel_major_k_order(device, case, monkeypatch):
     x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
     w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16()
     xd, wd = _nhwc(x.float()).to(device, torch.bfloat16), w.float().permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    monkeypatch.setenv("NOPESAC_CONV_FORCE", "glds")            # (small grids with a long K default to the 64x64-tile kernel since round 4)
     y_cm = ops.conv2d(xd, wd, stride=s, pad=p, out_dtype=torch.float32)
     monkeypatch.setenv("NOPESAC_GLDS_KMAJOR", "0")
     y_tm = ops.conv2d(xd, wd, stride=s, pad=p, out_dtype=torch.float32)
@@ -1178,3 +1215,35 @@ def test_encoder_tail_64_token_kernel_equals_the_32_token_one(device, M, monkeyp
     torch.cuda.synchronize()
     for k in ("y", "y16", "ypos16", "proj_pos", "proj"):
         assert torch.equal(new[k], old[k]), k
+
+
+def test_host_fetch_gather_kernel(device):
+    """ops.HostFetch through nopesac_gather_bytes: unaligned views, empty tensors, more than 32 segments (two launches), a segment whose
+    valid length only the device knows, a caller-provided pinned buffer, snapshot views."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(3)
+    base = torch.randint(0, 255, (5000,), generator=g, dtype=torch.uint8).to(device)
+    tensors = {"a": torch.randn(7, 3, generator=g).to(device), "odd": base[3:1000], "empty": torch.zeros(0, 4, device=device),
+               "i64": torch.arange(11, device=device), "b": torch.rand(5, generator=g).to(device) > 0.5,
+               "f64": torch.randn(4, 4, generator=g, dtype=torch.float64).to(device), "host": torch.arange(3)}
+    for i in range(40):
+        tensors["t%d" % i] = torch.full((i + 1,), float(i), device=device, dtype=torch.bfloat16)
+    big = torch.randint(0, 255, (300000,), generator=g, dtype=torch.uint8).to(device)
+    tensors["dyn"] = big
+    n_valid = torch.tensor([123457], device=device, dtype=torch.int64)
+    f = ops.HostFetch(tensors, dynamic={"dyn": n_valid})
+    h = f.wait().views()
+    for k, t in tensors.items():
+        if k == "dyn":
+            assert torch.equal(h[k][:123457], t.cpu()[:123457])
+        else:
+            assert h[k].dtype == t.dtype and h[k].shape == t.shape and torch.equal(h[k], t.cpu()), k
+    # caller-provided buffer + snapshots: a second fetch into the same buffer must not change views already handed out
+    buf = torch.empty(f.host_bytes() + 64, dtype=torch.uint8, pin_memory=True)
+    f1 = ops.HostFetch({"x": tensors["a"]}, private_views=True, host=buf)
+    v1 = f1.wait().views()["x"]
+    f2 = ops.HostFetch({"x": tensors["a"] * 2}, private_views=True, host=buf)
+    v2 = f2.wait().views()["x"]
+    assert torch.equal(v1, tensors["a"].cpu()) and torch.equal(v2, (tensors["a"] * 2).cpu())
+    with pytest.raises(Exception):
+        ops.HostFetch({"x": tensors["a"]}, host=torch.empty(4, dtype=torch.uint8, pin_memory=True))
