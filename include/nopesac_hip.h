@@ -467,6 +467,15 @@ int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_
                            const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
                            const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
                            const float* ln2_g, const float* ln2_b, void* stream);
+/* The same launch + a weight prefetch for the NEXT one (one pair per call: one or two workgroups per launch, each layer's 1.28 MB of
+ * weights cold in L2): next_weights6 = HOST array of the next launch's six fragment-major weight pointers (wq, wk, wv, wmerge, w0,
+ * w2), next_sets = its n_sets; 128 extra workgroups of this launch, dealt over the XCDs like the next launch's workgroups will be,
+ * read those weights into the L2s that will need them and exit.  No prefetch workgroups are added when this launch has more than 16
+ * layer workgroups.  next_weights6 = NULL: exactly nopesac_gnn_layer_bf16. */
+int nopesac_gnn_layer_bf16_pf(const float* x, int x_off, const float* src, int src_off, float* out, int out_off, int n_sets,
+                              int nq, const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
+                              const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
+                              const float* ln2_g, const float* ln2_b, const void* const* next_weights6, int next_sets, void* stream);
 
 /* Finest top-down level + mask head of the PlaneTR head in one launch (planeTR_head.py:148-162, 241-252), bf16:
  *   p1 = relu(scale * (w_lateral . c1) + bias) + relu(bilinear_2x(t1));   prob = [sigmoid](mask_w[b] . p1 + mask_b[b])

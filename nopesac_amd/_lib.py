@@ -31,6 +31,7 @@ SIGNATURES = {
     "nopesac_bottleneck_tail_bf16_ex": [P] * 9 + [I] * 9 + [P] * 4 + [I, P, I, P],
     "nopesac_conv2d_nhwc_fp8": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],
     "nopesac_gnn_layer_bf16": [P, I, P, I, P, I, I, I, P, P] + [P] * 10 + [P],
+    "nopesac_gnn_layer_bf16_pf": [P, I, P, I, P, I, I, I, P, P] + [P] * 10 + [P, I, P],
     "nopesac_encoder_tail_bf16": [P] * 13 + [I] + [P] * 3 + [I, P],
     "nopesac_resize_bilinear_u8": [P, I, I, I, P, I, I, P],
     "nopesac_mask_head_bf16": [P] * 9 + [I] * 5 + [P],

@@ -45,7 +45,15 @@ struct GnnArgs {
     const int* qlen; const int* klen;                   // int32 per set (indexed like x / src), may be null
     const bf16_t* wq; const bf16_t* wk; const bf16_t* wv; const bf16_t* wm; const bf16_t* w0; const bf16_t* w2;   // fragment-major
     const float* g1; const float* b1; const float* g2; const float* b2;
+    // weight prefetch for the NEXT launch (one pair per call: a layer's 1.28 MB arrive from HBM / the Infinity Cache through ONE
+    // workgroup's 128 KB of loads in flight - 20 us of the 45-52 us a cold launch takes): workgroups >= n_work do no layer work; those
+    // that sit on an XCD the next launch's workgroups will run on read a slice of the next layer's weights into that XCD's L2 and exit
+    const bf16_t* pf[6];                                // next wq, wk, wv, wm, w0, w2 (fragment-major) or all null
+    int n_work, pf_xcds;                                // layer workgroups of THIS launch; XCDs to warm (= min(8, next launch's workgroups))
 };
+constexpr int GN_PF_CHUNK = 512 * 16;                   // bytes one prefetch workgroup touches per step
+constexpr int GN_PF_CHUNKS = (4 * 256 * 256 + 512 * 512 + 256 * 512) * 2 / GN_PF_CHUNK;      // 160
+constexpr int GN_PF_PER_XCD = 16;                       // prefetch workgroups per warmed XCD (10 chunks = 80 KB each)
 
 __device__ __forceinline__ unsigned int gn_pack2(float lo, float hi) {
     return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
@@ -173,6 +181,22 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
     float* red = reinterpret_cast<float*>(Kt + GN_RC);      // [2][8][64]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= p.n_work) {
+        // prefetch workgroup (see GnnArgs): workgroup ids are dealt round-robin over the 8 XCDs
+        const int xcd = blockIdx.x & 7, slot = ((int)blockIdx.x - p.n_work) >> 3;     // every (XCD, slot) pair exists once
+        if (xcd >= p.pf_xcds || slot >= GN_PF_PER_XCD) return;
+        unsigned acc = 0u;
+        for (int c = slot; c < GN_PF_CHUNKS; c += GN_PF_PER_XCD) {
+            // chunk -> (array, byte offset): wq / wk / wv / wm 16 chunks each, w0 64, w2 32
+            const int a = c < 64 ? c >> 4 : (c < 128 ? 4 : 5);
+            const int o = c < 64 ? c & 15 : (c < 128 ? c - 64 : c - 128);
+            // (an ordinary load: a nontemporal one does not allocate in L2 / the Infinity Cache - measured: no effect at all)
+            const u32x4 v = *(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.pf[a]) + (long long)o * GN_PF_CHUNK) + tid);
+            acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+        asm volatile("" ::"v"(acc));                                                   // the loads must be issued; their values are not needed
+        return;
+    }
     const int nq = p.nq, nqb = (nq + 63) / 64;
     const int b = blockIdx.x / nqb, qb = blockIdx.x % nqb, row0 = qb * 64;          // set, block of 64 query rows
     const float* xg = p.x + ((long long)(p.x_off + b) * nq + row0) * GN_D;
@@ -366,10 +390,25 @@ __global__ __launch_bounds__(512, 2) void gnn_layer_kernel(const GnnArgs p) {
 
 }  // namespace nps
 
+extern "C" int nopesac_gnn_layer_bf16_pf(const float* x, int x_off, const float* src, int src_off, float* out, int out_off, int n_sets,
+                                         int nq, const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
+                                         const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
+                                         const float* ln2_g, const float* ln2_b, const void* const* next_weights6, int next_sets,
+                                         void* stream);
+
 extern "C" int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* src, int src_off, float* out, int out_off, int n_sets,
                                       int nq, const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
                                       const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
                                       const float* ln2_g, const float* ln2_b, void* stream) {
+    return nopesac_gnn_layer_bf16_pf(x, x_off, src, src_off, out, out_off, n_sets, nq, qlen, klen, wq, wk, wv, wmerge, w0, w2, ln1_g, ln1_b,
+                                     ln2_g, ln2_b, nullptr, 0, stream);
+}
+
+extern "C" int nopesac_gnn_layer_bf16_pf(const float* x, int x_off, const float* src, int src_off, float* out, int out_off, int n_sets,
+                                         int nq, const int32_t* qlen, const int32_t* klen, const void* wq, const void* wk, const void* wv,
+                                         const void* wmerge, const void* w0, const void* w2, const float* ln1_g, const float* ln1_b,
+                                         const float* ln2_g, const float* ln2_b, const void* const* next_weights6, int next_sets,
+                                         void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && src && out && wq && wk && wv && wmerge && w0 && w2 && ln1_g && ln1_b && ln2_g && ln2_b, "gnn_layer: null pointer");
     NPS_CHECK_ARG(n_sets > 0 && nq > 0 && nq <= 128 && x_off >= 0 && src_off >= 0 && out_off >= 0, "gnn_layer: bad sizes (nq <= 128)");
@@ -383,7 +422,24 @@ extern "C" int nopesac_gnn_layer_bf16(const float* x, int x_off, const float* sr
     a.qlen = qlen; a.klen = klen;
     a.wq = (const bf16_t*)wq; a.wk = (const bf16_t*)wk; a.wv = (const bf16_t*)wv; a.wm = (const bf16_t*)wmerge;
     a.w0 = (const bf16_t*)w0; a.w2 = (const bf16_t*)w2; a.g1 = ln1_g; a.b1 = ln1_b; a.g2 = ln2_g; a.b2 = ln2_b;
+    a.n_work = n_sets * ((nq + 63) / 64);
+    a.pf_xcds = 0;
+    for (int i = 0; i < 6; ++i) a.pf[i] = nullptr;
+    int n_pf = 0;
+    if (next_weights6) {
+        NPS_CHECK_ARG(next_sets > 0, "gnn_layer: next_sets must be > 0 with next_weights6");
+        for (int i = 0; i < 6; ++i) {
+            NPS_CHECK_ARG(next_weights6[i] && ((uintptr_t)next_weights6[i] & 15) == 0, "gnn_layer: next_weights6[%d] null / unaligned", i);
+            a.pf[i] = (const bf16_t*)next_weights6[i];
+        }
+        const int next_work = next_sets * ((nq + 63) / 64);
+        a.pf_xcds = next_work < 8 ? next_work : 8;
+        // GN_PF_PER_XCD octets of workgroups (consecutive ids = one per XCD); with many layer workgroups (batches) the weights are
+        // shared by all of them and stay in every L2 anyway: no prefetch workgroups
+        n_pf = a.n_work <= 16 ? 8 * GN_PF_PER_XCD : 0;
+        if (!n_pf) a.pf_xcds = 0;
+    }
     NPS_ENSURE_LDS((int)GN_LDS_BYTES, gnn_layer_kernel);
-    hipLaunchKernelGGL(gnn_layer_kernel, dim3(n_sets * ((nq + 63) / 64)), dim3(512), GN_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gnn_layer_kernel, dim3(a.n_work + n_pf), dim3(512), GN_LDS_BYTES, (hipStream_t)stream, a);
     NPS_LAUNCH_RET();
 }

@@ -84,11 +84,13 @@ class MatchingHead(ParamModule):
             cur, nxt = f.view(2 * B, nq, 256), torch.empty(2 * B, nq, 256, device=f.device, dtype=torch.float32)
             for i in range(18):
                 W = self._fused_weights(i)
+                # (few plane sets: the last launch that uses a layer's weights also pulls the next layer's into L2 - ops.gnn_layer)
+                Wn = self._fused_weights(i + 1) if i + 1 < 18 and 2 * B <= 16 else None
                 if i % 2 == 0:
-                    ops.gnn_layer(cur, 0, cur, 0, nxt, 0, 2 * B, n_all, W)
+                    ops.gnn_layer(cur, 0, cur, 0, nxt, 0, 2 * B, n_all, W, Wn, B)
                 else:                            # feat1 attends to the UPDATED feat0 (gnn.py:131-133)
                     ops.gnn_layer(cur, 0, cur, B, nxt, 0, B, n_all, W)
-                    ops.gnn_layer(cur, B, nxt, 0, nxt, B, B, n_all, W)
+                    ops.gnn_layer(cur, B, nxt, 0, nxt, B, B, n_all, W, Wn, 2 * B)
                 cur, nxt = nxt, cur
             d = ops.linear(cur.view(2 * B * nq, 256), P["desc"].w2d(gd), P["desc"].bias)
             return d[:B * nq].view(B, nq, 256), d[B * nq:].view(B, nq, 256)

@@ -993,9 +993,15 @@ def rle_compress_capped(positions: torch.Tensor, offsets: torch.Tensor, counts: 
     return out, out_off, lens, bbox, ends[-1:]
 
 
-def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict):
+GNN_PREFETCH = os.environ.get("NOPESAC_GNN_PREFETCH", "1") != "0"
+
+
+def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out: torch.Tensor, out_off: int, n_sets: int, lens, W: dict,
+              W_next: Optional[dict] = None, next_sets: int = 0):
     """One fused GNN layer (csrc/gnn_layer.hip): x/src/out f32 [sets, nq, 256]; lens int32 [sets] (indexed like x / src);
-    W: fragment-major bf16 weights "wq" (pre-scaled), "wk", "wv", "wm", "w0", "w2" and f32 "g1", "b1", "g2", "b2"."""
+    W: fragment-major bf16 weights "wq" (pre-scaled), "wk", "wv", "wm", "w0", "w2" and f32 "g1", "b1", "g2", "b2".
+    W_next / next_sets: the weights and the set count of the NEXT launch - with few plane sets (one pair per call) extra workgroups
+    of this launch read them into the L2s the next launch will run on (nopesac_gnn_layer_bf16_pf)."""
     for t in (x, src, out):
         _chk(t, torch.float32)
         _require(t.dim() == 3 and t.shape[2] == 256, 'argument check failed: t.dim() == 3 and t.shape[2] == 256')
@@ -1004,10 +1010,13 @@ def gnn_layer(x: torch.Tensor, x_off: int, src: torch.Tensor, src_off: int, out:
     _require(x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0], 'argument check failed: x_off + n_sets <= x.shape[0] and src_off + n_sets <= src.shape[0] and out_off + n_sets <= out.shape[0]')
     if lens is not None:
         _chk(lens, torch.int32)
-    rc = _L().nopesac_gnn_layer_bf16(_p(x), x_off, _p(src), src_off, _p(out), out_off, n_sets, nq, _p(lens), _p(lens),
-                                     _p(W["wq"]), _p(W["wk"]), _p(W["wv"]), _p(W["wm"]), _p(W["w0"]), _p(W["w2"]),
-                                     _p(W["g1"]), _p(W["b1"]), _p(W["g2"]), _p(W["b2"]), _stream())
-    _lib.check(rc, "nopesac_gnn_layer_bf16")
+    nxt = None
+    if W_next is not None and GNN_PREFETCH and next_sets > 0:
+        nxt = (ctypes.c_void_p * 6)(*[_p(W_next[k]) for k in ("wq", "wk", "wv", "wm", "w0", "w2")])
+    rc = _L().nopesac_gnn_layer_bf16_pf(_p(x), x_off, _p(src), src_off, _p(out), out_off, n_sets, nq, _p(lens), _p(lens),
+                                        _p(W["wq"]), _p(W["wk"]), _p(W["wv"]), _p(W["wm"]), _p(W["w0"]), _p(W["w2"]),
+                                        _p(W["g1"]), _p(W["b1"]), _p(W["g2"]), _p(W["b2"]), nxt, int(next_sets) if nxt is not None else 0, _stream())
+    _lib.check(rc, "nopesac_gnn_layer_bf16_pf")
     return out
 
 
