@@ -446,6 +446,38 @@ int nopesac_clock_probe(uint64_t* out2, int64_t spin_cycles, void* stream);
 #define NOPESAC_NONFINITE_MAX_TENSORS 16
 int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n_tensors, int32_t* count, void* stream);
 
+/* ---- Baseline-JPEG decode (the reference's image reader: detectron2 utils.read_image = PIL / libjpeg-turbo,
+ * NopeSAC_Net/data/planercnn_transforms.py:210-227 and :306-314 - the ScanNet colour frames).  Bit-exact with libjpeg-turbo's default
+ * decompression (JDCT_ISLOW, fancy upsampling, RGB).  The host (nopesac_amd/jpeg.py) walks the markers, splits the entropy-coded data
+ * at the restart markers, removes the byte stuffing and lays out the tables; all arrays below are DEVICE memory:
+ *   img32 [n_images][NOPESAC_JPEG_IMG_I32] int32: 0 width, 1 height, 2 components (1 | 3), 3 / 4 luma sampling h / v (1 | 2; chroma is
+ *     1x1), 5 / 6 MCUs per row / column, 7 MCUs per restart interval (all of them when the file has none), 8..10 blocks per row of
+ *     component c, 11..13 block rows, 14..16 downsampled_width, 17..19 downsampled_height, 20..22 index of the component's DC table
+ *     (0 | 1), 23..25 index of its AC table (2 | 3), 26 first block of the image in the batch-wide block list, 27 its block count
+ *   img64 [n_images][NOPESAC_JPEG_IMG_I64] int64: 0..2 element offset of component c's coefficients in `coef` ([block rows][blocks per
+ *     row][64] int16, ZIGZAG order, DC prediction resolved), 3..5 byte offset of its sample plane in `planes` ([block rows * 8][blocks
+ *     per row * 8] uint8), 6 byte offset of the image in `out` ([height][width][3] uint8)
+ *   tables [n_images][NOPESAC_JPEG_TABLES_BYTES]: Huffman tables DC0, DC1, AC0, AC1 (NOPESAC_JPEG_HUFF_BYTES each: 9-bit look-ahead
+ *     uint16[512] = (code length << 8) | symbol, 0 = longer code; maxcode int32[18]; valoffset int32[18]; huffval uint8[256] - jdhuff.c's
+ *     derived table), then the components' quantisation tables uint16[64] in NATURAL order
+ *   seg32 [n_segments][NOPESAC_JPEG_SEG_I32] int32: image, first MCU, MCU count, 0; seg64 [n_segments][NOPESAC_JPEG_SEG_I64] int64:
+ *     offset into `words`, word count.  words: the intervals' bytes without the stuffing as 32-bit words, first bit = most significant,
+ *     each interval followed by four zero words.
+ * nopesac_jpeg_huffman: one wave per segment, `coef` zero-filled by the caller.  nopesac_jpeg_idct: n_blocks = sum of img32[.][27].
+ * nopesac_jpeg_color: max_pixels = the largest width * height of the batch; bgr != 0 writes B, G, R. */
+#define NOPESAC_JPEG_HUFF_BYTES 1536
+#define NOPESAC_JPEG_TABLES_BYTES (4 * NOPESAC_JPEG_HUFF_BYTES + 3 * 128)
+#define NOPESAC_JPEG_IMG_I32 32
+#define NOPESAC_JPEG_IMG_I64 8
+#define NOPESAC_JPEG_SEG_I32 4
+#define NOPESAC_JPEG_SEG_I64 2
+int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32, const int64_t* seg64,
+                         int n_segments, const uint32_t* words, int16_t* coef, void* stream);
+int nopesac_jpeg_idct(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, int n_blocks, const int16_t* coef,
+                      uint8_t* planes, void* stream);
+int nopesac_jpeg_color(const int32_t* img32, const int64_t* img64, int n_images, int max_pixels, const uint8_t* planes, uint8_t* out,
+                       int bgr, void* stream);
+
 /* Result fetch (replaces the per-tensor `.cpu()` copies of siamese_planeTR.py:384-450 at the drop-in boundary): n_segments byte
  * ranges (HOST arrays of device pointers / sizes / destination offsets, n_segments <= NOPESAC_GATHER_MAX_SEGMENTS) are copied into
  * `dst` by ONE kernel.  dst is device memory or device-mapped pinned host memory (hipHostMalloc / torch pin_memory): the latter is the

@@ -85,6 +85,9 @@ SIGNATURES = {
     "nopesac_clock_probe": [P, L, P],
     "nopesac_u8_to_f32": [P, P, L, P],
     "nopesac_gather_bytes": [P, P, P, P, I, P, P],
+    "nopesac_jpeg_huffman": [P, P, P, P, P, I, P, P, P],
+    "nopesac_jpeg_idct": [P, P, P, I, I, P, P, P],
+    "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

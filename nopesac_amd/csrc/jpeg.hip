@@ -1,0 +1,283 @@
+// Baseline-JPEG decode on the device: the reference's data mapper reads its frames with detectron2's utils.read_image (PIL /
+// libjpeg-turbo, NopeSAC_Net/data/planercnn_transforms.py:210-227, :306-314) on host threads - 3200 pairs/s with 32 of them, less than
+// ONE GPU's model throughput.  Three kernels, results bit for bit those of libjpeg-turbo's default decompression (JDCT_ISLOW, fancy
+// upsampling, RGB), host side in nopesac_amd/jpeg.py (marker walk, restart split, stuffing removal, table layout - no entropy decoding):
+//
+//   jpeg_huffman_kernel  one WAVE per restart interval (per image when the file has none).  Entropy decoding is a serial chain per
+//                        interval (every code's position depends on all codes before it), so the wave runs it on the SCALAR unit:
+//                        all state is wave-uniform, the bit stream and the tables are read with scalar loads from the constant
+//                        address space, lane 0 stores the coefficients (zigzag order, DC prediction resolved).  Throughput comes from
+//                        the number of intervals in flight - restart intervals when the encoder wrote them, images otherwise.
+//   jpeg_idct_kernel     one thread per 8x8 block: de-zigzag + dequantise + jidctint.c's two-pass 13-bit fixed-point inverse DCT in
+//                        registers, samples into the component's plane.
+//   jpeg_color_kernel    one thread per output pixel: jdsample.c's h2v1 / h2v2 "fancy" (triangle) chroma upsampling evaluated at the
+//                        pixel (incl. its edge rules and jdmainct.c's replicated context rows), jdcolor.c's 16-bit fixed-point
+//                        YCbCr -> RGB, interleaved RGB or BGR bytes out (the layout nopesac_resize_bilinear_u8 reads).
+#include "common.h"
+
+namespace nps {
+
+constexpr int JP_LOOK = 9;
+constexpr int JP_HUFF_BYTES = NOPESAC_JPEG_HUFF_BYTES, JP_TABLES_BYTES = NOPESAC_JPEG_TABLES_BYTES;
+constexpr int JP_I32 = NOPESAC_JPEG_IMG_I32, JP_I64 = NOPESAC_JPEG_IMG_I64;
+
+typedef const __attribute__((address_space(4))) uint32_t* c_u32;      // constant address space: uniform loads become s_load
+typedef const __attribute__((address_space(4))) int32_t* c_i32;
+typedef const __attribute__((address_space(4))) int64_t* c_i64;
+typedef const __attribute__((address_space(4))) uint8_t* c_u8;
+template <typename P>
+__device__ __forceinline__ P as_const(const void* p) { return (P)(uintptr_t)p; }
+
+struct JpBits {
+    uint64_t acc;      // the next bits of the stream, most significant first
+    int nb;            // valid bits in acc
+    c_u32 w;           // next word
+};
+__device__ __forceinline__ void jp_fill(JpBits& b) {
+    if (b.nb <= 32) {
+        b.acc |= (uint64_t)(*b.w++) << (32 - b.nb);
+        b.nb += 32;
+    }
+}
+__device__ __forceinline__ void jp_skip(JpBits& b, int n) {
+    b.acc <<= n;
+    b.nb -= n;
+}
+// one Huffman symbol (jdhuff.c HUFF_DECODE: 9-bit look-ahead table, then one bit at a time against maxcode[])
+__device__ __forceinline__ int jp_symbol(JpBits& b, c_u8 tab) {
+    jp_fill(b);                                                     // >= 33 valid bits: a code (<= 16) and its value bits (<= 11)
+    // (whole dwords: 16- and 8-bit scalar loads do not exist on gfx950)
+    const unsigned li = (unsigned)(b.acc >> (64 - JP_LOOK));
+    const unsigned ew = ((c_u32)tab)[li >> 1];
+    const unsigned e = (li & 1) ? ew >> 16 : ew & 0xFFFFu;
+    if (e >> 8) {
+        jp_skip(b, e >> 8);
+        return e & 255;
+    }
+    c_i32 maxcode = (c_i32)(tab + 1024), valoff = (c_i32)(tab + 1096);
+    int l = JP_LOOK + 1;
+    int code = (int)(b.acc >> (64 - l));
+    while (code > maxcode[l]) {
+        ++l;
+        code = (int)(b.acc >> (64 - l));
+    }
+    if (l > 16) {                                                   // not a code of this table (corrupt data): libjpeg warns and returns 0
+        jp_skip(b, 16);
+        return 0;
+    }
+    jp_skip(b, l);
+    const unsigned vi = (unsigned)(code + valoff[l]) & 255u;
+    return (((c_u32)(tab + 1168))[vi >> 2] >> (8 * (vi & 3))) & 255;
+}
+// the s value bits after a symbol, sign-extended (T.81 F.2.2.1 EXTEND)
+__device__ __forceinline__ int jp_value(JpBits& b, int s) {
+    if (s == 0) return 0;
+    const int v = (int)(b.acc >> (64 - s));
+    jp_skip(b, s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
+                                                          const uint8_t* __restrict__ tables, const int32_t* __restrict__ seg32,
+                                                          const int64_t* __restrict__ seg64, const uint32_t* __restrict__ words,
+                                                          int16_t* __restrict__ coef) {
+    const int sg = blockIdx.x;
+    c_i32 S = as_const<c_i32>(seg32 + (long long)sg * NOPESAC_JPEG_SEG_I32);
+    const int im = S[0], first = S[1], count = S[2];
+    c_i32 I = as_const<c_i32>(img32 + (long long)im * JP_I32);
+    c_i64 I8 = as_const<c_i64>(img64 + (long long)im * JP_I64);
+    c_u8 T = as_const<c_u8>(tables + (long long)im * JP_TABLES_BYTES);
+    const int ncomp = I[2], mcux = I[5];
+    JpBits b;
+    b.acc = 0; b.nb = 0;
+    b.w = as_const<c_u32>(words + as_const<c_i64>(seg64 + (long long)sg * NOPESAC_JPEG_SEG_I64)[0]);
+    int pred[3] = {0, 0, 0};
+    const bool writer = threadIdx.x == 0;
+    int my = first / mcux, mx = first % mcux;
+    for (int m = 0; m < count; ++m) {
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            if (ci >= ncomp) break;
+            const int ch = ci == 0 ? I[3] : 1, cv = ci == 0 ? I[4] : 1, bw = I[8 + ci];
+            c_u8 dc = T + I[20 + ci] * JP_HUFF_BYTES, ac = T + I[23 + ci] * JP_HUFF_BYTES;
+            int16_t* cc = coef + I8[ci];
+            for (int v = 0; v < cv; ++v)
+                for (int h = 0; h < ch; ++h) {
+                    int16_t* blk = cc + ((long long)(my * cv + v) * bw + (mx * ch + h)) * 64;
+                    const int s = jp_symbol(b, dc);
+                    pred[ci] += jp_value(b, s & 15);
+                    if (writer) blk[0] = (int16_t)pred[ci];
+                    int k = 1;
+                    while (k < 64) {
+                        const int rs = jp_symbol(b, ac);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz) {
+                            k += r;
+                            const int val = jp_value(b, sz);
+                            if (writer) blk[k & 63] = (int16_t)val;
+                            ++k;
+                        } else if (r == 15) {
+                            k += 16;
+                        } else {
+                            break;
+                        }
+                    }
+                }
+        }
+        if (++mx == mcux) { mx = 0; ++my; }
+    }
+}
+
+// ---- jidctint.c jpeg_idct_islow: CONST_BITS 13, PASS1_BITS 2
+#define JP_IDCT_1D(i0, i1, i2, i3, i4, i5, i6, i7, SH, OUT)                                                  \
+    {                                                                                                        \
+        int z2 = i2, z3 = i6;                                                                                \
+        int z1 = (z2 + z3) * 4433;                                                                           \
+        int tmp2 = z1 - z3 * 15137, tmp3 = z1 + z2 * 6270;                                                   \
+        int tmp0 = (i0 + i4) << 13, tmp1 = (i0 - i4) << 13;                                                  \
+        const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;        \
+        tmp0 = i7; tmp1 = i5; tmp2 = i3; tmp3 = i1;                                                          \
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;                                                \
+        int z4 = tmp1 + tmp3;                                                                                \
+        const int z5 = (z3 + z4) * 9633;                                                                     \
+        tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;                                           \
+        z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;                              \
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;                                  \
+        const int rnd = 1 << ((SH) - 1);                                                                     \
+        OUT(0, (tmp10 + tmp3 + rnd) >> (SH)); OUT(7, (tmp10 - tmp3 + rnd) >> (SH));                          \
+        OUT(1, (tmp11 + tmp2 + rnd) >> (SH)); OUT(6, (tmp11 - tmp2 + rnd) >> (SH));                          \
+        OUT(2, (tmp12 + tmp1 + rnd) >> (SH)); OUT(5, (tmp12 - tmp1 + rnd) >> (SH));                          \
+        OUT(3, (tmp13 + tmp0 + rnd) >> (SH)); OUT(4, (tmp13 - tmp0 + rnd) >> (SH));                          \
+    }
+
+__global__ __launch_bounds__(64) void jpeg_idct_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
+                                                       const uint8_t* __restrict__ tables, int n_images, int n_blocks,
+                                                       const int16_t* __restrict__ coef, uint8_t* __restrict__ planes) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;            // block index in the batch-wide list
+    if (g >= n_blocks) return;
+    // image of the block: binary search over the images' first-block numbers (img32[.][26])
+    int lo = 0, hi = n_images - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (img32[(long long)mid * JP_I32 + 26] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int32_t* I = img32 + (long long)lo * JP_I32;
+    const int64_t* I8 = img64 + (long long)lo * JP_I64;
+    int bi = g - I[26], ci = 0;
+    while (ci < I[2] - 1 && bi >= I[8 + ci] * I[11 + ci]) { bi -= I[8 + ci] * I[11 + ci]; ++ci; }
+    const int bw = I[8 + ci], by = bi / bw, bx = bi % bw;
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(tables + (long long)lo * JP_TABLES_BYTES + 4 * JP_HUFF_BYTES + 128 * ci);
+    const int16_t* c = coef + I8[ci] + (long long)bi * 64;
+    int x[64];
+    {
+        short zz[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(zz + 8 * i) = *reinterpret_cast<const uint4*>(c + 8 * i);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            constexpr unsigned char ZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            x[ZZ[k]] = (int)zz[k] * (int)q[ZZ[k]];
+        }
+    }
+    // pass 1: columns -> workspace (in place), descale by CONST_BITS - PASS1_BITS
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+#define JP_O1(r, val) x[(r) * 8 + col] = (val)
+        JP_IDCT_1D(x[col], x[8 + col], x[16 + col], x[24 + col], x[32 + col], x[40 + col], x[48 + col], x[56 + col], 11, JP_O1)
+#undef JP_O1
+    }
+    // pass 2: rows, descale by CONST_BITS + PASS1_BITS + 3, range limit (the table of jdmaster.c: wraps mod 1024, centred on 128)
+    uint8_t* out = planes + I8[3 + ci] + ((long long)by * 8 * bw + bx) * 8;
+#pragma unroll
+    for (int row = 0; row < 8; ++row) {
+        int y[8];
+#define JP_O2(cidx, val) y[cidx] = (val)
+        JP_IDCT_1D(x[row * 8], x[row * 8 + 1], x[row * 8 + 2], x[row * 8 + 3], x[row * 8 + 4], x[row * 8 + 5], x[row * 8 + 6], x[row * 8 + 7], 18, JP_O2)
+#undef JP_O2
+        unsigned lo4 = 0, hi4 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int t = y[i] & 1023;
+            t = t >= 512 ? t - 1024 : t;
+            t = min(max(t + 128, 0), 255);
+            if (i < 4) lo4 |= (unsigned)t << (8 * i); else hi4 |= (unsigned)t << (8 * (i - 4));
+        }
+        *reinterpret_cast<uint2*>(out + (long long)row * bw * 8) = make_uint2(lo4, hi4);
+    }
+}
+
+// chroma sample at output pixel (y, x): jdsample.c fullsize / h2v1_fancy / h2v2_fancy (replication when downsampled_width <= 2)
+__device__ __forceinline__ int jp_chroma(const uint8_t* __restrict__ p, int pitch, int dw, int dh, int hs, int vs, int y, int x) {
+    if (hs == 1) return p[(long long)y * pitch + x];
+    const int i = x >> 1;
+    if (vs == 1) {
+        const uint8_t* r = p + (long long)y * pitch;
+        if (dw <= 2) return r[i];
+        if (x & 1) return i == dw - 1 ? r[i] : (3 * r[i] + r[i + 1] + 2) >> 2;
+        return i == 0 ? r[0] : (3 * r[i] + r[i - 1] + 1) >> 2;
+    }
+    const int rr = y >> 1;
+    if (dw <= 2) return p[(long long)rr * pitch + i];
+    const int ro = (y & 1) ? min(rr + 1, dh - 1) : max(rr - 1, 0);       // the context row: below for odd output rows, above for even
+    const uint8_t* r0 = p + (long long)rr * pitch;
+    const uint8_t* r1 = p + (long long)ro * pitch;
+    const int cs = 3 * r0[i] + r1[i];
+    if (x & 1) return i == dw - 1 ? (4 * cs + 7) >> 4 : (3 * cs + 3 * r0[i + 1] + r1[i + 1] + 7) >> 4;
+    return i == 0 ? (4 * cs + 8) >> 4 : (3 * cs + 3 * r0[i - 1] + r1[i - 1] + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
+                                                         const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, int bgr) {
+    const int32_t* I = img32 + (long long)blockIdx.y * JP_I32;
+    const int64_t* I8 = img64 + (long long)blockIdx.y * JP_I64;
+    const int W = I[0], H = I[1];
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= W * H) return;
+    const int y = px / W, x = px % W;
+    const int yy = planes[I8[3] + (long long)y * I[8] * 8 + x];
+    uint8_t* o = out + I8[6] + (long long)px * 3;
+    if (I[2] == 1) {
+        o[0] = o[1] = o[2] = (uint8_t)yy;
+        return;
+    }
+    const int cb = jp_chroma(planes + I8[4], I[9] * 8, I[15], I[18], I[3], I[4], y, x) - 128;
+    const int cr = jp_chroma(planes + I8[5], I[10] * 8, I[16], I[19], I[3], I[4], y, x) - 128;
+    // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, ONE_HALF folded into the Cr->R, Cb->B and Cb->G tables
+    const int r = min(max(yy + ((91881 * cr + 32768) >> 16), 0), 255);
+    const int g = min(max(yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0), 255);
+    const int b = min(max(yy + ((116130 * cb + 32768) >> 16), 0), 255);
+    o[0] = (uint8_t)(bgr ? b : r);
+    o[1] = (uint8_t)g;
+    o[2] = (uint8_t)(bgr ? r : b);
+}
+
+}  // namespace nps
+
+extern "C" int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32,
+                                    const int64_t* seg64, int n_segments, const uint32_t* words, int16_t* coef, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(img32 && img64 && tables && seg32 && seg64 && words && coef && n_segments > 0, "jpeg_huffman: bad args");
+    NPS_CHECK_ARG(((uintptr_t)tables & 3) == 0 && ((uintptr_t)coef & 15) == 0, "jpeg_huffman: tables / coef alignment");
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(64), 0, (hipStream_t)stream, img32, img64, tables, seg32, seg64, words, coef);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_jpeg_idct(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, int n_blocks,
+                                 const int16_t* coef, uint8_t* planes, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(img32 && img64 && tables && coef && planes && n_images > 0 && n_blocks > 0, "jpeg_idct: bad args");
+    NPS_CHECK_ARG(((uintptr_t)coef & 15) == 0 && ((uintptr_t)planes & 7) == 0, "jpeg_idct: coef / planes alignment");
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, (hipStream_t)stream, img32, img64, tables, n_images, n_blocks,
+                       coef, planes);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_jpeg_color(const int32_t* img32, const int64_t* img64, int n_images, int max_pixels, const uint8_t* planes,
+                                  uint8_t* out, int bgr, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(img32 && img64 && planes && out && n_images > 0 && max_pixels > 0, "jpeg_color: bad args");
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_pixels + 255) / 256, n_images), dim3(256), 0, (hipStream_t)stream, img32, img64, planes, out, bgr);
+    NPS_LAUNCH_RET();
+}

@@ -1,0 +1,281 @@
+"""GPU decode of baseline JPEG files (the ScanNet colour frames of the reference's data mapper: detectron2 `utils.read_image` = PIL /
+libjpeg-turbo decode, NopeSAC_Net/data/planercnn_transforms.py:210-227 and :306-314).
+
+Host side (this file): marker walk, restart-interval split, removal of the byte stuffing, Huffman lookup tables - a few numpy calls
+per file, no entropy decoding.  Device side (csrc/jpeg.hip, include/nopesac_hip.h `nopesac_jpeg_*`): Huffman decode (one wave per
+restart interval - per image when the file has none - on the scalar unit), dequantisation + libjpeg's 13-bit "islow" inverse DCT,
+"fancy" (triangle) chroma upsampling and the 16-bit fixed-point YCbCr -> RGB conversion, bit for bit what libjpeg-turbo produces with
+its default decompression parameters (tests/test_jpeg_gpu.py against Pillow-decoded fixtures and oracle/jpeg_oracle.py).
+
+Supported: SOF0 / SOF1 (baseline / extended sequential Huffman), 8-bit, ONE scan with all components, gray or YCbCr with luma sampling
+1x1 / 2x1 / 2x2 and 1x1 chroma.  Everything else (progressive, arithmetic, CMYK, multi-scan) raises JpegUnsupported: the caller
+(data.read_image_gpu) then decodes that file with PIL on the host, as the reference does for every file."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+                   62, 63], dtype=np.int64)
+
+# layout constants shared with csrc/jpeg.hip (include/nopesac_hip.h NOPESAC_JPEG_*)
+LOOK_BITS = 9
+HUFF_BYTES = 1536                 # one Huffman table: look u16[512] | maxcode i32[18] | valoffset i32[18] | huffval u8[256] | pad
+TABLES_BYTES = 4 * HUFF_BYTES + 3 * 128          # DC0, DC1, AC0, AC1, then three quantisation tables u16[64] (natural order)
+IMG_I32, IMG_I64, SEG_I32, SEG_I64 = 32, 8, 4, 2
+
+
+class JpegUnsupported(ValueError):
+    """The file is not a baseline JPEG this decoder handles."""
+
+
+class JpegInfo:
+    __slots__ = ("width", "height", "comps", "qt", "huff", "dri", "intervals", "hmax", "vmax", "mcux", "mcuy")
+
+
+def _u16(b, p):
+    return (b[p] << 8) | b[p + 1]
+
+
+def parse(data: bytes) -> JpegInfo:
+    """Marker segments (ITU T.81 Annex B) of one file -> geometry, tables and the entropy-coded data split at the restart markers with
+    the stuffed zero bytes removed."""
+    if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
+        raise JpegUnsupported("no SOI marker")
+    info = JpegInfo()
+    info.qt, info.huff, info.dri, info.comps, info.intervals = {}, {}, 0, None, None
+    adobe = None
+    p, n = 2, len(data)
+    while p + 4 <= n:
+        if data[p] != 0xFF:
+            raise JpegUnsupported("marker expected at byte %d" % p)
+        while p < n and data[p] == 0xFF:
+            p += 1
+        m = data[p]
+        p += 1
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+            continue
+        if m == 0xD9:
+            break
+        L = _u16(data, p)
+        seg = data[p + 2:p + L]
+        if m == 0xDB:
+            s = 0
+            while s < len(seg):
+                pq, tq = seg[s] >> 4, seg[s] & 15
+                s += 1
+                if pq:
+                    t = np.frombuffer(seg, dtype=">u2", count=64, offset=s).astype(np.uint16)
+                    s += 128
+                else:
+                    t = np.frombuffer(seg, dtype=np.uint8, count=64, offset=s).astype(np.uint16)
+                    s += 64
+                nat = np.zeros(64, np.uint16)
+                nat[ZIGZAG] = t
+                info.qt[tq] = nat
+        elif m == 0xC4:
+            s = 0
+            while s < len(seg):
+                tc, th = seg[s] >> 4, seg[s] & 15
+                cnt = sum(seg[s + 1:s + 17])
+                info.huff[(tc, th)] = bytes(seg[s + 1:s + 17 + cnt])
+                s += 17 + cnt
+        elif m in (0xC0, 0xC1):
+            if seg[0] != 8:
+                raise JpegUnsupported("%d-bit samples" % seg[0])
+            info.height, info.width = _u16(seg, 1), _u16(seg, 3)
+            info.comps = [{"id": seg[6 + 3 * i], "h": seg[7 + 3 * i] >> 4, "v": seg[7 + 3 * i] & 15, "tq": seg[8 + 3 * i]} for i in range(seg[5])]
+        elif 0xC2 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            raise JpegUnsupported("SOF%d (progressive / lossless / arithmetic coding)" % (m - 0xC0))
+        elif m == 0xDD:
+            info.dri = _u16(seg, 0)
+        elif m == 0xEE and bytes(seg[:5]) == b"Adobe" and len(seg) >= 12:
+            adobe = seg[11]
+        elif m == 0xDA:
+            if info.comps is None:
+                raise JpegUnsupported("SOS before SOF")
+            ns = seg[0]
+            if ns != len(info.comps):
+                raise JpegUnsupported("more than one scan")
+            for i in range(ns):
+                c = next((c for c in info.comps if c["id"] == seg[1 + 2 * i]), None)
+                if c is None:
+                    raise JpegUnsupported("scan names an unknown component")
+                c["td"], c["ta"] = seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15
+            if (seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns]) != (0, 63, 0):
+                raise JpegUnsupported("spectral selection / successive approximation")
+            p += L
+            e = p
+            while True:                                   # the scan ends at the first FF that is neither stuffing nor RSTn
+                e = data.find(b"\xff", e)
+                if e < 0 or e + 1 >= n:
+                    raise JpegUnsupported("truncated file (no EOI)")
+                if data[e + 1] == 0 or 0xD0 <= data[e + 1] <= 0xD7:
+                    e += 2
+                    continue
+                break
+            ecs = data[p:e]
+            parts, s = [], 0
+            if info.dri:
+                while True:
+                    k = s
+                    while True:
+                        k = ecs.find(b"\xff", k)
+                        if k < 0 or (k + 1 < len(ecs) and 0xD0 <= ecs[k + 1] <= 0xD7):
+                            break
+                        k += 2
+                    parts.append(ecs[s:k if k >= 0 else len(ecs)])
+                    if k < 0:
+                        break
+                    s = k + 2
+            else:
+                parts.append(ecs)
+            info.intervals = [q.replace(b"\xff\x00", b"\xff") for q in parts]
+            break
+        p += L
+    if info.comps is None or info.intervals is None:
+        raise JpegUnsupported("no frame / scan")
+    comps = info.comps
+    if len(comps) == 1:
+        comps[0]["h"] = comps[0]["v"] = 1                 # a one-component scan is never interleaved (T.81 A.2.2)
+    elif len(comps) == 3:
+        if adobe is not None and adobe != 1:
+            raise JpegUnsupported("Adobe colour transform %d" % adobe)
+        if (comps[1]["h"], comps[1]["v"], comps[2]["h"], comps[2]["v"]) != (1, 1, 1, 1) or (comps[0]["h"], comps[0]["v"]) not in ((1, 1), (2, 1), (2, 2)):
+            raise JpegUnsupported("sampling factors %r" % [(c["h"], c["v"]) for c in comps])
+    else:
+        raise JpegUnsupported("%d components" % len(comps))
+    for c in comps:
+        if c["tq"] not in info.qt or (0, c["td"]) not in info.huff or (1, c["ta"]) not in info.huff or c["td"] > 1 or c["ta"] > 1:
+            raise JpegUnsupported("missing / out-of-range table")
+    if info.width <= 0 or info.height <= 0:
+        raise JpegUnsupported("empty image")
+    info.hmax, info.vmax = comps[0]["h"], comps[0]["v"]
+    info.mcux, info.mcuy = -(-info.width // (8 * info.hmax)), -(-info.height // (8 * info.vmax))
+    n_mcu = info.mcux * info.mcuy
+    per = info.dri if info.dri else n_mcu
+    if len(info.intervals) != -(-n_mcu // per):
+        raise JpegUnsupported("%d restart intervals for %d MCUs of %d" % (len(info.intervals), n_mcu, per))
+    for c in comps:
+        c["bw"], c["bh"] = info.mcux * c["h"], info.mcuy * c["v"]
+        c["dw"], c["dh"] = -(-info.width * c["h"] // info.hmax), -(-info.height * c["v"] // info.vmax)
+    return info
+
+
+_HUFF_CACHE = {}
+
+
+def huffman_table_bytes(spec: bytes) -> np.ndarray:
+    """BITS[16] + HUFFVAL of a DHT segment -> the HUFF_BYTES device layout (T.81 Annex C canonical codes; the 9-bit look-ahead table
+    and the maxcode / valoffset arrays are the ones jdhuff.c's jpeg_make_d_derived_tbl builds)."""
+    t = _HUFF_CACHE.get(spec)
+    if t is not None:
+        return t
+    bits, vals = list(spec[:16]), list(spec[16:])
+    if sum(bits) != len(vals) or len(vals) > 256:
+        raise JpegUnsupported("bad Huffman table")
+    look = np.zeros(1 << LOOK_BITS, np.uint16)
+    maxcode = np.full(18, -1, np.int32)
+    valoff = np.zeros(18, np.int32)
+    code, k = 0, 0
+    for ln in range(1, 17):
+        if bits[ln - 1]:
+            valoff[ln] = k - code
+            for _ in range(bits[ln - 1]):
+                if ln <= LOOK_BITS:
+                    lo = code << (LOOK_BITS - ln)
+                    look[lo:lo + (1 << (LOOK_BITS - ln))] = (ln << 8) | vals[k]
+                code += 1
+                k += 1
+            maxcode[ln] = code - 1
+        if code > (1 << ln):
+            raise JpegUnsupported("bad Huffman code lengths")
+        code <<= 1
+    maxcode[17] = 0x7FFFFFFF                              # sentinel: the slow path always ends
+    out = np.zeros(HUFF_BYTES, np.uint8)
+    out[:1024] = look.view(np.uint8)
+    out[1024:1096] = maxcode.view(np.uint8)
+    out[1096:1168] = valoff.view(np.uint8)
+    out[1168:1168 + len(vals)] = np.asarray(vals, np.uint8)
+    _HUFF_CACHE[spec] = out
+    if len(_HUFF_CACHE) > 256:
+        _HUFF_CACHE.pop(next(iter(_HUFF_CACHE)))
+    return out
+
+
+def _words(interval: bytes) -> np.ndarray:
+    """bytes of one restart interval -> 32-bit words whose MOST significant bit is the first bit of the stream (+ 4 zero words: the
+    decoder may read ahead; libjpeg also feeds zero bits past the end of a segment)."""
+    pad = (-len(interval)) % 4
+    return np.frombuffer(interval + b"\0" * (pad + 16), dtype=">u4").astype(np.uint32)
+
+
+def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None) -> List[torch.Tensor]:
+    """JPEG files -> uint8 [H, W, 3] device tensors (RGB, or BGR for INPUT.FORMAT "BGR"), one launch chain for the whole batch on the
+    current stream.  Raises JpegUnsupported if any file is outside the supported subset (nothing is decoded then)."""
+    infos = list(infos) if infos is not None else [parse(f) for f in files]
+    n = len(infos)
+    if n == 0:
+        return []
+    img32, img64 = np.zeros((n, IMG_I32), np.int32), np.zeros((n, IMG_I64), np.int64)
+    tables = np.zeros((n, TABLES_BYTES), np.uint8)
+    seg32, seg64, words = [], [], []
+    coef_off = plane_off = out_off = word_off = 0
+    n_blocks, max_px = 0, 0
+    for i, f in enumerate(infos):
+        nc = len(f.comps)
+        a = img32[i]
+        a[0:8] = (f.width, f.height, nc, f.hmax, f.vmax, f.mcux, f.mcuy, f.dri if f.dri else f.mcux * f.mcuy)
+        for ci, c in enumerate(f.comps):
+            a[8 + ci], a[11 + ci], a[14 + ci], a[17 + ci] = c["bw"], c["bh"], c["dw"], c["dh"]
+            a[20 + ci], a[23 + ci] = c["td"], 2 + c["ta"]
+            img64[i, ci] = coef_off
+            img64[i, 3 + ci] = plane_off
+            coef_off += c["bw"] * c["bh"] * 64
+            plane_off += c["bw"] * c["bh"] * 64
+            tables[i, 4 * HUFF_BYTES + 128 * ci:4 * HUFF_BYTES + 128 * (ci + 1)] = f.qt[c["tq"]].view(np.uint8)
+        a[26] = n_blocks                                   # first block of the image in the batch-wide block list (IDCT kernel)
+        nb = sum(c["bw"] * c["bh"] for c in f.comps)
+        a[27] = nb
+        n_blocks += nb
+        img64[i, 6] = out_off
+        out_off += f.width * f.height * 3
+        max_px = max(max_px, f.width * f.height)
+        for (tc, th), spec in f.huff.items():
+            if th <= 1 and tc <= 1:
+                tables[i, (2 * tc + th) * HUFF_BYTES:(2 * tc + th + 1) * HUFF_BYTES] = huffman_table_bytes(spec)
+        per = int(a[7])
+        for k, part in enumerate(f.intervals):
+            w = _words(part)
+            seg32.append((i, k * per, min(per, f.mcux * f.mcuy - k * per), 0))
+            seg64.append((word_off, len(w)))
+            words.append(w)
+            word_off += len(w)
+    dev = torch.device(device)
+    up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev, non_blocking=True)
+    t_img32, t_img64, t_tab = up(img32), up(img64), up(tables)
+    t_seg32, t_seg64 = up(np.asarray(seg32, np.int32)), up(np.asarray(seg64, np.int64))
+    t_words = up(np.concatenate(words))
+    coef = torch.zeros(coef_off, device=dev, dtype=torch.int16)
+    planes = torch.empty(plane_off, device=dev, dtype=torch.uint8)
+    out = torch.empty(out_off, device=dev, dtype=torch.uint8)
+    L = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(L.nopesac_jpeg_huffman(p(t_img32), p(t_img64), p(t_tab), p(t_seg32), p(t_seg64), len(seg32), p(t_words), p(coef), st),
+               "nopesac_jpeg_huffman")
+    _lib.check(L.nopesac_jpeg_idct(p(t_img32), p(t_img64), p(t_tab), n, n_blocks, p(coef), p(planes), st), "nopesac_jpeg_idct")
+    _lib.check(L.nopesac_jpeg_color(p(t_img32), p(t_img64), n, max_px, p(planes), p(out), 1 if bgr else 0, st), "nopesac_jpeg_color")
+    res, o = [], 0
+    for f in infos:
+        res.append(out[o:o + f.width * f.height * 3].view(f.height, f.width, 3))
+        o += f.width * f.height * 3
+    for t in (t_img32, t_img64, t_tab, t_seg32, t_seg64, t_words, coef, planes):
+        t.record_stream(torch.cuda.current_stream(dev))
+    return res
