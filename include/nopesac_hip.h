@@ -463,7 +463,7 @@ int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n
  *   seg32 [n_segments][NOPESAC_JPEG_SEG_I32] int32: image, first MCU, MCU count, 0; seg64 [n_segments][NOPESAC_JPEG_SEG_I64] int64:
  *     offset into `words`, word count.  words: the intervals' bytes without the stuffing as 32-bit words, first bit = most significant,
  *     each interval followed by four zero words.
- * nopesac_jpeg_huffman: one wave per segment, `coef` zero-filled by the caller.  nopesac_jpeg_idct: n_blocks = sum of img32[.][27].
+ * nopesac_jpeg_huffman: one wave per segment, n_words = length of `words`, `coef` zero-filled by the caller.  nopesac_jpeg_idct: n_blocks = sum of img32[.][27].
  * nopesac_jpeg_color: max_pixels = the largest width * height of the batch; bgr != 0 writes B, G, R. */
 #define NOPESAC_JPEG_HUFF_BYTES 1536
 #define NOPESAC_JPEG_TABLES_BYTES (4 * NOPESAC_JPEG_HUFF_BYTES + 3 * 128)
@@ -472,7 +472,7 @@ int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n
 #define NOPESAC_JPEG_SEG_I32 4
 #define NOPESAC_JPEG_SEG_I64 2
 int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32, const int64_t* seg64,
-                         int n_segments, const uint32_t* words, int16_t* coef, void* stream);
+                         int n_segments, const uint32_t* words, int64_t n_words, int16_t* coef, void* stream);
 int nopesac_jpeg_idct(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, int n_blocks, const int16_t* coef,
                       uint8_t* planes, void* stream);
 int nopesac_jpeg_color(const int32_t* img32, const int64_t* img64, int n_images, int max_pixels, const uint8_t* planes, uint8_t* out,

@@ -28,32 +28,55 @@ typedef const __attribute__((address_space(4))) uint8_t* c_u8;
 template <typename P>
 __device__ __forceinline__ P as_const(const void* p) { return (P)(uintptr_t)p; }
 
+// Bit reader: the interval's words sit in a 64-word VGPR window (lane l = word l of the current 256-byte chunk, the next chunk already
+// requested into a second register); a word reaches the scalar side with v_readlane - no memory access on the decode chain (the first
+// version read the stream with scalar loads: every word a scalar-cache miss, ~450 cycles per symbol, 50 ms for a 968 x 1296 frame).
 struct JpBits {
     uint64_t acc;      // the next bits of the stream, most significant first
     int nb;            // valid bits in acc
-    c_u32 w;           // next word
+    uint32_t cur, nxt; // VGPR windows
+    int wi;            // next word of `cur`
+    long long pos;     // word index (in the batch's word array) of cur's lane 0
 };
-__device__ __forceinline__ void jp_fill(JpBits& b) {
+__device__ __forceinline__ uint32_t jp_load_window(const uint32_t* __restrict__ words, long long n_words, long long at) {
+    const long long i = at + (int)threadIdx.x;
+    return i < n_words ? words[i] : 0u;
+}
+__device__ __forceinline__ void jp_fill(JpBits& b, const uint32_t* __restrict__ words, long long n_words) {
     if (b.nb <= 32) {
-        b.acc |= (uint64_t)(*b.w++) << (32 - b.nb);
+        const uint32_t w = __builtin_amdgcn_readlane(b.cur, b.wi);
+        b.acc |= (uint64_t)w << (32 - b.nb);
         b.nb += 32;
+        if (++b.wi == 64) {
+            b.wi = 0;
+            b.cur = b.nxt;
+            b.pos += 64;
+            b.nxt = jp_load_window(words, n_words, b.pos + 64);
+        }
     }
 }
 __device__ __forceinline__ void jp_skip(JpBits& b, int n) {
     b.acc <<= n;
     b.nb -= n;
 }
-// one Huffman symbol (jdhuff.c HUFF_DECODE: 9-bit look-ahead table, then one bit at a time against maxcode[])
-__device__ __forceinline__ int jp_symbol(JpBits& b, c_u8 tab) {
-    jp_fill(b);                                                     // >= 33 valid bits: a code (<= 16) and its value bits (<= 11)
-    // (whole dwords: 16- and 8-bit scalar loads do not exist on gfx950)
+// the 9-bit look-ahead table of one Huffman table as four VGPRs (lane l of register j = dword 64 j + l of the uint16[512] array)
+struct JpLook {
+    uint32_t r[4];
+};
+// one Huffman symbol (jdhuff.c HUFF_DECODE: 9-bit look-ahead table, then one bit at a time against maxcode[]); >= 33 valid bits on
+// entry: a code (<= 16) and its value bits (<= 15)
+__device__ __forceinline__ int jp_symbol(JpBits& b, const JpLook& lk, c_u8 tab) {
     const unsigned li = (unsigned)(b.acc >> (64 - JP_LOOK));
-    const unsigned ew = ((c_u32)tab)[li >> 1];
+    const int lane = (li >> 1) & 63, j = li >> 7;
+    const uint32_t w0 = __builtin_amdgcn_readlane(lk.r[0], lane), w1 = __builtin_amdgcn_readlane(lk.r[1], lane);
+    const uint32_t w2 = __builtin_amdgcn_readlane(lk.r[2], lane), w3 = __builtin_amdgcn_readlane(lk.r[3], lane);
+    const uint32_t ew = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? w2 : w3));
     const unsigned e = (li & 1) ? ew >> 16 : ew & 0xFFFFu;
     if (e >> 8) {
         jp_skip(b, e >> 8);
         return e & 255;
     }
+    // longer codes (rare): maxcode / valoffset / huffval with scalar loads (whole dwords: there are no 8- / 16-bit ones on gfx950)
     c_i32 maxcode = (c_i32)(tab + 1024), valoff = (c_i32)(tab + 1096);
     int l = JP_LOOK + 1;
     int code = (int)(b.acc >> (64 - l));
@@ -80,17 +103,25 @@ __device__ __forceinline__ int jp_value(JpBits& b, int s) {
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
                                                           const uint8_t* __restrict__ tables, const int32_t* __restrict__ seg32,
                                                           const int64_t* __restrict__ seg64, const uint32_t* __restrict__ words,
-                                                          int16_t* __restrict__ coef) {
+                                                          long long n_words, int16_t* __restrict__ coef) {
     const int sg = blockIdx.x;
     c_i32 S = as_const<c_i32>(seg32 + (long long)sg * NOPESAC_JPEG_SEG_I32);
     const int im = S[0], first = S[1], count = S[2];
     c_i32 I = as_const<c_i32>(img32 + (long long)im * JP_I32);
     c_i64 I8 = as_const<c_i64>(img64 + (long long)im * JP_I64);
-    c_u8 T = as_const<c_u8>(tables + (long long)im * JP_TABLES_BYTES);
+    const uint8_t* Tg = tables + (long long)im * JP_TABLES_BYTES;
+    c_u8 T = as_const<c_u8>(Tg);
     const int ncomp = I[2], mcux = I[5];
+    JpLook look[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) look[t].r[j] = reinterpret_cast<const uint32_t*>(Tg + t * JP_HUFF_BYTES)[j * 64 + threadIdx.x];
     JpBits b;
-    b.acc = 0; b.nb = 0;
-    b.w = as_const<c_u32>(words + as_const<c_i64>(seg64 + (long long)sg * NOPESAC_JPEG_SEG_I64)[0]);
+    b.acc = 0; b.nb = 0; b.wi = 0;
+    b.pos = as_const<c_i64>(seg64 + (long long)sg * NOPESAC_JPEG_SEG_I64)[0];
+    b.cur = jp_load_window(words, n_words, b.pos);
+    b.nxt = jp_load_window(words, n_words, b.pos + 64);
     int pred[3] = {0, 0, 0};
     const bool writer = threadIdx.x == 0;
     int my = first / mcux, mx = first % mcux;
@@ -99,17 +130,26 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const int32_t* __restr
         for (int ci = 0; ci < 3; ++ci) {
             if (ci >= ncomp) break;
             const int ch = ci == 0 ? I[3] : 1, cv = ci == 0 ? I[4] : 1, bw = I[8 + ci];
-            c_u8 dc = T + I[20 + ci] * JP_HUFF_BYTES, ac = T + I[23 + ci] * JP_HUFF_BYTES;
+            const int tdc = I[20 + ci], tac = I[23 + ci];
+            c_u8 dc = T + tdc * JP_HUFF_BYTES, ac = T + tac * JP_HUFF_BYTES;
+            JpLook ldc, lac;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ldc.r[j] = tdc ? look[1].r[j] : look[0].r[j];
+                lac.r[j] = tac == 3 ? look[3].r[j] : look[2].r[j];
+            }
             int16_t* cc = coef + I8[ci];
             for (int v = 0; v < cv; ++v)
                 for (int h = 0; h < ch; ++h) {
                     int16_t* blk = cc + ((long long)(my * cv + v) * bw + (mx * ch + h)) * 64;
-                    const int s = jp_symbol(b, dc);
+                    jp_fill(b, words, n_words);
+                    const int s = jp_symbol(b, ldc, dc);
                     pred[ci] += jp_value(b, s & 15);
                     if (writer) blk[0] = (int16_t)pred[ci];
                     int k = 1;
                     while (k < 64) {
-                        const int rs = jp_symbol(b, ac);
+                        jp_fill(b, words, n_words);
+                        const int rs = jp_symbol(b, lac, ac);
                         const int r = rs >> 4, sz = rs & 15;
                         if (sz) {
                             k += r;
@@ -256,11 +296,13 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* __restri
 }  // namespace nps
 
 extern "C" int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32,
-                                    const int64_t* seg64, int n_segments, const uint32_t* words, int16_t* coef, void* stream) {
+                                    const int64_t* seg64, int n_segments, const uint32_t* words, int64_t n_words, int16_t* coef,
+                                    void* stream) {
     using namespace nps;
-    NPS_CHECK_ARG(img32 && img64 && tables && seg32 && seg64 && words && coef && n_segments > 0, "jpeg_huffman: bad args");
+    NPS_CHECK_ARG(img32 && img64 && tables && seg32 && seg64 && words && coef && n_segments > 0 && n_words > 0, "jpeg_huffman: bad args");
     NPS_CHECK_ARG(((uintptr_t)tables & 3) == 0 && ((uintptr_t)coef & 15) == 0, "jpeg_huffman: tables / coef alignment");
-    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(64), 0, (hipStream_t)stream, img32, img64, tables, seg32, seg64, words, coef);
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(64), 0, (hipStream_t)stream, img32, img64, tables, seg32, seg64, words,
+                       (long long)n_words, coef);
     NPS_LAUNCH_RET();
 }
 

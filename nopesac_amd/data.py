@@ -5,8 +5,10 @@
     a pair as float32 [3,H,W] tensors in cfg.INPUT.FORMAT channel order with values 0..255, file names / ids, `rel_pose`.
     Matterport3D images are used as stored (:210-227); ScanNet images are resized to 640 x 480 (:312-314, cv2.resize =
     8-bit INTER_LINEAR) - here on the GPU by `nopesac_resize_bilinear_u8` (csrc/resize.hip).
-Decoding is PIL on the host (the image has no GPU JPEG/PNG decoder; detectron2's `utils.read_image` is PIL too).  Ground-truth
-masks / depth / k-means pose classes are not read: nothing on the inference path consumes them.
+Decoding: baseline JPEG files (the ScanNet colour frames) are decoded ON THE GPU when one is present (nopesac_amd/jpeg.py,
+csrc/jpeg.hip - bit-exact with the PIL / libjpeg-turbo decode detectron2's `utils.read_image` performs); PNG files (Matterport3D) and
+JPEG variants outside the decoder's subset (progressive, CMYK, ...) are decoded by PIL on the host, as the reference decodes every
+file.  Ground-truth masks / depth / k-means pose classes are not read: nothing on the inference path consumes them.
 """
 from __future__ import annotations
 
@@ -56,14 +58,22 @@ def read_image(path: str, fmt: str = "BGR") -> np.ndarray:
     return np.ascontiguousarray(arr)
 
 
+def is_jpeg_path(path: str) -> bool:
+    return path.lower().endswith((".jpg", ".jpeg"))
+
+
 class PairMapper:
     """dataset dict -> model input dict (the `image` tensors stay on the host unless `device` is given, exactly like the
     reference mapper's output; ScanNet images pass through the GPU resize kernel)."""
 
-    def __init__(self, cfg, dataset_name: str = "", device=None, uint8: bool = False):
+    def __init__(self, cfg, dataset_name: str = "", device=None, uint8: bool = False, gpu_jpeg: bool = None):
         """uint8: keep the decoded 8-bit samples (uint8 CHW tensors; the model widens them on the device - bit-identical results,
-        a quarter of the host-to-device bytes) instead of the reference mapper's float32 tensors."""
+        a quarter of the host-to-device bytes) instead of the reference mapper's float32 tensors.
+        gpu_jpeg: decode baseline JPEG files on the GPU (default: whenever a GPU is present); files the decoder does not support go
+        through PIL like every file does in the reference (counted in `self.host_decoded`)."""
         self.uint8 = uint8
+        self.gpu_jpeg = gpu_jpeg
+        self.host_decoded = 0
         self.img_format = cfg.INPUT.FORMAT
         self.root_dir = cfg.DATASETS.ROOT_DIR
         name = dataset_name or (cfg.DATASETS.TEST[0] if len(cfg.DATASETS.TEST) else "")
@@ -73,7 +83,61 @@ class PairMapper:
         self._resize_device = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                                                  if torch.cuda.is_available() else None)
 
+    def _use_gpu_jpeg(self) -> bool:
+        if self.gpu_jpeg is None:
+            self.gpu_jpeg = self._resize_device is not None
+        return bool(self.gpu_jpeg) and self._resize_device is not None
+
+    def _finish_device_image(self, img_t: torch.Tensor) -> torch.Tensor:
+        """uint8 [H,W,3] on the GPU (cfg.INPUT.FORMAT order) -> what _image returns (resized for ScanNet, CHW, uint8 / float32, on
+        self.device or the host)"""
+        if self.scannet and tuple(img_t.shape[:2]) != (480, 640):
+            from . import ops
+            img_t = ops.resize_bilinear_u8(img_t.contiguous(), 480, 640)
+        t = img_t.permute(2, 0, 1).contiguous() if self.uint8 else img_t.permute(2, 0, 1).float()
+        return t if self.device is not None else t.cpu()
+
+    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None) -> List[torch.Tensor]:
+        """The images of `paths` as _image() returns them, the JPEG files among them decoded in ONE launch chain on the GPU (all
+        restart intervals / images of the batch in flight together).  blobs / infos: file contents and jpeg.parse results when the
+        caller (LazyPairs' reader threads) has them already."""
+        from . import jpeg
+        dev = self._resize_device
+        blobs = list(blobs) if blobs is not None else [None] * len(paths)
+        infos = list(infos) if infos is not None else [None] * len(paths)
+        gpu_idx = []
+        for i, p in enumerate(paths):
+            if not (self._use_gpu_jpeg() and is_jpeg_path(p)):
+                continue
+            if blobs[i] is None:
+                with open(p, "rb") as f:
+                    blobs[i] = f.read()
+            if infos[i] is None:
+                try:
+                    infos[i] = jpeg.parse(blobs[i])
+                except jpeg.JpegUnsupported:
+                    infos[i] = False
+            if infos[i]:
+                gpu_idx.append(i)
+        out = [None] * len(paths)
+        if gpu_idx:
+            with torch.cuda.device(dev):
+                dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
+                for i, t in zip(gpu_idx, dec):
+                    out[i] = self._finish_device_image(t)
+        for i, p in enumerate(paths):
+            if out[i] is None:
+                if is_jpeg_path(p) and self._use_gpu_jpeg():
+                    self.host_decoded += 1
+                out[i] = self._image_host(p)
+        return out
+
     def _image(self, path: str) -> torch.Tensor:
+        if self._use_gpu_jpeg() and is_jpeg_path(path):
+            return self.decode_files([path])[0]
+        return self._image_host(path)
+
+    def _image_host(self, path: str) -> torch.Tensor:
         img = read_image(path, self.img_format)
         if self.scannet and img.shape[:2] != (480, 640):
             from . import ops
@@ -85,17 +149,31 @@ class PairMapper:
         t = torch.as_tensor(np.ascontiguousarray(img.transpose(2, 0, 1)) if self.uint8 else img.transpose(2, 0, 1).astype("float32"))
         return t.to(self.device) if self.device is not None else t
 
-    def __call__(self, dataset_dict: dict) -> dict:
+    def __call__(self, dataset_dict: dict, images: List[torch.Tensor] = None) -> dict:
+        """images: the two decoded images when the caller decoded a whole batch at once (map_batch)"""
         d = copy.deepcopy(dataset_dict)
-        for v in "01":
+        for vi, v in enumerate("01"):
             if not self.scannet and self.root_dir:
                 d[v]["file_name"] = d[v]["file_name"].replace(MP3D_ORIGINAL_ROOT, self.root_dir)
-            d[v]["image"] = self._image(d[v]["file_name"])
+            d[v]["image"] = images[vi] if images is not None else self._image(d[v]["file_name"])
             h, w = d[v]["image"].shape[-2:]
             if "height" in d[v] and (d[v]["height"], d[v]["width"]) != (h, w) and not self.scannet:
                 raise ValueError(f"{d[v]['file_name']}: image is {h}x{w}, annotation says {d[v]['height']}x{d[v]['width']}")
             d[v]["height"], d[v]["width"] = h, w
         return d
+
+
+    def file_names(self, dataset_dict: dict) -> List[str]:
+        names = [dataset_dict[v]["file_name"] for v in "01"]
+        if not self.scannet and self.root_dir:
+            names = [n.replace(MP3D_ORIGINAL_ROOT, self.root_dir) for n in names]
+        return names
+
+    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None) -> List[dict]:
+        """The mapped dicts of a batch of pairs with all 2 * len(entries) images decoded together (decode_files)."""
+        paths = [n for e in entries for n in self.file_names(e)]
+        imgs = self.decode_files(paths, blobs, infos)
+        return [self(e, images=imgs[2 * i:2 * i + 2]) for i, e in enumerate(entries)]
 
 
 class LazyPairs:
@@ -134,7 +212,62 @@ class LazyPairs:
                     nxt += 1
                 yield item
 
+    def _read_batch(self, entries: List[dict]):
+        """reader thread: file contents + marker walk of a batch's JPEG files (host work only)"""
+        from . import jpeg
+        paths = [n for e in entries for n in self.mapper.file_names(e)]
+        blobs, infos = [None] * len(paths), [None] * len(paths)
+        for i, p in enumerate(paths):
+            if is_jpeg_path(p):
+                with open(p, "rb") as f:
+                    blobs[i] = f.read()
+                try:
+                    infos[i] = jpeg.parse(blobs[i])
+                except jpeg.JpegUnsupported:
+                    infos[i] = False
+        return entries, blobs, infos
+
+    def _iter_batches_gpu(self, pairs_per_batch: int, ahead: int = 3):
+        """JPEG splits with a GPU: reader threads load and parse the files of whole batches ahead of the consumer; this thread
+        launches each batch's decode (one chain for its 2 * pairs_per_batch images) on one of `ahead` decode streams, up to `ahead`
+        batches before the consumer needs them - the serial Huffman chains of different batches run next to each other and next to
+        the model; the consumer's stream waits for the batch's event."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        dev = self.mapper._resize_device
+        chunks = [self.entries[i:i + pairs_per_batch] for i in range(0, len(self.entries), pairs_per_batch)]
+        with torch.cuda.device(dev):
+            streams = [torch.cuda.Stream(device=dev) for _ in range(ahead)]
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            reading, decoding, nxt, k = deque(), deque(), 0, 0
+            depth = max(ahead + 1, self.prefetch // max(1, pairs_per_batch))
+            while nxt < len(chunks) or reading or decoding:
+                while nxt < len(chunks) and len(reading) + len(decoding) < depth:
+                    reading.append(pool.submit(self._read_batch, chunks[nxt]))
+                    nxt += 1
+                while reading and len(decoding) < ahead:
+                    entries, blobs, infos = reading.popleft().result()
+                    st = streams[k % ahead]
+                    k += 1
+                    with torch.cuda.device(dev), torch.cuda.stream(st):
+                        items = self.mapper.map_batch(entries, blobs, infos)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    decoding.append((items, ev, st))
+                items, ev, st = decoding.popleft()
+                torch.cuda.current_stream(dev).wait_event(ev)
+                for it in items:                          # the consumer's stream uses memory allocated on the decode stream
+                    for v in "01":
+                        if it[v]["image"].is_cuda:
+                            it[v]["image"].record_stream(torch.cuda.current_stream(dev))
+                if not any(it[v]["image"].is_cuda for it in items for v in "01"):
+                    ev.synchronize()                      # host tensors came through .cpu() on the decode stream: complete by now
+                yield items
+
     def iter_batches(self, pairs_per_batch: int):
+        if self.mapper._use_gpu_jpeg() and self.entries and is_jpeg_path(self.mapper.file_names(self.entries[0])[0]):
+            yield from self._iter_batches_gpu(pairs_per_batch)
+            return
         batch = []
         for item in self:
             batch.append(item)

@@ -13,6 +13,7 @@ Supported: SOF0 / SOF1 (baseline / extended sequential Huffman), 8-bit, ONE scan
 from __future__ import annotations
 
 import ctypes
+import re
 from typing import List, Sequence
 
 import numpy as np
@@ -29,6 +30,10 @@ LOOK_BITS = 9
 HUFF_BYTES = 1536                 # one Huffman table: look u16[512] | maxcode i32[18] | valoffset i32[18] | huffval u8[256] | pad
 TABLES_BYTES = 4 * HUFF_BYTES + 3 * 128          # DC0, DC1, AC0, AC1, then three quantisation tables u16[64] (natural order)
 IMG_I32, IMG_I64, SEG_I32, SEG_I64 = 32, 8, 4, 2
+
+
+_SCAN_END = re.compile(rb"\xff[^\x00\xd0-\xd7\xff]")        # (FF FF: fill bytes in front of a marker - the second FF decides)
+_RST = re.compile(rb"\xff[\xd0-\xd7]")
 
 
 class JpegUnsupported(ValueError):
@@ -111,31 +116,19 @@ def parse(data: bytes) -> JpegInfo:
             if (seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns]) != (0, 63, 0):
                 raise JpegUnsupported("spectral selection / successive approximation")
             p += L
-            e = p
-            while True:                                   # the scan ends at the first FF that is neither stuffing nor RSTn
-                e = data.find(b"\xff", e)
-                if e < 0 or e + 1 >= n:
+            # the scan ends at the first FF that is neither stuffing nor RSTn - normally the EOI that ends the file: take the last EOI
+            # and check with three memchr-speed counts that every FF before it is stuffing / a restart marker (else: regex scan)
+            e = data.rfind(b"\xff\xd9")
+            ecs = data[p:e] if e >= p else b""
+            cuts = [m_.start() for m_ in _RST.finditer(ecs)] if info.dri else []
+            if e < p or ecs.count(b"\xff") != ecs.count(b"\xff\x00") + len(cuts):
+                end = _SCAN_END.search(data, p)
+                if end is None:
                     raise JpegUnsupported("truncated file (no EOI)")
-                if data[e + 1] == 0 or 0xD0 <= data[e + 1] <= 0xD7:
-                    e += 2
-                    continue
-                break
-            ecs = data[p:e]
-            parts, s = [], 0
-            if info.dri:
-                while True:
-                    k = s
-                    while True:
-                        k = ecs.find(b"\xff", k)
-                        if k < 0 or (k + 1 < len(ecs) and 0xD0 <= ecs[k + 1] <= 0xD7):
-                            break
-                        k += 2
-                    parts.append(ecs[s:k if k >= 0 else len(ecs)])
-                    if k < 0:
-                        break
-                    s = k + 2
-            else:
-                parts.append(ecs)
+                ecs = data[p:end.start()]
+                cuts = [m_.start() for m_ in _RST.finditer(ecs)] if info.dri else []
+            # (after stuffing, FF D0..D7 inside the scan can only be a restart marker)
+            parts = [ecs[a:b] for a, b in zip([0] + [c + 2 for c in cuts], cuts + [len(ecs)])]
             info.intervals = [q.replace(b"\xff\x00", b"\xff") for q in parts]
             break
         p += L
@@ -209,11 +202,21 @@ def huffman_table_bytes(spec: bytes) -> np.ndarray:
     return out
 
 
-def _words(interval: bytes) -> np.ndarray:
-    """bytes of one restart interval -> 32-bit words whose MOST significant bit is the first bit of the stream (+ 4 zero words: the
-    decoder may read ahead; libjpeg also feeds zero bits past the end of a segment)."""
-    pad = (-len(interval)) % 4
-    return np.frombuffer(interval + b"\0" * (pad + 16), dtype=">u4").astype(np.uint32)
+def _words(intervals: Sequence[bytes]):
+    """the restart intervals of one image -> (32-bit words whose MOST significant bit is the first bit of the stream, every interval
+    padded to whole words + 4 zero words: the decoder reads ahead, and libjpeg also feeds zero bits past the end of a segment;
+    word offset of every interval; its word count)"""
+    lens = [len(q) + (-len(q)) % 4 + 16 for q in intervals]
+    if len(intervals) == 1:
+        buf = intervals[0] + b"\0" * (lens[0] - len(intervals[0]))
+    else:
+        buf = b"".join(q + b"\0" * (n - len(q)) for q, n in zip(intervals, lens))
+    w = np.frombuffer(buf, dtype=">u4").astype(np.uint32)
+    offs, o = [], 0
+    for n in lens:
+        offs.append(o)
+        o += n // 4
+    return w, offs, [n // 4 for n in lens]
 
 
 def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None) -> List[torch.Tensor]:
@@ -250,13 +253,13 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
         for (tc, th), spec in f.huff.items():
             if th <= 1 and tc <= 1:
                 tables[i, (2 * tc + th) * HUFF_BYTES:(2 * tc + th + 1) * HUFF_BYTES] = huffman_table_bytes(spec)
-        per = int(a[7])
-        for k, part in enumerate(f.intervals):
-            w = _words(part)
-            seg32.append((i, k * per, min(per, f.mcux * f.mcuy - k * per), 0))
-            seg64.append((word_off, len(w)))
-            words.append(w)
-            word_off += len(w)
+        per, n_mcu = int(a[7]), f.mcux * f.mcuy
+        w, offs, cnts = _words(f.intervals)
+        for k in range(len(f.intervals)):
+            seg32.append((i, k * per, min(per, n_mcu - k * per), 0))
+            seg64.append((word_off + offs[k], cnts[k]))
+        words.append(w)
+        word_off += len(w)
     dev = torch.device(device)
     up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev, non_blocking=True)
     t_img32, t_img64, t_tab = up(img32), up(img64), up(tables)
@@ -268,7 +271,7 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
     L = _lib.load()
     st = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.check(L.nopesac_jpeg_huffman(p(t_img32), p(t_img64), p(t_tab), p(t_seg32), p(t_seg64), len(seg32), p(t_words), p(coef), st),
+    _lib.check(L.nopesac_jpeg_huffman(p(t_img32), p(t_img64), p(t_tab), p(t_seg32), p(t_seg64), len(seg32), p(t_words), int(t_words.numel()), p(coef), st),
                "nopesac_jpeg_huffman")
     _lib.check(L.nopesac_jpeg_idct(p(t_img32), p(t_img64), p(t_tab), n, n_blocks, p(coef), p(planes), st), "nopesac_jpeg_idct")
     _lib.check(L.nopesac_jpeg_color(p(t_img32), p(t_img64), n, max_px, p(planes), p(out), 1 if bgr else 0, st), "nopesac_jpeg_color")

@@ -71,3 +71,67 @@ def test_scannet_sized_frames_match_pillow(device):
     outs = jpeg.decode_batch(files, device)
     for o, r in zip(outs, refs):
         assert np.array_equal(o.cpu().numpy(), r)
+
+
+def _scannet_cfg():
+    from nopesac_amd.config import get_cfg
+    from tests.util import ROOT
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_scannet.yaml"))
+    return cfg
+
+
+def test_scannet_mapper_decodes_jpeg_on_the_gpu_like_the_host_path(device, tmp_path):
+    """data.PairMapper on JPEG frames: GPU decode + GPU resize = the host path (PIL decode, the reference's reader) + the same resize,
+    bit for bit, as float32 / uint8, on the device / on the host; a progressive file goes through PIL and is counted."""
+    import shutil
+    from nopesac_amd import data
+    cfg = _scannet_cfg()
+    src = os.path.join(GOLD, "jpeg")
+    names = ["s420_q88_scannet_like_242x324.jpg", "s444_q85_33x41.jpg", "unsupported_progressive_40x56.jpg", "gray_q80_45x31.jpg"]
+    for n in names:
+        shutil.copy(os.path.join(src, n), tmp_path / n)
+    entries = [{"0": {"file_name": str(tmp_path / names[0]), "image_id": "a-0"}, "1": {"file_name": str(tmp_path / names[1]), "image_id": "a-1"}},
+               {"0": {"file_name": str(tmp_path / names[2]), "image_id": "b-0"}, "1": {"file_name": str(tmp_path / names[3]), "image_id": "b-1"}}]
+    for uint8 in (False, True):
+        host = data.PairMapper(cfg, "scannet_test", uint8=uint8, gpu_jpeg=False)
+        gpu = data.PairMapper(cfg, "scannet_test", uint8=uint8)
+        gpu_dev = data.PairMapper(cfg, "scannet_test", device=device, uint8=uint8)
+        assert gpu._use_gpu_jpeg() and gpu_dev._use_gpu_jpeg() and not host._use_gpu_jpeg()
+        ref = [host(e) for e in entries]
+        for m in (gpu, gpu_dev):
+            got = [m(e) for e in entries]
+            batch = m.map_batch(entries)
+            for r, g, b in zip(ref, got, batch):
+                for v in "01":
+                    assert g[v]["image"].shape == (3, 480, 640) and g[v]["image"].dtype == r[v]["image"].dtype
+                    assert torch.equal(g[v]["image"].cpu(), r[v]["image"]) and torch.equal(b[v]["image"].cpu(), r[v]["image"])
+                    assert g[v]["image"].is_cuda == (m is gpu_dev)
+            assert m.host_decoded == 2                    # the progressive file, once per pass
+
+
+def test_lazy_pairs_decode_batches_ahead_on_the_gpu(device, tmp_path):
+    """data.LazyPairs.iter_batches over a JPEG split: reader threads + one decode chain per batch on side streams; same mapped dicts, in
+    order, as the host decoder gives."""
+    import shutil
+    from nopesac_amd import data
+    cfg = _scannet_cfg()
+    files = [p for p in FILES]
+    entries = []
+    for i in range(7):
+        pair = {}
+        for v in "01":
+            srcp = files[(2 * i + int(v)) % len(files)]
+            dst = tmp_path / ("%d_%s_%s" % (i, v, os.path.basename(srcp)))
+            shutil.copy(srcp, dst)
+            pair[v] = {"file_name": str(dst), "image_id": "%d-%s" % (i, v)}
+        entries.append(pair)
+    host = data.PairMapper(cfg, "scannet_test", uint8=True, gpu_jpeg=False)
+    ref = [host(e) for e in entries]
+    lazy = data.LazyPairs(entries, data.PairMapper(cfg, "scannet_test", device=device, uint8=True), workers=3, prefetch=8)
+    got = [it for batch in lazy.iter_batches(3) for it in batch]
+    assert len(got) == 7
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        for v in "01":
+            assert g[v]["image_id"] == r[v]["image_id"] and g[v]["image"].is_cuda and torch.equal(g[v]["image"].cpu(), r[v]["image"])
