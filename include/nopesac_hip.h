@@ -456,7 +456,8 @@ int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n
  *     (0 | 1), 23..25 index of its AC table (2 | 3), 26 first block of the image in the batch-wide block list, 27 its block count
  *   img64 [n_images][NOPESAC_JPEG_IMG_I64] int64: 0..2 element offset of component c's coefficients in `coef` ([block rows][blocks per
  *     row][64] int16, ZIGZAG order, DC prediction resolved), 3..5 byte offset of its sample plane in `planes` ([block rows * 8][blocks
- *     per row * 8] uint8), 6 byte offset of the image in `out` ([height][width][3] uint8)
+ *     per row * 8] uint8), 6 byte offset of the image in `out` ([height][width][3] uint8), 7 offset of the image's first interval in
+ *     `words`; img32 28 / 29: first lane / subsequence count for nopesac_jpeg_huffman_parallel (29 = 0: not a parallel image)
  *   tables [n_images][NOPESAC_JPEG_TABLES_BYTES]: Huffman tables DC0, DC1, AC0, AC1 (NOPESAC_JPEG_HUFF_BYTES each: 9-bit look-ahead
  *     uint16[512] = (code length << 8) | symbol, 0 = longer code; maxcode int32[18]; valoffset int32[18]; huffval uint8[256] - jdhuff.c's
  *     derived table), then the components' quantisation tables uint16[64] in NATURAL order
@@ -472,7 +473,21 @@ int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n
 #define NOPESAC_JPEG_SEG_I32 4
 #define NOPESAC_JPEG_SEG_I64 2
 int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32, const int64_t* seg64,
-                         int n_segments, const uint32_t* words, int64_t n_words, int16_t* coef, void* stream);
+                         int n_segments, const uint32_t* words, int64_t n_words, int16_t* coef, const int32_t* par_done, void* stream);
+/* Files WITHOUT restart markers (one serial chain of codes per image): self-synchronising parallel decode.  The stream of image i is
+ * cut into img32[i][29] subsequences of NOPESAC_JPEG_SUB_WORDS words, one lane each (lanes img32[i][28] .. of the batch-wide lane list,
+ * every image's share padded to a multiple of 64 lanes; lane_img[lane] = image; img32[i][29] = 0: the image is left to
+ * nopesac_jpeg_huffman; img64[i][7] = offset of the image's words).  Lanes decode from guessed states, then re-decode from their
+ * predecessor's exit state for NOPESAC_JPEG_SYNC_PASSES passes (csrc/jpeg.hip); an image whose lanes no longer change gets
+ * par_done[i] = 1 and its coefficients written (DC prediction resolved by a scan); par_done[i] = 0: call nopesac_jpeg_huffman with
+ * the same par_done afterwards - it decodes exactly the images still open.  Work arrays (device, n_lanes entries unless noted):
+ * exit_state, entry_used (int64, entry_used initialised to -1), n_blk (int32), first_block (int64), changed (int32
+ * [NOPESAC_JPEG_SYNC_PASSES][n_images], zeroed), par_done (int32 [n_images], zeroed). */
+#define NOPESAC_JPEG_SUB_WORDS 256
+#define NOPESAC_JPEG_SYNC_PASSES 6
+int nopesac_jpeg_huffman_parallel(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, const int32_t* lane_img,
+                                  int64_t n_lanes, const uint32_t* words, int64_t n_words, int64_t* exit_state, int64_t* entry_used,
+                                  int32_t* n_blk, int64_t* first_block, int32_t* changed, int32_t* par_done, int16_t* coef, void* stream);
 int nopesac_jpeg_idct(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, int n_blocks, const int16_t* coef,
                       uint8_t* planes, void* stream);
 int nopesac_jpeg_color(const int32_t* img32, const int64_t* img64, int n_images, int max_pixels, const uint8_t* planes, uint8_t* out,

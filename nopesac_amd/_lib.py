@@ -85,7 +85,8 @@ SIGNATURES = {
     "nopesac_clock_probe": [P, L, P],
     "nopesac_u8_to_f32": [P, P, L, P],
     "nopesac_gather_bytes": [P, P, P, P, I, P, P],
-    "nopesac_jpeg_huffman": [P, P, P, P, P, I, P, L, P, P],
+    "nopesac_jpeg_huffman": [P, P, P, P, P, I, P, L, P, P, P],
+    "nopesac_jpeg_huffman_parallel": [P, P, P, I, P, L, P, L, P, P, P, P, P, P, P, P],
     "nopesac_jpeg_idct": [P, P, P, I, I, P, P, P],
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_mlp_padded_k": [I, I],

@@ -103,10 +103,11 @@ __device__ __forceinline__ int jp_value(JpBits& b, int s) {
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
                                                           const uint8_t* __restrict__ tables, const int32_t* __restrict__ seg32,
                                                           const int64_t* __restrict__ seg64, const uint32_t* __restrict__ words,
-                                                          long long n_words, int16_t* __restrict__ coef) {
+                                                          long long n_words, int16_t* __restrict__ coef, const int32_t* __restrict__ par_done) {
     const int sg = blockIdx.x;
     c_i32 S = as_const<c_i32>(seg32 + (long long)sg * NOPESAC_JPEG_SEG_I32);
     const int im = S[0], first = S[1], count = S[2];
+    if (par_done && par_done[im]) return;                           // the image went through the self-synchronising decoder below
     c_i32 I = as_const<c_i32>(img32 + (long long)im * JP_I32);
     c_i64 I8 = as_const<c_i64>(img64 + (long long)im * JP_I64);
     const uint8_t* Tg = tables + (long long)im * JP_TABLES_BYTES;
@@ -165,6 +166,261 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(const int32_t* __restr
                 }
         }
         if (++mx == mcux) { mx = 0; ++my; }
+    }
+}
+
+// ---- Self-synchronising parallel Huffman decode (files without restart markers: one serial chain of ~250 k codes per 968 x 1296 frame,
+// 60 ms on the scalar kernel above).  The stream is cut into subsequences of JP_SUB_BITS bits, one LANE each.  A decoder started at an
+// arbitrary bit with a guessed state (block-in-MCU, coefficient index) produces garbage at first, but Huffman streams re-align: after a
+// while it sits on real code boundaries with the real state (the block phase does a random walk while it is out of step, and once it
+// coincides it stays).  Scheme (after Klein / Wiseman and Weissenberger / Schmidt):
+//   init      lane t decodes its subsequence from (bit t S, block 0, DC next) and records the state at the first code boundary >= (t+1) S
+//             (its EXIT) and the blocks it completed; lane 0 starts from the true state
+//   iterate   lane t re-decodes from lane t-1's exit whenever that differs from the entry it used last time; a fixed point is the true
+//             decode (lane 0 is true; true exits propagate at least one subsequence per pass, in practice all lanes agree after 2-4)
+//   scan      exclusive scan of the completed blocks -> first block number of every lane
+//   write     every lane decodes once more from its entry and stores the coefficients of its blocks (DC as DIFFERENCE)
+//   dc        running sum of the DC differences per component in scan order
+// An image whose lanes still changed in the last pass keeps par_done = 0 and is decoded by the scalar kernel instead.
+constexpr int JP_SUB_WORDS = NOPESAC_JPEG_SUB_WORDS, JP_SUB_BITS = JP_SUB_WORDS * 32;
+constexpr int JP_ITERS = NOPESAC_JPEG_SYNC_PASSES;
+
+struct JpLaneBits {
+    uint64_t acc;
+    int nb;
+    long long wi;                      // next word (index into the batch's word array)
+};
+__device__ __forceinline__ uint32_t jp_word(const uint32_t* __restrict__ words, long long n_words, long long i) { return i < n_words ? words[i] : 0u; }
+__device__ __forceinline__ void jp_lane_seek(JpLaneBits& b, const uint32_t* __restrict__ words, long long n_words, long long word0, long long bit) {
+    const long long w = word0 + (bit >> 5);
+    const int sh = (int)(bit & 31);
+    b.acc = (((uint64_t)jp_word(words, n_words, w) << 32) | jp_word(words, n_words, w + 1)) << sh;
+    b.nb = 64 - sh;
+    b.wi = w + 2;
+}
+__device__ __forceinline__ void jp_lane_fill(JpLaneBits& b, const uint32_t* __restrict__ words, long long n_words) {
+    if (b.nb <= 32) {
+        b.acc |= (uint64_t)jp_word(words, n_words, b.wi++) << (32 - b.nb);
+        b.nb += 32;
+    }
+}
+// tables of one image in LDS: look u16[4][512], maxcode i32[4][18], valoff i32[4][18], huffval u8[4][256]
+struct JpLdsTables {
+    unsigned short look[4][512];
+    int maxcode[4][18], valoff[4][18];
+    unsigned char huffval[4][256];
+};
+__device__ __forceinline__ int jp_lane_symbol(JpLaneBits& b, const JpLdsTables& T, int t) {
+    const unsigned e = T.look[t][(unsigned)(b.acc >> (64 - JP_LOOK))];
+    if (e >> 8) {
+        b.acc <<= (e >> 8); b.nb -= (e >> 8);
+        return e & 255;
+    }
+    int l = JP_LOOK + 1;
+    int code = (int)(b.acc >> (64 - l));
+    while (code > T.maxcode[t][l]) {
+        ++l;
+        code = (int)(b.acc >> (64 - l));
+    }
+    if (l > 16) {
+        b.acc <<= 16; b.nb -= 16;
+        return 0;
+    }
+    b.acc <<= l; b.nb -= l;
+    return T.huffval[t][(code + T.valoff[t][l]) & 255];
+}
+__device__ __forceinline__ int jp_lane_value(JpLaneBits& b, int s) {
+    if (s == 0) return 0;
+    const int v = (int)(b.acc >> (64 - s));
+    b.acc <<= s; b.nb -= s;
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+__device__ __forceinline__ long long jp_pack(long long bit, int blk, int k) { return bit | ((long long)blk << 40) | ((long long)k << 44); }
+
+// One lane's pass over its subsequence.  WRITE = false: returns the exit state and the number of completed blocks.  WRITE = true:
+// stores the coefficients of blocks first_block .. (DC differences), nothing beyond the image's last block.
+template <bool WRITE>
+__device__ __forceinline__ long long jp_lane_decode(const JpLdsTables& T, const int32_t* __restrict__ I, const int64_t* __restrict__ I8,
+                                                    const uint32_t* __restrict__ words, long long n_words, long long entry, long long end_bit,
+                                                    int& n_blocks, long long first_block, int16_t* __restrict__ coef) {
+    const long long word0 = I8[7];
+    const int hs = I[3], vs = I[4], hv = hs * vs, bpm = I[2] == 1 ? 1 : hv + 2, mcux = I[5];
+    const long long total_blocks = (long long)I[5] * I[6] * bpm;
+    long long bit = entry & ((1ll << 40) - 1);
+    int blk = (int)((entry >> 40) & 15), k = (int)((entry >> 44) & 127);
+    JpLaneBits b;
+    jp_lane_seek(b, words, n_words, word0, bit);
+    n_blocks = 0;
+    long long g = first_block;                                      // number of the block being decoded (scan order)
+    int16_t* dst = nullptr;
+    auto block_address = [&]() {
+        if (!WRITE) return;
+        dst = nullptr;
+        if (g >= total_blocks) return;
+        const long long m = g / bpm;
+        const int bb = (int)(g - m * bpm);
+        const int ci = bb < hv ? 0 : bb - hv + 1, v = bb < hv ? bb / hs : 0, h = bb < hv ? bb - v * hs : 0;
+        const int my = (int)(m / mcux), mx = (int)(m - (long long)my * mcux);
+        const int cv = ci == 0 ? vs : 1, ch = ci == 0 ? hs : 1;
+        dst = coef + I8[ci] + ((long long)(my * cv + v) * I[8 + ci] + (mx * ch + h)) * 64;
+    };
+    block_address();
+    while (true) {
+        const long long pos = (b.wi << 5) - b.nb - (word0 << 5);
+        if (pos >= end_bit) return jp_pack(pos, blk, k);
+        jp_lane_fill(b, words, n_words);
+        const int ci = blk < hv ? 0 : blk - hv + 1;
+        if (k == 0) {
+            const int s = jp_lane_symbol(b, T, I[20 + ci]);
+            const int val = jp_lane_value(b, s & 15);
+            if (WRITE && dst) dst[0] = (int16_t)val;
+            k = 1;
+        } else {
+            const int rs = jp_lane_symbol(b, T, I[23 + ci]);
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz) {
+                k += r;
+                const int val = jp_lane_value(b, sz);
+                if (WRITE && dst) dst[k & 63] = (int16_t)val;
+                ++k;
+            } else if (r == 15) {
+                k += 16;
+            } else {
+                k = 64;
+            }
+        }
+        if (k >= 64) {
+            k = 0;
+            if (++blk == bpm) blk = 0;
+            ++n_blocks;
+            ++g;
+            block_address();
+        }
+    }
+}
+
+__device__ __forceinline__ void jp_load_tables(JpLdsTables& T, const uint8_t* __restrict__ Tg) {
+    for (int t = 0; t < 4; ++t) {
+        const uint8_t* src = Tg + t * JP_HUFF_BYTES;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint32_t*>(T.look[t])[i] = reinterpret_cast<const uint32_t*>(src)[i];
+        for (int i = threadIdx.x; i < 18; i += blockDim.x) {
+            T.maxcode[t][i] = reinterpret_cast<const int32_t*>(src + 1024)[i];
+            T.valoff[t][i] = reinterpret_cast<const int32_t*>(src + 1096)[i];
+        }
+        for (int i = threadIdx.x; i < 64; i += blockDim.x) reinterpret_cast<uint32_t*>(T.huffval[t])[i] = reinterpret_cast<const uint32_t*>(src + 1168)[i];
+    }
+    __syncthreads();
+}
+
+// MODE 0 init, 1 iterate (pass number in `pass`), 2 write.  One wave = 64 consecutive subsequences of ONE image (lane_img[first lane]).
+template <int MODE>
+__global__ __launch_bounds__(64) void jpeg_sync_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
+                                                       const uint8_t* __restrict__ tables, const int32_t* __restrict__ lane_img,
+                                                       const uint32_t* __restrict__ words, long long n_words, long long* __restrict__ exit_state,
+                                                       long long* __restrict__ entry_used, int32_t* __restrict__ n_blk,
+                                                       const long long* __restrict__ first_block, int32_t* __restrict__ changed, int pass,
+                                                       int n_images, const int32_t* __restrict__ par_done, int16_t* __restrict__ coef) {
+    __shared__ JpLdsTables T;
+    const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int im = lane_img[(long long)blockIdx.x * 64];
+    if (MODE == 2 && !par_done[im]) return;
+    if (MODE == 1 && pass > 0 && changed[(pass - 1) * n_images + im] == 0) return;      // nothing moved in the previous pass: fixed point
+    const int32_t* I = img32 + (long long)im * JP_I32;
+    const int64_t* I8 = img64 + (long long)im * JP_I64;
+    jp_load_tables(T, tables + (long long)im * JP_TABLES_BYTES);
+    const int t = (int)(gid - I[28]);
+    if (t >= I[29]) return;                                          // padding lane
+    long long entry;
+    if (t == 0) entry = 0;                                           // bit 0, block 0, DC next: the true start
+    else if (MODE == 0) entry = jp_pack((long long)t * JP_SUB_BITS, 0, 0);
+    else entry = exit_state[gid - 1];
+    if (MODE == 1) {
+        if (t == 0 || entry == entry_used[gid]) return;
+        atomicAdd(&changed[pass * n_images + im], 1);
+    }
+    int nb = 0;
+    if (MODE == 2) {
+        jp_lane_decode<true>(T, I, I8, words, n_words, entry, (long long)(t + 1) * JP_SUB_BITS, nb, first_block[gid], coef);
+        return;
+    }
+    const long long ex = jp_lane_decode<false>(T, I, I8, words, n_words, entry, (long long)(t + 1) * JP_SUB_BITS, nb, 0, nullptr);
+    exit_state[gid] = ex;
+    entry_used[gid] = entry;
+    n_blk[gid] = nb;
+}
+
+// per image: converged? (no lane changed in the last pass) -> par_done; exclusive scan of the lanes' block counts
+__global__ __launch_bounds__(256) void jpeg_sync_scan_kernel(const int32_t* __restrict__ img32, const int32_t* __restrict__ n_blk,
+                                                             const int32_t* __restrict__ changed, int n_images, long long* __restrict__ first_block,
+                                                             int32_t* __restrict__ par_done) {
+    __shared__ long long wsum[4];
+    __shared__ long long carry;
+    const int im = blockIdx.x;
+    const int32_t* I = img32 + (long long)im * JP_I32;
+    const int n = I[29];
+    if (n == 0) return;                                              // not a parallel image
+    const bool ok = changed[(JP_ITERS - 1) * n_images + im] == 0;
+    if (threadIdx.x == 0) { par_done[im] = ok ? 1 : 0; carry = 0; }
+    __syncthreads();
+    if (!ok) return;
+    const long long base = I[28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const long long v = i < n ? n_blk[base + i] : 0;
+        long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        long long off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (i < n) first_block[base + i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = off + incl;
+        __syncthreads();
+    }
+}
+
+// running sum of the DC differences of component blockIdx.y of image blockIdx.x, in scan order
+__global__ __launch_bounds__(256) void jpeg_dc_kernel(const int32_t* __restrict__ img32, const int64_t* __restrict__ img64,
+                                                      const int32_t* __restrict__ par_done, int16_t* __restrict__ coef) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int im = blockIdx.x, ci = blockIdx.y;
+    const int32_t* I = img32 + (long long)im * JP_I32;
+    if (!par_done[im] || ci >= I[2]) return;
+    const int hs = ci == 0 ? I[3] : 1, vs = ci == 0 ? I[4] : 1, hv = hs * vs, mcux = I[5], bw = I[8 + ci];
+    const int n = I[5] * I[6] * hv;
+    int16_t* c = coef + img64[(long long)im * JP_I64 + ci];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        int16_t* p = nullptr;
+        if (j < n) {
+            const int m = j / hv, sub = j - m * hv, v = sub / hs, h = sub - v * hs, my = m / mcux, mx = m - my * mcux;
+            p = c + ((long long)(my * vs + v) * bw + (mx * hs + h)) * 64;
+        }
+        const int v0 = p ? (int)*p : 0;
+        int incl = v0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (p) *p = (int16_t)(off + incl);
+        __syncthreads();
+        if (threadIdx.x == 255) carry = off + incl;
+        __syncthreads();
     }
 }
 
@@ -297,12 +553,37 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* __restri
 
 extern "C" int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8_t* tables, const int32_t* seg32,
                                     const int64_t* seg64, int n_segments, const uint32_t* words, int64_t n_words, int16_t* coef,
-                                    void* stream) {
+                                    const int32_t* par_done, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(img32 && img64 && tables && seg32 && seg64 && words && coef && n_segments > 0 && n_words > 0, "jpeg_huffman: bad args");
     NPS_CHECK_ARG(((uintptr_t)tables & 3) == 0 && ((uintptr_t)coef & 15) == 0, "jpeg_huffman: tables / coef alignment");
     hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(64), 0, (hipStream_t)stream, img32, img64, tables, seg32, seg64, words,
-                       (long long)n_words, coef);
+                       (long long)n_words, coef, par_done);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_jpeg_huffman_parallel(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images,
+                                             const int32_t* lane_img, int64_t n_lanes, const uint32_t* words, int64_t n_words,
+                                             int64_t* exit_state, int64_t* entry_used, int32_t* n_blk, int64_t* first_block,
+                                             int32_t* changed, int32_t* par_done, int16_t* coef, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(img32 && img64 && tables && lane_img && words && exit_state && entry_used && n_blk && first_block && changed && par_done && coef,
+                  "jpeg_huffman_parallel: null pointer");
+    NPS_CHECK_ARG(n_images > 0 && n_lanes > 0 && n_lanes % 64 == 0 && n_words > 0, "jpeg_huffman_parallel: bad sizes (n_lanes: a multiple of 64)");
+    const dim3 grid((unsigned)(n_lanes / 64)), blk(64);
+    hipStream_t st = (hipStream_t)stream;
+    long long* ex = (long long*)exit_state;
+    long long* eu = (long long*)entry_used;
+    long long* fb = (long long*)first_block;
+    hipLaunchKernelGGL(jpeg_sync_kernel<0>, grid, blk, 0, st, img32, img64, tables, lane_img, words, (long long)n_words, ex, eu, n_blk, fb, changed, 0,
+                       n_images, par_done, coef);
+    for (int pass = 0; pass < JP_ITERS; ++pass)
+        hipLaunchKernelGGL(jpeg_sync_kernel<1>, grid, blk, 0, st, img32, img64, tables, lane_img, words, (long long)n_words, ex, eu, n_blk, fb, changed,
+                           pass, n_images, par_done, coef);
+    hipLaunchKernelGGL(jpeg_sync_scan_kernel, dim3(n_images), dim3(256), 0, st, img32, n_blk, changed, n_images, fb, par_done);
+    hipLaunchKernelGGL(jpeg_sync_kernel<2>, grid, blk, 0, st, img32, img64, tables, lane_img, words, (long long)n_words, ex, eu, n_blk, fb, changed, 0,
+                       n_images, par_done, coef);
+    hipLaunchKernelGGL(jpeg_dc_kernel, dim3(n_images, 3), dim3(256), 0, st, img32, img64, par_done, coef);
     NPS_LAUNCH_RET();
 }
 

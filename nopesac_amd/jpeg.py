@@ -30,6 +30,8 @@ LOOK_BITS = 9
 HUFF_BYTES = 1536                 # one Huffman table: look u16[512] | maxcode i32[18] | valoffset i32[18] | huffval u8[256] | pad
 TABLES_BYTES = 4 * HUFF_BYTES + 3 * 128          # DC0, DC1, AC0, AC1, then three quantisation tables u16[64] (natural order)
 IMG_I32, IMG_I64, SEG_I32, SEG_I64 = 32, 8, 4, 2
+SUB_WORDS, SYNC_PASSES = 256, 6                # NOPESAC_JPEG_SUB_WORDS / NOPESAC_JPEG_SYNC_PASSES
+PARALLEL_MIN_BYTES = 4 * SUB_WORDS * 4         # shorter restart-free streams stay on the one-wave-per-interval kernel
 
 
 _SCAN_END = re.compile(rb"\xff[^\x00\xd0-\xd7\xff]")        # (FF FF: fill bytes in front of a marker - the second FF decides)
@@ -219,17 +221,21 @@ def _words(intervals: Sequence[bytes]):
     return w, offs, [n // 4 for n in lens]
 
 
-def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None) -> List[torch.Tensor]:
+def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None, parallel: bool = True,
+                 stats: dict = None) -> List[torch.Tensor]:
     """JPEG files -> uint8 [H, W, 3] device tensors (RGB, or BGR for INPUT.FORMAT "BGR"), one launch chain for the whole batch on the
-    current stream.  Raises JpegUnsupported if any file is outside the supported subset (nothing is decoded then)."""
+    current stream.  Raises JpegUnsupported if any file is outside the supported subset (nothing is decoded then).
+    parallel: restart-free streams go through the self-synchronising decoder (nopesac_jpeg_huffman_parallel; images it does not
+    settle fall through to the one-wave-per-interval kernel on the device, no host involvement).  stats: receives the device tensors
+    "par_done" (int32 per image) and "changed" (lanes that moved per pass and image) for diagnostics."""
     infos = list(infos) if infos is not None else [parse(f) for f in files]
     n = len(infos)
     if n == 0:
         return []
     img32, img64 = np.zeros((n, IMG_I32), np.int32), np.zeros((n, IMG_I64), np.int64)
     tables = np.zeros((n, TABLES_BYTES), np.uint8)
-    seg32, seg64, words = [], [], []
-    coef_off = plane_off = out_off = word_off = 0
+    seg32, seg64, words, lane_img = [], [], [], []
+    coef_off = plane_off = out_off = word_off = n_lanes = 0
     n_blocks, max_px = 0, 0
     for i, f in enumerate(infos):
         nc = len(f.comps)
@@ -255,6 +261,13 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
                 tables[i, (2 * tc + th) * HUFF_BYTES:(2 * tc + th + 1) * HUFF_BYTES] = huffman_table_bytes(spec)
         per, n_mcu = int(a[7]), f.mcux * f.mcuy
         w, offs, cnts = _words(f.intervals)
+        img64[i, 7] = word_off
+        if parallel and not f.dri and len(f.intervals[0]) >= PARALLEL_MIN_BYTES:
+            nsub = -(-len(f.intervals[0]) * 8 // (SUB_WORDS * 32))
+            a[28], a[29] = n_lanes, nsub
+            lanes = -(-nsub // 64) * 64
+            lane_img.append(np.full(lanes, i, np.int32))
+            n_lanes += lanes
         for k in range(len(f.intervals)):
             seg32.append((i, k * per, min(per, n_mcu - k * per), 0))
             seg64.append((word_off + offs[k], cnts[k]))
@@ -271,14 +284,29 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
     L = _lib.load()
     st = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.check(L.nopesac_jpeg_huffman(p(t_img32), p(t_img64), p(t_tab), p(t_seg32), p(t_seg64), len(seg32), p(t_words), int(t_words.numel()), p(coef), st),
-               "nopesac_jpeg_huffman")
+    par_done, work = None, []
+    if n_lanes:
+        t_lane = up(np.concatenate(lane_img))
+        exit_state = torch.empty(n_lanes, device=dev, dtype=torch.int64)
+        entry_used = torch.full((n_lanes,), -1, device=dev, dtype=torch.int64)
+        n_blk = torch.zeros(n_lanes, device=dev, dtype=torch.int32)
+        first_block = torch.zeros(n_lanes, device=dev, dtype=torch.int64)
+        changed = torch.zeros(SYNC_PASSES * n, device=dev, dtype=torch.int32)
+        par_done = torch.zeros(n, device=dev, dtype=torch.int32)
+        _lib.check(L.nopesac_jpeg_huffman_parallel(p(t_img32), p(t_img64), p(t_tab), n, p(t_lane), n_lanes, p(t_words), int(t_words.numel()),
+                                                   p(exit_state), p(entry_used), p(n_blk), p(first_block), p(changed), p(par_done), p(coef), st),
+                   "nopesac_jpeg_huffman_parallel")
+        work = [t_lane, exit_state, entry_used, n_blk, first_block, changed, par_done]
+        if stats is not None:
+            stats["par_done"], stats["changed"] = par_done, changed.view(SYNC_PASSES, n)
+    _lib.check(L.nopesac_jpeg_huffman(p(t_img32), p(t_img64), p(t_tab), p(t_seg32), p(t_seg64), len(seg32), p(t_words), int(t_words.numel()), p(coef),
+                                      p(par_done) if par_done is not None else None, st), "nopesac_jpeg_huffman")
     _lib.check(L.nopesac_jpeg_idct(p(t_img32), p(t_img64), p(t_tab), n, n_blocks, p(coef), p(planes), st), "nopesac_jpeg_idct")
     _lib.check(L.nopesac_jpeg_color(p(t_img32), p(t_img64), n, max_px, p(planes), p(out), 1 if bgr else 0, st), "nopesac_jpeg_color")
     res, o = [], 0
     for f in infos:
         res.append(out[o:o + f.width * f.height * 3].view(f.height, f.width, 3))
         o += f.width * f.height * 3
-    for t in (t_img32, t_img64, t_tab, t_seg32, t_seg64, t_words, coef, planes):
+    for t in [t_img32, t_img64, t_tab, t_seg32, t_seg64, t_words, coef, planes] + work:
         t.record_stream(torch.cuda.current_stream(dev))
     return res

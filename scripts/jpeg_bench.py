@@ -31,9 +31,13 @@ for label, opt in (("no restart markers", dict(quality=90, subsampling=2)), ("re
     t0 = time.perf_counter()
     infos = [jpeg.parse(f) for f in files]
     parse_ms = 1e3 * (time.perf_counter() - t0) / N
-    outs = jpeg.decode_batch(files, dev, infos=infos)
+    st = {}
+    outs = jpeg.decode_batch(files, dev, infos=infos, stats=st)
     ref = np.asarray(Image.open(io.BytesIO(files[0])).convert("RGB"))
     assert np.array_equal(outs[0].cpu().numpy(), ref)
+    if st:
+        print("   self-synchronising decoder: %d of %d images settled; lanes that moved per pass (all images): %s of %d lanes" % (
+            int(st["par_done"].sum()), N, st["changed"].sum(1).tolist(), sum(int(i.width > 0) * -(-len(i.intervals[0]) * 8 // 8192) for i in infos)), flush=True)
     print("%s: %d KB per file; Pillow %.2f ms per image on one core; host parse + stuffing removal %.3f ms per image" % (label, len(base[0]) // 1024, pil_ms, parse_ms), flush=True)
     for n_streams in (1, 2, 4):
         streams = [torch.cuda.Stream() for _ in range(n_streams)]

@@ -135,3 +135,19 @@ def test_lazy_pairs_decode_batches_ahead_on_the_gpu(device, tmp_path):
     for r, g in zip(ref, got):
         for v in "01":
             assert g[v]["image_id"] == r[v]["image_id"] and g[v]["image"].is_cuda and torch.equal(g[v]["image"].cpu(), r[v]["image"])
+
+
+def test_self_synchronising_decoder_settles_and_matches_the_serial_kernel(device):
+    """restart-free files of >= 4 KB go through nopesac_jpeg_huffman_parallel: every image must settle (par_done) and give the bytes the
+    one-wave-per-interval kernel gives (parallel=False)"""
+    from nopesac_amd import jpeg
+    big = [p for p in FILES if os.path.getsize(p) >= 8192 and "rst" not in p]
+    assert len(big) >= 2
+    files = [open(p, "rb").read() for p in big] * 3
+    st = {}
+    a = jpeg.decode_batch(files, device, stats=st)
+    b = jpeg.decode_batch(files, device, parallel=False)
+    assert st and int(st["par_done"].sum()) == len(files), (st["par_done"].tolist(), st["changed"].tolist())
+    assert int(st["changed"][-1].sum()) == 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
