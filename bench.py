@@ -707,6 +707,10 @@ def rank_main(args):
     if rank == 0 and world == 1 and not args.no_boundary and args.dtype == "bfloat16":
         out["boundary"] = boundary_rate(model, raw, forced, B, streams=streams)
         out["boundary"]["one_pair_per_call"] = one_pair_latency(model)
+        try:
+            out["boundary"]["jpeg_decode"] = jpeg_decode_rate(device, 2 * B)
+        except Exception as e:                                  # (no Pillow on the box: the frames are encoded with it)
+            out["boundary"]["jpeg_decode"] = {"skipped": repr(e)}
     if (rank == 0 and world == 1 and not args.no_other_configs and args.dtype == "bfloat16" and not args.fp8 and args.config == "mp3d"
             and K == 32 and not args.ablate):
         del model
@@ -948,6 +952,48 @@ def one_pair_latency(model, calls=24):
         model.output_rle, model.use_hip_graph, model.graph_slots = saved
         model._graphs = {}
     return out
+
+
+def jpeg_decode_rate(device, n_images=64, rounds=3, in_flight=4):
+    """The data mapper's GPU JPEG decoder (nopesac_amd/jpeg.py, csrc/jpeg.hip; the reference decodes with PIL on host threads:
+    planercnn_transforms.py:210-227, :306-314) on ScanNet-sized frames: synthetic 968 x 1296 pictures encoded by Pillow (4:2:0, q 90,
+    no restart markers - one serial Huffman chain per file), `in_flight` batches of n_images on their own streams, files parsed
+    beforehand (the loader's reader threads do that), output checked against Pillow; + the 640 x 480 resize of every frame."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from nopesac_amd import jpeg, ops
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:968, 0:1296].astype(np.float32)
+    base = []
+    for i in range(4):
+        a = np.stack([128 + 90 * np.sin(xx / (40 + i) + yy / 90), 128 + 70 * np.cos(yy / (35 + i)) * np.sin(xx / 140), 120 + 100 * ((xx // 160 + yy // 120) % 2)], -1)
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(a + rng.normal(0, 3.0, a.shape), 0, 255).astype(np.uint8)).save(buf, format="JPEG", quality=90, subsampling=2)
+        base.append(buf.getvalue())
+    t0 = time.perf_counter()
+    refs = [np.asarray(Image.open(io.BytesIO(f)).convert("RGB")) for f in base]
+    pil_ms = 1e3 * (time.perf_counter() - t0) / len(base)
+    files = [base[i % len(base)] for i in range(n_images)]
+    infos = [jpeg.parse(f) for f in files]
+    st = {}
+    outs = jpeg.decode_batch(files, device, infos=infos, stats=st)
+    exact = all(np.array_equal(outs[i].cpu().numpy(), refs[i]) for i in range(len(base)))
+    streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        for s in streams:
+            with torch.cuda.stream(s):
+                for o in jpeg.decode_batch(files, device, infos=infos):
+                    ops.resize_bilinear_u8(o, 480, 640)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rate = rounds * in_flight * n_images / el
+    return {"images_per_s": round(rate, 0), "pairs_per_s": round(rate / 2, 0), "ms_per_batch_round": round(1e3 * el / rounds, 2), "images_per_batch": n_images,
+            "batches_in_flight": in_flight, "frame": "968x1296, 4:2:0, q90, %d KB, no restart markers" % (len(base[0]) // 1024),
+            "bit_exact_vs_pillow": bool(exact), "settled_by_the_parallel_decoder": int(st["par_done"].sum()) if st else 0,
+            "pillow_ms_per_image_one_core": round(pil_ms, 2)}
 
 
 def fp32_path_throughput(m32, raw, forced, B, steps=4):

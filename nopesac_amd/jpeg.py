@@ -222,7 +222,7 @@ def _words(intervals: Sequence[bytes]):
 
 
 def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None, parallel: bool = True,
-                 stats: dict = None) -> List[torch.Tensor]:
+                 stats: dict = None, _force_unsettled: bool = False) -> List[torch.Tensor]:
     """JPEG files -> uint8 [H, W, 3] device tensors (RGB, or BGR for INPUT.FORMAT "BGR"), one launch chain for the whole batch on the
     current stream.  Raises JpegUnsupported if any file is outside the supported subset (nothing is decoded then).
     parallel: restart-free streams go through the self-synchronising decoder (nopesac_jpeg_huffman_parallel; images it does not
@@ -293,6 +293,8 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
         first_block = torch.zeros(n_lanes, device=dev, dtype=torch.int64)
         changed = torch.zeros(SYNC_PASSES * n, device=dev, dtype=torch.int32)
         par_done = torch.zeros(n, device=dev, dtype=torch.int32)
+        if _force_unsettled:                              # test hook: pretend lanes still moved in the last pass -> the serial kernel decodes
+            changed[(SYNC_PASSES - 1) * n:] = 1
         _lib.check(L.nopesac_jpeg_huffman_parallel(p(t_img32), p(t_img64), p(t_tab), n, p(t_lane), n_lanes, p(t_words), int(t_words.numel()),
                                                    p(exit_state), p(entry_used), p(n_blk), p(first_block), p(changed), p(par_done), p(coef), st),
                    "nopesac_jpeg_huffman_parallel")

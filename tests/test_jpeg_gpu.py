@@ -151,3 +151,15 @@ def test_self_synchronising_decoder_settles_and_matches_the_serial_kernel(device
     assert int(st["changed"][-1].sum()) == 0
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_unsettled_images_fall_through_to_the_serial_kernel_on_the_device(device):
+    """an image whose lanes still moved in the last pass keeps par_done = 0: nopesac_jpeg_huffman decodes it (no host involvement)"""
+    from nopesac_amd import jpeg
+    dec = np.load(os.path.join(GOLD, "jpeg_decoded.npz"))
+    files = [open(p, "rb").read() for p in FILES]
+    st = {}
+    outs = jpeg.decode_batch(files, device, stats=st, _force_unsettled=True)
+    assert st and int(st["par_done"].sum()) == 0
+    for p, o in zip(FILES, outs):
+        assert np.array_equal(o.cpu().numpy(), dec[_name(p)]), _name(p)
