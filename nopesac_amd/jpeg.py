@@ -2,14 +2,15 @@
 libjpeg-turbo decode, NopeSAC_Net/data/planercnn_transforms.py:210-227 and :306-314).
 
 Host side (this file): marker walk, restart-interval split, removal of the byte stuffing, Huffman lookup tables - a few numpy calls
-per file, no entropy decoding.  Device side (csrc/jpeg.hip, include/nopesac_hip.h `nopesac_jpeg_*`): Huffman decode (one wave per
-restart interval - per image when the file has none - on the scalar unit), dequantisation + libjpeg's 13-bit "islow" inverse DCT,
+per file, no entropy decoding.  Device side (csrc/jpeg.hip, include/nopesac_hip.h `nopesac_jpeg_*`): Huffman decode (restart-free
+files: self-synchronising, one lane per 8192-bit subsequence; files with restart markers and streams the lanes do not settle on: one
+wave per restart interval on the scalar unit), dequantisation + libjpeg's 13-bit "islow" inverse DCT,
 "fancy" (triangle) chroma upsampling and the 16-bit fixed-point YCbCr -> RGB conversion, bit for bit what libjpeg-turbo produces with
 its default decompression parameters (tests/test_jpeg_gpu.py against Pillow-decoded fixtures and oracle/jpeg_oracle.py).
 
 Supported: SOF0 / SOF1 (baseline / extended sequential Huffman), 8-bit, ONE scan with all components, gray or YCbCr with luma sampling
 1x1 / 2x1 / 2x2 and 1x1 chroma.  Everything else (progressive, arithmetic, CMYK, multi-scan) raises JpegUnsupported: the caller
-(data.read_image_gpu) then decodes that file with PIL on the host, as the reference does for every file."""
+(data.PairMapper.decode_files) then decodes that file with PIL on the host, as the reference does for every file."""
 from __future__ import annotations
 
 import ctypes
