@@ -84,8 +84,8 @@ class PairMapper:
                                                                  if torch.cuda.is_available() else None)
 
     def _use_gpu_jpeg(self) -> bool:
-        if self.gpu_jpeg is None:
-            self.gpu_jpeg = self._resize_device is not None
+        if self.gpu_jpeg is None:                        # NOPESAC_GPU_JPEG=0: decode every file with PIL on the host (A/B runs)
+            self.gpu_jpeg = self._resize_device is not None and os.environ.get("NOPESAC_GPU_JPEG", "1") != "0"
         return bool(self.gpu_jpeg) and self._resize_device is not None
 
     def _finish_device_image(self, img_t: torch.Tensor) -> torch.Tensor:

@@ -363,6 +363,57 @@ def test_cli_runner_on_a_dataset_split_from_disk(device, tmp_path):
     assert res["pairs"]["count"] == 5 and res["timing(rank0)"]["pairs"] == 5 and res["timing(rank0)"]["batches_in_flight"] == 2
 
 
+def test_cli_runner_on_a_scannet_style_jpeg_split(device, tmp_path, monkeypatch):
+    """The runner on a ScanNet-style split on disk: 968 x 1296 JPEG frames -> reader threads (file + marker walk) -> GPU JPEG decode of
+    whole batches ahead of the consumer -> GPU resize to 480 x 640 -> batches in flight -> evaluator.  The decode is bit-exact with the
+    PIL decode the reference performs, so the run with NOPESAC_GPU_JPEG=0 (host decode) must give the same pose rows."""
+    import json
+    import os
+    from PIL import Image
+    from nopesac_amd import run
+    from tests.util import ROOT
+    rng = np.random.default_rng(12)
+    root = tmp_path / "datasets" / "scannet_dataset"
+    (root / "scannet_json").mkdir(parents=True)
+    yy, xx = np.mgrid[0:968, 0:1296].astype(np.float32)
+    entries = []
+    for k in range(3):
+        pair = {"rel_pose": {"position": [0.1 * k, 0.2, 0.3], "rotation": [1.0, 0.0, 0.0, 0.0]}}
+        for v in "01":
+            f = root / f"frame_{k}_{v}.jpg"
+            a = np.stack([128 + 90 * np.sin(xx / (30 + 7 * k) + yy / 80), 128 + 70 * np.cos(yy / (25 + 3 * int(v))) * np.sin(xx / 120),
+                          120 + 100 * ((xx // (100 + 20 * k) + yy // 90) % 2)], -1)
+            Image.fromarray(np.clip(a + rng.normal(0, 4, a.shape), 0, 255).astype(np.uint8)).save(f, format="JPEG", quality=88, subsampling=2)
+            pair[v] = {"file_name": str(f), "image_id": f"scene_{k}_{v}", "height": 480, "width": 640}
+        entries.append(pair)
+    json.dump({"categories": [], "data": entries}, open(root / "scannet_json" / "cached_set_testV2.json", "w"))
+    argv = ["--config-file", os.path.join(ROOT, "configs", "inference_scannet.yaml"), "--eval-only", "--synthetic-weights",
+            "--dataset", "scannet_test", "--datasets-dir", str(tmp_path / "datasets"), "--pairs-per-batch", "2", "--uint8-images",
+            "--inflight", "2"]
+    opts = ["MODEL.DEVICE", str(device), "MODEL.AMD.AUTOTUNE", False]
+    a = run.main(argv + ["--output", str(tmp_path / "gpu.json")] + opts)
+    monkeypatch.setenv("NOPESAC_GPU_JPEG", "0")
+    b = run.main(argv + ["--output", str(tmp_path / "host.json")] + opts)
+    assert a["pairs"]["count"] == b["pairs"]["count"] == 3
+    ja, jb = json.load(open(tmp_path / "gpu.json")), json.load(open(tmp_path / "host.json"))
+    seen = []
+
+    def same(x, y, path):
+        if isinstance(x, dict):
+            assert sorted(x) == sorted(y), path
+            for k in x:
+                same(x[k], y[k], path + "/" + k)
+        elif isinstance(x, list):
+            assert len(x) == len(y), path
+            for i, (p, q) in enumerate(zip(x, y)):
+                same(p, q, path + "/%d" % i)
+        elif isinstance(x, float):
+            assert abs(x - y) <= 1e-6 * (1 + abs(x)), (path, x, y)
+            seen.append(path)
+    same(ja["pairs"], jb["pairs"], "pairs")
+    assert len(seen) >= 2, seen
+
+
 def test_cli_runner_autotunes_and_keeps_a_routing_file(device, tmp_path):
     """bfloat16 mode of the runner: MODEL.AMD.AUTOTUNE times the kernel candidates of every conv / GEMM shape of a pairs-per-batch
     forward before the first batch, MODEL.AMD.ROUTING_FILE persists the decisions; a second run loads them and measures nothing;
