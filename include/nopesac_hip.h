@@ -483,6 +483,15 @@ int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8
  * the same par_done afterwards - it decodes exactly the images still open.  Work arrays (device, n_lanes entries unless noted):
  * exit_state, entry_used (int64, entry_used initialised to -1), n_blk (int32), first_block (int64), changed (int32
  * [NOPESAC_JPEG_SYNC_PASSES][n_images], zeroed), par_done (int32 [n_images], zeroed). */
+/* HOST function (no device work, thread-safe): one pass over the entropy-coded bytes that follow a scan header - stuffed zero bytes
+ * removed, the stream cut at RSTn markers when has_restart != 0, every interval written to `words` as 32-bit words whose most
+ * significant bit is the first bit of the stream, padded to whole words and followed by four zero words (the layout
+ * nopesac_jpeg_huffman / _parallel read).  seg_off / seg_cnt / seg_bytes [max_segs]: word offset, word count and byte length of every
+ * interval; *consumed = offset of the marker that ended the scan (or n).  Returns the number of intervals, -1 when `words` (capacity
+ * words_cap; n / 4 + 5 * max_segs + 8 always suffices) or max_segs is too small.  (RSTn inside a scan without a restart interval
+ * ends the scan like any other marker: has_restart = 0.) */
+int64_t nopesac_jpeg_prepare_scan(const uint8_t* data, int64_t n, int has_restart, uint32_t* words, int64_t words_cap, int64_t* seg_off,
+                                  int64_t* seg_cnt, int64_t* seg_bytes, int64_t max_segs, int64_t* consumed);
 #define NOPESAC_JPEG_SUB_WORDS 256
 #define NOPESAC_JPEG_SYNC_PASSES 6
 int nopesac_jpeg_huffman_parallel(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, const int32_t* lane_img,

@@ -87,13 +87,14 @@ SIGNATURES = {
     "nopesac_gather_bytes": [P, P, P, P, I, P, P],
     "nopesac_jpeg_huffman": [P, P, P, P, P, I, P, L, P, P, P],
     "nopesac_jpeg_huffman_parallel": [P, P, P, I, P, L, P, L, P, P, P, P, P, P, P, P],
+    "nopesac_jpeg_prepare_scan": [P, L, I, P, L, P, P, P, L, P],
     "nopesac_jpeg_idct": [P, P, P, I, I, P, P, P],
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],
 }
-_RESTYPE = {"nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64}
+_RESTYPE = {"nopesac_jpeg_prepare_scan": c_int64, "nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64}
 
 MLP_MAX_IN, MLP_MAX_WIDTH, MLP_MAX_LAYERS = 1280, 1024, 12       # NOPESAC_MLP_* of the header
 

@@ -606,3 +606,76 @@ extern "C" int nopesac_jpeg_color(const int32_t* img32, const int64_t* img64, in
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_pixels + 255) / 256, n_images), dim3(256), 0, (hipStream_t)stream, img32, img64, planes, out, bgr);
     NPS_LAUNCH_RET();
 }
+
+// ---- host side of the scan (plain C++, no device work): what nopesac_amd/jpeg.py did with bytes.replace / regex / numpy per file (0.25 ms,
+// under the interpreter lock) as one pass over the entropy-coded bytes, callable from many reader threads at once (ctypes releases the lock)
+extern "C" int64_t nopesac_jpeg_prepare_scan(const uint8_t* data, int64_t n, int has_restart, uint32_t* words, int64_t words_cap,
+                                             int64_t* seg_off, int64_t* seg_cnt, int64_t* seg_bytes, int64_t max_segs, int64_t* consumed) {
+    if (!data || n < 0 || !words || !seg_off || !seg_cnt || !seg_bytes || max_segs < 1 || !consumed) return -1;
+    int64_t nseg = 0, w = 0, seg_start_w = 0, nbytes = 0, i = 0;
+    uint32_t cur = 0;
+    int fill = 0;
+    auto put = [&](uint8_t b) -> bool {
+        cur = (cur << 8) | b;
+        ++nbytes;
+        if (++fill == 4) {
+            if (w >= words_cap) return false;
+            words[w++] = cur;
+            cur = 0; fill = 0;
+        }
+        return true;
+    };
+    auto close_segment = [&]() -> bool {
+        if (nseg >= max_segs) return false;
+        const int64_t real = nbytes;
+        while (fill != 0)
+            if (!put(0)) return false;
+        if (w + 4 > words_cap) return false;
+        for (int k = 0; k < 4; ++k) words[w++] = 0u;                 // the decoder reads ahead; libjpeg also feeds zero bits past the end
+        seg_off[nseg] = seg_start_w; seg_cnt[nseg] = w - seg_start_w; seg_bytes[nseg] = real;
+        ++nseg;
+        seg_start_w = w; nbytes = 0;
+        return true;
+    };
+    while (i < n) {
+        if (data[i] != 0xFF) {                                        // the run up to the next FF (1 byte in 256 of coded data): bulk copy
+            const uint8_t* q = (const uint8_t*)memchr(data + i, 0xFF, (size_t)(n - i));
+            int64_t run = q ? (int64_t)(q - (data + i)) : n - i;
+            const uint8_t* src = data + i;
+            i += run;
+            while (fill != 0 && run > 0) {
+                if (!put(*src++)) return -1;
+                --run;
+            }
+            const int64_t nw = run >> 2;
+            if (w + nw > words_cap) return -1;
+            for (int64_t k = 0; k < nw; ++k) {
+                uint32_t v;
+                memcpy(&v, src + 4 * k, 4);
+                words[w + k] = __builtin_bswap32(v);
+            }
+            w += nw; nbytes += 4 * nw; src += 4 * nw; run -= 4 * nw;
+            while (run > 0) {
+                if (!put(*src++)) return -1;
+                --run;
+            }
+            continue;
+        }
+        if (i + 1 >= n) break;                                        // a lone FF at the end of the buffer: truncated file
+        const uint8_t m = data[i + 1];
+        if (m == 0x00) {                                              // stuffed zero: the FF is data
+            if (!put(0xFF)) return -1;
+            i += 2;
+        } else if (m >= 0xD0 && m <= 0xD7 && has_restart) {          // RSTn: the interval ends
+            if (!close_segment()) return -1;
+            i += 2;
+        } else if (m == 0xFF) {                                       // fill byte in front of a marker
+            ++i;
+        } else {
+            break;                                                    // any other marker ends the scan (normally EOI)
+        }
+    }
+    if (!close_segment()) return -1;
+    *consumed = i;
+    return nseg;
+}

@@ -44,20 +44,23 @@ class JpegUnsupported(ValueError):
 
 
 class JpegInfo:
-    __slots__ = ("width", "height", "comps", "qt", "huff", "dri", "intervals", "hmax", "vmax", "mcux", "mcuy")
+    __slots__ = ("width", "height", "comps", "qt", "huff", "dri", "intervals", "hmax", "vmax", "mcux", "mcuy", "words", "seg_off", "seg_cnt",
+                 "seg_bytes")
 
 
 def _u16(b, p):
     return (b[p] << 8) | b[p + 1]
 
 
-def parse(data: bytes) -> JpegInfo:
+def parse(data: bytes, fast: bool = True) -> JpegInfo:
     """Marker segments (ITU T.81 Annex B) of one file -> geometry, tables and the entropy-coded data split at the restart markers with
-    the stuffed zero bytes removed."""
+    the stuffed zero bytes removed.  fast (default): the pass over the entropy-coded bytes runs in the library
+    (`nopesac_jpeg_prepare_scan`, host C++, interpreter lock released) and leaves the device word layout in info.words / seg_off /
+    seg_cnt / seg_bytes; fast = False: the same in Python (info.intervals = the unstuffed bytes of every interval)."""
     if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise JpegUnsupported("no SOI marker")
     info = JpegInfo()
-    info.qt, info.huff, info.dri, info.comps, info.intervals = {}, {}, 0, None, None
+    info.qt, info.huff, info.dri, info.comps, info.intervals, info.words = {}, {}, 0, None, None, None
     adobe = None
     p, n = 2, len(data)
     while p + 4 <= n:
@@ -119,6 +122,9 @@ def parse(data: bytes) -> JpegInfo:
             if (seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns]) != (0, 63, 0):
                 raise JpegUnsupported("spectral selection / successive approximation")
             p += L
+            if fast:
+                _prepare_scan(info, data, p)
+                break
             # the scan ends at the first FF that is neither stuffing nor RSTn - normally the EOI that ends the file: take the last EOI
             # and check with three memchr-speed counts that every FF before it is stuffing / a restart marker (else: regex scan)
             e = data.rfind(b"\xff\xd9")
@@ -135,7 +141,7 @@ def parse(data: bytes) -> JpegInfo:
             info.intervals = [q.replace(b"\xff\x00", b"\xff") for q in parts]
             break
         p += L
-    if info.comps is None or info.intervals is None:
+    if info.comps is None or (info.intervals is None and info.words is None):
         raise JpegUnsupported("no frame / scan")
     comps = info.comps
     if len(comps) == 1:
@@ -156,12 +162,32 @@ def parse(data: bytes) -> JpegInfo:
     info.mcux, info.mcuy = -(-info.width // (8 * info.hmax)), -(-info.height // (8 * info.vmax))
     n_mcu = info.mcux * info.mcuy
     per = info.dri if info.dri else n_mcu
-    if len(info.intervals) != -(-n_mcu // per):
-        raise JpegUnsupported("%d restart intervals for %d MCUs of %d" % (len(info.intervals), n_mcu, per))
+    n_int = len(info.seg_off) if info.words is not None else len(info.intervals)
+    if n_int != -(-n_mcu // per):
+        raise JpegUnsupported("%d restart intervals for %d MCUs of %d" % (n_int, n_mcu, per))
     for c in comps:
         c["bw"], c["bh"] = info.mcux * c["h"], info.mcuy * c["v"]
         c["dw"], c["dh"] = -(-info.width * c["h"] // info.hmax), -(-info.height * c["v"] // info.vmax)
     return info
+
+
+def _prepare_scan(info: JpegInfo, data: bytes, p: int):
+    """fast path of parse(): nopesac_jpeg_prepare_scan over data[p:]"""
+    n = len(data) - p
+    cap_segs = (n // 2 + 2) if info.dri else 1            # (an interval is at least its two marker bytes)
+    cap_segs = min(cap_segs, 1 << 20)
+    words = np.empty(n // 4 + 5 * cap_segs + 8, np.uint32)
+    so, sc, sb = (np.empty(cap_segs, np.int64) for _ in range(3))
+    consumed = ctypes.c_int64(0)
+    base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value
+    k = _lib.load().nopesac_jpeg_prepare_scan(ctypes.c_void_p(base + p), n, 1 if info.dri else 0, words.ctypes.data, words.size, so.ctypes.data,
+                                              sc.ctypes.data, sb.ctypes.data, cap_segs, ctypes.byref(consumed))
+    if k < 1:
+        raise JpegUnsupported("scan data could not be prepared")
+    if p + consumed.value + 1 >= len(data):
+        raise JpegUnsupported("truncated file (no EOI)")
+    info.seg_off, info.seg_cnt, info.seg_bytes = so[:k].tolist(), sc[:k].tolist(), sb[:k].tolist()
+    info.words = words[:info.seg_off[-1] + info.seg_cnt[-1]]
 
 
 _HUFF_CACHE = {}
@@ -261,15 +287,19 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
             if th <= 1 and tc <= 1:
                 tables[i, (2 * tc + th) * HUFF_BYTES:(2 * tc + th + 1) * HUFF_BYTES] = huffman_table_bytes(spec)
         per, n_mcu = int(a[7]), f.mcux * f.mcuy
-        w, offs, cnts = _words(f.intervals)
+        if f.words is not None:
+            w, offs, cnts, first_bytes = f.words, f.seg_off, f.seg_cnt, f.seg_bytes[0]
+        else:
+            w, offs, cnts = _words(f.intervals)
+            first_bytes = len(f.intervals[0])
         img64[i, 7] = word_off
-        if parallel and not f.dri and len(f.intervals[0]) >= PARALLEL_MIN_BYTES:
-            nsub = -(-len(f.intervals[0]) * 8 // (SUB_WORDS * 32))
+        if parallel and not f.dri and first_bytes >= PARALLEL_MIN_BYTES:
+            nsub = -(-first_bytes * 8 // (SUB_WORDS * 32))
             a[28], a[29] = n_lanes, nsub
             lanes = -(-nsub // 64) * 64
             lane_img.append(np.full(lanes, i, np.int32))
             n_lanes += lanes
-        for k in range(len(f.intervals)):
+        for k in range(len(offs)):
             seg32.append((i, k * per, min(per, n_mcu - k * per), 0))
             seg64.append((word_off + offs[k], cnts[k]))
         words.append(w)

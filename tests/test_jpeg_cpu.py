@@ -49,8 +49,14 @@ def test_product_parser_agrees_with_the_oracle_parser(path):
     """geometry, tables and restart intervals of nopesac_amd/jpeg.py (what the device kernels are fed) = the oracle's reading"""
     from nopesac_amd import jpeg
     data = open(path, "rb").read()
-    a, b = jpeg.parse(data), J.parse(data)
+    a, b = jpeg.parse(data, fast=False), J.parse(data)
     g = J.geometry(b)
+    # the library's one-pass scan preparation (the default) lays out the words the Python path does
+    fast = jpeg.parse(data)
+    w, offs, cnts = jpeg._words(a.intervals)
+    assert fast.intervals is None and np.array_equal(fast.words, w) and fast.seg_off == offs and fast.seg_cnt == cnts
+    assert fast.seg_bytes == [len(q) for q in a.intervals]
+    assert (fast.width, fast.height, fast.dri, fast.mcux, fast.mcuy) == (a.width, a.height, a.dri, a.mcux, a.mcuy)
     assert (a.width, a.height, a.mcux, a.mcuy, a.dri) == (b["W"], b["H"], g["mcux"], g["mcuy"], b["dri"])
     assert [(c["h"], c["v"], c["bw"], c["bh"], c["dw"], c["dh"], c["td"], c["ta"]) for c in a.comps] == \
            [(c["h"], c["v"], c["bw"], c["bh"], c["dw"], c["dh"], c["td"], c["ta"]) for c in b["comps"]]
