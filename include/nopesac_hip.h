@@ -456,7 +456,7 @@ int nopesac_count_nonfinite_batch(const float* const* x, const int64_t* n, int n
  *     (0 | 1), 23..25 index of its AC table (2 | 3), 26 first block of the image in the batch-wide block list, 27 its block count
  *   img64 [n_images][NOPESAC_JPEG_IMG_I64] int64: 0..2 element offset of component c's coefficients in `coef` ([block rows][blocks per
  *     row][64] int16, ZIGZAG order, DC prediction resolved), 3..5 byte offset of its sample plane in `planes` ([block rows * 8][blocks
- *     per row * 8] uint8), 6 byte offset of the image in `out` ([height][width][3] uint8), 7 offset of the image's first interval in
+ *     per row * 8] uint8), 6 byte offset (a multiple of 16) of the image in `out` ([height][width][3] uint8), 7 offset of the image's first interval in
  *     `words`; img32 28 / 29: first lane / subsequence count for nopesac_jpeg_huffman_parallel (29 = 0: not a parallel image)
  *   tables [n_images][NOPESAC_JPEG_TABLES_BYTES]: Huffman tables DC0, DC1, AC0, AC1 (NOPESAC_JPEG_HUFF_BYTES each: 9-bit look-ahead
  *     uint16[512] = (code length << 8) | symbol, 0 = longer code; maxcode int32[18]; valoffset int32[18]; huffval uint8[256] - jdhuff.c's

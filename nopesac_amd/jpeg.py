@@ -281,7 +281,7 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
         a[27] = nb
         n_blocks += nb
         img64[i, 6] = out_off
-        out_off += f.width * f.height * 3
+        out_off += -(-f.width * f.height * 3 // 16) * 16   # (16-byte aligned images: the colour kernel stores dwords)
         max_px = max(max_px, f.width * f.height)
         for (tc, th), spec in f.huff.items():
             if th <= 1 and tc <= 1:
@@ -336,10 +336,10 @@ def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Seque
                                       p(par_done) if par_done is not None else None, st), "nopesac_jpeg_huffman")
     _lib.check(L.nopesac_jpeg_idct(p(t_img32), p(t_img64), p(t_tab), n, n_blocks, p(coef), p(planes), st), "nopesac_jpeg_idct")
     _lib.check(L.nopesac_jpeg_color(p(t_img32), p(t_img64), n, max_px, p(planes), p(out), 1 if bgr else 0, st), "nopesac_jpeg_color")
-    res, o = [], 0
-    for f in infos:
+    res = []
+    for i, f in enumerate(infos):
+        o = int(img64[i, 6])
         res.append(out[o:o + f.width * f.height * 3].view(f.height, f.width, 3))
-        o += f.width * f.height * 3
     for t in [t_img32, t_img64, t_tab, t_seg32, t_seg64, t_words, coef, planes] + work:
         t.record_stream(torch.cuda.current_stream(dev))
     return res
