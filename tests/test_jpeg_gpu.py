@@ -163,3 +163,29 @@ def test_unsettled_images_fall_through_to_the_serial_kernel_on_the_device(device
     assert st and int(st["par_done"].sum()) == 0
     for p, o in zip(FILES, outs):
         assert np.array_equal(o.cpu().numpy(), dec[_name(p)]), _name(p)
+
+
+def test_parallel_decoder_on_every_sampling_mode(device):
+    """gray, 4:4:4, 4:2:2 and 4:2:0 streams long enough for the self-synchronising path (odd sizes, optimised Huffman tables as well):
+    settled, equal to the serial kernel and to Pillow"""
+    Image = pytest.importorskip("PIL.Image")
+    from nopesac_amd import jpeg
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:203, 0:317].astype(np.float32)
+    base = np.stack([128 + 100 * np.sin(xx / 11 + yy / 23), 128 + 90 * np.cos(yy / 7) * np.sin(xx / 19), 255 * ((xx // 9 + yy // 6) % 2)], -1)
+    img = np.clip(base + rng.normal(0, 10, base.shape), 0, 255).astype(np.uint8)
+    files, refs = [], []
+    for opt in (dict(subsampling=0, quality=92), dict(subsampling=1, quality=90), dict(subsampling=2, quality=95), dict(quality=93),
+                dict(subsampling=2, quality=85, optimize=True)):
+        a = img[..., 0] if "subsampling" not in opt else img
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, format="JPEG", **opt)
+        files.append(b.getvalue())
+        refs.append(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB")))
+    assert all(len(f) >= 8192 for f in files), [len(f) for f in files]
+    st = {}
+    a = jpeg.decode_batch(files, device, stats=st)
+    b = jpeg.decode_batch(files, device, parallel=False)
+    assert int(st["par_done"].sum()) == len(files), st["par_done"].tolist()
+    for x, y, r in zip(a, b, refs):
+        assert torch.equal(x, y) and np.array_equal(x.cpu().numpy(), r)
