@@ -115,22 +115,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         constexpr int SET = decltype(SETC)::value;
         vec_t (&a_reg)[A_VECS] = a_regs[SET];
         vec_t (&b_reg)[B_VECS] = b_regs[SET];
-        if constexpr (PF2) {                                   // K % 128 == 0 here: no k tail
+        if constexpr (PF2) {
             // 256 % VPR == 0: all of a thread's vectors sit at the same k -> one tap decode per tile, no branch anywhere (a 1x1 layer
-            // has Cin == K: tap 0; the dense form has ih0 = iw0 = 0)
+            // has Cin == K: tap 0; the dense form has ih0 = iw0 = 0).  k >= K (the last tile of a K that is no multiple of 128): both
+            // operands out of range -> zeros
             const int k = kt * BK + (tid % VPR) * VEC;
+            const bool kin = k < p.K;
             const int tap = k / p.Cin, c = k - tap * p.Cin;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             const unsigned tapoff = (unsigned)((kh * p.W + kw) * (int)p.x_cs + c) * 2u;
 #pragma unroll
             for (int i = 0; i < A_VECS; ++i) {
                 const bool in = (unsigned)(a_ih0[i] + kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + kw) < (unsigned)p.W;
-                const unsigned vo = in ? a_rel[i] + tapoff : OOB;       // a_rel: pixel (ih0, iw0) - may be "negative", the sum is not
+                const unsigned vo = in && kin ? a_rel[i] + tapoff : OOB;       // a_rel: pixel (ih0, iw0) - may be "negative", the sum is not
                 a_reg[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)vo, 0, 0));
             }
 #pragma unroll
             for (int i = 0; i < B_VECS; ++i)
-                b_reg[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (int)b_off[i], kt * BK * 2, 0));
+                b_reg[i] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (int)(kin ? b_off[i] : OOB), kt * BK * 2, 0));
             __builtin_amdgcn_sched_barrier(0);                 // the requests go out HERE, not after the MFMAs of the tile in LDS
             return;
         }
@@ -707,7 +709,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
         // (bf16 activations: 32-bit offsets relative to the tile's first image - see PF2 in the kernel - must cover the images one
         //  tile of BM rows can span)
         const long long span = ((long long)BM / p.rows_per_b + 2) * p.H * p.W * p.x_cs * 2;
-        if (vec == VW && p.K % 128 == 0 && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048 &&
+        if (vec == VW && (p.K % 128 == 0 || (sizeof(TA) == 2 && p.K > 128)) && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048 &&
             (sizeof(TA) != 2 || span < 0x7FFFFFFFll)) {
             hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 4>), grid, dim3(256), 0, stream, p);
             return 0;
@@ -748,7 +750,7 @@ static int launch_dtype(const ConvParams& p, hipStream_t stream) {
         // few tiles but a long K loop (K >= 4096, e.g. one pair's res5 3x3 convs: 40 workgroups of 128x64 walking 72 K-tiles, 60 us): the
         // 64x64-tile kernel with two tiles of prefetch (PF2 in conv_igemm_kernel) has twice the workgroups and half the steps and
         // took the one-pair call from 4.04 to 3.97 ms; the DMA kernel keeps these shapes only when asked for (tuner / NOPESAC_CONV_FORCE)
-        const bool pf2_small = p.K % 128 == 0 && (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (p.batched ? p.B : 1) <= 2048;
+        const bool pf2_small = p.K >= 128 && (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (p.batched ? p.B : 1) <= 2048;
         const bool dma_ok = p.use_glds && vec == 8 && p.Cin % 64 == 0 && (tiles128 >= 192 || (p.K >= 4096 && (p.force >= 3 || !pf2_small))) &&
                             (p.KH * p.KW > 1 || p.K >= 1024 || p.force >= 3) && p.KH * p.KW <= 32 &&
                             (long long)p.B * p.H * p.W * p.x_cs * 2 + ((long long)p.pad * p.W + p.pad) * p.x_cs * 2 < (1ll << 31) && (long long)p.N * p.K * 2 < (1ll << 31);

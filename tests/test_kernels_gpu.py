@@ -92,7 +92,9 @@ def test_conv2d_batched_weights(device):
                                   (2, 8, 10, 256, 70, 1, 1, 0),       # two K-tiles (no steady-state iteration), N tail
                                   (1, 8, 10, 384, 64, 1, 1, 0),       # three (one iteration, clamped second request)
                                   (1, 15, 20, 256, 128, 3, 1, 1),     # 18 K-tiles, one pair's res5-sized 3x3
-                                  (2, 12, 16, 512, 128, 1, 2, 0)])    # strided 1x1
+                                  (2, 12, 16, 512, 128, 1, 2, 0),     # strided 1x1
+                                  (2, 15, 20, 320, 128, 3, 1, 1),     # K = 2880 = 22.5 tiles: zero-filled K tail (pose-net branch conv0)
+                                  (1, 9, 7, 200, 64, 1, 1, 0)])       # K = 200: one full tile + a 72-wide tail
 def test_conv2d_small_grid_two_tile_prefetch(device, case, monkeypatch):
     """conv_igemm.hip, bf16 / K % 128 == 0 / <= 2048 tiles of 64x64: two tiles of branch-free buffer loads in flight (PF2).  The
     input is a channel slice of a wider buffer (x_cstride > Cin) and the output goes into one."""
