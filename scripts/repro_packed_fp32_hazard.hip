@@ -1,15 +1,21 @@
-// Stand-alone reproducer attempt for the round-3 finding "a wave executing packed-f32 VALU instructions gets lanes 48-63 of the results
-// corrupted while a wave of ANOTHER kernel issues MFMAs on the same SIMD" (profiles/r3_packed_fp32_hazard.txt).  The finding came from this
-// repository's own kernels (victim: ransac_score_maps_kernel built with the SLP vectoriser's v_pk_*_f32; aggressors: its MFMA conv kernels);
-// the round-3 verdict asked for a reproducer that does not depend on them.  This file has no dependency but the HIP runtime:
+// Stand-alone reproducer for the round-3 finding "results of a kernel that executes packed-f32 VALU instructions (v_pk_*_f32) are corrupted
+// while certain MFMA kernels run next to it" (profiles/r3_packed_fp32_hazard.txt, profiles/r4_packed_fp32_recheck.txt).  No dependency but
+// the HIP runtime.  What reproduces (MI355X, ROCm 7.2):
 //
-//   victim<PACKED>   every thread runs a chain of fused multiply-adds on two floats - as ONE v_pk_fma_f32 per step (PACKED = 1, inline asm)
-//                    or as two v_fma_f32 (PACKED = 0) - and stores the pair.  Deterministic: every launch must give the same bytes.
-//   aggressor<MFMA>  a long loop of v_mfma_f32_32x32x16_bf16 (MFMA = 1) or of plain v_fma_f32 (MFMA = 0) with few registers, so that victim
-//                    waves are co-resident with it on the SIMDs.
+//     victim_scoremaps   the geometry of this repository's score-map kernel (quaternion -> rotation, plane warps, normalisations, exp),
+//                        plain C; with the default target features the SLP vectoriser turns it into ~66 v_pk_*_f32 instructions
+//     aggressor_c64like  an MFMA loop shaped like the library's 3x3 conv: accumulators in VGPRs, one 16-byte LDS fragment read per MFMA,
+//                        a 16-slot register ring of weight fragments refilled from global memory, 50 KB of LDS, a barrier per round
 //
-// The victim runs alone (reference), then repeatedly on stream A while the aggressor runs on stream B; mismatching 32-bit words are counted
-// per lane.  build + run on the GPU box:  hipcc --offload-arch=gfx950 -O2 scripts/repro_packed_fp32_hazard.hip -o /tmp/repro && /tmp/repro
+//   victim next to that aggressor: a few per cent of the launches differ from the idle-GPU result;  the SAME source built with
+//   -fno-slp-vectorize (no packed-f32 instruction): never.  What does NOT reproduce: hand-written v_pk_* chains (incl. SGPR-pair sources,
+//   op_sel / neg modifiers, transcendental-fed ones) next to the same aggressor; the geometry victim next to simpler MFMA loops
+//   (accumulators in AGPRs, no global refill).  So: compiler-generated packed-f32 code + a register- / LDS-heavy MFMA neighbour.
+//
+// build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/repro_packed_fp32_hazard.hip -o /tmp/repro && /tmp/repro
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize scripts/repro_packed_fp32_hazard.hip -o /tmp/repro2 && /tmp/repro2
+// Every victim is compared with its own idle-GPU run; mismatching results are counted.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -97,6 +103,69 @@ __global__ __launch_bounds__(256) void victim_forms(f32x2* __restrict__ out, int
     out[gid] = r;
 }
 
+// ---- the geometry of the library's score-map kernel (this repository's own csrc/ransac.hip + common.h, reduced to what the kernel needs):
+// (K + 1) pose hypotheses x K matched planes, plane warp under each hypothesis, normal / parameter distances, exp(-d).  Built with the
+// default target features the SLP vectoriser packs its scalar f32 math into ~140 v_pk_*_f32; with -fno-slp-vectorize into none.
+__device__ __forceinline__ void g_quat_to_rot(const float q[4], float R[9]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+    R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
+    R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
+}
+__device__ __forceinline__ void g_warp_plane(const float p[3], const float R[9], const float t[3], float out[3]) {
+    const float f0 = p[0], f1 = -p[1], f2 = -p[2];
+    float e[3], b[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float s = __fmul_rn(R[3 * i], f0);
+        s = __fmaf_rn(R[3 * i + 1], f1, s);
+        s = __fmaf_rn(R[3 * i + 2], f2, s);
+        e[i] = __fadd_rn(s, t[i]);
+        b[i] = __fsub_rn(e[i], t[i]);
+    }
+    const float dot = e[0] * b[0] + e[1] * b[1] + e[2] * b[2];
+    const float nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]) + 1e-5f;
+    const float c = dot / (nb * nb);
+    out[0] = c * b[0]; out[1] = c * b[1]; out[2] = c * b[2];
+}
+__device__ __forceinline__ float g_norm3(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+__device__ __forceinline__ void g_normalize3(const float v[3], float o[3]) {
+    const float n = fmaxf(g_norm3(v), 1e-12f);
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+__global__ __launch_bounds__(256) void victim_scoremaps(const float* __restrict__ geo, const float* __restrict__ rot_raw,
+                                                        const float* __restrict__ trans_raw, int nq, f32x2* __restrict__ out) {
+    const int b = blockIdx.x, tid = threadIdx.x, NH = nq + 1;
+    __shared__ float sR[129 * 9], sT[129 * 3], sG[128 * 6];
+    for (int h = tid; h < NH; h += 256) {
+        const float* rr = rot_raw + ((long long)b * NH + h) * 4;
+        const float nn = fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3]), 1e-12f);
+        float q[4];
+        for (int d = 0; d < 4; ++d) q[d] = rr[d] / nn;
+        g_quat_to_rot(q, sR + 9 * h);
+        for (int d = 0; d < 3; ++d) sT[3 * h + d] = trans_raw[((long long)b * NH + h) * 3 + d];
+    }
+    for (int e = tid; e < nq * 6; e += 256) sG[e] = geo[(long long)b * nq * 6 + e];
+    __syncthreads();
+    for (int e = tid; e < NH * nq; e += 256) {
+        const int h = e / nq, j = e % nq;
+        const float* gl = sG + 6 * j;
+        const float* Rm = sR + 9 * h;
+        const float* t = sT + 3 * h;
+        const float p0[3] = {gl[0], gl[1], gl[2]}, p1[3] = {gl[3], -gl[4], -gl[5]}, z[3] = {0.f, 0.f, 0.f};
+        float w_r[3], w_rt[3], n0[3], n1v[3];
+        g_warp_plane(p0, Rm, z, w_r);
+        g_warp_plane(p0, Rm, t, w_rt);
+        g_normalize3(w_r, n0);
+        g_normalize3(p1, n1v);
+        const float d0 = n0[0] - n1v[0], d1 = n0[1] - n1v[1], d2 = n0[2] - n1v[2];
+        const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float e0 = w_rt[0] - p1[0], e1 = w_rt[1] - p1[1], e2 = w_rt[2] - p1[2];
+        const float dl2 = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        out[(long long)b * NH * nq + e] = f32x2{expf(-dn), expf(-dl2)};
+    }
+}
+
 // compiler-generated packed arithmetic fed by TRANSCENDENTAL results (v_rsq_f32 / v_exp_f32 / v_rcp_f32 - what the original victim's
 // quaternion and score math has and the kernels above lack): plain C on float2 vectors, no inline asm, so the compiler's own hazard
 // handling is what runs - exactly as in the library
@@ -142,6 +211,39 @@ __global__ __launch_bounds__(256) void aggressor_agpr(float* __restrict__ sink, 
     if (s == 12345.678f) sink[0] = s;
 }
 
+// closer to the library's conv3x3_c64_kernel: accumulators in VGPRs, one 16-byte LDS fragment read per MFMA, a 16-slot register ring of
+// weight fragments re-filled from global memory inside the loop, 50 KB of LDS (three workgroups per CU), a barrier per round
+__global__ __launch_bounds__(256, 3) void aggressor_c64like(const bf16x8* __restrict__ wfrag, float* __restrict__ sink, int rounds) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[50688];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 50688 / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+    __syncthreads();
+    bf16x8 ring[16];
+    const bf16x8* wp = wfrag + lane;
+    for (int s2 = 0; s2 < 16; ++s2) ring[s2] = wp[s2 * 64];
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t)
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds + ((t * 2816 + (lane & 31) * 144 + (lane >> 5) * 16 + ks * 32) % 50000 & ~15));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[ks % 16], af, acc[t], 0, 0, 0);
+            }
+            if (ks + 16 < 36) ring[ks % 16] = wp[(ks + 16) * 64];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) ring[s2] = wp[s2 * 64];
+    }
+    float s2 = 0.f;
+    for (int t = 0; t < 4; ++t)
+        for (int e = 0; e < 16; ++e) s2 += acc[t][e];
+    if (s2 == 12345.678f) sink[0] = s2;
+}
+
 template <int MFMA>
 __global__ __launch_bounds__(256) void aggressor(float* __restrict__ sink, int iters) {
     f32x16 acc;
@@ -172,6 +274,7 @@ static void experiment(const char* label, int victim_blocks, int launches, V lau
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     std::vector<f32x2> ref(n), got(n);
+    CK(hipMemsetAsync(d_out, 0, n * sizeof(f32x2), sa));     // (a victim may write fewer than n results)
     launch_victim(sa, d_out);
     CK(hipStreamSynchronize(sa));
     CK(hipMemcpy(ref.data(), d_out, n * sizeof(f32x2), hipMemcpyDeviceToHost));
@@ -217,6 +320,9 @@ extern "C" void repro_victim_forms(void* out, int blocks, int steps, void* strea
 extern "C" void repro_victim_trans(void* out, int blocks, int steps, void* stream) {
     hipLaunchKernelGGL(victim_trans, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f32x2*)out, steps);
 }
+extern "C" void repro_aggressor_c64like(void* wfrag, void* sink, int blocks, int rounds, void* stream) {
+    hipLaunchKernelGGL(aggressor_c64like, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)wfrag, (float*)sink, rounds);
+}
 extern "C" void repro_aggressor_mfma(void* sink, int blocks, int iters, void* stream) {
     hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters);
 }
@@ -228,7 +334,7 @@ int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, %d CUs\n", prop.gcnArchName, prop.multiProcessorCount);
-    const int cus = prop.multiProcessorCount, steps = 4000, launches = 200;
+    const int cus = prop.multiProcessorCount, steps = 4000, launches = 400;
     auto none = [](hipStream_t, float*) { return false; };
     auto mfma = [&](int blocks, int iters) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, s, sink, iters); return true; }; };
     auto valu = [&](int blocks, int iters) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor<0>, dim3(blocks), dim3(256), 0, s, sink, iters); return true; }; };
@@ -254,6 +360,34 @@ int main() {
     experiment("transcendental -> packed victim, no aggressor", 4 * cus, launches, vt(4 * cus), none);
     experiment("transcendental -> packed victim next to an MFMA aggressor", 4 * cus, launches, vt(4 * cus), mfma(2 * cus, 12000000));
     experiment("transcendental -> packed victim next to an AGPR + LDS MFMA aggressor (3 blocks per CU)", 4 * cus, launches, vt(4 * cus), agpr(3 * cus, 3000000));
+    bf16x8* d_w;
+    CK(hipMalloc(&d_w, 36 * 64 * sizeof(bf16x8)));
+    CK(hipMemset(d_w, 0x3c, 36 * 64 * sizeof(bf16x8)));
+    auto c64 = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_c64like, dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
+    experiment("packed chain victim next to the c64-like aggressor", 2 * cus, launches, v1p(2 * cus), c64(20 * cus, 60));
+    experiment("dense packed victim next to the c64-like aggressor", 4 * cus, launches, v8p(4 * cus), c64(20 * cus, 60));
+    experiment("operand-form victim next to the c64-like aggressor", 4 * cus, launches, vf(4 * cus), c64(20 * cus, 60));
+    experiment("transcendental -> packed victim next to the c64-like aggressor", 4 * cus, launches, vt(4 * cus), c64(20 * cus, 60));
+    experiment("dense SCALAR victim next to the c64-like aggressor", 4 * cus, launches, v8s(4 * cus), c64(20 * cus, 60));
+    {   // the score-map geometry: 32 pairs x 51 hypotheses x 50 planes, constant pseudo-random inputs
+        const int B = 32, nq = 50, NH = 51;
+        std::vector<float> hg(B * nq * 6), hr(B * NH * 4), ht(B * NH * 3);
+        unsigned x = 12345u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+        for (auto& v : hg) v = rnd();
+        for (auto& v : hr) v = rnd();
+        for (auto& v : ht) v = rnd();
+        float *dg, *dr, *dt;
+        CK(hipMalloc(&dg, hg.size() * 4)); CK(hipMalloc(&dr, hr.size() * 4)); CK(hipMalloc(&dt, ht.size() * 4));
+        CK(hipMemcpy(dg, hg.data(), hg.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+        const int out_blocks = (B * NH * nq + 255) / 256;         // experiment() sizes the output as blocks x 256 pairs
+        auto vs = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_scoremaps, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o); };
+        experiment("score-map geometry victim (as compiled: see the v_pk count), no aggressor", out_blocks, launches, vs, none);
+        experiment("score-map geometry victim next to an MFMA loop", out_blocks, launches, vs, mfma(2 * cus, 12000000));
+        experiment("score-map geometry victim next to the c64-like aggressor", out_blocks, launches, vs, c64(20 * cus, 1500));
+    }
     experiment("dense scalar victim next to an AGPR + LDS MFMA aggressor (3 blocks per CU)", 4 * cus, launches, v8s(4 * cus), agpr(3 * cus, 3000000));
     return 0;
 }

@@ -27,12 +27,16 @@ s512, b512, s128, b128 = torch.ones(512, device=dev), torch.zeros(512, device=de
 x64, w64 = bf(64, 120, 160, 64).relu(), bf(64, 3, 3, 64)
 s64, b64 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
 sink = torch.zeros(16, device=dev)
+R.repro_aggressor_c64like.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+R.repro_aggressor_c64like.restype = None
+wfrag = (torch.randn(36 * 64 * 8, device=dev) * 0.1).bfloat16()
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 st = lambda s: ctypes.c_void_p(s.cuda_stream)
 lib_aggr = {"library res3 tail": lambda: ops.bottleneck_tail(xb3, w3f, s512, b512, residual=res3, w1=w1f, s1=s128, b1=b128),
             "library conv3x3_c64": lambda: ops.conv3x3_c64(x64, w64, s64, b64)}
 syn_aggr = {"stand-alone MFMA loop (2 blocks per CU)": lambda: R.repro_aggressor_mfma(sink.data_ptr(), 512, 400000, st(sb)),
-            "stand-alone AGPR + LDS MFMA loop (3 blocks per CU)": lambda: R.repro_aggressor_agpr(sink.data_ptr(), 768, 100000, st(sb))}
+            "stand-alone AGPR + LDS MFMA loop (3 blocks per CU)": lambda: R.repro_aggressor_agpr(sink.data_ptr(), 768, 100000, st(sb)),
+            "stand-alone c64-like loop (VGPR acc, LDS fragments, ring)": lambda: R.repro_aggressor_c64like(wfrag.data_ptr(), sink.data_ptr(), 5120, 4, st(sb))}
 ref = lib_victim()
 torch.cuda.synchronize()
 for name, agg in list(lib_aggr.items()) + list(syn_aggr.items()):
