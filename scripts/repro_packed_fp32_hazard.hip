@@ -7,10 +7,12 @@
 //     aggressor_c64like  an MFMA loop shaped like the library's 3x3 conv: accumulators in VGPRs, one 16-byte LDS fragment read per MFMA,
 //                        a 16-slot register ring of weight fragments refilled from global memory, 50 KB of LDS, a barrier per round
 //
-//   victim next to that aggressor: a few per cent of the launches differ from the idle-GPU result;  the SAME source built with
-//   -fno-slp-vectorize (no packed-f32 instruction): never.  What does NOT reproduce: hand-written v_pk_* chains (incl. SGPR-pair sources,
-//   op_sel / neg modifiers, transcendental-fed ones) next to the same aggressor; the geometry victim next to simpler MFMA loops
-//   (accumulators in AGPRs, no global refill).  So: compiler-generated packed-f32 code + a register- / LDS-heavy MFMA neighbour.
+//   victim next to that aggressor: ~100 of 400 launches differ from the idle-GPU result;  the SAME source built with -fno-slp-vectorize
+//   (no packed-f32 instruction): never.  Bisected here as well: the aggressor still disturbs without its LDS reads OR without its global
+//   refill, but not without both; nothing but MFMAs (VGPR or AGPR destinations), MFMA into AGPRs + LDS reads, VALU-only loops with 128 /
+//   168 VGPRs per wave and wave-launch storms never do; hand-written v_pk_* chains (SGPR-pair sources, op_sel / neg modifiers,
+//   transcendental-fed) are never disturbed; the victim's tables may live in global memory instead of LDS.  So: compiler-generated
+//   packed-f32 code + a neighbour that issues MFMAs into VGPR tiles while loads return into its VGPRs.
 //
 // build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/repro_packed_fp32_hazard.hip -o /tmp/repro && /tmp/repro
@@ -133,10 +135,16 @@ __device__ __forceinline__ void g_normalize3(const float v[3], float o[3]) {
     const float n = fmaxf(g_norm3(v), 1e-12f);
     o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
 }
+// USE_LDS = 0: the rotation / translation / geometry tables live in global scratch memory instead of LDS (is the victim's LDS use needed?)
+template <int USE_LDS>
 __global__ __launch_bounds__(256) void victim_scoremaps(const float* __restrict__ geo, const float* __restrict__ rot_raw,
-                                                        const float* __restrict__ trans_raw, int nq, f32x2* __restrict__ out) {
+                                                        const float* __restrict__ trans_raw, int nq, f32x2* __restrict__ out,
+                                                        float* __restrict__ scratch) {
     const int b = blockIdx.x, tid = threadIdx.x, NH = nq + 1;
-    __shared__ float sR[129 * 9], sT[129 * 3], sG[128 * 6];
+    __shared__ float lR[USE_LDS ? 129 * 9 : 1], lT[USE_LDS ? 129 * 3 : 1], lG[USE_LDS ? 128 * 6 : 1];
+    float* sR = USE_LDS ? lR : scratch + (long long)b * 2400;
+    float* sT = USE_LDS ? lT : sR + 129 * 9;
+    float* sG = USE_LDS ? lG : sT + 129 * 3;
     for (int h = tid; h < NH; h += 256) {
         const float* rr = rot_raw + ((long long)b * NH + h) * 4;
         const float nn = fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3]), 1e-12f);
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) void victim_scoremaps(const float* __restrict_
         for (int d = 0; d < 3; ++d) sT[3 * h + d] = trans_raw[((long long)b * NH + h) * 3 + d];
     }
     for (int e = tid; e < nq * 6; e += 256) sG[e] = geo[(long long)b * nq * 6 + e];
+    if (!USE_LDS) __threadfence_block();
     __syncthreads();
     for (int e = tid; e < NH * nq; e += 256) {
         const int h = e / nq, j = e % nq;
@@ -211,8 +220,60 @@ __global__ __launch_bounds__(256) void aggressor_agpr(float* __restrict__ sink, 
     if (s == 12345.678f) sink[0] = s;
 }
 
+// the minimal pair: nothing but MFMAs, four accumulator tiles, destination registers forced into VGPRs (ACC_VGPR = 1) or AGPRs (0)
+template <int ACC_VGPR>
+__global__ __launch_bounds__(256, 3) void aggressor_pure(float* __restrict__ sink, int iters) {
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t)
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (threadIdx.x & 7)); b[e] = (__bf16)(0.002f * (threadIdx.x & 3)); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (ACC_VGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(a), "v"(b));
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t)
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+// wave-launch storm: very many very short workgroups (WORK = 0: a few VALU operations; WORK = 1: a few MFMAs) - is it the neighbour's
+// instructions or the LAUNCHING of its waves (register initialisation by the dispatcher) that disturbs the victim?
+template <int WORK>
+__global__ __launch_bounds__(256) void aggressor_storm(float* __restrict__ sink, int reps) {
+    float s = threadIdx.x * 0.5f;
+    if (WORK == 0) {
+        for (int i = 0; i < reps; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s) : "v"(1.0000001f), "v"(1e-6f));
+    } else {
+        f32x16 acc;
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (threadIdx.x & 7)); b[e] = (__bf16)(0.002f * (threadIdx.x & 3)); }
+        for (int i = 0; i < reps; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) s += acc[e];
+    }
+    if (s == 12345.678f) sink[0] = s;
+}
+
+// no MFMA, no LDS: a VALU spin loop whose only special property is its REGISTER ALLOCATION (v127 / v167 marked as used: 128 / 168 VGPRs
+// per wave, like the library's conv / tail kernels) - a co-resident victim wave then gets its registers from a different part of the file
+template <int NREG>
+__global__ __launch_bounds__(256) void aggressor_bigreg(float* __restrict__ sink, int iters) {
+    float s = threadIdx.x * 0.5f;
+    for (int i = 0; i < iters; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s) : "v"(1.0000001f), "v"(1e-6f));
+    if (NREG == 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+    if (NREG == 168) asm volatile("v_mov_b32 v167, 0" ::: "v167");
+    if (s == 12345.678f) sink[0] = s;
+}
+
 // closer to the library's conv3x3_c64_kernel: accumulators in VGPRs, one 16-byte LDS fragment read per MFMA, a 16-slot register ring of
 // weight fragments re-filled from global memory inside the loop, 50 KB of LDS (three workgroups per CU), a barrier per round
+// USE_LDS = 0: the MFMA's second operand is a register constant (no LDS reads);  REFILL = 0: the weight ring is loaded once
+template <int USE_LDS, int REFILL>
 __global__ __launch_bounds__(256, 3) void aggressor_c64like(const bf16x8* __restrict__ wfrag, float* __restrict__ sink, int rounds) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[50688];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -229,14 +290,17 @@ __global__ __launch_bounds__(256, 3) void aggressor_c64like(const bf16x8* __rest
         for (int ks = 0; ks < 36; ++ks) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds + ((t * 2816 + (lane & 31) * 144 + (lane >> 5) * 16 + ks * 32) % 50000 & ~15));
+                bf16x8 af = ring[(ks + t) % 16];
+                if (USE_LDS) af = *reinterpret_cast<const bf16x8*>(lds + ((t * 2816 + (lane & 31) * 144 + (lane >> 5) * 16 + ks * 32) % 50000 & ~15));
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[ks % 16], af, acc[t], 0, 0, 0);
             }
-            if (ks + 16 < 36) ring[ks % 16] = wp[(ks + 16) * 64];
+            if (REFILL && ks + 16 < 36) ring[ks % 16] = wp[(ks + 16) * 64];
         }
         __syncthreads();
+        if (REFILL) {
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) ring[s2] = wp[s2 * 64];
+            for (int s2 = 0; s2 < 16; ++s2) ring[s2] = wp[s2 * 64];
+        }
     }
     float s2 = 0.f;
     for (int t = 0; t < 4; ++t)
@@ -321,7 +385,7 @@ extern "C" void repro_victim_trans(void* out, int blocks, int steps, void* strea
     hipLaunchKernelGGL(victim_trans, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f32x2*)out, steps);
 }
 extern "C" void repro_aggressor_c64like(void* wfrag, void* sink, int blocks, int rounds, void* stream) {
-    hipLaunchKernelGGL(aggressor_c64like, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)wfrag, (float*)sink, rounds);
+    hipLaunchKernelGGL((aggressor_c64like<1, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)wfrag, (float*)sink, rounds);
 }
 extern "C" void repro_aggressor_mfma(void* sink, int blocks, int iters, void* stream) {
     hipLaunchKernelGGL(aggressor<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters);
@@ -363,7 +427,9 @@ int main() {
     bf16x8* d_w;
     CK(hipMalloc(&d_w, 36 * 64 * sizeof(bf16x8)));
     CK(hipMemset(d_w, 0x3c, 36 * 64 * sizeof(bf16x8)));
-    auto c64 = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_c64like, dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
+    auto c64 = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<1, 1>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
+    auto c64_nolds = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<0, 1>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
+    auto c64_norefill = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<1, 0>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
     experiment("packed chain victim next to the c64-like aggressor", 2 * cus, launches, v1p(2 * cus), c64(20 * cus, 60));
     experiment("dense packed victim next to the c64-like aggressor", 4 * cus, launches, v8p(4 * cus), c64(20 * cus, 60));
     experiment("operand-form victim next to the c64-like aggressor", 4 * cus, launches, vf(4 * cus), c64(20 * cus, 60));
@@ -383,10 +449,32 @@ int main() {
         CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
         const int out_blocks = (B * NH * nq + 255) / 256;         // experiment() sizes the output as blocks x 256 pairs
-        auto vs = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_scoremaps, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o); };
+        float* dscr;
+        CK(hipMalloc(&dscr, (size_t)B * 2400 * 4));
+        auto vs = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_scoremaps<1>, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o, dscr); };
+        auto vsg = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_scoremaps<0>, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o, dscr); };
         experiment("score-map geometry victim (as compiled: see the v_pk count), no aggressor", out_blocks, launches, vs, none);
         experiment("score-map geometry victim next to an MFMA loop", out_blocks, launches, vs, mfma(2 * cus, 12000000));
         experiment("score-map geometry victim next to the c64-like aggressor", out_blocks, launches, vs, c64(20 * cus, 1500));
+        experiment("   the victim's tables in global memory instead of LDS, same aggressor", out_blocks, launches, vsg, c64(20 * cus, 1500));
+        experiment("   LDS victim, aggressor WITHOUT its LDS fragment reads", out_blocks, launches, vs, c64_nolds(20 * cus, 1500));
+        experiment("   LDS victim, aggressor WITHOUT the weight-ring refill from global memory", out_blocks, launches, vs, c64_norefill(20 * cus, 1500));
+        auto pure_v = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_pure<1>, dim3(3 * cus), dim3(256), 0, s, sink, 3000000); return true; };
+        auto pure_a = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_pure<0>, dim3(3 * cus), dim3(256), 0, s, sink, 3000000); return true; };
+        auto c64_bare = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<0, 0>), dim3(20 * cus), dim3(256), 0, s, d_w, sink, 1500); return true; };
+        experiment("   aggressor with NEITHER LDS reads NOR refill (MFMAs on a loaded-once ring + a barrier per round)", out_blocks, launches, vs, c64_bare);
+        auto big128 = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_bigreg<128>, dim3(3 * cus), dim3(256), 0, s, sink, 40000000); return true; };
+        auto big168 = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_bigreg<168>, dim3(3 * cus), dim3(256), 0, s, sink, 40000000); return true; };
+        auto big0 = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_bigreg<0>, dim3(3 * cus), dim3(256), 0, s, sink, 40000000); return true; };
+        experiment("   next to a VALU-only spin loop that allocates 128 VGPRs per wave (no MFMA, no LDS)", out_blocks, launches, vs, big128);
+        experiment("   next to a VALU-only spin loop that allocates 168 VGPRs per wave", out_blocks, launches, vs, big168);
+        experiment("   next to the same spin loop with a handful of VGPRs", out_blocks, launches, vs, big0);
+        auto storm_v = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_storm<0>, dim3(4000000), dim3(256), 0, s, sink, 64); return true; };
+        auto storm_m = [=](hipStream_t s, float* sink) { hipLaunchKernelGGL(aggressor_storm<1>, dim3(4000000), dim3(256), 0, s, sink, 16); return true; };
+        experiment("   next to a wave-launch storm of short VALU-only workgroups (no MFMA anywhere)", out_blocks, launches, vs, storm_v);
+        experiment("   next to a wave-launch storm of short MFMA workgroups", out_blocks, launches, vs, storm_m);
+        experiment("   next to NOTHING BUT MFMAs whose destination tiles are VGPRs (3 blocks per CU)", out_blocks, launches, vs, pure_v);
+        experiment("   next to NOTHING BUT MFMAs whose destination tiles are AGPRs (3 blocks per CU)", out_blocks, launches, vs, pure_a);
     }
     experiment("dense scalar victim next to an AGPR + LDS MFMA aggressor (3 blocks per CU)", 4 * cus, launches, v8s(4 * cus), agpr(3 * cus, 3000000));
     return 0;
