@@ -175,6 +175,43 @@ __global__ __launch_bounds__(256) void victim_scoremaps(const float* __restrict_
     }
 }
 
+// pieces of the geometry victim on their own (plain C, compiler-packed): PART 0 = the two plane warps only, 1 = the normalisations +
+// distances only (IEEE divisions and square roots), 2 = rotation-matrix build only
+template <int PART>
+__global__ __launch_bounds__(256) void victim_part(const float* __restrict__ geo, const float* __restrict__ rot_raw,
+                                                   const float* __restrict__ trans_raw, int nq, f32x2* __restrict__ out) {
+    const int b = blockIdx.x, tid = threadIdx.x, NH = nq + 1;
+    for (int e = tid; e < NH * nq; e += 256) {
+        const int h = e / nq, j = e % nq;
+        const float* gl = geo + ((long long)b * nq + j) * 6;
+        const float* rr = rot_raw + ((long long)b * NH + h) * 4;
+        const float* t = trans_raw + ((long long)b * NH + h) * 3;
+        float x = 0.f, y = 0.f;
+        if (PART == 0) {
+            float Rm[9] = {rr[0], rr[1], rr[2], rr[3], rr[0] + rr[1], rr[1] - rr[2], rr[2] * 0.5f, rr[3] * 0.5f, rr[0] - rr[3]};
+            const float p0[3] = {gl[0], gl[1], gl[2]}, z[3] = {0.f, 0.f, 0.f}, tt[3] = {t[0], t[1], t[2]};
+            float w_r[3], w_rt[3];
+            g_warp_plane(p0, Rm, z, w_r);
+            g_warp_plane(p0, Rm, tt, w_rt);
+            x = w_r[0] + w_r[1] + w_r[2]; y = w_rt[0] + w_rt[1] + w_rt[2];
+        } else if (PART == 1) {
+            const float a[3] = {gl[0] + rr[0], gl[1] + rr[1], gl[2] + rr[2]}, c[3] = {gl[3], -gl[4], -gl[5]}, d[3] = {t[0] + gl[0], t[1] + gl[1], t[2] + gl[2]};
+            float n0[3], n1[3], n2[3];
+            g_normalize3(a, n0); g_normalize3(c, n1); g_normalize3(d, n2);
+            const float d0 = n0[0] - n1[0], d1 = n0[1] - n1[1], d2 = n0[2] - n1[2];
+            const float e0 = n2[0] - c[0], e1 = n2[1] - c[1], e2 = n2[2] - c[2];
+            x = sqrtf(d0 * d0 + d1 * d1 + d2 * d2); y = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        } else {
+            const float nn = fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3]), 1e-12f);
+            float q[4], Rm[9];
+            for (int d = 0; d < 4; ++d) q[d] = rr[d] / nn;
+            g_quat_to_rot(q, Rm);
+            x = Rm[0] + Rm[1] + Rm[2] + Rm[3] + Rm[4]; y = Rm[5] + Rm[6] + Rm[7] + Rm[8];
+        }
+        out[(long long)b * NH * nq + e] = f32x2{x, y};
+    }
+}
+
 // compiler-generated packed arithmetic fed by TRANSCENDENTAL results (v_rsq_f32 / v_exp_f32 / v_rcp_f32 - what the original victim's
 // quaternion and score math has and the kernels above lack): plain C on float2 vectors, no inline asm, so the compiler's own hazard
 // handling is what runs - exactly as in the library
@@ -196,6 +233,29 @@ __global__ __launch_bounds__(256) void victim_trans(f32x2* __restrict__ out, int
     }
     f32x2 r = acc[0];
     for (int k = 1; k < 4; ++k) r = r + acc[k];
+    out[gid] = r;
+}
+
+// hand-written packed chains WITH loads returning into the victim's own registers while they run (the geometry victim reads its tables
+// in the loop; the chain victims above touch no memory): SRC = 0 global memory, 1 LDS
+template <int SRC>
+__global__ __launch_bounds__(256) void victim8_loads(const f32x2* __restrict__ tab, f32x2* __restrict__ out, int steps) {
+    __shared__ f32x2 ltab[1024];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += 256) ltab[i] = tab[i];
+    __syncthreads();
+    f32x2 acc[4];
+    for (int k = 0; k < 4; ++k) acc[k] = f32x2{1.0f + 1e-3f * ((gid + 37 * k) & 1023), 2.0f - 1e-3f * ((gid + 11 * k) & 511)};
+    const f32x2 b = {1e-4f, -1e-4f};
+    for (int i = 0; i < steps; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 a = SRC ? ltab[(gid * 7 + i * 13 + k * 101) & 1023] : tab[(gid * 7 + i * 13 + k * 101) & 1023];
+            asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %2\n\tv_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc[k]) : "v"(a), "v"(b));
+        }
+    }
+    f32x2 r = acc[0];
+    for (int k = 1; k < 4; ++k) { r.x += acc[k].x; r.y += acc[k].y; }
     out[gid] = r;
 }
 
@@ -430,6 +490,17 @@ int main() {
     auto c64 = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<1, 1>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
     auto c64_nolds = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<0, 1>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
     auto c64_norefill = [&](int blocks, int rounds) { return [=](hipStream_t s, float* sink) { hipLaunchKernelGGL((aggressor_c64like<1, 0>), dim3(blocks), dim3(256), 0, s, d_w, sink, rounds); return true; }; };
+    {
+        std::vector<f32x2> ht(1024);
+        for (int i = 0; i < 1024; ++i) ht[i] = f32x2{1.0f + 1e-7f * (i % 7), 1.0f - 1e-7f * (i % 5)};
+        f32x2* dtab;
+        CK(hipMalloc(&dtab, 1024 * sizeof(f32x2)));
+        CK(hipMemcpy(dtab, ht.data(), 1024 * sizeof(f32x2), hipMemcpyHostToDevice));
+        auto vlg = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim8_loads<0>, dim3(4 * cus), dim3(256), 0, s, dtab, o, steps / 4); };
+        auto vll = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim8_loads<1>, dim3(4 * cus), dim3(256), 0, s, dtab, o, steps / 4); };
+        experiment("packed chains fed by GLOBAL loads in the loop, next to the c64-like aggressor", 4 * cus, launches, vlg, c64(20 * cus, 1500));
+        experiment("packed chains fed by LDS loads in the loop, next to the c64-like aggressor", 4 * cus, launches, vll, c64(20 * cus, 1500));
+    }
     experiment("packed chain victim next to the c64-like aggressor", 2 * cus, launches, v1p(2 * cus), c64(20 * cus, 60));
     experiment("dense packed victim next to the c64-like aggressor", 4 * cus, launches, v8p(4 * cus), c64(20 * cus, 60));
     experiment("operand-form victim next to the c64-like aggressor", 4 * cus, launches, vf(4 * cus), c64(20 * cus, 60));
@@ -456,6 +527,12 @@ int main() {
         experiment("score-map geometry victim (as compiled: see the v_pk count), no aggressor", out_blocks, launches, vs, none);
         experiment("score-map geometry victim next to an MFMA loop", out_blocks, launches, vs, mfma(2 * cus, 12000000));
         experiment("score-map geometry victim next to the c64-like aggressor", out_blocks, launches, vs, c64(20 * cus, 1500));
+        auto vp0 = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_part<0>, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o); };
+        auto vp1 = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_part<1>, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o); };
+        auto vp2 = [=](hipStream_t s, f32x2* o) { hipLaunchKernelGGL(victim_part<2>, dim3(B), dim3(256), 0, s, dg, dr, dt, nq, o); };
+        experiment("   only the two plane warps (compiler-packed), same aggressor", out_blocks, launches, vp0, c64(20 * cus, 1500));
+        experiment("   only the normalisations + distances (divisions, square roots), same aggressor", out_blocks, launches, vp1, c64(20 * cus, 1500));
+        experiment("   only the quaternion -> rotation build, same aggressor", out_blocks, launches, vp2, c64(20 * cus, 1500));
         experiment("   the victim's tables in global memory instead of LDS, same aggressor", out_blocks, launches, vsg, c64(20 * cus, 1500));
         experiment("   LDS victim, aggressor WITHOUT its LDS fragment reads", out_blocks, launches, vs, c64_nolds(20 * cus, 1500));
         experiment("   LDS victim, aggressor WITHOUT the weight-ring refill from global memory", out_blocks, launches, vs, c64_norefill(20 * cus, 1500));
