@@ -583,6 +583,16 @@ int nopesac_transformer_tail_bf16(const void* attn, const float* src, const void
                                   void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
                                   void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
                                   void* stream);
+/* The same launch + a weight prefetch for the NEXT one (few workgroups - one pair per call): next_ptrs / next_bytes = HOST arrays of up to
+ * 8 device byte ranges (the next tail's wo / w1 / w2 and projection matrices), next_workgroups = the next launch's workgroup count; with
+ * at most 64 layer workgroups in THIS launch, 128 extra workgroups read those ranges into the L2s of the XCDs the next launch will
+ * run on and exit (csrc/enc_tail.hip, like nopesac_gnn_layer_bf16_pf).  n_next = 0: exactly nopesac_transformer_tail_bf16. */
+int nopesac_transformer_tail_bf16_pf(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
+                                     const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                     const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                     void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
+                                     void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
+                                     const void* const* next_ptrs, const int64_t* next_bytes, int n_next, int next_workgroups, void* stream);
 
 /* ---- COCO RLE of the kept plane masks (replaces pycocotools.mask.encode / toBbox at
  *      meta_arch/siamese_planeTR.py:703-704, 747-748; consumed by evaluation/mp3d_evaluation.py:203-205) ----

@@ -38,6 +38,7 @@ SIGNATURES = {
     "nopesac_mask_operands": [P, I, P, P, I, I, I, P],
     "nopesac_decoder_tail_bf16": [P] * 13 + [I] + [P] * 4 + [I, P],
     "nopesac_transformer_tail_bf16": [P] * 13 + [I] + [P] * 4 + [I, I, P, P, P, I, P, P, P, I, I, P],
+    "nopesac_transformer_tail_bf16_pf": [P] * 13 + [I] + [P] * 4 + [I, I, P, P, P, I, P, P, P, I, I, P, P, I, I, P],
     "nopesac_conv3x3_c64_bf16": [P, P, P, P, P, I, I, I, I, P],
     "nopesac_conv3x3_halo_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, P],
     "nopesac_rle_labels": [P, P, P, P, P, I, I, I, I, P],

@@ -29,6 +29,7 @@ constexpr int ET_A = ET_BM * ET_LD;                      // elements of one [32]
 constexpr size_t ET_LDS_BYTES = 2 * (size_t)(2 * ET_A + ET_BM * ET_HLD) + 2 * 8 * 32 * sizeof(float);
 static_assert(2 * (size_t)ET_BM * ET_D * 4 <= 2 * (size_t)ET_BM * ET_HLD, "two f32 staging tiles must fit the hidden tile");
 
+constexpr int ET_PF_MAX = 8;
 struct EncTailArgs {
     const bf16_t* attn; const float* src;                 // [M][256]
     const bf16_t* wo; const float* bo; const float* g1; const float* be1;
@@ -42,7 +43,32 @@ struct EncTailArgs {
     const bf16_t* wpa; const float* bpa; bf16_t* pa; int npa;
     const bf16_t* wpb; const float* bpb; bf16_t* pb; int npb;
     int skip_ffn;                                         // decoder self-attention half: s = src + out_proj(attn), n = LN(s), no FFN
+    // weight prefetch for the NEXT launch (few workgroups - one pair per call: a tail's 0.4-1.5 MB of weights are cold in L2 and arrive
+    // through each workgroup's own 128 KB of loads in flight): workgroups >= n_work do no layer work; those on an XCD the next launch
+    // will run on read a slice of the listed byte ranges into that XCD's L2 and exit (as gnn_layer.hip does)
+    const unsigned char* pf[ET_PF_MAX]; int pf_bytes[ET_PF_MAX]; int n_pf, n_work, pf_xcds;
 };
+constexpr int ET_PF_CHUNK = 512 * 16, ET_PF_PER_XCD = 16;
+
+// prefetch workgroup of a tail launch (512 threads): its XCD = id & 7 (workgroup ids are dealt round-robin over the XCDs)
+__device__ __forceinline__ void et_prefetch(const EncTailArgs& p) {
+    const int xcd = blockIdx.x & 7, slot = ((int)blockIdx.x - p.n_work) >> 3;
+    if (xcd >= p.pf_xcds || slot >= ET_PF_PER_XCD) return;
+    unsigned acc = 0u;
+    int c = slot;                                          // chunk counter over all ranges
+    for (int s = 0; s < p.n_pf; ++s) {
+        const int nch = (p.pf_bytes[s] + ET_PF_CHUNK - 1) / ET_PF_CHUNK;
+        for (; c < nch; c += ET_PF_PER_XCD) {
+            const int off = c * ET_PF_CHUNK + (int)threadIdx.x * 16;
+            if (off + 16 <= p.pf_bytes[s]) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.pf[s] + off);      // an ordinary load: it must allocate in L2
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+        c -= nch;
+    }
+    asm volatile("" ::"v"(acc));
+}
 
 struct EtRing {
     bf16x8 f[2][16];
@@ -103,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     bf16_t* Yt = At + ET_A;                                  // bf16(y1) [32][264]; later bf16(y2)
     bf16_t* Ht = Yt + ET_A;                                  // hidden [32][1032]; later the f32 / bf16 output staging
     float* red = reinterpret_cast<float*>(Ht + ET_BM * ET_HLD);
+    if ((int)blockIdx.x >= p.n_work) { et_prefetch(p); return; }
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * ET_BM;
@@ -556,7 +583,12 @@ static int et_launch(const EncTailArgs& a, hipStream_t stream) {
         // the 32-token kernel issues its projection tiles in four unrolled rounds of 8 column tiles: 32 tiles = 1024 output columns
         NPS_CHECK_ARG((a.wpa ? a.npa : 0) + (a.wpb ? a.npb : 0) <= 1024, "transformer_tail: n_pos + n_proj > 1024 on the 32-token kernel");
         NPS_ENSURE_LDS((int)ET_LDS_BYTES, enc_tail_kernel);
-        hipLaunchKernelGGL(enc_tail_kernel, dim3((a.M + ET_BM - 1) / ET_BM), dim3(512), ET_LDS_BYTES, stream, a);
+        EncTailArgs b = a;
+        b.n_work = (a.M + ET_BM - 1) / ET_BM;
+        int extra = 0;
+        if (b.n_pf > 0 && b.pf_xcds > 0 && b.n_work <= 64) extra = 8 * ET_PF_PER_XCD;      // (many workgroups share the weights in every L2 anyway)
+        else b.n_pf = 0;
+        hipLaunchKernelGGL(enc_tail_kernel, dim3(b.n_work + extra), dim3(512), ET_LDS_BYTES, stream, b);
     }
     return 0;
 }
@@ -579,6 +611,7 @@ extern "C" int nopesac_encoder_tail_bf16(const void* attn, const float* src, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = nullptr; a.pre_norm = 0;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
+    a.n_pf = 0; a.n_work = 0; a.pf_xcds = 0;
     if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }
@@ -603,6 +636,7 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
     a.pos = pos; a.pos_rows = pos_rows; a.y = y; a.y16 = (bf16_t*)y_bf16; a.ypos16 = (bf16_t*)ypos_bf16; a.M = M;
     a.yn = yn; a.pre_norm = 1;
     a.wpa = a.wpb = nullptr; a.bpa = a.bpb = nullptr; a.pa = a.pb = nullptr; a.npa = a.npb = 0; a.skip_ffn = 0;
+    a.n_pf = 0; a.n_work = 0; a.pf_xcds = 0;
     if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }
@@ -613,13 +647,35 @@ extern "C" int nopesac_decoder_tail_bf16(const void* attn, const float* tgt, con
 //   skip_ffn = 1 (the decoder's self-attention half, :300-306): s = src + out_proj(attn), n = LN_a(s), y = s  (w1 / w2 / ln_b unused)
 //   proj_pos [M][n_pos] = bf16((n + pos) Wpos^T + bpos), proj [M][n_proj] = bf16(n Wp^T + bp): e.g. the next layer's q|k and v
 //   (encoder / decoder self-attention) or the cross-attention's q; fragment-major weights (K = 256), n_pos / n_proj multiples of 32.
+extern "C" int nopesac_transformer_tail_bf16_pf(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
+                                                const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                                const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                                void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
+                                                void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
+                                                const void* const* next_ptrs, const int64_t* next_bytes, int n_next, int next_workgroups,
+                                                void* stream);
+
 extern "C" int nopesac_transformer_tail_bf16(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
                                              const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
                                              const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
                                              void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
                                              void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
                                              void* stream) {
+    return nopesac_transformer_tail_bf16_pf(attn, src, wo, bo, lna_g, lna_b, w1, b1, w2, b2, lnb_g, lnb_b, pos, pos_rows, y, y_bf16, ypos_bf16, yn,
+                                            pre_norm, skip_ffn, w_pos, b_pos, proj_pos, n_pos, w_proj, b_proj, proj, n_proj, M, nullptr, nullptr, 0, 0,
+                                            stream);
+}
+
+extern "C" int nopesac_transformer_tail_bf16_pf(const void* attn, const float* src, const void* wo, const float* bo, const float* lna_g,
+                                                const float* lna_b, const void* w1, const float* b1, const void* w2, const float* b2,
+                                                const float* lnb_g, const float* lnb_b, const float* pos, int pos_rows, float* y, void* y_bf16,
+                                                void* ypos_bf16, float* yn, int pre_norm, int skip_ffn, const void* w_pos, const float* b_pos,
+                                                void* proj_pos, int n_pos, const void* w_proj, const float* b_proj, void* proj, int n_proj, int M,
+                                                const void* const* next_ptrs, const int64_t* next_bytes, int n_next, int next_workgroups,
+                                                void* stream) {
     using namespace nps;
+    NPS_CHECK_ARG(n_next >= 0 && n_next <= ET_PF_MAX && (n_next == 0 || (next_ptrs && next_bytes && next_workgroups > 0)),
+                  "transformer_tail: bad prefetch list (at most %d ranges)", ET_PF_MAX);
     NPS_CHECK_ARG(attn && src && wo && bo && lna_g && lna_b && M > 0, "transformer_tail: null pointer");
     NPS_CHECK_ARG(skip_ffn || (w1 && b1 && w2 && b2 && lnb_g && lnb_b), "transformer_tail: FFN / second norm parameters missing");
     NPS_CHECK_ARG(!skip_ffn || pre_norm, "transformer_tail: skip_ffn is the pre-norm (decoder) form");
@@ -637,6 +693,12 @@ extern "C" int nopesac_transformer_tail_bf16(const void* attn, const float* src,
     a.yn = yn; a.pre_norm = pre_norm ? 1 : 0; a.skip_ffn = skip_ffn ? 1 : 0;
     a.wpa = proj_pos ? (const bf16_t*)w_pos : nullptr; a.bpa = b_pos; a.pa = (bf16_t*)proj_pos; a.npa = n_pos;
     a.wpb = proj ? (const bf16_t*)w_proj : nullptr; a.bpb = b_proj; a.pb = (bf16_t*)proj; a.npb = n_proj;
+    a.n_pf = n_next; a.n_work = 0; a.pf_xcds = next_workgroups < 8 ? next_workgroups : 8;
+    for (int i = 0; i < n_next; ++i) {
+        NPS_CHECK_ARG(next_ptrs[i] && ((uintptr_t)next_ptrs[i] & 15) == 0 && next_bytes[i] > 0 && next_bytes[i] < (1ll << 30),
+                      "transformer_tail: prefetch range %d null / unaligned / too large", i);
+        a.pf[i] = (const unsigned char*)next_ptrs[i]; a.pf_bytes[i] = (int)next_bytes[i];
+    }
     if (const int rc = et_launch(a, (hipStream_t)stream)) return rc;
     NPS_LAUNCH_RET();
 }

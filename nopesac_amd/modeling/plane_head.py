@@ -258,6 +258,21 @@ class PlaneTRHead(ParamModule):
 
         src16, q_in16 = ops.add_rows_bf16(src, pos)            # src and src + pos as bf16 GEMM operands, one launch
         chain = self.fused_encoder_tail and self.fused_decoder_tail and self.chain_projections
+        wg_enc, wg_dec = (B * L + 31) // 32, (B * nq + 31) // 32
+
+        def tail_pf(kind, i):
+            """(weight tensors, workgroups) of the tail launch (kind, i): what the launch before it prefetches (ops.transformer_tail)"""
+            Wt = self._tail_weights(kind, i)
+            tens = [Wt["wo"], Wt.get("w1"), Wt.get("w2")]
+            if kind == "enc" and i < 5:
+                a = P[f"context_SA.layers.{i + 1}"]["attn"]
+                tens += [a["qk"].wfrag(bf), a["v"].wfrag(bf)]
+            elif kind == "dec_self":
+                tens += [P[f"context2plane_decoder.layers.{i}"]["cross"]["q"].wfrag(bf)]
+            elif kind == "dec" and i < 5:
+                a = P[f"context2plane_decoder.layers.{i + 1}"]["self"]
+                tens += [a["qk"].wfrag(bf), a["v"].wfrag(bf)]
+            return tens, (wg_enc if kind == "enc" else wg_dec)
         qk = v = None
         for i in range(6):
             p = f"context_SA.layers.{i}"
@@ -271,7 +286,8 @@ class PlaneTRHead(ParamModule):
                 Wn = P[f"context_SA.layers.{i + 1}"]["attn"] if i < 5 else None
                 r = ops.transformer_tail(o, src, self._tail_weights("enc", i), pre_norm=False, pos=pos, want=("y",),
                                          proj_pos=(Wn["qk"].wfrag(bf), Wn["qk"].bias, 512) if Wn else None,
-                                         proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256) if Wn else None)
+                                         proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256) if Wn else None,
+                                         prefetch=tail_pf("enc", i + 1) if i < 5 else tail_pf("dec_self", 0))
                 src = r["y"]
                 if Wn:
                     qk, v = r["proj_pos"], r["proj"]
@@ -309,7 +325,7 @@ class PlaneTRHead(ParamModule):
             qk = v = None
             if chain:      # self out-proj + residual + norm2 + the cross-attention's q projection: one launch
                 r = ops.transformer_tail(o, tgt, self._tail_weights("dec_self", i), pre_norm=True, skip_ffn=True, pos=qpos, want=("y",),
-                                         proj_pos=(W["cross"]["q"].wfrag(bf), W["cross"]["q"].bias, 256))
+                                         proj_pos=(W["cross"]["q"].wfrag(bf), W["cross"]["q"].bias, 256), prefetch=tail_pf("dec", i))
                 tgt, q = r["y"], r["proj_pos"]
             else:
                 tgt = lin(o, W["self"]["o"].w2d(bf), W["self"]["o"].bias, residual=tgt, out_dtype=f32)
@@ -320,7 +336,8 @@ class PlaneTRHead(ParamModule):
             if chain and i < 5:      # cross out-proj + LN3 + FFN + the next norm + the next layer's self q|k and v projections
                 Wn = P[f"context2plane_decoder.layers.{i + 1}"]["self"]
                 r = ops.transformer_tail(o, tgt, self._tail_weights("dec", i), pre_norm=True, pos=qpos, want=("y",),
-                                         proj_pos=(Wn["qk"].wfrag(bf), Wn["qk"].bias, 512), proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256))
+                                         proj_pos=(Wn["qk"].wfrag(bf), Wn["qk"].bias, 512), proj=(Wn["v"].wfrag(bf), Wn["v"].bias, 256),
+                                         prefetch=tail_pf("dec_self", i + 1))
                 tgt, qk, v = r["y"], r["proj_pos"], r["proj"]
                 continue
             if self.fused_decoder_tail:      # cross out-proj + LN3 + FFN + the next norm in one launch (csrc/enc_tail.hip)

@@ -1092,12 +1092,17 @@ def decoder_tail(attn: torch.Tensor, tgt: torch.Tensor, W: dict, pos=None, want=
     return out
 
 
+TAIL_PREFETCH = os.environ.get("NOPESAC_TAIL_PREFETCH", "1") != "0"
+
+
 def transformer_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, *, pre_norm: bool, skip_ffn: bool = False, pos=None,
-                     want=("y",), proj_pos=None, proj=None) -> dict:
+                     want=("y",), proj_pos=None, proj=None, prefetch=None) -> dict:
     """The tail of a transformer layer + the input projections of the next attention in one launch (nopesac_transformer_tail_bf16).
     W: "wo", "bo", "ga", "bea" (first norm) and - unless skip_ffn - "w1", "b1", "w2", "b2", "gb", "beb" (second norm); fragment-major
     bf16 matrices, f32 vectors.  proj_pos / proj = (fragment-major weight, f32 bias or None, width): projections of the normalised
-    result + pos / of the normalised result, returned as "proj_pos" / "proj" (bf16 [M, width]).  want: any of "y", "y16", "ypos16", "yn"."""
+    result + pos / of the normalised result, returned as "proj_pos" / "proj" (bf16 [M, width]).  want: any of "y", "y16", "ypos16", "yn".
+    prefetch = (tensors, workgroups): the weight tensors and the workgroup count of the NEXT tail launch - with few rows (one pair per
+    call) extra workgroups of this launch read them into the L2s the next launch will run on (nopesac_transformer_tail_bf16_pf)."""
     _chk(attn, torch.bfloat16); _chk(src, torch.float32)
     M = src.shape[0]
     _require(attn.shape == (M, 256) and src.shape == (M, 256), "transformer_tail: attn / src [M, 256]")
@@ -1111,12 +1116,20 @@ def transformer_tail(attn: torch.Tensor, src: torch.Tensor, W: dict, *, pre_norm
     if nb:
         out["proj"] = torch.empty(M, nb, device=src.device, dtype=torch.bfloat16)
     g = W.get
-    rc = _L().nopesac_transformer_tail_bf16(
+    nptr = nbytes = None
+    n_next = next_wg = 0
+    if prefetch is not None and TAIL_PREFETCH and M <= 64 * 32:
+        tens = [t for t in prefetch[0] if t is not None][:8]
+        if tens and prefetch[1] > 0:
+            n_next, next_wg = len(tens), int(prefetch[1])
+            nptr = (ctypes.c_void_p * n_next)(*[_p(t) for t in tens])
+            nbytes = (ctypes.c_int64 * n_next)(*[t.numel() * t.element_size() for t in tens])
+    rc = _L().nopesac_transformer_tail_bf16_pf(
         _p(attn), _p(src), _p(W["wo"]), _p(W["bo"]), _p(W["ga"]), _p(W["bea"]), _p(g("w1")), _p(g("b1")), _p(g("w2")), _p(g("b2")),
         _p(g("gb")), _p(g("beb")), _p(pos), 0 if pos is None else pos.shape[0], _p(out.get("y")), _p(out.get("y16")), _p(out.get("ypos16")),
         _p(out.get("yn")), int(pre_norm), int(skip_ffn), _p(wa), _p(ba), _p(out.get("proj_pos")), na, _p(wb), _p(bb), _p(out.get("proj")), nb, M,
-        _stream())
-    _lib.check(rc, "nopesac_transformer_tail_bf16")
+        nptr, nbytes, n_next, next_wg, _stream())
+    _lib.check(rc, "nopesac_transformer_tail_bf16_pf")
     return out
 
 
