@@ -1153,6 +1153,30 @@ def test_transformer_tail_with_chained_projections(device, M):
     assert float((out["proj_pos"].float() - q.float()).abs().mean()) < 2e-3 * float(q.float().abs().mean() + 1)
 
 
+@pytest.mark.parametrize("M", [300, 77, 2048])
+def test_transformer_tail_next_weight_prefetch_changes_nothing(device, M):
+    """nopesac_transformer_tail_bf16_pf: the extra workgroups that read the NEXT tail's matrices into L2 (one pair per call: few row
+    tiles) leave every output bit for bit what the plain launch writes; tensors whose size is no multiple of the prefetch chunk and a
+    list longer than the entry's 8 slots are accepted."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    attn, src, pos = rn(M, 256).bfloat16(), rn(M, 256), rn(M, 256)
+    fm = ops.mfma_fragment_major
+    W = {"wo": fm(rn(256, 256, k=1 / 16).bfloat16()), "w1": fm(rn(1024, 256, k=1 / 16).bfloat16()), "w2": fm(rn(256, 1024, k=1 / 32).bfloat16()),
+         "bo": rn(256, k=0.1), "b1": rn(1024, k=0.1), "b2": rn(256, k=0.1), "ga": 1 + rn(256, k=0.1), "bea": rn(256, k=0.1),
+         "gb": 1 + rn(256, k=0.1), "beb": rn(256, k=0.1)}
+    pp, pj = (fm(rn(512, 256, k=1 / 16).bfloat16()), rn(512, k=0.1), 512), (fm(rn(256, 256, k=1 / 16).bfloat16()), None, 256)
+    kw = dict(pre_norm=False, pos=pos, want=("y", "y16", "ypos16"), proj_pos=pp, proj=pj)
+    ref = ops.transformer_tail(attn, src, W, **kw)
+    nxt = [rn(1024, 256).bfloat16(), rn(256, 1024).bfloat16(), None, rn(4099).bfloat16(), rn(3), rn(256, 256).bfloat16()] + \
+          [rn(512, 256).bfloat16() for _ in range(5)]
+    for wg in (1, 10, 64):
+        out = ops.transformer_tail(attn, src, W, prefetch=(nxt, wg), **kw)
+        assert all(torch.equal(out[k], ref[k]) for k in ref)
+    torch.cuda.synchronize()
+
+
 def test_metric_rows_kernel_equals_the_torch_formulation(device):
     """runner.metric_rows on the GPU (nopesac_metric_rows, one launch) = the torch formulation the CPU / gloo tests use."""
     from nopesac_amd import runner
