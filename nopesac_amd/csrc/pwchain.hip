@@ -716,23 +716,29 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * BM;
     // GEMM 2 ownership: CN >= 128: column tile = wave, all four row tiles; CN = 64: column tile wave & 1, row tiles 2 * (wave >> 1) + {0, 1}
+    // Channel order inside a 32-channel column tile: MFMA row i = 8q + 4h + e of the accumulator layout (lane half h holds rows
+    // 8q + 4h + {0..3}, q = 0..3) is fed with the weights of channel 16h + 4q + e, so a lane's 16 accumulators are 16 CONSECUTIVE
+    // channels: the epilogues move 16-byte pieces (ds_read_b128 / ds_write_b128 at a 4-dword row skew: conflict-free) instead of 8-byte
+    // ones (rows l and l + 16 of a 32-lane group on one bank: two-way conflicts, profiles/r4_pmc_res2_tail.json 28.7 %).  The weight
+    // matrices stay in the plain fragment-major order: a lane just loads another lane's 16 bytes of the same 1 KB fragment.
+    const int wl = half * 32 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
     const int nt2 = CN >= 128 ? wave : (wave & 1);
     const int r2 = CN >= 128 ? 0 : 2 * (wave >> 1);
 
     bf16x8 wa[KF1], wb[CN ? KF2 : 1], ws[C2 ? KF1S : 1];
     auto load_wa = [&](int c) {                              // expand-conv (+ shortcut-conv) fragments of y channels c*128 + wave*32 .. +32
-        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + wave) * KF1) * 64 + lane) * 8;
+        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + wave) * KF1) * 64 + wl) * 8;
 #pragma unroll
         for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
         if constexpr (C2 > 0) {
-            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + wave) * KF1S) * 64 + lane) * 8;
+            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + wave) * KF1S) * 64 + wl) * 8;
 #pragma unroll
             for (int kk = 0; kk < KF1S; ++kk) ws[kk] = *reinterpret_cast<const bf16x8*>(v + kk * 512);
         }
     };
     auto load_wb = [&](int c) {                              // conv1 fragments of this wave's column tile, K-slice c
         if constexpr (CN > 0) {
-            const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + lane) * 8;
+            const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + wl) * 8;
 #pragma unroll
             for (int kk = 0; kk < KF2; ++kk) wb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
         }
@@ -742,6 +748,11 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     // loop, were 50 registers: spills)
     const int trow = tid >> 4;
     const unsigned toff = (unsigned)(trow * C4 + (tid & 15) * 8) * 2u;                  // bytes
+    // y store: ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32); with the 4-dword row skew
+    // a group is conflict-free when its lanes read ONE row (16 x 16 bytes = all 64 banks), so the group index - not lane >> 4 - picks
+    // the row of a pair
+    const int srow = (tid >> 5) * 2 + (((lane >> 2) ^ (lane >> 3) ^ (lane >> 4)) & 1);
+    const unsigned soff = (unsigned)(srow * C4 + (tid & 15) * 8) * 2u;
     const char* res_b = reinterpret_cast<const char*>(C2 ? p.y : p.res) + m0 * C4 * 2;   // (never read in a projection block)
     char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
     us8 rres[RCH];
@@ -841,33 +852,38 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
                         if (r == 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
                     }
             }
-            // lane holds, for pixel (2 rp + r)*32 + l31, channels wave*32 + 8q + 4*half + {0..3} of the chunk
+            // lane holds, for pixel (2 rp + r)*32 + l31, channels wave*32 + 16*half + 4q + {0..3} of the chunk (q = 0..3)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = wave * 32 + 8 * q + 4 * half, n = c * CH + nl;
-                const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n), b3 = *reinterpret_cast<const f32x4*>(B3 + n);
-                f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n); bs = *reinterpret_cast<const f32x4*>(BSC + n); }
+            for (int qq = 0; qq < 2; ++qq) {
+                const int nl = wave * 32 + 16 * half + 8 * qq, n = c * CH + nl;
+                f32x4 s3[2], b3[2], ss[2], bs[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    s3[j] = *reinterpret_cast<const f32x4*>(S3 + n + 4 * j); b3[j] = *reinterpret_cast<const f32x4*>(B3 + n + 4 * j);
+                    if constexpr (C2 > 0) { ss[j] = *reinterpret_cast<const f32x4*>(SSC + n + 4 * j); bs[j] = *reinterpret_cast<const f32x4*>(BSC + n + 4 * j); }
+                }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     bf16_t* yp = Y + ((2 * rp + r) * 32 + l31) * Y_LD + nl;
-                    us4 r4 = {0, 0, 0, 0};
-                    if constexpr (C2 == 0) r4 = *reinterpret_cast<const us4*>(yp);
-                    us4 o4;
+                    us8 r8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (C2 == 0) r8 = *reinterpret_cast<const us8*>(yp);
+                    us8 o8;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[r][4 * q + e] * s3[e];
-                        v += b3[e];
-                        if constexpr (C2 > 0) {
-                            float sc = accs[r][4 * q + e] * ss[e];
-                            sc += bs[e];
-                            v += sc;
-                        } else {
-                            v += bf16_to_f32(r4[e]);
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[r][4 * (2 * qq + j) + e] * s3[j][e];
+                            v += b3[j][e];
+                            if constexpr (C2 > 0) {
+                                float sc = accs[r][4 * (2 * qq + j) + e] * ss[j][e];
+                                sc += bs[j][e];
+                                v += sc;
+                            } else {
+                                v += bf16_to_f32(r8[4 * j + e]);
+                            }
+                            o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
                         }
-                        o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
-                    }
-                    *reinterpret_cast<us4*>(yp) = o4;
+                    *reinterpret_cast<us8*>(yp) = o8;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -875,8 +891,8 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
         __syncthreads();                                     // y chunk complete
 #pragma unroll
         for (int i = 0; i < RCH; ++i) {
-            const us8 v = *reinterpret_cast<const us8*>(Y + (trow + 16 * i) * Y_LD + (tid & 15) * 8);
-            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2))) = v;
+            const us8 v = *reinterpret_cast<const us8*>(Y + (srow + 16 * i) * Y_LD + (tid & 15) * 8);
+            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (soff + (unsigned)(i * 16 * C4 * 2))) = v;
         }
         __builtin_amdgcn_sched_barrier(0);                   // (the store's staging registers are dead before the prefetches below go live)
         if (c + 1 < NCH) {
@@ -902,19 +918,23 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     }
     if constexpr (CN > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = nt2 * 32 + 8 * q + 4 * half;
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+        for (int qq = 0; qq < 2; ++qq) {
+            const int n = nt2 * 32 + 16 * half + 8 * qq;
+            f32x4 s1[2], b1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s1[j] = *reinterpret_cast<const f32x4*>(p.s1 + n + 4 * j); b1[j] = *reinterpret_cast<const f32x4*>(p.b1 + n + 4 * j); }
 #pragma unroll
             for (int r = 0; r < NR2; ++r) {
-                us4 o4;
+                us8 o8;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc2[r][4 * q + e] * s1[e];
-                    v += b1[e];
-                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
-                }
-                *reinterpret_cast<us4*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o4;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[r][4 * (2 * qq + j) + e] * s1[j][e];
+                        v += b1[j][e];
+                        o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                *reinterpret_cast<us8*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o8;
             }
         }
         __syncthreads();
