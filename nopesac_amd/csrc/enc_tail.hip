@@ -26,8 +26,11 @@ typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 constexpr int ET_D = 256, ET_FF = 1024, ET_BM = 32;
 constexpr int ET_LD = ET_D + 8, ET_HLD = ET_FF + 8;
 constexpr int ET_A = ET_BM * ET_LD;                      // elements of one [32][264] bf16 tile
-constexpr size_t ET_LDS_BYTES = 2 * (size_t)(2 * ET_A + ET_BM * ET_HLD) + 2 * 8 * 32 * sizeof(float);
-static_assert(2 * (size_t)ET_BM * ET_D * 4 <= 2 * (size_t)ET_BM * ET_HLD, "two f32 staging tiles must fit the hidden tile");
+// f32 output staging rows are ET_FLD floats apart: a 4-dword skew, so the eight rows one ds_write_b128 lane group touches fall on
+// different banks (at 256 floats all eight hit the same four: 8-way conflicts, profiles/r3_pmc_enc_tail.json)
+constexpr int ET_FLD = ET_D + 4;
+constexpr size_t ET_STAGE_BYTES = 2 * (size_t)ET_BM * ET_FLD * 4 > 2 * (size_t)ET_BM * ET_HLD ? 2 * (size_t)ET_BM * ET_FLD * 4 : 2 * (size_t)ET_BM * ET_HLD;
+constexpr size_t ET_LDS_BYTES = 2 * (size_t)(2 * ET_A) + ET_STAGE_BYTES + 2 * 8 * 32 * sizeof(float);
 
 constexpr int ET_PF_MAX = 8;
 struct EncTailArgs {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     bf16_t* At = reinterpret_cast<bf16_t*>(et_smem);         // attention rows [32][264]
     bf16_t* Yt = At + ET_A;                                  // bf16(y1) [32][264]; later bf16(y2)
     bf16_t* Ht = Yt + ET_A;                                  // hidden [32][1032]; later the f32 / bf16 output staging
-    float* red = reinterpret_cast<float*>(Ht + ET_BM * ET_HLD);
+    float* red = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Ht) + ET_STAGE_BYTES);
     if ((int)blockIdx.x >= p.n_work) { et_prefetch(p); return; }
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,17 +229,17 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
 
     // ---- outputs through LDS so that they leave as whole rows: f32 tile(s) in the hidden region, bf16 tiles in At / Yt
     float* Yf = reinterpret_cast<float*>(Ht);                 // [32][256] f32: the residual-stream output
-    float* Yn = Yf + ET_BM * ET_D;                            // [32][256] f32: normalised copy (pre-norm, optional)
+    float* Yn = Yf + ET_BM * ET_FLD;                           // [32][256] f32: normalised copy (pre-norm, optional)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = wave * 32 + 8 * q + 4 * half;
         f32x4 v = {y2[4 * q], y2[4 * q + 1], y2[4 * q + 2], y2[4 * q + 3]};
         if (p.pre_norm) {
             const f32x4 uv = {u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = uv;
-            *reinterpret_cast<f32x4*>(Yn + l31 * ET_D + n) = v;
+            *reinterpret_cast<f32x4*>(Yf + l31 * ET_FLD + n) = uv;
+            *reinterpret_cast<f32x4*>(Yn + l31 * ET_FLD + n) = v;
         } else {
-            *reinterpret_cast<f32x4*>(Yf + l31 * ET_D + n) = v;
+            *reinterpret_cast<f32x4*>(Yf + l31 * ET_FLD + n) = v;
         }
         us4 o, op;
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
@@ -251,14 +254,14 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
 #pragma unroll
         for (int i = 0; i < ET_BM * 64 / 512; ++i) {          // 64 16-byte chunks per f32 row
             const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
-            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_D + col);
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_FLD + col);
         }
     }
     if (p.yn && p.pre_norm) {
 #pragma unroll
         for (int i = 0; i < ET_BM * 64 / 512; ++i) {
             const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
-            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.yn + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yn + r * ET_D + col);
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.yn + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yn + r * ET_FLD + col);
         }
     }
 #pragma unroll
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
 constexpr int E6_BM = 64, E6_HW = 512, E6_HLD = E6_HW + 8;
 constexpr int E6_A = E6_BM * ET_LD;
 constexpr size_t E6_LDS_BYTES = 2 * (size_t)(2 * E6_A + E6_BM * E6_HLD) + 2 * 8 * 64 * sizeof(float);
-static_assert((size_t)E6_BM * ET_D * 4 <= 2 * (size_t)E6_BM * E6_HLD, "the f32 staging tile must fit the hidden region");
+static_assert((size_t)E6_BM * ET_FLD * 4 <= 2 * (size_t)E6_BM * E6_HLD, "the f32 staging tile must fit the hidden region");
 
 struct E6Ring {
     bf16x8 f[2][8];
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
             const int n = wave * 32 + 8 * q + 4 * half, rl = r * 32 + l31;
             const long long row = m0 + rl;
             const f32x4 v = {y2[r][4 * q], y2[r][4 * q + 1], y2[r][4 * q + 2], y2[r][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(Yf + rl * ET_D + n) = v;
+            *reinterpret_cast<f32x4*>(Yf + rl * ET_FLD + n) = v;
             f32x4 pv = {0.f, 0.f, 0.f, 0.f};
             if (p.pos && row < p.M) pv = *reinterpret_cast<const f32x4*>(p.pos + (row % p.pos_rows) * ET_D + n);
             us4 o, op;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
 #pragma unroll
         for (int i = 0; i < E6_BM * 64 / 512; ++i) {
             const int c = tid + i * 512, r = c >> 6, col = (c & 63) * 4;
-            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_D + col);
+            if (m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = *reinterpret_cast<const f32x4*>(Yf + r * ET_FLD + col);
         }
     }
 #pragma unroll

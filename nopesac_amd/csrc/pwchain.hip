@@ -1025,28 +1025,32 @@ __global__ __launch_bounds__(512, 2) void pw_chain_rt8_kernel(const PwArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * BM;
+    // (pw_chain_rt4_kernel's channel order: MFMA row 8q + 4h + e carries channel 16h + 4q + e of the column tile - 16-byte epilogues)
+    const int wl = half * 32 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
     const int ct = wave & 3, rh = wave >> 2;                 // GEMM 1: column tile of the chunk, 64-pixel half
     const int nt2 = CN >= 256 ? wave : (wave & 3);           // GEMM 2: column tile of a'
     const int r2 = CN >= 256 ? 0 : 2 * (wave >> 2);          //         first row tile
 
     bf16x8 wa[KF1], wb[KF2], ws[C2 ? KF1S : 1];
     auto load_wa = [&](int c) {
-        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + ct) * KF1) * 64 + lane) * 8;
+        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + ct) * KF1) * 64 + wl) * 8;
 #pragma unroll
         for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
         if constexpr (C2 > 0) {
-            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + ct) * KF1S) * 64 + lane) * 8;
+            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + ct) * KF1S) * 64 + wl) * 8;
 #pragma unroll
             for (int kk = 0; kk < KF1S; ++kk) ws[kk] = *reinterpret_cast<const bf16x8*>(v + kk * 512);
         }
     };
     auto load_wb = [&](int c) {
-        const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + lane) * 8;
+        const bf16_t* w = p.w1 + ((long long)(nt2 * (C4 / 16) + c * KF2) * 64 + wl) * 8;
 #pragma unroll
         for (int kk = 0; kk < KF2; ++kk) wb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
     };
     const int trow = tid >> 4;                               // 32 rows per pass of the 512 threads, 16-byte column tid & 15
     const unsigned toff = (unsigned)(trow * C4 + (tid & 15) * 8) * 2u;
+    const int srow = (tid >> 5) * 2 + (((lane >> 2) ^ (lane >> 3) ^ (lane >> 4)) & 1);   // y store: one row per ds_read_b128 lane group
+    const unsigned soff = (unsigned)(srow * C4 + (tid & 15) * 8) * 2u;
     const char* res_b = reinterpret_cast<const char*>(C2 ? p.y : p.res) + m0 * C4 * 2;       // (never read in the projection form)
     char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
     us8 rres[RCH];
@@ -1139,37 +1143,41 @@ __global__ __launch_bounds__(512, 2) void pw_chain_rt8_kernel(const PwArgs p) {
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = ct * 32 + 8 * q + 4 * half, n = c * CH + nl;
-                const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n), b3 = *reinterpret_cast<const f32x4*>(B3 + n);
-                f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n); bs = *reinterpret_cast<const f32x4*>(BSC + n); }
+            for (int qq = 0; qq < 2; ++qq) {
+                const int nl = ct * 32 + 16 * half + 8 * qq, n = c * CH + nl;
                 bf16_t* yp = Y + (rt * 32 + l31) * Y_LD + nl;
-                us4 r4 = {0, 0, 0, 0};
-                if constexpr (C2 == 0) r4 = *reinterpret_cast<const us4*>(yp);
-                us4 o4;
+                us8 r8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (C2 == 0) r8 = *reinterpret_cast<const us8*>(yp);
+                us8 o8;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[4 * q + e] * s3[e];
-                    v += b3[e];
-                    if constexpr (C2 > 0) {
-                        float sc = accs[4 * q + e] * ss[e];
-                        sc += bs[e];
-                        v += sc;
-                    } else {
-                        v += bf16_to_f32(r4[e]);
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n + 4 * j), b3 = *reinterpret_cast<const f32x4*>(B3 + n + 4 * j);
+                    f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n + 4 * j); bs = *reinterpret_cast<const f32x4*>(BSC + n + 4 * j); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[4 * (2 * qq + j) + e] * s3[e];
+                        v += b3[e];
+                        if constexpr (C2 > 0) {
+                            float sc = accs[4 * (2 * qq + j) + e] * ss[e];
+                            sc += bs[e];
+                            v += sc;
+                        } else {
+                            v += bf16_to_f32(r8[4 * j + e]);
+                        }
+                        o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
                     }
-                    o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    if (C2 > 0) __builtin_amdgcn_sched_barrier(0);
                 }
-                *reinterpret_cast<us4*>(yp) = o4;
+                *reinterpret_cast<us8*>(yp) = o8;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                     // y chunk complete
 #pragma unroll
         for (int i = 0; i < RCH; ++i) {
-            const us8 v = *reinterpret_cast<const us8*>(Y + (trow + 32 * i) * Y_LD + (tid & 15) * 8);
-            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (toff + (unsigned)(i * 32 * C4 * 2))) = v;
+            const us8 v = *reinterpret_cast<const us8*>(Y + (srow + 32 * i) * Y_LD + (tid & 15) * 8);
+            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (soff + (unsigned)(i * 32 * C4 * 2))) = v;
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) {
@@ -1193,19 +1201,23 @@ __global__ __launch_bounds__(512, 2) void pw_chain_rt8_kernel(const PwArgs p) {
     }
     // ---- a' = relu(bn1(acc2)) -> LDS -> whole rows
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int n = nt2 * 32 + 8 * q + 4 * half;
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + n), b1 = *reinterpret_cast<const f32x4*>(p.b1 + n);
+    for (int qq = 0; qq < 2; ++qq) {
+        const int n = nt2 * 32 + 16 * half + 8 * qq;
+        f32x4 s1[2], b1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { s1[j] = *reinterpret_cast<const f32x4*>(p.s1 + n + 4 * j); b1[j] = *reinterpret_cast<const f32x4*>(p.b1 + n + 4 * j); }
 #pragma unroll
         for (int r = 0; r < NR2; ++r) {
-            us4 o4;
+            us8 o8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc2[r][4 * q + e] * s1[e];
-                v += b1[e];
-                o4[e] = f32_to_bf16(v > 0.f ? v : 0.f);
-            }
-            *reinterpret_cast<us4*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o4;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc2[r][4 * (2 * qq + j) + e] * s1[j][e];
+                    v += b1[j][e];
+                    o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+            *reinterpret_cast<us8*>(O + ((r2 + r) * 32 + l31) * O_LD + n) = o8;
         }
     }
     __syncthreads();

@@ -132,7 +132,13 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         const int cy = p / ST_CW, cx = p % ST_CW;
         a_base[t] = ((2 * cy) * ST_IW + 2 * cx + 2 * half) * 8;
     }
-    const int b_off = ((lane & 31) * ST_WLD + 8 * half) * 2;
+    // Channel order of a 32-channel half: MFMA row 8q + 4h + e (lane half h holds rows 8q + 4h + {0..3}) is fed with the weights of
+    // channel 16h + 4q + e, so a lane's 16 accumulators are 16 CONSECUTIVE channels and the conv tile is written in 16-byte pieces
+    // (ds_write_b128 at the tile's 4-dword row skew: conflict-free; the 8-byte pieces of the natural order were two-way conflicts).  The
+    // permuted rows of a ds_read_b128 lane group are the same SET of rows as before: the weight reads stay conflict-free.
+    const int l31 = lane & 31;
+    const int wrow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+    const int b_off = (wrow * ST_WLD + 8 * half) * 2;
     f32x16 acc[3][2];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[t], acc[t][j], 0, 0, 0);
     }
     __syncthreads();                                            // patch / weights are dead: reuse LDS for the conv tile
-    // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 8q + 4*half + {0..3}
+    // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 16*half + 4q + {0..3}
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int p = (wave * 3 + t) * 32 + (lane & 31);
@@ -165,23 +171,32 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = j * 32 + 8 * q + 4 * half;
-                const float4 s4 = *reinterpret_cast<const float4*>(scale + n), b4 = *reinterpret_cast<const float4*>(bias + n);
-                const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                us4 o;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int n = j * 32 + 16 * half + 8 * qq;
+                us8 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaxf(acc[t][j][4 * q + e] * sv[e] + bv[e], 0.f);
-                    o[e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(scale + n + 4 * jj), b4 = *reinterpret_cast<const float4*>(bias + n + 4 * jj);
+                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(acc[t][j][4 * (2 * qq + jj) + e] * sv[e] + bv[e], 0.f);
+                        o[4 * jj + e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
+                    }
                 }
-                if (p < ST_M) *reinterpret_cast<us4*>(ctile + p * ST_CLD + n) = o;
+                if (p < ST_M) *reinterpret_cast<us8*>(ctile + p * ST_CLD + n) = o;
             }
     }
     __syncthreads();
     // ---- 3x3 / s2 max-pool out of LDS; 8 channels (16 bytes) per work item
-    for (int i = tid; i < ST_PH * ST_PW * 8; i += 256) {
-        const int c8 = (i & 7) * 8, pp = i >> 3;
+    // Item -> (pooled pixel, 16-byte channel piece): ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
+    // (+32); a group reads the 2 x 128 bytes of two pooled pixels FOUR apart (8 conv pixels = 288 dwords = 32 banks): conflict-free
+    // (consecutive pooled pixels per 8 lanes put three of a group's four pixels on overlapping banks).  A block of 8 pooled pixels per
+    // wave and pass; any bijection is correct, the pairing only matters for the banks.
+    static_assert(ST_PH * ST_PW % 8 == 0, "pool blocks");
+    for (int blk = wave; blk < ST_PH * ST_PW / 8; blk += 4) {
+        const int c8 = (lane & 7) * 8;
+        const int pp = blk * 8 + 4 * ((lane >> 4) & 1) + 2 * (lane >> 5) + (((lane >> 2) ^ (lane >> 3) ^ (lane >> 4)) & 1);
         const int ly = pp / ST_PW, lx = pp % ST_PW;
         const int py = py0 + ly, px = px0 + lx;
         if (py >= PH || px >= PW) continue;
