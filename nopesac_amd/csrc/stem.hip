@@ -123,13 +123,27 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     }
     __syncthreads();
     // ---- implicit GEMM: wave owns row tiles t = wave*3 .. +3 (32 conv pixels each), both 32-channel halves
+    // Row tile T -> conv pixels: T = 0..8: columns 0..31 of conv row T; T = 9..11: the nine leftover columns - columns 32..39 as
+    // 8-lane runs of rows 0..8, then column 40.  A lane's 16-byte A fragment sits at dword 352 cy + 4 cx, i.e. on bank slot
+    // (8 cy + cx) mod 16: 32 consecutive columns of ONE row give every ds_read_b128 lane group sixteen different slots, and the 8-lane
+    // runs of consecutive rows alternate between slots 0-7 and 8-15.  (32 consecutive pixels of the 41-wide tile wrap to the next row
+    // inside most tiles, which shifts the lanes behind the wrap by one slot: a two-way conflict in every group the wrap splits.)
     const int half = lane >> 5;
+    auto tile_pixel = [&](int T, int& cy, int& cx) -> bool {
+        const int l = lane & 31;
+        if (T < ST_CH) { cy = T; cx = l; return true; }
+        const int q = (T - ST_CH) * 32 + l;
+        if (q < 8 * ST_CH) { cy = q >> 3; cx = 32 + (q & 7); return true; }
+        if (q < 9 * ST_CH) { cy = q - 8 * ST_CH; cx = 40; return true; }
+        cy = 0; cx = 0;                                         // padded lanes compute garbage that is never stored
+        return false;
+    };
+    static_assert(ST_CW == 41 && ST_CH == 9 && 12 * 32 >= ST_M, "row-tile enumeration");
     int a_base[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        int p = (wave * 3 + t) * 32 + (lane & 31);
-        if (p >= ST_M) p = 0;                                   // padded rows compute garbage that is never stored
-        const int cy = p / ST_CW, cx = p % ST_CW;
+        int cy, cx;
+        tile_pixel(wave * 3 + t, cy, cx);
         a_base[t] = ((2 * cy) * ST_IW + 2 * cx + 2 * half) * 8;
     }
     // Channel order of a 32-channel half: MFMA row 8q + 4h + e (lane half h holds rows 8q + 4h + {0..3}) is fed with the weights of
@@ -164,10 +178,11 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 16*half + 4q + {0..3}
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int p = (wave * 3 + t) * 32 + (lane & 31);
-        const int cy = p / ST_CW, cx = p % ST_CW;
+        int cy, cx;
+        const bool valid = tile_pixel(wave * 3 + t, cy, cx);
+        const int p = cy * ST_CW + cx;
         const int gy = cy0 + cy, gx = cx0 + cx;
-        const bool inside = p < ST_M && (unsigned)gy < (unsigned)CH && (unsigned)gx < (unsigned)CW;
+        const bool inside = valid && (unsigned)gy < (unsigned)CH && (unsigned)gx < (unsigned)CW;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                         o[4 * jj + e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
                     }
                 }
-                if (p < ST_M) *reinterpret_cast<us8*>(ctile + p * ST_CLD + n) = o;
+                if (valid) *reinterpret_cast<us8*>(ctile + p * ST_CLD + n) = o;
             }
     }
     __syncthreads();
