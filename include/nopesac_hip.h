@@ -371,7 +371,9 @@ int nopesac_ransac_score_maps(const float* geo_local, const float* rot_raw, cons
  *   score_feat_{rot,trans} f32[B,nq+1,64] (outputs of the score MLPs), reg_{rot,trans}_{w f32[64], b f32[1]};
  *   init_{rot,trans}_feat f32[B,256]; fused_{rot,trans}_feat f32[B,nq,256] (already ReLU'd);
  *   rots_{w f32[4,256], b f32[4]}, trans_{w f32[3,256], b f32[3]}.
- *   mode: 0 soft, 1 avg-all, 2 min-cost, 3 max-score.
+ *   mode: 0 soft, 1 avg-all, 2 min-cost, 3 max-score; + 16 = the TRAINING-side twin (__forward_PlaneCamRefHead,
+ *   camera_head.py:737-923): no m == 0 / m <= 1 shortcuts, scores clamped to [0.01, 0.9], masked and renormalised
+ *   (:814-818, :852-854), avg_* from the per-plane features only (:858-867), pred_* = the soft pose (:869-875).
  * Outputs: pred_rot f32[B,4], pred_trans f32[B,3], avg_rot f32[B,4], avg_trans f32[B,3],
  *   score_rot/score_trans f32[B,nq+1]. */
 int nopesac_ransac_soft_vote(const float* score_feat_rot, const float* score_feat_trans,
@@ -385,6 +387,18 @@ int nopesac_ransac_soft_vote(const float* score_feat_rot, const float* score_fea
                              int B, int nq, int mode,
                              float* pred_rot, float* pred_trans, float* avg_rot, float* avg_trans,
                              float* score_rot, float* score_trans, void* stream);
+
+/* The seven refinement losses of the training-side twin (camera_head.py:883-921, CameraPoseLoss camera_modules.py:355-365)
+ * from the outputs of nopesac_ransac_score_maps (rots_all, trans_all, l2_dist - the diagnostic map is REQUIRED here) and
+ * nopesac_ransac_soft_vote in mode 16 (pred_* = soft pose, avg_*, score_*); gt_pose f32[B,7] = trans | quaternion (normalised
+ * inside), m int32[B] (>= 1 each, as in the reference: the parameter loss divides by it).
+ * losses f32[7] = { tran_planeAvgReg, rot_planeAvgReg, tran_planeSoftReg, rot_planeSoftReg, rotIdx * 0.01, transIdx * 0.02,
+ * paramL2_dist * 0.1 } * weight.  Forward only: no gradient kernels exist for this path. */
+int nopesac_plane_cam_ref_losses(const float* pred_rot, const float* pred_trans, const float* avg_rot,
+                                 const float* avg_trans, const float* rots_all, const float* trans_all,
+                                 const float* score_rot, const float* score_trans, const float* l2_dist,
+                                 const int32_t* m, const float* gt_pose, int B, int nq, float weight,
+                                 float* losses, void* stream);
 
 /* assignment re-filter under the refined pose (:605-629): keep matches with normal angle < 45 deg and
  * offset distance < 1; `rot` is sign-canonicalised inside (w >= 0). In/out f32[B,nq,nq]. */

@@ -172,8 +172,12 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
     const int NH = nq + 1;
     __shared__ float s_r[129], s_t[129], sh4[4], outv[16];
     const int m = min(max(mp[b], 0), nq);
+    // mode bit 4: the TRAINING-side twin (__forward_PlaneCamRefHead, camera_head.py:737-923): no m == 0 / m == 1 shortcuts, scores
+    // clamped to [0.01, 0.9] and renormalised over the live hypotheses, average pose from the per-plane features only, soft pose out
+    const bool train = (mode & 16) != 0;
+    mode &= 15;
     for (int h = tid; h < NH; h += 256) { score_rot[(long long)b * NH + h] = 0.f; score_trans[(long long)b * NH + h] = 0.f; }
-    if (m == 0) {   // :964-969
+    if (m == 0 && !train) {   // :964-969
         if (tid < 4) { pred_rot[4 * b + tid] = init_rot[4 * b + tid]; avg_rot[4 * b + tid] = init_rot[4 * b + tid]; }
         if (tid < 3) { pred_trans[3 * b + tid] = init_trans[3 * b + tid]; avg_trans[3 * b + tid] = init_trans[3 * b + tid]; }
         return;
@@ -195,6 +199,12 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
         float sum = 0.f;
         for (int h = 0; h <= m; ++h) { s[h] = expf(s[h] - mx); sum += s[h]; }
         for (int h = 0; h <= m; ++h) s[h] = s[h] / sum;
+        if (train) {   // :814-818, :852-854: clamp, mask (live = h <= m and m >= 1), renormalise
+            const float live = m >= 1 ? 1.f : 0.f;
+            float cs = 0.f;
+            for (int h = 0; h <= m; ++h) { s[h] = fminf(fmaxf(s[h], 0.01f), 0.9f) * live; cs += s[h]; }
+            for (int h = 0; h <= m; ++h) s[h] = s[h] / (cs + 1e-10f);
+        }
     }
     __syncthreads();
     for (int h = tid; h <= m; h += 256) { score_rot[(long long)b * NH + h] = s_r[h]; score_trans[(long long)b * NH + h] = s_t[h]; }
@@ -204,7 +214,21 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
     float fr_avg, ft_avg, fr_soft = 0.f, ft_soft = 0.f;
     const float* FR = fused_rot + (long long)b * nq * 256;
     const float* FT = fused_trans + (long long)b * nq * 256;
-    if (m > 1) {
+    if (train) {   // :856-873: average over the per-plane features (weights avg[1:] / avg[1:].sum()), soft sum over all live hypotheses
+        const float a = m >= 1 ? avg_w : 0.f;
+        float sa = 0.f;
+        for (int h = 1; h <= m; ++h) sa += a;
+        float ar = 0.f, at = 0.f;
+        fr_soft = init_rot_feat[256 * b + d] * s_r[0];
+        ft_soft = init_trans_feat[256 * b + d] * s_t[0];
+        for (int h = 1; h <= m; ++h) {
+            const float xr = FR[(h - 1) * 256 + d], xt = FT[(h - 1) * 256 + d];
+            ar += xr * a / sa; at += xt * a / sa;
+            fr_soft += xr * s_r[h]; ft_soft += xt * s_t[h];
+        }
+        if (m == 0) ar = at = a / sa;   // 0 / 0: the reference's own result for an empty sequence
+        fr_avg = ar; ft_avg = at;
+    } else if (m > 1) {
         float ar = init_rot_feat[256 * b + d] * avg_w, at = init_trans_feat[256 * b + d] * avg_w;
         fr_soft = init_rot_feat[256 * b + d] * s_r[0];
         ft_soft = init_trans_feat[256 * b + d] * s_t[0];
@@ -235,7 +259,10 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
         float pr[4], pt[3];
         for (int o = 0; o < 4; ++o) pr[o] = ra[o];
         for (int o = 0; o < 3; ++o) pt[o] = ta[o];
-        if (m > 1) {
+        if (train) {
+            for (int o = 0; o < 4; ++o) pr[o] = rs[o];
+            for (int o = 0; o < 3; ++o) pt[o] = ts[o];
+        } else if (m > 1) {
             if (mode == 0) {
                 for (int o = 0; o < 4; ++o) pr[o] = rs[o];
                 for (int o = 0; o < 3; ++o) pt[o] = ts[o];
@@ -260,6 +287,64 @@ __global__ __launch_bounds__(256) void ransac_soft_vote_kernel(
         }
         for (int o = 0; o < 4; ++o) pred_rot[4 * b + o] = pr[o];
         for (int o = 0; o < 3; ++o) pred_trans[3 * b + o] = pt[o];
+    }
+}
+
+// The seven refinement losses of the training-side twin (camera_head.py:883-921; CameraPoseLoss camera_modules.py:355-365) from the
+// outputs of the two kernels above: ONE wave, lane = pair (strided), fixed-order wave sums (deterministic).
+// losses[0..6] = tran_planeAvgReg, rot_planeAvgReg, tran_planeSoftReg, rot_planeSoftReg, rotIdx, transIdx, paramL2_dist.
+__device__ __forceinline__ float quat_dist_normalised(const float* a, const float* b) {
+    const float na = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]), 1e-12f);
+    const float nb = fmaxf(sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]), 1e-12f);
+    float s = 0.f;
+    for (int d = 0; d < 4; ++d) { const float e = a[d] / na - b[d] / nb; s += e * e; }
+    return sqrtf(s);
+}
+__device__ __forceinline__ float vec3_dist(const float* a, const float* b) {
+    const float e0 = a[0] - b[0], e1 = a[1] - b[1], e2 = a[2] - b[2];
+    return sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+}
+
+__global__ __launch_bounds__(64) void plane_cam_ref_losses_kernel(
+    const float* __restrict__ pred_rot, const float* __restrict__ pred_trans, const float* __restrict__ avg_rot,
+    const float* __restrict__ avg_trans, const float* __restrict__ rots_all, const float* __restrict__ trans_all,
+    const float* __restrict__ score_rot, const float* __restrict__ score_trans, const float* __restrict__ l2_dist,
+    const int* __restrict__ mp, const float* __restrict__ gt_pose, int B, int nq, float weight, float* __restrict__ losses) {
+    const int NH = nq + 1;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const int m = min(max(mp[b], 0), nq);
+        const float* gt = gt_pose + 7 * b;
+        acc[0] += vec3_dist(gt, avg_trans + 3 * b);
+        acc[1] += quat_dist_normalised(gt + 3, avg_rot + 4 * b);
+        acc[2] += vec3_dist(gt, pred_trans + 3 * b);
+        acc[3] += quat_dist_normalised(gt + 3, pred_rot + 4 * b);
+        // best one-plane hypotheses against the ground truth (dead hypotheses count 1e10; first minimum as torch.min)
+        float br = INFINITY, bt = INFINITY;
+        int hr = 0, ht = 0;
+        for (int h = 0; h < NH; ++h) {
+            const bool live = h <= m && m >= 1;
+            const float er = live ? quat_dist_normalised(gt + 3, rots_all + ((long long)b * NH + h) * 4) : 1e10f;
+            const float et = live ? vec3_dist(gt, trans_all + ((long long)b * NH + h) * 3) : 1e10f;
+            if (er < br) { br = er; hr = h; }
+            if (et < bt) { bt = et; ht = h; }
+        }
+        acc[4] += fabsf(1.f - score_rot[(long long)b * NH + hr]);
+        acc[5] += fabsf(1.f - score_trans[(long long)b * NH + ht]);
+        float dsum = 0.f;   // diag(dist_l2_mid_ori[b, 1:]) over ALL nq planes (padded pairs contribute 0), :906-908
+        for (int j = 0; j < nq; ++j) dsum += l2_dist[((long long)b * NH + 1 + j) * nq + j];
+        acc[6] += dsum / (float)mp[b];
+    }
+    for (int k = 0; k < 7; ++k) acc[k] = wave_sum(acc[k]);
+    if (threadIdx.x == 0) {
+        const float inv = 1.f / (float)B;
+        losses[0] = acc[0] * inv * weight;
+        losses[1] = acc[1] * inv * weight;
+        losses[2] = acc[2] * inv * weight;
+        losses[3] = acc[3] * inv * weight;
+        losses[4] = acc[4] * inv * 0.01f * weight;
+        losses[5] = acc[5] * inv * 0.02f * weight;
+        losses[6] = acc[6] * inv * 0.1f * weight;
     }
 }
 
@@ -361,11 +446,25 @@ extern "C" int nopesac_ransac_soft_vote(const float* score_feat_rot, const float
                       init_trans_feat && fused_rot_feat && fused_trans_feat && rots_w && rots_b && trans_w && trans_b && rots_all &&
                       trans_all && init_rot && init_trans && m && pred_rot && pred_trans && avg_rot && avg_trans && score_rot && score_trans,
                   "ransac_soft_vote: null pointer");
-    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && mode >= 0 && mode <= 3, "ransac_soft_vote: bad dims/mode");
-    NPS_CHECK_ARG(mode != 2 || (dn_sum && dl2_sum), "ransac_soft_vote: min-cost needs dn_sum/dl2_sum");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128 && mode >= 0 && ((mode & 15) <= 3) && mode < 32, "ransac_soft_vote: bad dims/mode");
+    NPS_CHECK_ARG((mode & 15) != 2 || (dn_sum && dl2_sum), "ransac_soft_vote: min-cost needs dn_sum/dl2_sum");
     hipLaunchKernelGGL(ransac_soft_vote_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, score_feat_rot, score_feat_trans,
                        reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot_feat,
                        fused_trans_feat, rots_w, rots_b, trans_w, trans_b, rots_all, trans_all, dn_sum, dl2_sum, init_rot,
                        init_trans, m, nq, mode, pred_rot, pred_trans, avg_rot, avg_trans, score_rot, score_trans);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_plane_cam_ref_losses(const float* pred_rot, const float* pred_trans, const float* avg_rot,
+                                            const float* avg_trans, const float* rots_all, const float* trans_all,
+                                            const float* score_rot, const float* score_trans, const float* l2_dist,
+                                            const int32_t* m, const float* gt_pose, int B, int nq, float weight,
+                                            float* losses, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(pred_rot && pred_trans && avg_rot && avg_trans && rots_all && trans_all && score_rot && score_trans && l2_dist && m &&
+                      gt_pose && losses, "plane_cam_ref_losses: null pointer");
+    NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "plane_cam_ref_losses: bad dims (nq<=128)");
+    hipLaunchKernelGGL(plane_cam_ref_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pred_rot, pred_trans, avg_rot, avg_trans,
+                       rots_all, trans_all, score_rot, score_trans, l2_dist, m, gt_pose, B, nq, weight, losses);
     NPS_LAUNCH_RET();
 }

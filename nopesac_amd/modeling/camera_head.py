@@ -163,7 +163,8 @@ class PlaneCameraHead(ParamModule):
         return rec_trans, rec_rot, trans_feat, rot_feat
 
     # ---------------------------------------------------------------- (iv) neural one-plane RANSAC
-    def refine(self, A0, planes1, planes2, n1, n2, rec_trans, rec_rot, trans_feat, rot_feat, diagnostics=False):
+    def refine(self, A0, planes1, planes2, n1, n2, rec_trans, rec_rot, trans_feat, rot_feat, diagnostics=False, train=False):
+        """`train=True`: the scoring / aggregation of the training-side twin (mode + 16 of nopesac_ransac_soft_vote)."""
         P, nq, gd = self.packed, self.num_queries, self._gd("refine")
         B = A0.shape[0]
         dev = A0.device
@@ -187,9 +188,32 @@ class PlaneCameraHead(ParamModule):
         vote = ops.ransac_soft_vote(sf_rot, sf_tran, P["rot_score_reg"].w2d().view(-1), P["rot_score_reg"].bias,
                                     P["trans_score_reg"].w2d().view(-1), P["trans_score_reg"].bias, rot_feat, trans_feat,
                                     fused_rot.view(B, nq, 256), fused_tran.view(B, nq, 256), P["rots"].w2d(), P["rots"].bias,
-                                    P["trans"].w2d(), P["trans"].bias, maps, rec_rot, rec_trans, m, CAM_MODES[self.out_cam_type])
+                                    P["trans"].w2d(), P["trans"].bias, maps, rec_rot, rec_trans, m,
+                                    16 if train else CAM_MODES[self.out_cam_type])
         vote.update(m=m, geo_local=geo_local, geo_global=geo_global, sig=sig, maps=maps)
         return vote
+
+    def forward_plane_cam_ref_head(self, A0, planes1, planes2, n1, n2, initial_trans, initial_rot, initial_trans_feat,
+                                   initial_rot_feat, gt_pose, suffix: str = "", weight: float = 1.0):
+        """Training-side twin of `refine` = the reference's __forward_PlaneCamRefHead (camera_head.py:737-923), FORWARD ONLY:
+        clamp-renormalised hypothesis scores (:814-818, :852-854), average pose from the per-plane features (:858-867), soft pose as the
+        prediction, and the seven refinement losses (:883-921) in one launch (nopesac_plane_cam_ref_losses).  The matched-plane
+        sequence is given as in `refine` - an assignment matrix over the two plane sets (GT correspondences over GT planes for the
+        'initCamRef' / 'initRecCamRef' calls :452-474, the predicted assignment for 'initCamRef_Aux' :480-500); every pair needs
+        m >= 1 matches, as in the reference.  No gradient kernels exist: the losses are values (validation curves, loss parity),
+        not a training step.  Returns (losses, pred_cam) with the reference's keys; pred_cam's per-hypothesis entries describe pair 0."""
+        out = self.refine(A0, planes1, planes2, n1, n2, initial_trans, initial_rot, initial_trans_feat, initial_rot_feat,
+                          diagnostics=True, train=True)
+        maps, m = out["maps"], out["m"]
+        lv = ops.plane_cam_ref_losses(out, maps, m, gt_pose, weight)
+        losses = {"%s_%s" % (nm, suffix): lv[i] for i, nm in enumerate(ops.PLANE_CAM_REF_LOSS_NAMES)}
+        m0 = int(m[0])
+        pred_cam = {"pred_trans": out["pred_trans"], "pred_rot": out["pred_rot"], "pred_trans_avg": out["avg_trans"],
+                    "pred_rot_avg": out["avg_rot"], "all_pred_trans": maps["trans_all"][0:1, :m0 + 1],
+                    "all_pred_rots": maps["rots_all"][0:1, :m0 + 1], "score_soft_rot": out["score_rot"][0:1, :m0 + 1, None],
+                    "score_soft_offset": out["score_trans"][0:1, :m0 + 1, None], "l2_dist": maps["l2_dist"][0:1, :m0 + 1, :m0],
+                    "normal_dist": maps["normal_angle"][0:1, :m0 + 1, :m0], "offset_dist": maps["offset_dist"][0:1, :m0 + 1, :m0]}
+        return losses, pred_cam
 
     # ---------------------------------------------------------------- whole head
     def initial_pose(self, feats: dict, B: int):

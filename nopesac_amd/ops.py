@@ -892,6 +892,28 @@ def ransac_soft_vote(sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_tr
     return out
 
 
+PLANE_CAM_REF_LOSS_NAMES = ("loss_tran_planeAvgReg", "loss_rot_planeAvgReg", "loss_tran_planeSoftReg", "loss_rot_planeSoftReg",
+                            "loss_rotIdx", "loss_transIdx", "loss_paramL2_dist")
+
+
+def plane_cam_ref_losses(vote: dict, maps: dict, m, gt_pose, weight: float = 1.0):
+    """The seven refinement losses of the training-side twin (include/nopesac_hip.h: nopesac_plane_cam_ref_losses; reference
+    camera_head.py:883-921) -> f32[7] in PLANE_CAM_REF_LOSS_NAMES order.  `vote` from ransac_soft_vote(mode | 16), `maps` from
+    ransac_score_maps(diagnostics=True)."""
+    _require("l2_dist" in maps, "plane_cam_ref_losses: ransac_score_maps must run with diagnostics=True (the parameter loss reads l2_dist)")
+    B, NH, _ = maps["rots_all"].shape
+    _chk(gt_pose, torch.float32)
+    _require(tuple(gt_pose.shape) == (B, 7) and m.dtype == torch.int32 and m.numel() == B, "plane_cam_ref_losses: gt_pose [B,7], m int32[B]")
+    args = [vote["pred_rot"], vote["pred_trans"], vote["avg_rot"], vote["avg_trans"], maps["rots_all"], maps["trans_all"],
+            vote["score_rot"], vote["score_trans"], maps["l2_dist"]]
+    for t in args:
+        _chk(t, torch.float32)
+    losses = torch.empty(7, device=gt_pose.device, dtype=torch.float32)
+    rc = _L().nopesac_plane_cam_ref_losses(*[_p(t) for t in args], _p(m), _p(gt_pose), B, NH - 1, float(weight), _p(losses), _stream())
+    _lib.check(rc, "nopesac_plane_cam_ref_losses")
+    return losses
+
+
 def refilter_assignment(assignment, planes1, planes2, n1, n2, rot, trans):
     B, nq, _ = assignment.shape
     out = torch.empty_like(assignment)

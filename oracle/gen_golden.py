@@ -293,6 +293,53 @@ def main():
         run_refine(model64, sd64, 64, 64, 164, "soft")
         run_refine(model64, sd64, 64, 33, 133, "soft")
 
+        # ---- H refine, TRAINING-side twin (__forward_PlaneCamRefHead, camera_head.py:737-923) -----------
+        print("[H] RANSAC refine, training twin (clamp-renormalised scores + losses)")
+
+        def run_refine_train(mdl, sdict, nq, ms, seeds, tag, weight):
+            hd = mdl.camera_head_list[0]
+            cases = [GI.refine_case(nq, m, s) for m, s in zip(ms, seeds)]
+            B = len(cases)
+            dev = torch.device("cpu")
+            pad = lambda t: torch.cat([t, torch.zeros(nq - t.shape[0], 3)], 0)
+            A = torch.zeros(B, nq, nq)
+            for b, c in enumerate(cases):
+                A[b, : c["A"].shape[0], : c["A"].shape[1]] = c["A"]
+            st = lambda k: torch.stack([c[k] for c in cases])
+            kw = dict(planes1=torch.stack([pad(c["planes1"]) for c in cases]), planes2=torch.stack([pad(c["planes2"]) for c in cases]),
+                      pred_assignment_matrix=A, device=dev)
+            gl, _, _ = hd.get_pred_geo_sequence(pred_cams=None, **kw)
+            gg, sc, mn = hd.get_pred_geo_sequence(pred_cams={"tran": st("init_trans"), "rot": st("init_rot")}, **kw)
+            ga, _, _ = hd.get_pred_geo_sequence(pred_cams={"tran": torch.zeros(B, 3), "rot": st("init_rot")}, **kw)
+            sig = (((gg[:, :, 0:1] * ga[:, :, 0:1]) >= 0).float() - 0.5) * 2.0
+            assert [int(v) for v in mn] == list(ms), (mn, ms)
+            gt_pose = GI.gt_pose_case(B, seeds[0])
+            hd.training = True
+            try:
+                with quiet():
+                    losses, pr = hd._PlaneCameraHead__forward_PlaneCamRefHead(
+                        st("trans_feat"), st("rot_feat"), gg, gt_pose=gt_pose, geo_sequence_local=gl, suffix=tag,
+                        matched_nums=mn, out_cam_type="soft", weight=weight, sig_seq=sig, initial_trans=st("init_trans"),
+                        initial_rot=st("init_rot"))
+            finally:
+                hd.training = False
+            ocfg = O.OracleConfig(num_queries=nq, out_cam_type="soft")
+            o_loss, o_pr = O.ransac_refine_train(sdict, st("trans_feat"), st("rot_feat"), gg, gl, sig, list(ms), st("init_trans"),
+                                                 st("init_rot"), gt_pose, ocfg, suffix=tag, weight=weight)
+            assert set(o_loss) == set(losses) and set(o_pr) == set(pr), (set(o_loss) ^ set(losses), set(o_pr) ^ set(pr))
+            out = {"geo_global": gg, "geo_local": gl, "sig": sig, "gt_pose": gt_pose}
+            for k, v in pr.items():
+                rep.check(f"refine_train.{tag}.{k}", o_pr[k], v, 3e-5)
+                out[k] = v
+            for k, v in losses.items():
+                rep.check(f"refine_train.{tag}.{k}", o_loss[k], v, 3e-5)
+                out[k] = v
+            save(f"H_refine_train_nq{nq}_{tag}", **out)
+
+        run_refine_train(model, sd, 50, (7, 2, 32, 50, 1), (67, 62, 92, 110, 61), "initCamRef", 1.0)
+        run_refine_train(model, sd, 50, (32,), (92,), "initRecCamRef", 0.5)
+        run_refine_train(model64, sd64, 64, (33, 64), (133, 164), "initCamRef_Aux", 2.0)
+
         # ---- camera head D->E->F on designed planes + designed features ----------------------
         print("[DEF] camera head")
         for n1, n2, seed in ((12, 9, 70), (32, 32, 71), (1, 1, 72)):

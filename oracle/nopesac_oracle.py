@@ -574,6 +574,95 @@ def ransac_refine(sd, init_trans_feat, init_rot_feat, geo_global, geo_local, sig
             "l2_dist": d_l2[:m + 1, :m], "normal_dist": ang[:m + 1, :m], "offset_dist": d_off[:m + 1, :m]}
 
 
+def camera_pose_loss(est_pose: Tensor, gt_pose: Tensor):
+    """CameraPoseLoss.forward, reduce=True, no mask (camera_modules.py:355-365): poses are [B,7] = trans | quaternion."""
+    l_x = (gt_pose[:, 0:3] - est_pose[:, 0:3]).norm(dim=1).mean()
+    l_q = (F.normalize(gt_pose[:, 3:], dim=1) - F.normalize(est_pose[:, 3:], dim=1)).norm(dim=1).mean()
+    return l_x, l_q
+
+
+def ransac_refine_train(sd, init_trans_feat, init_rot_feat, geo_global, geo_local, sig_seq, ms, init_trans, init_rot, gt_pose,
+                        cfg: OracleConfig, suffix: str = "", weight: float = 1.0, p: str = "camera_head_list.0"):
+    """__forward_PlaneCamRefHead, the TRAINING-side twin of ransac_refine, for a batch (camera_head.py:737-923): scores are
+    clamped to [0.01, 0.9] and renormalised (:816-818, :852-854), the average pose uses the per-plane features only (:862-865),
+    the soft pose is always the prediction, and the seven refinement losses are returned (:883-921).
+    feats [B,256]; geo_* [B,nq,6]; sig_seq [B,nq,1]; ms: list of B ints (each >= 1); init_trans [B,3]; init_rot [B,4];
+    gt_pose [B,7] (trans | quaternion).  Returns (losses, pred_cam) with the reference's keys."""
+    B, nq, _ = geo_global.shape
+    src = geo_global if cfg.warp_plane_in_cam_ref else geo_local
+    g0, g1 = src[..., :3], src[..., 3:]
+    o0, o1 = g0.norm(dim=-1, keepdim=True), g1.norm(dim=-1, keepdim=True)
+    n0, n1 = g0 / (o0 + 1e-10), g1 / (o1 + 1e-10)
+    if cfg.warp_plane_in_cam_ref:
+        o0, n0 = o0 * sig_seq, n0 * sig_seq
+    geo = mlp(torch.cat((n0, o0, n1, o1), -1), sd, p + ".geo_encoder")
+    s1 = mlp(geo, sd, p + ".geo_proj_s1")
+    f_rot = mlp(s1, sd, p + ".decoder_rot")
+    s2 = mlp(torch.cat([s1, f_rot], -1), sd, p + ".geo_proj_s2")
+    f_tran = mlp(s2, sd, p + ".decoder_tran")
+    lin = lambda x, n: F.linear(x, sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"])
+    mask = torch.zeros(B, nq + 1, nq)
+    for b, m in enumerate(ms):
+        mask[b, :m + 1, :m] = 1.0
+    live = mask[:, :, 0:1]                                                   # [B,nq+1,1]: hypothesis h <= m (and m >= 1)
+    fused_rot = F.relu(mlp(torch.cat((init_rot_feat.unsqueeze(1).expand(-1, nq, -1), f_rot), -1), sd, p + ".decoder_rot2"))
+    fused_tran = F.relu(mlp(torch.cat((init_trans_feat.unsqueeze(1).expand(-1, nq, -1), f_tran), -1), sd, p + ".decoder_tran2"))
+    rots_all = torch.cat([init_rot.unsqueeze(1), F.normalize(lin(fused_rot, "rots"), dim=-1)], 1)      # B,nq+1,4
+    trans_all = torch.cat([init_trans.unsqueeze(1), lin(fused_tran, "trans")], 1)                        # B,nq+1,3
+    pl0 = geo_local[:, :, :3].unsqueeze(1).expand(-1, nq + 1, -1, -1)                                    # B,nq+1,nq,3
+    pl1 = flip_planes(geo_local[:, :, 3:]).unsqueeze(1).expand(-1, nq + 1, -1, -1)
+    warp = lambda t: torch.stack([warp_planes(pl0[b], rots_all[b], t[b]) for b in range(B)])
+    pl0_r = warp(torch.zeros(B, nq + 1, 3))
+    nrm0, nrm1 = F.normalize(pl0_r, dim=-1), F.normalize(pl1, dim=-1)
+    ang = torch.acos(torch.clamp((nrm0 * nrm1).sum(-1), -1.0, 1.0)) / np.pi * 180.0
+    d_normal = (nrm0 - nrm1).norm(dim=-1) * mask
+    sc = lin(mlp(torch.exp(-d_normal) * mask, sd, p + ".normal_score_proj"), "rot_score_reg")           # B,nq+1,1
+
+    def clamp_renorm(raw):                                                   # :811-818
+        s = torch.zeros_like(raw)
+        for b, m in enumerate(ms):
+            s[b, :m + 1] = raw[b, :m + 1].softmax(0)
+        s = torch.clamp(s, max=0.9, min=0.01) * live
+        return s / (s.sum(dim=1, keepdim=True) + 1e-10)
+
+    score_rot = clamp_renorm(sc)
+    pl0_rt = warp(trans_all)
+    off0, off1 = pl0_rt.norm(dim=-1), pl1.norm(dim=-1)
+    ntn = (F.normalize(pl0_rt, dim=-1) * nrm1).sum(-1)
+    d_off = torch.where(ntn < 0, (off0 + off1).abs(), (off0 - off1).abs())
+    d_l2 = (pl0_rt - pl1).norm(dim=-1)                                       # B,nq+1,nq (unmasked: the loss reads its diagonal)
+    st = lin(mlp(torch.exp(-(d_l2 * mask)) * mask, sd, p + ".param_score_proj"), "trans_score_reg")
+    score_tran = clamp_renorm(st)
+    avg = live / (live.sum(dim=1, keepdim=True) + 1e-10)                     # :858-861
+    w_avg = avg[:, 1:] / avg[:, 1:].sum(dim=1, keepdim=True)
+    ft_avg, fr_avg = (fused_tran * w_avg).sum(1), (fused_rot * w_avg).sum(1)
+    rot_avg, tran_avg = F.normalize(lin(fr_avg, "rots"), dim=-1), lin(ft_avg, "trans")
+    feats_t = torch.cat((init_trans_feat.unsqueeze(1), fused_tran), 1)
+    feats_r = torch.cat((init_rot_feat.unsqueeze(1), fused_rot), 1)
+    rot_soft = F.normalize(lin((feats_r * score_rot).sum(1), "rots"), dim=-1)
+    tran_soft = lin((feats_t * score_tran).sum(1), "trans")
+    m0 = ms[0]
+    pred_cam = {"pred_trans": tran_soft, "pred_rot": rot_soft, "pred_trans_avg": tran_avg, "pred_rot_avg": rot_avg,
+                "all_pred_trans": trans_all[0:1, :m0 + 1], "all_pred_rots": rots_all[0:1, :m0 + 1],
+                "score_soft_rot": score_rot[0:1, :m0 + 1], "score_soft_offset": score_tran[0:1, :m0 + 1],
+                "l2_dist": d_l2[0:1, :m0 + 1, :m0], "normal_dist": ang[0:1, :m0 + 1, :m0], "offset_dist": d_off[0:1, :m0 + 1, :m0]}
+    # ---- losses (:883-921)
+    l_t_avg, l_r_avg = camera_pose_loss(torch.cat((tran_avg, rot_avg), -1), gt_pose)
+    l_t_soft, l_r_soft = camera_pose_loss(torch.cat((tran_soft, rot_soft), -1), gt_pose)
+    bi = torch.arange(B)
+    rot_err = (F.normalize(gt_pose[:, 3:].unsqueeze(1), dim=-1) - F.normalize(rots_all, dim=-1)).norm(dim=-1)
+    rot_err = rot_err.masked_fill(live[:, :, 0] < 0.5, 1e10)
+    l_rot_idx = (1.0 - score_rot[:, :, 0][bi, rot_err.argmin(dim=-1)]).abs().mean()
+    tr_err = (gt_pose[:, :3].unsqueeze(1) - trans_all).norm(dim=-1).masked_fill(live[:, :, 0] < 0.5, 1e10)
+    l_tr_idx = (1.0 - score_tran[:, :, 0][bi, tr_err.argmin(dim=-1)]).abs().mean()
+    l_param = sum(torch.diag(d_l2[b, 1:]).sum() / ms[b] for b in range(B)) / B
+    losses = {f"loss_tran_planeAvgReg_{suffix}": l_t_avg * weight, f"loss_rot_planeAvgReg_{suffix}": l_r_avg * weight,
+              f"loss_tran_planeSoftReg_{suffix}": l_t_soft * weight, f"loss_rot_planeSoftReg_{suffix}": l_r_soft * weight,
+              f"loss_rotIdx_{suffix}": l_rot_idx * 0.01 * weight, f"loss_transIdx_{suffix}": l_tr_idx * 0.02 * weight,
+              f"loss_paramL2_dist_{suffix}": l_param * 0.1 * weight}
+    return losses, pred_cam
+
+
 def camera_head(sd, feats1, feats2, planes1, planes2, app1, app2, cfg: OracleConfig, forced_assignment=None):
     """PlaneCameraHead.inference_Joint for ONE pair (camera_head.py:400-640).
     feats: dict res2..res5 [1,C,H,W]; planes [n,3]; app [n,256].  Returns (cameras, assignments, aux).

@@ -53,6 +53,14 @@ def refine_case(nq: int, m: int, seed: int, n1: int | None = None, n2: int | Non
             "trans_feat": trans_feat, "rot_feat": rot_feat}
 
 
+def gt_pose_case(B: int, seed: int):
+    """Ground-truth relative poses [B,7] = trans | quaternion for the training-side refine twin (the quaternions are NOT unit
+    length: the losses normalise them, camera_modules.py:363)."""
+    g = _g(1000 + seed)
+    q = torch.stack([rand_unit_quat(g) for _ in range(B)]) * (0.7 + 0.6 * torch.rand(B, 1, generator=g))
+    return torch.cat([0.6 * torch.randn(B, 3, generator=g), q], dim=1)
+
+
 def _blob_field(h, w, g, cells=6):
     """Smooth random field in [-1,1] (bilinear up-sampling of a coarse random grid)."""
     coarse = torch.rand(1, 1, cells, cells + 2, generator=g) * 2 - 1

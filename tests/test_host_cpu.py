@@ -281,3 +281,14 @@ def test_round4_argument_checks_without_a_gpu():
     assert lib.nopesac_tape_create_ex(fake_graph, 18, ctypes.byref(out), None) != 0 and "max_streams" in err()
     assert lib.nopesac_tape_create_ex(fake_graph, 0, ctypes.byref(out), None) != 0 and "tape_create" in err()
     assert lib.nopesac_matcher_sinkhorn(*([None] * 7), 1.0, 1.0, 200, 0.2, 1, 50, None, None, None) != 0 and "sinkhorn" in err()
+
+
+def test_training_twin_argument_checks_without_a_gpu():
+    """The loss entry of the training-side refine twin and the twin's mode bit of the soft vote check their arguments before any HIP
+    call (camera_head.py:737-923 counterpart; include/nopesac_hip.h)."""
+    from nopesac_amd import _lib
+    lib = _lib.load()
+    err = lambda: lib.nopesac_last_error().decode()
+    assert lib.nopesac_plane_cam_ref_losses(*([None] * 11), 2, 50, 1.0, None, None) != 0 and "plane_cam_ref_losses" in err()
+    assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 16 + 4, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()
+    assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 32, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()

@@ -92,6 +92,40 @@ def test_refine(sd50, m):
         assert rel_err(v, g[k]) < 5e-5, k
 
 
+def _refine_train_inputs(nq, ms, seeds):
+    cases = [GI.refine_case(nq, m, s) for m, s in zip(ms, seeds)]
+    geo = []
+    for c in cases:
+        gl, mm = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq)
+        gg, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], c["init_trans"])
+        ga, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], torch.zeros(3))
+        geo.append((gl, gg, (((gg[:, 0:1] * ga[:, 0:1]) >= 0).float() - 0.5) * 2.0, mm))
+    st = lambda k: torch.stack([c[k] for c in cases])
+    return cases, st, torch.stack([g[0] for g in geo]), torch.stack([g[1] for g in geo]), torch.stack([g[2] for g in geo]), [g[3] for g in geo]
+
+
+REFINE_TRAIN_CASES = [(50, (7, 2, 32, 50, 1), (67, 62, 92, 110, 61), "initCamRef", 1.0), (50, (32,), (92,), "initRecCamRef", 0.5),
+                      (64, (33, 64), (133, 164), "initCamRef_Aux", 2.0)]
+
+
+@pytest.mark.parametrize("nq,ms,seeds,tag,weight", REFINE_TRAIN_CASES)
+def test_refine_training_twin(sd50, nq, ms, seeds, tag, weight):
+    """Oracle restatement of __forward_PlaneCamRefHead (camera_head.py:737-923) against the reference's own outputs and losses."""
+    from nopesac_amd.synth import synth_state_dict
+    sd = sd50 if nq == 50 else synth_state_dict(nq)
+    cases, st, gl, gg, sig, mm = _refine_train_inputs(nq, ms, seeds)
+    g = gold(f"H_refine_train_nq{nq}_{tag}")
+    assert mm == list(ms) and rel_err(gg, g["geo_global"]) < 1e-5 and rel_err(gl, g["geo_local"]) < 1e-6 and torch.equal(sig, g["sig"])
+    gt = GI.gt_pose_case(len(ms), seeds[0])
+    assert torch.equal(gt, g["gt_pose"])
+    with torch.no_grad():
+        losses, pr = O.ransac_refine_train(sd, st("trans_feat"), st("rot_feat"), gg, gl, sig, mm, st("init_trans"), st("init_rot"), gt,
+                                           O.OracleConfig(num_queries=nq, out_cam_type="soft"), suffix=tag, weight=weight)
+    assert len(losses) == 7 and all(k.endswith("_" + tag) for k in losses)
+    for k, v in {**losses, **pr}.items():
+        assert rel_err(v, g[k]) < 5e-5, k
+
+
 @pytest.mark.parametrize("tag,structured,idx", [("default_noise", False, 0), ("loose_structured", True, 2)])
 def test_e2e(sd50, tag, structured, idx):
     from nopesac_amd.synth import synth_pair

@@ -184,6 +184,58 @@ def _refine_batch(device, model, O, sd, nq, ms, seeds, cam_type="soft"):
             assert float(out["score_rot"][b, m + 1:].abs().sum()) == 0
 
 
+def _refine_train_batch(device, model, O, sd, nq, ms, seeds, tag, weight):
+    """HIP training-side twin (PlaneCameraHead.forward_plane_cam_ref_head) vs the oracle's restatement of
+    __forward_PlaneCamRefHead (camera_head.py:737-923) and vs the reference's own outputs / losses (H_refine_train_*.npz)."""
+    head = model.camera_head_list[0]
+    cases = [GI.refine_case(nq, m, s) for m, s in zip(ms, seeds)]
+    B = len(cases)
+    A = torch.zeros(B, nq, nq)
+    for b, c in enumerate(cases):
+        A[b, : c["A"].shape[0], : c["A"].shape[1]] = c["A"]
+    p1 = torch.stack([_pad(c["planes1"], nq) for c in cases]).to(device)
+    p2 = torch.stack([_pad(c["planes2"], nq) for c in cases]).to(device)
+    n1 = torch.tensor([c["planes1"].shape[0] for c in cases], dtype=torch.int32, device=device)
+    n2 = torch.tensor([c["planes2"].shape[0] for c in cases], dtype=torch.int32, device=device)
+    st = lambda k: torch.stack([c[k] for c in cases])
+    gt = GI.gt_pose_case(B, seeds[0])
+    with torch.no_grad():
+        losses, pr = head.forward_plane_cam_ref_head(A.to(device), p1, p2, n1, n2, st("init_trans").to(device), st("init_rot").to(device),
+                                                     st("trans_feat").to(device), st("rot_feat").to(device), gt.to(device),
+                                                     suffix=tag, weight=weight)
+    geo = []
+    for c in cases:
+        gl, mm = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq)
+        gg, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], c["init_trans"])
+        ga, _ = O.geo_sequence(c["planes1"], c["planes2"], c["A"], nq, c["init_rot"], torch.zeros(3))
+        geo.append((gl, gg, (((gg[:, 0:1] * ga[:, 0:1]) >= 0).float() - 0.5) * 2.0, mm))
+    with torch.no_grad():
+        o_loss, o_pr = O.ransac_refine_train(sd, st("trans_feat"), st("rot_feat"), torch.stack([g[1] for g in geo]),
+                                             torch.stack([g[0] for g in geo]), torch.stack([g[2] for g in geo]), [g[3] for g in geo],
+                                             st("init_trans"), st("init_rot"), gt, O.OracleConfig(num_queries=nq, out_cam_type="soft"),
+                                             suffix=tag, weight=weight)
+    g = gold(f"H_refine_train_nq{nq}_{tag}")
+    assert set(losses) == set(o_loss) and set(pr) == set(o_pr)
+    for k in o_pr:
+        tol = 1e-3 if k == "normal_dist" else 2e-4           # acos near 0 amplifies rounding (as in the inference test)
+        assert tuple(pr[k].shape) == tuple(o_pr[k].shape), (k, pr[k].shape, o_pr[k].shape)
+        assert rel_err(pr[k], o_pr[k]) < tol, (tag, k, rel_err(pr[k], o_pr[k]))
+        assert rel_err(pr[k].cpu(), g[k]) < tol, (tag, k)
+    for k in o_loss:
+        assert rel_err(losses[k], o_loss[k]) < 2e-4, (tag, k, float(losses[k]), float(o_loss[k]))
+        assert rel_err(losses[k].cpu(), g[k]) < 2e-4, (tag, k, float(losses[k]), float(g[k]))
+
+
+def test_refine_training_twin(device, model, O, sd50):
+    _refine_train_batch(device, model, O, sd50, 50, (7, 2, 32, 50, 1), (67, 62, 92, 110, 61), "initCamRef", 1.0)
+    _refine_train_batch(device, model, O, sd50, 50, (32,), (92,), "initRecCamRef", 0.5)
+
+
+def test_refine_training_twin_nq64(device, O):
+    from nopesac_amd.synth import synth_state_dict
+    _refine_train_batch(device, make_model(device, nq=64), O, synth_state_dict(64), 64, (33, 64), (133, 164), "initCamRef_Aux", 2.0)
+
+
 def test_refine_ragged_batch(device, model, O, sd50):
     ms = (0, 1, 2, 7, 32, 50)
     _refine_batch(device, model, O, sd50, 50, ms, [60 + m for m in ms])
