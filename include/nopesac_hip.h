@@ -400,6 +400,15 @@ int nopesac_plane_cam_ref_losses(const float* pred_rot, const float* pred_trans,
                                  const int32_t* m, const float* gt_pose, int B, int nq, float weight,
                                  float* losses, void* stream);
 
+/* CameraPoseLoss, reduce=True without mask (camera_modules.py:355-365) - also the form of the AIM's reconstruction losses
+ * (camera_head.py:700-705, :725-731, with trans_eps = 1e-10 as the reference adds it to the re-embedded translation):
+ *   out[0] = mean_b |gt_trans[b] + trans_eps - est_trans[b]|_2 * weight, out[1] = mean_b |n(gt_rot[b]) - n(est_rot[b])|_2 * weight.
+ * est_trans f32[B,3], est_rot f32[B,4]; gt_trans / gt_rot are rows of `stride` floats (7 and 7 for a [B,7] pose tensor with
+ * gt_rot = gt_pose + 3).  Forward only. */
+int nopesac_camera_pose_loss(const float* est_trans, const float* est_rot, const float* gt_trans, int gt_trans_stride,
+                             const float* gt_rot, int gt_rot_stride, int B, float trans_eps, float weight, float* out,
+                             void* stream);
+
 /* assignment re-filter under the refined pose (:605-629): keep matches with normal angle < 45 deg and
  * offset distance < 1; `rot` is sign-canonicalised inside (w >= 0). In/out f32[B,nq,nq]. */
 int nopesac_refilter_assignment(const float* assignment_in, const float* planes1, const float* planes2,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "nopesac_ransac_score_maps": [P, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P],
     "nopesac_ransac_soft_vote": [P] * 21 + [I, I, I] + [P] * 6 + [P],
     "nopesac_plane_cam_ref_losses": [P] * 11 + [I, I, F, P, P],
+    "nopesac_camera_pose_loss": [P, P, P, I, P, I, I, F, F, P, P],
     "nopesac_refilter_assignment": [P, P, P, P, P, P, P, I, I, P, P],
     "nopesac_tape_create": [P, ctypes.POINTER(c_void_p), P],
     "nopesac_tape_create_ex": [P, I, ctypes.POINTER(c_void_p), P],

@@ -348,6 +348,23 @@ __global__ __launch_bounds__(64) void plane_cam_ref_losses_kernel(
     }
 }
 
+// CameraPoseLoss.forward, reduce=True, no mask (camera_modules.py:355-365), also the form of the AIM's reconstruction losses
+// (camera_head.py:700-705, :725-731): out[0] = mean_b |gt_t + trans_eps - est_t| * weight, out[1] = mean_b |n(gt_q) - n(est_q)| * weight.
+__global__ __launch_bounds__(64) void camera_pose_loss_kernel(const float* __restrict__ est_trans, const float* __restrict__ est_rot,
+                                                              const float* __restrict__ gt_trans, int gt_trans_stride,
+                                                              const float* __restrict__ gt_rot, int gt_rot_stride, int B,
+                                                              float trans_eps, float weight, float* __restrict__ out) {
+    float lx = 0.f, lq = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const float* gt = gt_trans + (long long)b * gt_trans_stride;
+        const float g[3] = {gt[0] + trans_eps, gt[1] + trans_eps, gt[2] + trans_eps};
+        lx += vec3_dist(g, est_trans + 3 * b);
+        lq += quat_dist_normalised(gt_rot + (long long)b * gt_rot_stride, est_rot + 4 * b);
+    }
+    lx = wave_sum(lx); lq = wave_sum(lq);
+    if (threadIdx.x == 0) { out[0] = lx / (float)B * weight; out[1] = lq / (float)B * weight; }
+}
+
 // BENCHMARK-ONLY K control (PlaneTR_NopeSAC._force_k, oracle force_k): with the name-seeded random weights the
 // threshold-based selection keeps ~1 plane per view, so the stages behind it would see K = 1.  One workgroup per pair: the K
 // highest-scoring queries of view 1 (score = logit 0 - logit 1; ascending query order, as topk(..).indices.sort() gives them) become
@@ -466,5 +483,16 @@ extern "C" int nopesac_plane_cam_ref_losses(const float* pred_rot, const float* 
     NPS_CHECK_ARG(B > 0 && nq > 0 && nq <= 128, "plane_cam_ref_losses: bad dims (nq<=128)");
     hipLaunchKernelGGL(plane_cam_ref_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pred_rot, pred_trans, avg_rot, avg_trans,
                        rots_all, trans_all, score_rot, score_trans, l2_dist, m, gt_pose, B, nq, weight, losses);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_camera_pose_loss(const float* est_trans, const float* est_rot, const float* gt_trans, int gt_trans_stride,
+                                        const float* gt_rot, int gt_rot_stride, int B, float trans_eps, float weight, float* out,
+                                        void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(est_trans && est_rot && gt_trans && gt_rot && out, "camera_pose_loss: null pointer");
+    NPS_CHECK_ARG(B > 0 && gt_trans_stride >= 3 && gt_rot_stride >= 4, "camera_pose_loss: bad dims / strides");
+    hipLaunchKernelGGL(camera_pose_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, est_trans, est_rot, gt_trans, gt_trans_stride,
+                       gt_rot, gt_rot_stride, B, trans_eps, weight, out);
     NPS_LAUNCH_RET();
 }

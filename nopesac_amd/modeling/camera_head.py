@@ -40,6 +40,10 @@ class PlaneCameraHead(ParamModule):
         self.out_cam_type = C.INFERENCE_OUT_CAM_TYPE
         self.warp_plane_in_cam_ref_on = bool(C.WARP_PLANE_IN_CAM_REF_ON)
         self.matching_score_threshold = float(cfg.TEST.MATCHING_SCORE_THRESHOLD)
+        # loss weights of the training-side forward (camera_head.py:46-48); forward_train only
+        self.initial_cam_weight = float(getattr(C, "INITIAL_CAM_WEIGHT", 1.0))
+        self.plane_cam_weight = float(getattr(C, "PLANE_CAM_WEIGHT", 1.0))
+        self.plane_cam_weight_predplane = float(getattr(C, "PLANE_CAM_WEIGHT_PREDPLANE", 0.1))
         assert C.REFINE_ON and C.CAM_REC_ON and not C.INFERENCE_SP_TOPCAM_ON and cfg.MODEL.EMBEDDING_ON and cfg.MODEL.MASK_ON, \
             "implemented: the shipped inference configuration (REFINE_ON, CAM_REC_ON, plane matcher on; inference_mp3d.yaml:17-23)"
         assert not cfg.TEST.POSE_REFINEMENT_WITH_GT_MATCHERS, "GT matchers are an evaluation-only mode"
@@ -88,9 +92,9 @@ class PlaneCameraHead(ParamModule):
         return ops.groupnorm(x, self.raw(f"pixel_decoder.{nm}.norm.weight"), self.raw(f"pixel_decoder.{nm}.norm.bias"), 32, 1e-5, act)
 
     # ---------------------------------------------------------------- (i) pixel pose net
-    def pixel_pose_net(self, feats: dict, B: int):
+    def pixel_pose_net(self, feats: dict, B: int, canonical_sign: bool = True):
         """feats: NHWC res3..res5 for 2B images (view-1 images first) -> trans0 [B,3], rot0 [B,4] (unit, w>=0),
-        trans_feat, rots_feat [B,256]."""
+        trans_feat, rots_feat [B,256].  `canonical_sign=False`: the training forward keeps the regressed sign (:667)."""
         P, gd = self.packed, self._gd("decoder")
         r3, r4, r5 = feats["res3"], feats["res4"], feats["res5"]
         if "decoder" in self.fp32_parts and r5.dtype != torch.float32:
@@ -149,7 +153,7 @@ class PlaneCameraHead(ParamModule):
             (trans_feat, trans0), (rots_feat, rot_raw) = head(yt, "fc_trans", "trans"), head(yr, "fc_rots", "rots")
         else:
             (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
-        rot0 = ops.normalize_rows(rot_raw, canonical_sign=True)                                   # :667, :436-437
+        rot0 = ops.normalize_rows(rot_raw, canonical_sign=canonical_sign)                         # :667, :436-437
         return trans0, rot0, trans_feat, rots_feat
 
     # ---------------------------------------------------------------- (ii) AIM
@@ -214,6 +218,44 @@ class PlaneCameraHead(ParamModule):
                     "score_soft_offset": out["score_trans"][0:1, :m0 + 1, None], "l2_dist": maps["l2_dist"][0:1, :m0 + 1, :m0],
                     "normal_dist": maps["normal_angle"][0:1, :m0 + 1, :m0], "offset_dist": maps["offset_dist"][0:1, :m0 + 1, :m0]}
         return losses, pred_cam
+
+    def forward_train(self, feats: dict, B: int, gt_planes1, gt_planes2, gt_n1, gt_n2, gt_assignment, gt_pose, planes1=None,
+                      planes2=None, n1=None, n2=None, assignment=None, rand_rot=None, rand_trans=None):
+        """The reference's PlaneCameraHead.forward in TRAINING mode, FORWARD + LOSSES ONLY (camera_head.py:140-189 ->
+        forward_withInitialCam_Joint :191-323, forward_withRandCam_Joint :325-344): pixel pose loss (:672-680), the AIM's
+        reconstruction losses on the pixel pose (:700-705, :725-731), the refinement twin from the pixel pose and from its re-embedding over
+        the GT planes + GT correspondences ('initCamRef', 'initRecCamRef', weight PLANE_CAM_WEIGHT) and, if predicted planes + an
+        assignment are given, over those ('..._Aux', weight PLANE_CAM_WEIGHT_PREDPLANE), and the AIM's losses on caller-provided
+        random poses (the reference draws them, :687-690, :718).  Planes are [B,nq,3] zero-padded with counts int32[B]; assignments
+        [B,nq,nq]; gt_pose [B,7].  BatchNorm / GroupNorm layers run with their stored statistics: this evaluates the losses of a
+        checkpoint (validation curves, loss parity); there are no gradient kernels, so it is not an optimiser step.
+        Returns (losses, trans_list, rot_list) as the reference does."""
+        losses = {}
+        trans0, rot0, tf0, rf0 = self.pixel_pose_net(feats, B, canonical_sign=False)
+        lp = ops.camera_pose_loss(trans0, rot0, gt_pose[:, 0:3], gt_pose[:, 3:7], self.initial_cam_weight)
+        losses["loss_tran_pixelReg"], losses["loss_rot_pixelReg"] = lp[0], lp[1]
+
+        def rec(trans_in, rot_in, suffix):
+            rot_c = ops.normalize_rows(rot_in, canonical_sign=True)          # input_rot * sig (:695-696)
+            rec_t, rec_r, rec_tf, rec_rf = self.aim(trans_in, rot_c)
+            lr = ops.camera_pose_loss(rec_t, rec_r, trans_in, rot_c, 1.0, trans_eps=1e-10)
+            losses["loss_rot" + suffix], losses["loss_trans" + suffix] = lr[1], lr[0]
+            return rec_t, rec_r, rec_tf, rec_rf
+
+        rec_t, rec_r, rec_tf, rec_rf = rec(trans0, rot0, "_initCamRec")
+        trans_list, rot_list = [trans0, rec_t], [rot0, rec_r]
+        passes = [("", gt_planes1, gt_planes2, gt_n1, gt_n2, gt_assignment, self.plane_cam_weight)]
+        if assignment is not None:
+            passes.append(("_Aux", planes1, planes2, n1, n2, assignment, self.plane_cam_weight_predplane))
+        for sfx, pl1, pl2, c1, c2, A, w in passes:
+            for name, it, ir, itf, irf in (("initCamRef", trans0, rot0, tf0, rf0), ("initRecCamRef", rec_t, rec_r, rec_tf, rec_rf)):
+                ls, pr = self.forward_plane_cam_ref_head(A, pl1, pl2, c1, c2, it, ir, itf, irf, gt_pose, suffix=name + sfx, weight=w)
+                losses.update(ls)
+                trans_list += [pr["pred_trans_avg"], pr["pred_trans"]]
+                rot_list += [pr["pred_rot_avg"], pr["pred_rot"]]
+        if rand_rot is not None:
+            rec(rand_trans, rand_rot, "_randCamRecLBS_N1")
+        return losses, trans_list, rot_list
 
     # ---------------------------------------------------------------- whole head
     def initial_pose(self, feats: dict, B: int):

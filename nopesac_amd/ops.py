@@ -914,6 +914,24 @@ def plane_cam_ref_losses(vote: dict, maps: dict, m, gt_pose, weight: float = 1.0
     return losses
 
 
+def camera_pose_loss(est_trans, est_rot, gt_trans, gt_rot, weight: float = 1.0, trans_eps: float = 0.0):
+    """CameraPoseLoss / the AIM's reconstruction losses (include/nopesac_hip.h: nopesac_camera_pose_loss) -> f32[2] = (l_x, l_q) * weight.
+    `gt_trans` / `gt_rot` may be column views of one [B,7] pose tensor (row strides are passed on)."""
+    for t in (est_trans, est_rot):
+        _chk(t, torch.float32)
+    for t in (gt_trans, gt_rot):
+        _chk(t, torch.float32, contiguous=False)
+        _require(t.dim() == 2 and t.stride(1) == 1, "camera_pose_loss: gt rows must be dense")
+    B = est_trans.shape[0]
+    _require(tuple(est_trans.shape) == (B, 3) and tuple(est_rot.shape) == (B, 4) and tuple(gt_trans.shape) == (B, 3) and
+             tuple(gt_rot.shape) == (B, 4), "camera_pose_loss: shapes")
+    out = torch.empty(2, device=est_trans.device, dtype=torch.float32)
+    rc = _L().nopesac_camera_pose_loss(_p(est_trans), _p(est_rot), _p(gt_trans), gt_trans.stride(0), _p(gt_rot), gt_rot.stride(0), B,
+                                       float(trans_eps), float(weight), _p(out), _stream())
+    _lib.check(rc, "nopesac_camera_pose_loss")
+    return out
+
+
 def refilter_assignment(assignment, planes1, planes2, n1, n2, rot, trans):
     B, nq, _ = assignment.shape
     out = torch.empty_like(assignment)

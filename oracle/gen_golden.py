@@ -340,6 +340,49 @@ def main():
         run_refine_train(model, sd, 50, (32,), (92,), "initRecCamRef", 0.5)
         run_refine_train(model64, sd64, 64, (33, 64), (133, 164), "initCamRef_Aux", 2.0)
 
+        # ---- I camera head, TRAINING forward + losses (camera_head.py:140-323) ---------------------------
+        print("[I] camera head, training forward (losses)")
+        for ms, seed in (((7, 2, 19), 80),):
+            c = GI.camera_train_case(50, ms, seed)
+            B = len(ms)
+            binp = []
+            for b in range(B):
+                n1, n2 = int(c["n1"][b]), int(c["n2"][b])
+                binp.append({"0": {"annotations": [{"plane": c["gt_planes1"][b, i].tolist()} for i in range(n1)]},
+                             "1": {"annotations": [{"plane": c["gt_planes2"][b, i].tolist()} for i in range(n2)]},
+                             "gt_corrs": torch.nonzero(c["gt_A"][b]).tolist()})
+            gcm = torch.zeros(B, 51, 51)
+            gcm[:, :50, :50] = c["A"]
+            old = (head.training, head.cam_rec_on, head.cam_ref_on, head.rand_cam_on)
+            head.training, head.rand_cam_on = True, False
+            assert head.cam_rec_on and head.cam_ref_on
+            try:
+                with quiet(), torch.enable_grad():    # forward() drops every loss without a gradient history (:180-183)
+                    losses, tl, rl, _, _, _ = head(c["feats1"], c["feats2"], c["planes1"], c["planes2"], gt_pose=c["gt_pose"],
+                                                   gt_corr_matrix=gcm, batched_inputs=binp)
+                    l_rr, _, _ = head._PlaneCameraHead__forward_RotRecHead(input_rot=c["rand_rot"], suffix="_randCamRecLBS_N1")
+                    l_rt, _, _ = head._PlaneCameraHead__forward_TransRecHead(input_trans=c["rand_trans"], suffix="_randCamRecLBS_N1")
+            finally:
+                head.training, head.cam_rec_on, head.cam_ref_on, head.rand_cam_on = old
+            losses = {k: v.detach() for k, v in losses.items()}
+            tl, rl = [t.detach() for t in tl], [r.detach() for r in rl]
+            l_rr, l_rt = {k: v.detach() for k, v in l_rr.items()}, {k: v.detach() for k, v in l_rt.items()}
+            o_loss, o_tl, o_rl = O.camera_head_train(sd, c["feats1"], c["feats2"], c["gt_planes1"], c["gt_planes2"], c["gt_A"], c["gt_pose"],
+                                                     c["planes1"], c["planes2"], c["A"], cfg, head.initial_cam_weight, head.plane_cam_weight,
+                                                     head.plane_cam_weight_predplane, c["rand_rot"], c["rand_trans"])
+            losses.update(l_rr); losses.update(l_rt)
+            assert set(losses) == set(o_loss), set(losses) ^ set(o_loss)
+            assert len(tl) == len(o_tl) == len(rl) == len(o_rl), (len(tl), len(o_tl))
+            out = {}
+            for k, v in losses.items():
+                rep.check(f"camhead_train.{k}", o_loss[k], v, 5e-5)
+                out[k] = v
+            for i, (t, r) in enumerate(zip(tl, rl)):
+                rep.check(f"camhead_train.trans_list.{i}", o_tl[i], t, 5e-5)
+                rep.check(f"camhead_train.rot_list.{i}", o_rl[i], r, 5e-5)
+                out[f"trans_list_{i}"], out[f"rot_list_{i}"] = t, r
+            save(f"I_camhead_train_seed{seed}", **out)
+
         # ---- camera head D->E->F on designed planes + designed features ----------------------
         print("[DEF] camera head")
         for n1, n2, seed in ((12, 9, 70), (32, 32, 71), (1, 1, 72)):

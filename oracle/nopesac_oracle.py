@@ -663,6 +663,57 @@ def ransac_refine_train(sd, init_trans_feat, init_rot_feat, geo_global, geo_loca
     return losses, pred_cam
 
 
+def _refine_train_from_assignment(sd, planes1, planes2, A, init_trans, init_rot, trans_feat, rot_feat, gt_pose, cfg, suffix, weight, p):
+    """forawrd_refineLoop (camera_head.py:346-398) for a batch given as padded planes [B,nq,3] + assignment [B,nq,nq]."""
+    B, nq = A.shape[0], cfg.num_queries
+    gl, gg, sg, ms = [], [], [], []
+    for b in range(B):
+        l, m = geo_sequence(planes1[b], planes2[b], A[b], nq)
+        g, _ = geo_sequence(planes1[b], planes2[b], A[b], nq, init_rot[b], init_trans[b])
+        a, _ = geo_sequence(planes1[b], planes2[b], A[b], nq, init_rot[b], torch.zeros(3))
+        gl.append(l); gg.append(g); ms.append(m)
+        sg.append((((g[:, 0:1] * a[:, 0:1]) >= 0).float() - 0.5) * 2.0)
+    return ransac_refine_train(sd, trans_feat, rot_feat, torch.stack(gg), torch.stack(gl), torch.stack(sg), ms, init_trans, init_rot,
+                               gt_pose, cfg, suffix=suffix, weight=weight, p=p)
+
+
+def camera_head_train(sd, feats1, feats2, gt_planes1, gt_planes2, gt_A, gt_pose, planes1, planes2, A, cfg: OracleConfig,
+                      initial_cam_weight: float = 1.0, plane_cam_weight: float = 1.0, plane_cam_weight_predplane: float = 0.1,
+                      rand_rot=None, rand_trans=None, p: str = "camera_head_list.0"):
+    """PlaneCameraHead.forward in TRAINING mode, forward + losses only (camera_head.py:140-189 -> forward_withInitialCam_Joint
+    :191-323, forward_withRandCam_Joint :325-344 with the random poses given), CAM_REC_ON and REFINE_ON set.  BatchNorm layers use
+    their running statistics (the fixtures are taken with the sub-modules in eval mode: a loss evaluation, not an optimiser step).
+    feats: dicts res2..res5 [B,C,H,W]; gt_planes* / planes* [B,nq,3] zero-padded; gt_A / A [B,nq,nq] (ground-truth correspondences over
+    the GT planes / over the predicted planes); gt_pose [B,7].  Returns (losses, trans_list, rot_list)."""
+    losses = {}
+    trans0, rot0, tf0, rf0, _ = pixel_pose_net(sd, feats1, feats2, p)       # :642-683 (no sign flip in training)
+    l_t, l_r = camera_pose_loss(torch.cat((trans0, rot0), -1), gt_pose)
+    losses["loss_tran_pixelReg"], losses["loss_rot_pixelReg"] = l_t * initial_cam_weight, l_r * initial_cam_weight
+
+    def rec_losses(trans_in, rot_in, suffix):                               # :685-735
+        sig = ((rot_in[:, 0:1] >= 0.0).float() - 0.5) * 2.0
+        rec_t, rec_r, rec_tf, rec_rf = aim_reembed(sd, trans_in, rot_in, p)
+        out = {}
+        if rot_in is not None:
+            out["loss_rot" + suffix] = (F.normalize(rot_in * sig, dim=1) - rec_r).norm(dim=1).mean()
+            out["loss_trans" + suffix] = ((trans_in + 1e-10) - rec_t).norm(dim=1).mean()
+        return out, rec_t, rec_r, rec_tf, rec_rf
+
+    l, rec_t, rec_r, rec_tf, rec_rf = rec_losses(trans0, rot0, "_initCamRec")
+    losses.update(l)
+    trans_list, rot_list = [trans0, rec_t], [rot0, rec_r]
+    for sfx, pl1, pl2, AA, w in (("", gt_planes1, gt_planes2, gt_A, plane_cam_weight), ("_Aux", planes1, planes2, A, plane_cam_weight_predplane)):
+        for name, it, ir, itf, irf in (("initCamRef", trans0, rot0, tf0, rf0), ("initRecCamRef", rec_t, rec_r, rec_tf, rec_rf)):
+            ls, pr = _refine_train_from_assignment(sd, pl1, pl2, AA, it, ir, itf, irf, gt_pose, cfg, name + sfx, w, p)
+            losses.update(ls)
+            trans_list += [pr["pred_trans_avg"], pr["pred_trans"]]
+            rot_list += [pr["pred_rot_avg"], pr["pred_rot"]]
+    if rand_rot is not None:                                                # :325-344: AIM on random poses (given, not drawn)
+        l, _, _, _, _ = rec_losses(rand_trans, rand_rot, "_randCamRecLBS_N1")
+        losses.update(l)
+    return losses, trans_list, rot_list
+
+
 def camera_head(sd, feats1, feats2, planes1, planes2, app1, app2, cfg: OracleConfig, forced_assignment=None):
     """PlaneCameraHead.inference_Joint for ONE pair (camera_head.py:400-640).
     feats: dict res2..res5 [1,C,H,W]; planes [n,3]; app [n,256].  Returns (cameras, assignments, aux).

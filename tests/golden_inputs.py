@@ -61,6 +61,27 @@ def gt_pose_case(B: int, seed: int):
     return torch.cat([0.6 * torch.randn(B, 3, generator=g), q], dim=1)
 
 
+def camera_train_case(nq: int, ms, seed: int):
+    """Inputs of the camera head's training forward (camera_head.py:140-323): backbone maps of a batch, GT planes + GT
+    correspondences per pair, noisy 'predicted' planes with the same correspondences, GT poses, and the random poses of the AIM's
+    LBS losses."""
+    cases = [refine_case(nq, m, seed + 10 * b) for b, m in enumerate(ms)]
+    B = len(cases)
+    g = _g(2000 + seed)
+    pad = lambda t: torch.cat([t, torch.zeros(nq - t.shape[0], 3)], 0)
+    A = torch.zeros(B, nq, nq)
+    for b, c in enumerate(cases):
+        A[b, : c["A"].shape[0], : c["A"].shape[1]] = c["A"]
+    gp1, gp2 = torch.stack([pad(c["planes1"]) for c in cases]), torch.stack([pad(c["planes2"]) for c in cases])
+    noisy = lambda P: P + 0.03 * torch.randn(P.shape, generator=g) * (P.abs().sum(-1, keepdim=True) > 0)
+    rr = F.normalize(torch.randn(2 * B, 4, generator=g), dim=1)
+    return {"feats1": feature_maps(seed + 100, batch=B), "feats2": feature_maps(seed + 200, batch=B), "gt_planes1": gp1, "gt_planes2": gp2,
+            "gt_A": A, "planes1": noisy(gp1), "planes2": noisy(gp2), "A": A.clone(), "gt_pose": gt_pose_case(B, seed),
+            "n1": torch.tensor([c["planes1"].shape[0] for c in cases], dtype=torch.int32),
+            "n2": torch.tensor([c["planes2"].shape[0] for c in cases], dtype=torch.int32),
+            "rand_rot": rr, "rand_trans": (torch.rand(2 * B, 3, generator=g) - 0.5) * 5.0}
+
+
 def _blob_field(h, w, g, cells=6):
     """Smooth random field in [-1,1] (bilinear up-sampling of a coarse random grid)."""
     coarse = torch.rand(1, 1, cells, cells + 2, generator=g) * 2 - 1

@@ -292,3 +292,4 @@ def test_training_twin_argument_checks_without_a_gpu():
     assert lib.nopesac_plane_cam_ref_losses(*([None] * 11), 2, 50, 1.0, None, None) != 0 and "plane_cam_ref_losses" in err()
     assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 16 + 4, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()
     assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 32, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()
+    assert lib.nopesac_camera_pose_loss(None, None, None, 7, None, 7, 4, 0.0, 1.0, None, None) != 0 and "camera_pose_loss" in err()

@@ -126,6 +126,22 @@ def test_refine_training_twin(sd50, nq, ms, seeds, tag, weight):
         assert rel_err(v, g[k]) < 5e-5, k
 
 
+def test_camera_head_training_forward(sd50):
+    """Oracle restatement of PlaneCameraHead.forward in training mode (camera_head.py:140-344: 34 losses + the pose lists) against
+    the imported reference's outputs."""
+    c = GI.camera_train_case(50, (7, 2, 19), 80)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        losses, tl, rl = O.camera_head_train(sd50, c["feats1"], c["feats2"], c["gt_planes1"], c["gt_planes2"], c["gt_A"], c["gt_pose"],
+                                             c["planes1"], c["planes2"], c["A"], CFG, 1.0, 1.0, 0.1, c["rand_rot"], c["rand_trans"])
+    g = gold("I_camhead_train_seed80")
+    assert len(losses) == 34 and len(tl) == len(rl) == 10
+    for k, v in losses.items():
+        assert rel_err(v, g[k]) < 5e-5, k
+    for i, (t, r) in enumerate(zip(tl, rl)):
+        assert rel_err(t, g[f"trans_list_{i}"]) < 5e-5 and rel_err(r, g[f"rot_list_{i}"]) < 5e-5, i
+
+
 @pytest.mark.parametrize("tag,structured,idx", [("default_noise", False, 0), ("loose_structured", True, 2)])
 def test_e2e(sd50, tag, structured, idx):
     from nopesac_amd.synth import synth_pair

@@ -236,6 +236,32 @@ def test_refine_training_twin_nq64(device, O):
     _refine_train_batch(device, make_model(device, nq=64), O, synth_state_dict(64), 64, (33, 64), (133, 164), "initCamRef_Aux", 2.0)
 
 
+def test_camera_head_training_forward(device, model, O, sd50):
+    """PlaneCameraHead.forward_train (HIP) = the reference's training-mode forward of the camera head (camera_head.py:140-344), forward
+    + losses: 34 losses and the ten recorded poses against the oracle's restatement and the imported reference's own values
+    (I_camhead_train_seed80.npz)."""
+    nq, ms = 50, (7, 2, 19)
+    c = GI.camera_train_case(nq, ms, 80)
+    B = len(ms)
+    feats = {k: torch.cat([nhwc(c["feats1"][k]), nhwc(c["feats2"][k])]).to(device) for k in ("res3", "res4", "res5")}
+    d = lambda k: c[k].to(device)
+    head = model.camera_head_list[0]
+    with torch.no_grad():
+        losses, tl, rl = head.forward_train(feats, B, d("gt_planes1"), d("gt_planes2"), d("n1"), d("n2"), d("gt_A"), d("gt_pose"),
+                                            d("planes1"), d("planes2"), d("n1"), d("n2"), d("A"), d("rand_rot"), d("rand_trans"))
+        o_loss, o_tl, o_rl = O.camera_head_train(sd50, c["feats1"], c["feats2"], c["gt_planes1"], c["gt_planes2"], c["gt_A"], c["gt_pose"],
+                                                 c["planes1"], c["planes2"], c["A"], O.OracleConfig(num_queries=nq), head.initial_cam_weight,
+                                                 head.plane_cam_weight, head.plane_cam_weight_predplane, c["rand_rot"], c["rand_trans"])
+    g = gold("I_camhead_train_seed80")
+    assert set(losses) == set(o_loss) and len(losses) == 34 and len(tl) == len(o_tl) == 10
+    for k in o_loss:
+        assert rel_err(losses[k], o_loss[k]) < 3e-4, (k, float(losses[k]), float(o_loss[k]))
+        assert rel_err(losses[k].cpu(), g[k]) < 3e-4, (k, float(losses[k]), float(g[k]))
+    for i in range(10):
+        assert rel_err(tl[i], o_tl[i]) < 3e-4 and rel_err(rl[i], o_rl[i]) < 3e-4, i
+        assert rel_err(tl[i].cpu(), g[f"trans_list_{i}"]) < 3e-4 and rel_err(rl[i].cpu(), g[f"rot_list_{i}"]) < 3e-4, i
+
+
 def test_refine_ragged_batch(device, model, O, sd50):
     ms = (0, 1, 2, 7, 32, 50)
     _refine_batch(device, model, O, sd50, 50, ms, [60 + m for m in ms])
