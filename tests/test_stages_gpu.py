@@ -262,6 +262,27 @@ def test_camera_head_training_forward(device, model, O, sd50):
         assert rel_err(tl[i].cpu(), g[f"trans_list_{i}"]) < 3e-4 and rel_err(rl[i].cpu(), g[f"rot_list_{i}"]) < 3e-4, i
 
 
+def test_camera_head_training_forward_bf16(device, model):
+    """The same call on the bf16 kernel set (fused branch tail, MFMA MLP chains): every loss within 5 % of the fp32 path's (or 5e-3
+    absolute for the small index losses) - a smoke bound on operand rounding, the parity gates are the fp32 tests above."""
+    nq, ms = 50, (7, 2, 19)
+    c = GI.camera_train_case(nq, ms, 80)
+    d = lambda k: c[k].to(device)
+    args = lambda: (d("gt_planes1"), d("gt_planes2"), d("n1"), d("n2"), d("gt_A"), d("gt_pose"), d("planes1"), d("planes2"), d("n1"),
+                    d("n2"), d("A"), d("rand_rot"), d("rand_trans"))
+    m16 = make_model(device, dtype="bfloat16")
+    f32 = {k: torch.cat([nhwc(c["feats1"][k]), nhwc(c["feats2"][k])]).to(device) for k in ("res3", "res4", "res5")}
+    f16 = {k: v.to(torch.bfloat16) for k, v in f32.items()}
+    with torch.no_grad():
+        l32, _, _ = model.camera_head_list[0].forward_train(f32, len(ms), *args())
+        l16, t16, r16 = m16.camera_head_list[0].forward_train(f16, len(ms), *args())
+    assert set(l16) == set(l32)
+    for k in l32:
+        a, b = float(l16[k]), float(l32[k])
+        assert abs(a - b) <= max(0.05 * abs(b), 5e-3), (k, a, b)
+    assert all(torch.isfinite(t).all() for t in t16 + r16)
+
+
 def test_refine_ragged_batch(device, model, O, sd50):
     ms = (0, 1, 2, 7, 32, 50)
     _refine_batch(device, model, O, sd50, 50, ms, [60 + m for m in ms])
