@@ -73,6 +73,16 @@ __device__ __forceinline__ int mask_lane_sum(unsigned long long m) {            
            8 * __popcll(m & 0xFF00FF00FF00FF00ull) + 16 * __popcll(m & 0xFFFF0000FFFF0000ull) + 32 * __popcll(m & 0xFFFFFFFF00000000ull);
 }
 
+// v_writelane_b32 with a wave-uniform value and lane index (no compiler builtin in this toolchain).  The s_nops cover the
+// "VALU writes SGPR -> lane select" and "SALU writes M0 -> use" wait states, which the compiler does not see through inline asm.
+__device__ __forceinline__ int ps_writelane(int value, int lane_index, int old) {
+    int saved_m0;                                                  // M0 is reserved: saved and restored instead of clobbered
+    asm volatile("s_mov_b32 %1, m0\n\ts_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(old), "=&s"(saved_m0) : "s"(value), "s"(lane_index));
+    return old;
+}
+
+template <int ROWS>
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
                                                         int W, float mask_thr, int src_rows, int src_cols,
                                                         int* __restrict__ work, uint8_t* __restrict__ winner, int planar, int th) {
@@ -134,50 +144,72 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    int cnt_lo = 0, cnt_hi = 0;                                  // lane k: pixels of this wave with p >= thr for list entry k (k + 64)
-    for (int it = 0; it < th / 4; ++it) {
-        const int X = X0 + lane, Y = Y0 + it * 4 + wave;
-        const bool in = X < W && Y < H;
-        const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
-        const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
-        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-        const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-        // clamp the local indices so that out-of-image lanes still read inside the tile
+    // Round 4 (end): the query loop is the OUTER loop and the ROWS = th / 4 pixel rows of this wave the inner one, so that the per-query
+    // pixel count of the wave is a SCALAR sum of ballot popcounts (s_bcnt1 + s_add) that is dropped into lane k once per query
+    // (v_writelane) - it was a v_mov + v_cmp + v_cndmask + v_add and two scalar branches per (pixel, query) pair - and the padded
+    // list entries need no validity compare (their lanes are never flushed).  Arithmetic per pixel is unchanged (same operations in
+    // the same order): 21 -> 14 VALU instructions per pair.
+    const int X = X0 + lane;
+    const float sx = fmaxf(scw * (X + 0.5f) - 0.5f, 0.f);
+    const int x0 = min((int)sx, w - 1), x1 = min(x0 + 1, w - 1);
+    const float lx = sx - x0, hx = 1.f - lx;
+    const int c0 = min(max(x0 - cx0, 0), ncols - 1), c1 = min(max(x1 - cx0, 0), ncols - 1);   // clamped: out-of-image lanes read inside the tile
+    float hy[ROWS], ly[ROWS], best[ROWS];
+    int win[ROWS];
+    const float *p00[ROWS], *p01[ROWS], *p10[ROWS], *p11[ROWS];
+    unsigned long long inm[ROWS];
+    bool in[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int Y = Y0 + r * 4 + wave;
+        in[r] = X < W && Y < H;
+        inm[r] = __ballot(in[r]);
+        const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)sy, h - 1), y1 = min(y0 + 1, h - 1);
+        ly[r] = sy - y0; hy[r] = 1.f - ly[r];
         const int r0 = min(max(y0 - ry0, 0), nrows - 1), r1 = min(max(y1 - ry0, 0), nrows - 1);
-        const int c0 = min(max(x0 - cx0, 0), ncols - 1), c1 = min(max(x1 - cx0, 0), ncols - 1);
-        const float* p00 = tile + (r0 * src_cols + c0) * kp;
-        const float* p01 = tile + (r0 * src_cols + c1) * kp;
-        const float* p10 = tile + (r1 * src_cols + c0) * kp;
-        const float* p11 = tile + (r1 * src_cols + c1) * kp;
-        float best = -INFINITY;
-        int win = -1;
-        for (int k4 = 0; k4 < nk4; ++k4) {
-            const float4 a = *reinterpret_cast<const float4*>(p00 + 4 * k4), bq = *reinterpret_cast<const float4*>(p01 + 4 * k4);
-            const float4 c = *reinterpret_cast<const float4*>(p10 + 4 * k4), d = *reinterpret_cast<const float4*>(p11 + 4 * k4);
-            const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);          // wave-uniform (LDS broadcast)
-            const float4 s4 = *reinterpret_cast<const float4*>(vs + 4 * k4);
+        p00[r] = tile + (r0 * src_cols + c0) * kp; p01[r] = tile + (r0 * src_cols + c1) * kp;
+        p10[r] = tile + (r1 * src_cols + c0) * kp; p11[r] = tile + (r1 * src_cols + c1) * kp;
+        best[r] = -INFINITY; win[r] = -1;
+    }
+    int cnt_lo = 0, cnt_hi = 0;                                  // lane k: pixels of this wave with p >= thr for list entry k (k + 64)
+    for (int k4 = 0; k4 < nk4; ++k4) {
+        const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);          // wave-uniform (LDS broadcast)
+        const float4 s4 = *reinterpret_cast<const float4*>(vs + 4 * k4);
+        const int qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+        int np[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(p00[r] + 4 * k4), bq = *reinterpret_cast<const float4*>(p01[r] + 4 * k4);
+            const float4 c = *reinterpret_cast<const float4*>(p10[r] + 4 * k4), d = *reinterpret_cast<const float4*>(p11[r] + 4 * k4);
             const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
-            const int qv[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = hy * (hx * av[e] + lx * bv[e]) + ly * (hx * cv[e] + lx * dv[e]);
+                const float p = hy[r] * (hx * av[e] + lx * bv[e]) + ly[r] * (hx * cv[e] + lx * dv[e]);
                 const float wgt = sv[e] * p;
-                if (wgt > best) { best = wgt; win = qv[e]; }
-                const int np = __popcll(__ballot(in && p >= mask_thr && sv[e] >= 0.f));
-                const int k = 4 * k4 + e;
-                if (k < 64) cnt_lo += (lane == k) ? np : 0;
-                else cnt_hi += (lane == k - 64) ? np : 0;
+                if (wgt > best[r]) { best[r] = wgt; win[r] = qv[e]; }
+                np[e] += __popcll(__builtin_amdgcn_ballot_w64(p >= mask_thr) & inm[r]);
             }
         }
-        const bool ok = in && win >= 0;
-        const bool pass = ok && best > mask_thr;
-        if (ok) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win | (pass ? 0x80 : 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                            // every list entry is visited once: its lane is written, not accumulated
+            const int k = 4 * k4 + e;
+            if (k4 < 16) cnt_lo = ps_writelane(np[e], k, cnt_lo);
+            else cnt_hi = ps_writelane(np[e], k - 64, cnt_hi);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int Y = Y0 + r * 4 + wave;
+        const bool ok = in[r] && win[r] >= 0;
+        const bool pass = ok && best[r] > mask_thr;
+        if (ok) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win[r] | (pass ? 0x80 : 0));
         // per distinct winner of the wave (usually one): counts and coordinate sums from the ballots
         unsigned long long rem = __ballot(ok);
         while (rem) {
-            const int w0 = __builtin_amdgcn_readlane(win, __ffsll((long long)rem) - 1);
-            const unsigned long long m = __ballot(ok && win == w0), mp = __ballot(pass && win == w0);
+            const int w0 = __builtin_amdgcn_readlane(win[r], __ffsll((long long)rem) - 1);
+            const unsigned long long m = __ballot(ok && win[r] == w0), mp = __ballot(pass && win[r] == w0);
             if (lane == 0) {
                 const int cnt = __popcll(m), cp = __popcll(mp);
                 atomicAdd(&sh[6 * nq + w0], cnt); atomicAdd(&sh[7 * nq + w0], X0 * cnt + mask_lane_sum(m)); atomicAdd(&sh[8 * nq + w0], Y * cnt);
@@ -302,7 +334,7 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
     // best at 480x640 x 64 images with ~nq valid queries (437 us; 16 rows 560 us, 32 rows 675 us: the kernel is bound by the
     // per-(pixel, valid query) instruction stream, and small workgroups balance it better); halved until the source tile fits
     int th = 8, src_rows = 0;
-    if (const char* e = getenv("NOPESAC_PS_TH")) th = atoi(e) >= 4 ? (atoi(e) & ~3) : 8;   // tuning aid
+    if (const char* e = getenv("NOPESAC_PS_TH")) { const int v = atoi(e); th = v >= 32 ? 32 : (v >= 16 ? 16 : (v >= 8 ? 8 : 4)); }   // tuning aid: 4 / 8 / 16 / 32
     const int src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
     size_t lds = 0;
     for (;; th >>= 1) {
@@ -312,8 +344,14 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
     }
     NPS_CHECK_ARG(lds <= 64 * 1024, "postselect: up-sampling ratio too small for the LDS tile (%zu bytes)", lds);
     dim3 grid((W + PS_TW - 1) / PS_TW, (H + th - 1) / th, B);
-    hipLaunchKernelGGL(ps_pixels_kernel, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols,
-                       work, winner, prob_planar, th);
+    auto launch_pixels = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols, work, winner,
+                           prob_planar, th);
+    };
+    if (th == 4) launch_pixels(ps_pixels_kernel<1>);             // th = 4 * ROWS (8 by default; halved above while the tile exceeds 64 KB)
+    else if (th == 8) launch_pixels(ps_pixels_kernel<2>);
+    else if (th == 16) launch_pixels(ps_pixels_kernel<4>);
+    else launch_pixels(ps_pixels_kernel<8>);
     hipLaunchKernelGGL(ps_finalize_kernel, dim3(B), dim3(64), 0, st, params, query_feat, nq, D, H, W, overlap_thr, work,
                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags);
     NPS_LAUNCH_RET();
