@@ -330,10 +330,10 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
     hipError_t e = hipMemsetAsync(work, 0, (size_t)B * work_words(nq) * sizeof(int), st);
     if (e != hipSuccess) { set_error("postselect: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(ps_classify_kernel, dim3(B), dim3(64), 0, st, cls_logits, nq, score_thr, work);
-    // source extent touched by one PS_TW x th output tile (+2 for the second tap and the start rounding).  th = 8 rows measured
-    // best at 480x640 x 64 images with ~nq valid queries (437 us; 16 rows 560 us, 32 rows 675 us: the kernel is bound by the
-    // per-(pixel, valid query) instruction stream, and small workgroups balance it better); halved until the source tile fits
-    int th = 8, src_rows = 0;
+    // source extent touched by one PS_TW x th output tile (+2 for the second tap and the start rounding).  With the query loop
+    // outside (round 4) th = 16 rows measured best at 480x640 x 64 images, 32 valid queries: 256 us (8 rows 298 us, 32 rows 272 us;
+    // the row-inside form it replaced: 347 us at its best height of 8 rows); halved until the source tile fits
+    int th = 16, src_rows = 0;
     if (const char* e = getenv("NOPESAC_PS_TH")) { const int v = atoi(e); th = v >= 32 ? 32 : (v >= 16 ? 16 : (v >= 8 ? 8 : 4)); }   // tuning aid: 4 / 8 / 16 / 32
     const int src_cols = (int)(((long long)PS_TW * w + W - 1) / W) + 2;
     size_t lds = 0;
@@ -348,7 +348,7 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols, work, winner,
                            prob_planar, th);
     };
-    if (th == 4) launch_pixels(ps_pixels_kernel<1>);             // th = 4 * ROWS (8 by default; halved above while the tile exceeds 64 KB)
+    if (th == 4) launch_pixels(ps_pixels_kernel<1>);             // th = 4 * ROWS (16 by default; halved above while the tile exceeds 64 KB)
     else if (th == 8) launch_pixels(ps_pixels_kernel<2>);
     else if (th == 16) launch_pixels(ps_pixels_kernel<4>);
     else launch_pixels(ps_pixels_kernel<8>);
