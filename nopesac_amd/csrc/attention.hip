@@ -125,8 +125,11 @@ __device__ __forceinline__ void att_load8<bf16_t>(const bf16_t* p, float (&t)[8]
     }
 }
 
-template <typename TIO>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(
+// NW = waves per workgroup (32 query rows each).  4 for short query sets; 10 for 257..320 rows (the encoder's 15 x 20 = 300 tokens): ONE
+// workgroup per (batch, head) stages K / V once instead of three times (the staging was half of a workgroup's time) and no
+// wave slot idles on a 44-row remainder block.
+template <typename TIO, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_mfma_kernel(
     const TIO* __restrict__ q, long long q_stride, const TIO* __restrict__ k, long long k_stride,
     const TIO* __restrict__ v, long long v_stride, TIO* __restrict__ o, long long o_stride, int Lq, int Lk,
     int Lk_pad, float scale, const int* __restrict__ qlen, const int* __restrict__ klen) {
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
     const int nq = qlen ? min(qlen[b], Lq) : Lq;
     const int nk = klen ? min(klen[b], Lk) : Lk;
     // ---- this wave's 32 query rows; lane l: row = l&31, k-half = l>>5 (requested first: in flight while K / V are staged)
-    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    constexpr int NT = NW * 64;
+    const int row = blockIdx.x * (NW * 32) + wave * 32 + (lane & 31);
     const bool row_ok = row < nq;
     const int half = lane >> 5;
     float tq[2][8];
@@ -156,19 +160,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
         // bf16 in memory: the 16-byte pieces of up to five passes are requested back to back (unconditional, row clamped) and only then
         // consumed - one memory round trip for the whole K / V of a (batch, head) instead of one per pass (300 keys = 5 passes: the
         // staging was ~10 us of the kernel's 15-20 us per workgroup)
-        constexpr int UB = 5;
+        constexpr int UB = NW == 4 ? 5 : 2;
         const int nkc = max(nk, 1) - 1;
-        for (int base = 0; base < Lk_pad * 4; base += 256 * UB) {
+        for (int base = 0; base < Lk_pad * 4; base += NT * UB) {
             u32x4 kr[UB], vr[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * 256 + tid, j = min(idx >> 2, nkc), c = (idx & 3) * 8;
+                const int idx = base + u * NT + tid, j = min(idx >> 2, nkc), c = (idx & 3) * 8;
                 kr[u] = *(const u32x4*)(kb + (long long)j * k_stride + c);
                 vr[u] = *(const u32x4*)(vb + (long long)j * v_stride + c);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * 256 + tid, j = idx >> 2, c = (idx & 3) * 8;
+                const int idx = base + u * NT + tid, j = idx >> 2, c = (idx & 3) * 8;
                 if (idx >= Lk_pad * 4) continue;
                 const bool live = j < nk;
                 u32x4 pk = kr[u];
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(
             }
         }
     } else
-    for (int idx = tid; idx < Lk_pad * 4; idx += 256) {                  // 8 floats per chunk
+    for (int idx = tid; idx < Lk_pad * 4; idx += NT) {                   // 8 floats per chunk
         const int j = idx >> 2, c = (idx & 3) * 8;
         float kv[8], vv[8];
 #pragma unroll
@@ -312,10 +316,17 @@ static int launch_attention_mfma(const TIO* q, int64_t q_stride, const TIO* k, i
                   "attention_bf16: rows must be 16-byte aligned");
     const int Lk_pad = ((Lk + 31) / 32) * 32;
     const size_t lds = (size_t)Lk_pad * ATT_KSTRIDE * 2 + (size_t)32 * (Lk_pad + 8) * 2;
-    NPS_ENSURE_LDS(96 * 1024, attention_mfma_kernel<TIO>);
-    dim3 grid((Lq + 127) / 128, heads, B);
-    hipLaunchKernelGGL(attention_mfma_kernel<TIO>, grid, dim3(256), lds, (hipStream_t)stream, q, (long long)q_stride, k,
-                       (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad, scale, qlen, klen);
+    static const bool wide_off = getenv("NOPESAC_ATT_WIDE") && atoi(getenv("NOPESAC_ATT_WIDE")) == 0;   // A/B aid
+    if (Lq > 256 && Lq <= 320 && !wide_off) {
+        NPS_ENSURE_LDS(96 * 1024, (attention_mfma_kernel<TIO, 10>));
+        hipLaunchKernelGGL((attention_mfma_kernel<TIO, 10>), dim3(1, heads, B), dim3(640), lds, (hipStream_t)stream, q, (long long)q_stride, k,
+                           (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad, scale, qlen, klen);
+    } else {
+        NPS_ENSURE_LDS(96 * 1024, (attention_mfma_kernel<TIO, 4>));
+        hipLaunchKernelGGL((attention_mfma_kernel<TIO, 4>), dim3((Lq + 127) / 128, heads, B), dim3(256), lds, (hipStream_t)stream, q,
+                           (long long)q_stride, k, (long long)k_stride, v, (long long)v_stride, o, (long long)o_stride, Lq, Lk, Lk_pad,
+                           scale, qlen, klen);
+    }
     NPS_LAUNCH_RET();
 }
 

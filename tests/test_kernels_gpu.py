@@ -394,6 +394,17 @@ def test_layernorm_ex_and_attention_bf16io(device):
     o16 = ops.attention(q, k, v, B, Lq, Lk, H, 0.25, mfma_bf16=True)           # scale 2^-2: the q scaling is exact in bf16
     o32 = ops.attention(q.float(), k.float().contiguous(), v.float().contiguous(), B, Lq, Lk, H, 0.25, mfma_bf16=True)
     assert o16.dtype == torch.bfloat16 and torch.equal(o16, o32.bfloat16())
+    # 300 query rows: the ten-wave build (one workgroup per (batch, head)), ragged lengths
+    B, Lq, Lk = 3, 300, 300
+    q = torch.randn(B * Lq, 256, generator=g).to(device).bfloat16()
+    kv = torch.randn(B * Lk, 1536, generator=g).to(device).bfloat16()
+    k, v = kv[:, 256:512], kv[:, 768:1024]
+    ql, kl = torch.tensor([300, 257, 31], dtype=torch.int32, device=device), torch.tensor([300, 299, 33], dtype=torch.int32, device=device)
+    o16 = ops.attention(q, k, v, B, Lq, Lk, H, 0.25, ql, kl, mfma_bf16=True)
+    o32 = ops.attention(q.float(), k.float().contiguous(), v.float().contiguous(), B, Lq, Lk, H, 0.25, ql, kl, mfma_bf16=True)
+    for b in range(B):
+        n = int(ql[b])
+        assert torch.equal(o16[b * Lq: b * Lq + n], o32[b * Lq: b * Lq + n].bfloat16()), b
 
 
 @pytest.mark.parametrize("M", [19200 // 8, 333])
