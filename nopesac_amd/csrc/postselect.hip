@@ -82,7 +82,12 @@ __device__ __forceinline__ int ps_writelane(int value, int lane_index, int old) 
     return old;
 }
 
-template <int ROWS>
+// X4 (requires ROWS == 4 and H == 4 h): a wave owns four CONSECUTIVE output rows 4j .. 4j+3; with exact 4x up-sampling these tap only the
+// source rows clamp(j-1), clamp(j), clamp(j+1) (rows 4j, 4j+1 the first two, rows 4j+2, 4j+3 the last two; the clamped duplicates at the
+// image border carry weight 0 or the same value, so the result is the generic formula's bit for bit): the horizontal blends
+// hx * a + lx * b of the three source rows are computed once per query and shared by the four output rows - 6 instead of 16
+// 16-byte LDS reads and 21 instead of 36 interpolation instructions per four (pixel, query) pairs.
+template <int ROWS, bool X4>
 __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict__ prob, int nq, int h, int w, int H,
                                                         int W, float mask_thr, int src_rows, int src_cols,
                                                         int* __restrict__ work, uint8_t* __restrict__ winner, int planar, int th) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
     bool in[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int Y = Y0 + r * 4 + wave;
+        const int Y = X4 ? Y0 + wave * 4 + r : Y0 + r * 4 + wave;
         in[r] = X < W && Y < H;
         inm[r] = __ballot(in[r]);
         const float sy = fmaxf(sch * (Y + 0.5f) - 0.5f, 0.f);
@@ -179,6 +184,31 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
         const int qv[4] = {q4.x, q4.y, q4.z, q4.w};
         const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
         int np[4] = {0, 0, 0, 0};
+        if constexpr (X4) {
+            static_assert(!X4 || ROWS == 4, "X4 needs four rows per wave");
+            float T[3][4];                                       // horizontal blends of source rows clamp(j-1), clamp(j), clamp(j+1)
+#pragma unroll
+            for (int sr = 0; sr < 3; ++sr) {
+                // rows 0/1 tap (max(j-1, 0), j), rows 2/3 tap (j, min(j+1, h-1)); row j is taken from row 2's FIRST tap: at the top border
+                // row 0's second tap is row 1, with weight 0 - replacing it by row j = 0 (weight 0 as well) leaves the value unchanged
+                const float* pa = sr == 0 ? p00[0] : (sr == 1 ? p00[2] : p10[2]);
+                const float* pb = sr == 0 ? p01[0] : (sr == 1 ? p01[2] : p11[2]);
+                const float4 a = *reinterpret_cast<const float4*>(pa + 4 * k4), bq = *reinterpret_cast<const float4*>(pb + 4 * k4);
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[sr][e] = hx * av[e] + lx * bv[e];
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = hy[r] * T[r >> 1][e] + ly[r] * T[(r >> 1) + 1][e];
+                    const float wgt = sv[e] * p;
+                    if (wgt > best[r]) { best[r] = wgt; win[r] = qv[e]; }
+                    np[e] += __popcll(__builtin_amdgcn_ballot_w64(p >= mask_thr) & inm[r]);
+                }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const float4 a = *reinterpret_cast<const float4*>(p00[r] + 4 * k4), bq = *reinterpret_cast<const float4*>(p01[r] + 4 * k4);
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int Y = Y0 + r * 4 + wave;
+        const int Y = X4 ? Y0 + wave * 4 + r : Y0 + r * 4 + wave;
         const bool ok = in[r] && win[r] >= 0;
         const bool pass = ok && best[r] > mask_thr;
         if (ok) winner[((long long)b * H + Y) * W + X] = (uint8_t)(win[r] | (pass ? 0x80 : 0));
@@ -348,10 +378,12 @@ extern "C" int nopesac_postselect_planes_ex(const float* cls_logits, const float
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, mask_prob, nq, h, w, H, W, mask_thr, src_rows, src_cols, work, winner,
                            prob_planar, th);
     };
-    if (th == 4) launch_pixels(ps_pixels_kernel<1>);             // th = 4 * ROWS (16 by default; halved above while the tile exceeds 64 KB)
-    else if (th == 8) launch_pixels(ps_pixels_kernel<2>);
-    else if (th == 16) launch_pixels(ps_pixels_kernel<4>);
-    else launch_pixels(ps_pixels_kernel<8>);
+    static const bool x4_off = getenv("NOPESAC_PS_X4") && atoi(getenv("NOPESAC_PS_X4")) == 0;          // A/B aid
+    if (th == 4) launch_pixels(ps_pixels_kernel<1, false>);      // th = 4 * ROWS (16 by default; halved above while the tile exceeds 64 KB)
+    else if (th == 8) launch_pixels(ps_pixels_kernel<2, false>);
+    else if (th == 16 && H == 4 * h && !x4_off) launch_pixels(ps_pixels_kernel<4, true>);   // the architecture's 480 x 640 / 120 x 160
+    else if (th == 16) launch_pixels(ps_pixels_kernel<4, false>);
+    else launch_pixels(ps_pixels_kernel<8, false>);
     hipLaunchKernelGGL(ps_finalize_kernel, dim3(B), dim3(64), 0, st, params, query_feat, nq, D, H, W, overlap_thr, work,
                        n_kept, kept_idx, planes, feats, scores, areas, centers, winner, flags);
     NPS_LAUNCH_RET();

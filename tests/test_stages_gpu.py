@@ -136,6 +136,37 @@ def test_matcher_ragged_batch(device, model, O, sd50):
         assert float(A[b, n1:].abs().sum() + A[b, :, n2:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("env", [{"NOPESAC_PS_TH": "8"}, {"NOPESAC_PS_TH": "32"}, {"NOPESAC_PS_TH": "4"}])
+def test_postselect_tile_variants_agree(device, env):
+    """The pixel kernel's builds (4 / 8 / 32-row tiles: the generic per-row form; default: 16 rows with the shared horizontal blends of
+    exact 4x up-sampling) produce identical winner maps, counts, areas and centres."""
+    import os
+    from nopesac_amd import ops
+    from oracle import nopesac_oracle
+    cfg = nopesac_oracle.OracleConfig()
+    logits, params, masks, feat = GI.postselect_case("multi", 11)
+    g = torch.Generator().manual_seed(3)
+    masks = masks + 2.0 * torch.randn(masks.shape, generator=g)             # noisy maps: many winners per tile, border rows included
+    logits = logits.clone(); logits[:, 0] += 4.0                            # most queries pass the score test
+    prob = torch.sigmoid(masks).permute(1, 2, 0).contiguous()[None].to(device)
+    args = (logits[None].to(device), prob, params[None].to(device), feat[None].to(device), 480, 640, cfg.plane_score_threshold,
+            cfg.mask_prob_threshold, cfg.overlap_threshold)
+    ref = ops.postselect_planes(*args)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        got = ops.postselect_planes(*args)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for k in ref:
+        if torch.is_tensor(ref[k]):
+            assert torch.equal(ref[k], got[k]), (env, k)
+
+
 def _refine_batch(device, model, O, sd, nq, ms, seeds, cam_type="soft"):
     head = model.camera_head_list[0]
     cases = [GI.refine_case(nq, m, s) for m, s in zip(ms, seeds)]
