@@ -37,6 +37,14 @@ GFLOP_PER_PAIR = {32: 181.6, 64: 183.7, 128: 189.4}   # SURVEY.md §8d algorithm
 CONFIG_FILES = {"mp3d": "inference_mp3d.yaml", "scannet": "inference_scannet.yaml"}
 
 
+def _profile_order(path):
+    """profiles/rN_<tag>_*.json: newest round last, then by tag."""
+    import re
+    b = os.path.basename(path)
+    m = re.match(r"r(\d+)", b)
+    return (int(m.group(1)) if m else -1, b)
+
+
 def build_model(device, nq, dtype, overrides=(), config="mp3d"):
     from nopesac_amd.config import get_cfg
     from nopesac_amd.registry import build_model as _build
@@ -260,7 +268,7 @@ def parse_args(argv=None):
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 (NOT the headline line): the backbone's 3x3 convs on the fp8 "
                     "(e4m3fn) MFMA, static activation scales calibrated on the synthetic pairs; the JSON line says dtype fp8+bf16")
     ap.add_argument("--config", default="mp3d", choices=sorted(CONFIG_FILES), help="configs/inference_<name>.yaml (BASELINE configs[2] = scannet, --k 64)")
-    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r4.json"),
+    ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r5.json"),
                     help="kernel routing file (autotuner decisions per conv/GEMM shape): loaded when it exists so that every run - "
                          "driver, PMC, rocprofv3 - launches identical kernels; shapes it does not list are tuned and added")
     ap.add_argument("--retune", action="store_true", help="ignore the routing file's contents, tune every shape again and rewrite it")
@@ -391,6 +399,13 @@ def rank_main(args):
     # load-time kernel selection, outside the timed region.  The decisions are kept in a routing file: when it exists its entries are
     # installed (no re-measurement), only shapes it does not list are timed; rank 0 writes new decisions back.
     routing_loaded = 0
+    routing_explicit = any(a == "--routing" or a.startswith("--routing=") for a in sys.argv[1:])
+    if args.routing:
+        args.routing = os.path.abspath(args.routing)       # profilers run this command from /tmp: never resolve against the cwd later
+    if args.autotune and args.routing and routing_explicit and not args.retune and not os.path.exists(args.routing):
+        # a routing file named on the command line that is not there would silently re-tune under whatever tool wraps this run (the
+        # round-4 PMC pass measured a different kernel mix that way): refuse
+        sys.exit("bench.py: --routing %s does not exist (pass --retune to create it)" % args.routing)
     if args.autotune and args.routing and os.path.exists(args.routing) and not args.retune:
         routing_loaded = ops.TUNER.load(args.routing)
     tuned = model.autotune(B) if args.autotune else 0
@@ -603,17 +618,26 @@ def rank_main(args):
     fam_achieved = fam["flops"] / (fam["ms"] * 1e-3) / 1e12
     # HBM traffic of the same kernel from the PMC counters (cannot be collected from inside this process: measured by
     # scripts/pmc_bench.sh on this benchmark command and committed as profiles/*pmc_traffic.json)
-    traffic, traffic_src, fam_traffic = None, None, None
+    # The PMC file is only used when it counted THE SAME launches as this run (same routing): its launch count of the dominant kernel and
+    # of the conv family per step must equal this run's, otherwise `traffic` stays null and both counts are printed.
+    traffic, traffic_src, fam_traffic, traffic_check = None, None, None, None
     if args.dtype == "bfloat16":
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=_profile_order)[-1:]:
             pm = json.load(open(path))
             f2 = pm["bf16_conv_family"]
-            fam_traffic = round((f2["read_bytes_per_step"] + f2["write_bytes_per_step"]) / max(f2["launches_per_step"], 1))
             hit = [kv for kname, kv in pm.get("kernels", {}).items() if dom_name in kname and kv.get("launches_per_step")]
-            if hit:
-                traffic = round(sum(kv["read_bytes_per_step"] + kv["write_bytes_per_step"] for kv in hit) / sum(kv["launches_per_step"] for kv in hit))
+            pmc_dom = round(sum(kv["launches_per_step"] for kv in hit), 3) if hit else 0
+            pmc_fam = round(f2["launches_per_step"], 3)
             traffic_src = os.path.relpath(path, ROOT)
+            traffic_check = {"dominant_kernel_launches_per_step": {"pmc_file": pmc_dom, "this_run": dom["launches"]},
+                             "conv_family_launches_per_step": {"pmc_file": pmc_fam, "this_run": fam["launches"]},
+                             "pmc_routing_file": pm.get("routing_file")}
+            if hit and pmc_dom == dom["launches"]:
+                traffic = round(sum(kv["read_bytes_per_step"] + kv["write_bytes_per_step"] for kv in hit) / pmc_dom)
+            if pmc_fam == fam["launches"]:
+                fam_traffic = round((f2["read_bytes_per_step"] + f2["write_bytes_per_step"]) / max(pmc_fam, 1))
+            traffic_check["same_launch_set"] = traffic is not None and fam_traffic is not None
     split = timer.split_by_bound(dom_name, key) if args.dtype == "bfloat16" else None
     by_bound = None
     if split:
@@ -630,6 +654,7 @@ def rank_main(args):
     roofline = {"bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (PMC)", "traffic_source": traffic_src,
+                "traffic_launch_check": traffic_check,
                 "algorithmic_bytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1)),
                 "launches_per_step": dom["launches"], "flops_per_step": dom["flops"],
                 "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
@@ -743,7 +768,7 @@ def other_configs(args, steps=12, warmup=4):
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--pairs", str(args.pairs),
                "--inflight", str(args.inflight), "--no-cpu-baseline", "--no-accuracy", "--no-fp32-path", "--no-boundary", "--no-other-configs", "--no-tape",
-               "--routing", os.path.join(ROOT, "profiles", "routing_r4_%s.json" % name.replace("bf16_k128", "fp8_k128"))] + extra
+               "--routing", os.path.join(ROOT, "profiles", "routing_r5_%s.json" % name.replace("bf16_k128", "fp8_k128"))] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)

@@ -709,7 +709,12 @@ static int launch_cfg(const ConvParams& p0, hipStream_t stream, int vec) {
         // (bf16 activations: 32-bit offsets relative to the tile's first image - see PF2 in the kernel - must cover the images one
         //  tile of BM rows can span)
         const long long span = ((long long)BM / p.rows_per_b + 2) * p.H * p.W * p.x_cs * 2;
-        if (vec == VW && (p.K % 128 == 0 || (sizeof(TA) == 2 && p.K > 128)) && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048 &&
+#ifdef NPS_NO_PF2                                           // A/B build: without PF2's out-of-bounds zero fill a K tail is not handled
+        constexpr bool K_TAIL_OK = false;
+#else
+        constexpr bool K_TAIL_OK = sizeof(TA) == 2;
+#endif
+        if (vec == VW && (p.K % 128 == 0 || (K_TAIL_OK && p.K > 128)) && (long long)p.tiles_m * p.tiles_n * (p.batched ? p.B : 1) <= 2048 &&
             (sizeof(TA) != 2 || span < 0x7FFFFFFFll)) {
             hipLaunchKernelGGL((conv_igemm_kernel<TA, T, BM, BN, VW, 4>), grid, dim3(256), 0, stream, p);
             return 0;

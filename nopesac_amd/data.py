@@ -97,10 +97,12 @@ class PairMapper:
         t = img_t.permute(2, 0, 1).contiguous() if self.uint8 else img_t.permute(2, 0, 1).float()
         return t if self.device is not None else t.cpu()
 
-    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None) -> List[torch.Tensor]:
+    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None, sync: bool = True) -> List[torch.Tensor]:
         """The images of `paths` as _image() returns them, the JPEG files among them decoded in ONE launch chain on the GPU (all
         restart intervals / images of the batch in flight together).  blobs / infos: file contents and jpeg.parse results when the
-        caller (LazyPairs' reader threads) has them already."""
+        caller (LazyPairs' reader threads) has them already.  sync (default): device tensors are COMPLETE when this returns - the
+        decode ran on the calling thread's current stream and whoever consumes the images may use any other stream; sync = False only
+        for a caller that records its own event behind the decode (LazyPairs._iter_batches_gpu)."""
         from . import jpeg
         dev = self._resize_device
         blobs = list(blobs) if blobs is not None else [None] * len(paths)
@@ -125,6 +127,8 @@ class PairMapper:
                 dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
                 for i, t in zip(gpu_idx, dec):
                     out[i] = self._finish_device_image(t)
+                if sync and self.device is not None:          # (device = None: .cpu() above has synchronised already)
+                    torch.cuda.current_stream(dev).synchronize()
         for i, p in enumerate(paths):
             if out[i] is None:
                 if is_jpeg_path(p) and self._use_gpu_jpeg():
@@ -169,10 +173,10 @@ class PairMapper:
             names = [n.replace(MP3D_ORIGINAL_ROOT, self.root_dir) for n in names]
         return names
 
-    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None) -> List[dict]:
+    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None, sync: bool = True) -> List[dict]:
         """The mapped dicts of a batch of pairs with all 2 * len(entries) images decoded together (decode_files)."""
         paths = [n for e in entries for n in self.file_names(e)]
-        imgs = self.decode_files(paths, blobs, infos)
+        imgs = self.decode_files(paths, blobs, infos, sync=sync)
         return [self(e, images=imgs[2 * i:2 * i + 2]) for i, e in enumerate(entries)]
 
 
@@ -250,18 +254,16 @@ class LazyPairs:
                     st = streams[k % ahead]
                     k += 1
                     with torch.cuda.device(dev), torch.cuda.stream(st):
-                        items = self.mapper.map_batch(entries, blobs, infos)
+                        items = self.mapper.map_batch(entries, blobs, infos, sync=False)
                         ev = torch.cuda.Event()
                         ev.record()
                     decoding.append((items, ev, st))
                 items, ev, st = decoding.popleft()
-                torch.cuda.current_stream(dev).wait_event(ev)
-                for it in items:                          # the consumer's stream uses memory allocated on the decode stream
-                    for v in "01":
-                        if it[v]["image"].is_cuda:
-                            it[v]["image"].record_stream(torch.cuda.current_stream(dev))
-                if not any(it[v]["image"].is_cuda for it in items for v in "01"):
-                    ev.synchronize()                      # host tensors came through .cpu() on the decode stream: complete by now
+                # The consumer picks its own stream AFTER next() returns (run.inference_on_dataset rotates side streams), so a
+                # wait_event on this thread's current stream would order nothing: the batch is handed out COMPLETE.  The decode was
+                # launched `ahead` batches ago - this wait is normally over already.  (Memory: the images were allocated on the decode
+                # stream; PlaneTR_NopeSAC._copy_images records the consumer's stream on every device image it reads.)
+                ev.synchronize()
                 yield items
 
     def iter_batches(self, pairs_per_batch: int):

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import ctypes
 import re
+import struct
+import threading
 from typing import List, Sequence
 
 import numpy as np
@@ -53,6 +55,18 @@ def _u16(b, p):
 
 
 def parse(data: bytes, fast: bool = True) -> JpegInfo:
+    """parse_markers() with every failure a JpegUnsupported: truncated or malformed files (a marker past the end, an empty segment,
+    a short DQT / DHT, component ids a scan never names) surface from the marker walk as IndexError / KeyError / ValueError /
+    struct.error - the callers (data.PairMapper, LazyPairs' reader threads) promise to fall back to PIL on JpegUnsupported only."""
+    try:
+        return parse_markers(data, fast)
+    except JpegUnsupported:
+        raise
+    except (IndexError, KeyError, ValueError, TypeError, OverflowError, struct.error) as e:
+        raise JpegUnsupported("malformed file: %s: %s" % (type(e).__name__, e)) from e
+
+
+def parse_markers(data: bytes, fast: bool = True) -> JpegInfo:
     """Marker segments (ITU T.81 Annex B) of one file -> geometry, tables and the entropy-coded data split at the restart markers with
     the stuffed zero bytes removed.  fast (default): the pass over the entropy-coded bytes runs in the library
     (`nopesac_jpeg_prepare_scan`, host C++, interpreter lock released) and leaves the device word layout in info.words / seg_off /
@@ -61,7 +75,7 @@ def parse(data: bytes, fast: bool = True) -> JpegInfo:
         raise JpegUnsupported("no SOI marker")
     info = JpegInfo()
     info.qt, info.huff, info.dri, info.comps, info.intervals, info.words = {}, {}, 0, None, None, None
-    adobe = None
+    adobe, jfif = None, False
     p, n = 2, len(data)
     while p + 4 <= n:
         if data[p] != 0xFF:
@@ -108,6 +122,8 @@ def parse(data: bytes, fast: bool = True) -> JpegInfo:
             info.dri = _u16(seg, 0)
         elif m == 0xEE and bytes(seg[:5]) == b"Adobe" and len(seg) >= 12:
             adobe = seg[11]
+        elif m == 0xE0 and bytes(seg[:5]) == b"JFIF\0":
+            jfif = True
         elif m == 0xDA:
             if info.comps is None:
                 raise JpegUnsupported("SOS before SOF")
@@ -149,11 +165,16 @@ def parse(data: bytes, fast: bool = True) -> JpegInfo:
     elif len(comps) == 3:
         if adobe is not None and adobe != 1:
             raise JpegUnsupported("Adobe colour transform %d" % adobe)
+        if adobe is None and not jfif and [c["id"] for c in comps] == [82, 71, 66]:
+            # jdapimin.c default_decompress_parms: no JFIF / Adobe marker and component ids 'R','G','B' -> the data IS RGB
+            raise JpegUnsupported("RGB-coded file (component ids R, G, B without a JFIF / Adobe marker)")
         if (comps[1]["h"], comps[1]["v"], comps[2]["h"], comps[2]["v"]) != (1, 1, 1, 1) or (comps[0]["h"], comps[0]["v"]) not in ((1, 1), (2, 1), (2, 2)):
             raise JpegUnsupported("sampling factors %r" % [(c["h"], c["v"]) for c in comps])
     else:
         raise JpegUnsupported("%d components" % len(comps))
     for c in comps:
+        if "td" not in c:
+            raise JpegUnsupported("the scan does not name component %d" % c["id"])
         if c["tq"] not in info.qt or (0, c["td"]) not in info.huff or (1, c["ta"]) not in info.huff or c["td"] > 1 or c["ta"] > 1:
             raise JpegUnsupported("missing / out-of-range table")
     if info.width <= 0 or info.height <= 0:
@@ -191,12 +212,14 @@ def _prepare_scan(info: JpegInfo, data: bytes, p: int):
 
 
 _HUFF_CACHE = {}
+_HUFF_LOCK = threading.Lock()                             # parse() / decode_batch run on LazyPairs' reader threads
 
 
 def huffman_table_bytes(spec: bytes) -> np.ndarray:
     """BITS[16] + HUFFVAL of a DHT segment -> the HUFF_BYTES device layout (T.81 Annex C canonical codes; the 9-bit look-ahead table
     and the maxcode / valoffset arrays are the ones jdhuff.c's jpeg_make_d_derived_tbl builds)."""
-    t = _HUFF_CACHE.get(spec)
+    with _HUFF_LOCK:
+        t = _HUFF_CACHE.get(spec)
     if t is not None:
         return t
     bits, vals = list(spec[:16]), list(spec[16:])
@@ -225,9 +248,10 @@ def huffman_table_bytes(spec: bytes) -> np.ndarray:
     out[1024:1096] = maxcode.view(np.uint8)
     out[1096:1168] = valoff.view(np.uint8)
     out[1168:1168 + len(vals)] = np.asarray(vals, np.uint8)
-    _HUFF_CACHE[spec] = out
-    if len(_HUFF_CACHE) > 256:
-        _HUFF_CACHE.pop(next(iter(_HUFF_CACHE)))
+    with _HUFF_LOCK:
+        _HUFF_CACHE[spec] = out
+        while len(_HUFF_CACHE) > 256:
+            _HUFF_CACHE.pop(next(iter(_HUFF_CACHE)))
     return out
 
 

@@ -124,6 +124,11 @@ class PlaneTR_NopeSAC(nn.Module):
         """imgs (host or device, float32 as the reference mapper makes them or uint8 as PairMapper(uint8=True) does) -> `out`
         (f32 [2B,3,H,W], device).  uint8 images cross PCIe as bytes (a quarter of the traffic) and are widened on the device."""
         assert len({i.dtype for i in imgs}) == 1, "all images of a batch must share one dtype (float32 or uint8)"
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream()
+            for im in imgs:                                   # device images decoded on another stream (data.LazyPairs): their memory
+                if im.is_cuda:                                # must not be recycled there while this stream still reads it
+                    im.record_stream(cur)
         if imgs[0].dtype == torch.uint8 and self.device.type == "cuda":
             u8 = staging if staging is not None else torch.empty(out.shape, device=self.device, dtype=torch.uint8)
             for k, im in enumerate(imgs):
@@ -272,9 +277,16 @@ class PlaneTR_NopeSAC(nn.Module):
             # the slot's previous replay (its stem still reads `buf`) and the copy-out of its results must be complete before the new
             # images overwrite the static input buffer - also when the caller rotates its slots across streams
             torch.cuda.current_stream().wait_event(st.pop("clone_done"))
+        if st.get("fetch_pending"):
+            # the slot's recorded fetch writes the SAME pinned host buffers on every replay: replaying it before package() has
+            # snapshotted the previous batch's results would silently hand that caller this batch's numbers
+            raise RuntimeError("PlaneTR_NopeSAC: graph slot %d is replayed before the results of its previous batch were packaged - more "
+                               "batches in flight than model.graph_slots (%d); raise model.graph_slots to the in-flight depth" % (slot, self.graph_slots))
         self._copy_images(imgs, buf, st.get("in_u8"))
         st["calls"] += 1
         if st["graph"] is not None:
+            if st["out"].get("static_fetch") is not None:
+                st["fetch_pending"] = True
             if st.get("tape") is not None:
                 st["tape"].replay(sides=self._tape_sides())   # the recorded launches, on the caller's current stream
             else:
@@ -384,6 +396,8 @@ class PlaneTR_NopeSAC(nn.Module):
             f["ready"].synchronize()                           # the only host wait
             hostd = f["small"].views()
             sel = f.get("sel", sel)
+            if d.get("static_fetch") is not None and d.get("_owner") is not None and "rle" not in f:
+                d["_owner"]["fetch_pending"] = False           # (with RLE strings: cleared below, once they are copied out too)
         else:
             hostd = {k: v for k, v in (("n_kept", sel["n_kept"]), ("kept_idx", sel["kept_idx"]), ("planes", sel["planes"]),
                                        ("centers", sel["centers"]), ("scores", sel["scores"]), ("areas", sel["areas"]),
@@ -409,6 +423,8 @@ class PlaneTR_NopeSAC(nn.Module):
         if self.output_rle:
             rles = (f["rle"].finish(n_kept) if f is not None and "rle" in f else
                     rle.encode_views(sel["winner"], sel["kept_idx"], sel["n_kept"], sel["flags"], n_kept_host=n_kept))
+        if d.get("_owner") is not None:
+            d["_owner"]["fetch_pending"] = False               # every pinned buffer of the slot's recorded fetch is copied out: replay allowed
         # the per-view tensors below are VIEWS of this call's private host copies (one D2H copy per field, no per-view clone);
         # scalars come from .tolist() once (indexing a tensor per instance cost 4 ms per 32-pair step)
         kept_l, scores_l = kept_idx.tolist(), scores.tolist()

@@ -15,7 +15,7 @@ from nopesac_amd import ops  # noqa: E402
 B = 32
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 50, "bfloat16")
-routing = os.path.join(ROOT, "profiles", "routing_r3.json")
+routing = os.path.join(ROOT, "profiles", "routing_r5.json")
 if os.path.exists(routing):
     ops.TUNER.load(routing)
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640)).float().to(dev)

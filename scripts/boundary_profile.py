@@ -18,7 +18,7 @@ DEPTH = int(os.environ.get("DEPTH", "4"))
 U8 = os.environ.get("U8", "1") == "1"
 GRAPH = os.environ.get("GRAPH", "1") == "1"
 model = bench.build_model(dev, 50, "bfloat16")
-ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
+ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r5.json"))
 forced = bench.make_forced(B, K, 50, dev, 7)
 g = torch.Generator().manual_seed(0)
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640), generator=g)

@@ -22,7 +22,7 @@ B, K, nq = 32, 32, 50
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, nq, "bfloat16")
 model.two_streams = two
-routing = os.path.join(ROOT, "profiles", "routing_r3.json")
+routing = os.path.join(ROOT, "profiles", "routing_r5.json")
 if os.path.exists(routing):
     ops.TUNER.load(routing)
 model.autotune(B)

@@ -22,7 +22,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 B, K, nq = args.pairs, 32, 50
 model = bench.build_model(dev, nq, "bfloat16")
-routing = os.path.join(ROOT, "profiles", "routing_r3.json")
+routing = os.path.join(ROOT, "profiles", "routing_r5.json")
 if os.path.exists(routing):
     ops.TUNER.load(routing)
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640)).float().to(dev)

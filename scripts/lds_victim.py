@@ -32,7 +32,7 @@ ref = victim()
 torch.cuda.synchronize()
 bf = lambda *s: (torch.randn(*s, device=dev) * 0.1).bfloat16()
 model = bench.build_model(dev, nq, "bfloat16")
-routing = os.path.join(ROOT, "profiles", "routing_r3.json")
+routing = os.path.join(ROOT, "profiles", "routing_r5.json")
 if os.path.exists(routing):
     ops.TUNER.load(routing)
 raw = torch.randint(0, 256, (64, 3, 480, 640), device=dev).float()

@@ -1,7 +1,18 @@
 #!/bin/bash
 # HBM traffic of the conv kernels inside the real benchmark (one batch in flight, so per-dispatch counters are clean).
 # Separate passes for FETCH_SIZE and WRITE_SIZE (TCC slot limits); counters only (no trace domains).
-R=$PWD; export TMPDIR=/tmp; cd /tmp
+# Every path argument is made absolute BEFORE the cd (round 4 passed a relative --routing: bench.py did not find it under /tmp,
+# re-tuned under the profiler and the PMC pass counted a different kernel mix than the benchmark line).
+R=$PWD; export TMPDIR=/tmp
+ARGS=(); ROUTING=""
+while [ $# -gt 0 ]; do
+  if [ "$1" = "--routing" ]; then ROUTING=$(realpath "$2"); ARGS+=(--routing "$ROUTING"); shift 2; else ARGS+=("$1"); shift; fi
+done
+if [ -z "$ROUTING" ]; then ROUTING=$R/profiles/routing_r5.json; ARGS+=(--routing "$ROUTING"); fi
+[ -f "$ROUTING" ] || { echo "pmc_bench.sh: routing file $ROUTING does not exist" >&2; exit 2; }
+export PMC_ROUTING_FILE=$ROUTING
+set -- "${ARGS[@]}"
+cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench/$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-accuracy --no-fp32-path --no-boundary --no-other-configs --no-tape "$@" > $R/gpurun_out/pmc_bench_$c.log 2>&1
 done
@@ -31,7 +42,8 @@ print("per step: kernel, launches, HBM read GB (2x FETCH_SIZE), write GB")
 for t,k,rd,wr,n in rows[:16]:
     print("%-80s %6.1f  %7.3f  %7.3f"%(k,n,rd/1e9,wr/1e9))
 fam=[r for r in rows if any(s in r[1] for s in ("conv_igemm", "pw_chain", "stem_fused", "conv3x3_halo", "conv3x3_c64")) and "float" not in r[1]]
-out={"routing_file": "the routing file bench.py loads by default (the same kernels as every other run)",
+import os
+out={"routing_file": os.path.relpath(os.environ["PMC_ROUTING_FILE"]),
      "note": "HBM bytes per forward pass of 32 pairs (bench.py --inflight 1, kernel routing from the routing file, the 6 forward passes after the tuning), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
              "read = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md), write = WRITE_SIZE x 1024",
      "bf16_conv_family": {"launches_per_step": sum(r[4] for r in fam), "read_bytes_per_step": sum(r[2] for r in fam), "write_bytes_per_step": sum(r[3] for r in fam)},

@@ -19,7 +19,7 @@ mimic = [a for a in sys.argv[3:] if a.startswith("mimic")]
 B = 32
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 50, "bfloat16")
-ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
+ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r5.json"))
 if "mimic_autotune" in mimic:
     model.autotune(B)
 policy = [a for a in sys.argv[3:] if a.startswith("shift")]

@@ -11,7 +11,7 @@ from nopesac_amd.synth import synth_pair, synth_state_dict  # noqa: E402
 B, N = int(os.environ.get("B", "32")), int(os.environ.get("N", "1024"))
 cfg = get_cfg()
 cfg.merge_from_file(os.path.join(ROOT, "configs", "inference_mp3d.yaml"))
-cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r3.json")])
+cfg.merge_from_list(["MODEL.DEVICE", "cuda", "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r5.json")])
 model = build_model(cfg).eval()
 model.load_state_dict(synth_state_dict(50))
 run.tune_kernels(model, cfg, B)

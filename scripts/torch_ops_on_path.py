@@ -34,7 +34,7 @@ class Log(TorchDispatchMode):
 B = 32
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 50, "bfloat16")
-ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r3.json"))
+ops.TUNER.load(os.path.join(ROOT, "profiles", "routing_r5.json"))
 raw = torch.randint(0, 256, (2 * B, 3, 480, 640)).float().to(dev)
 forced = bench.make_forced(B, 32, 50, dev, 7)
 with torch.no_grad():
