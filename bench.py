@@ -271,6 +271,8 @@ def parse_args(argv=None):
     ap.add_argument("--routing", default=os.path.join(ROOT, "profiles", "routing_r5.json"),
                     help="kernel routing file (autotuner decisions per conv/GEMM shape): loaded when it exists so that every run - "
                          "driver, PMC, rocprofv3 - launches identical kernels; shapes it does not list are tuned and added")
+    ap.add_argument("--pose-fp32-parts", default=None, help="override MODEL.AMD.POSE_FP32_PARTS (camera-head stages on f32 operands in bf16 mode), "
+                    "e.g. '' or 'aim' - A/B runs of the bf16 pose-error budget")
     ap.add_argument("--retune", action="store_true", help="ignore the routing file's contents, tune every shape again and rewrite it")
     ap.add_argument("--no-fp32-path", action="store_true", help="skip the fp32 parity path's own throughput figure")
     ap.add_argument("--no-boundary", action="store_true", help="skip the drop-in boundary figure (model(list[dict]) -> list[dict], host tensors in)")
@@ -280,6 +282,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--layers", default="", help="write a per-GEMM-launch timing table to this path")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight (HIP streams) per GPU")
+    ap.add_argument("--gather-every", type=int, default=8, help="steps per RCCL all_gather of the per-pair result rows (1 = one collective per "
+                    "step as in rounds 1-4; G > 1: the rows of G steps travel together, the last partial group inside the timed region's closing "
+                    "barrier) - every step's rows are gathered either way")
     ap.add_argument("--no-autotune", dest="autotune", action="store_false", help="skip the load-time conv kernel autotuning")
     ap.add_argument("--graph", action="store_true", help="capture each in-flight slot's forward once and replay it through the launch tape "
                     "(nopesac_amd/tape.py: the captured kernel nodes re-issued as plain launches by a C loop)")
@@ -309,7 +314,9 @@ def timed_region(loop, step, steps, world, device=None):
     for i in range(steps):
         _, host = step(i)
     host_ms = 1e3 * loop.host_seconds / max(steps, 1)
-    loop.barrier()
+    loop.barrier()                                         # (gather_every > 1: gathers the last partial group first)
+    if loop.G > 1:
+        host = loop.last_step_rows()
     el = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([el], device=device if device is not None else "cpu", dtype=torch.float64)
@@ -342,7 +349,7 @@ def stub_rank_main(args, rank, world, local):
     cuda = torch.cuda.is_available()
     device = torch.device("cuda", local) if cuda else None
     B = args.pairs
-    loop = runner.InflightLoop(max(1, args.inflight), B, device, world, side_shift=None)
+    loop = runner.InflightLoop(max(1, args.inflight), B, device, world, side_shift=None, gather_every=args.gather_every)
 
     def slot_step(slot):
         idx = torch.arange(B, dtype=torch.float32, device=device)
@@ -360,6 +367,7 @@ def stub_rank_main(args, rank, world, local):
     if rank == 0:
         print(json.dumps({"INVALID_stub_model": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 4), "rows_gathered": int(host.shape[0]), "rows_in_rank_order": bool(ok),
+                          "steps_per_all_gather": loop.G, "collectives_in_run": getattr(loop, "collectives", None),
                           "config": {"rccl_ranks": ranks, "backend": torch.distributed.get_backend() if ranks > 1 else None,
                                      "pairs_per_gpu": B, "global_batch": world * B, "device": str(device) if cuda else "cpu"}}))
     if world > 1:
@@ -384,7 +392,8 @@ def rank_main(args):
     B, K = args.pairs, args.k
     nq = 50 if K <= 50 else K
     assert not args.fp8 or args.dtype == "bfloat16"
-    model = build_model(device, nq, args.dtype, ["MODEL.AMD.BACKBONE_FP8", True] if args.fp8 else (), config=args.config)
+    model = build_model(device, nq, args.dtype, (["MODEL.AMD.BACKBONE_FP8", True] if args.fp8 else []) +
+                        (["MODEL.AMD.POSE_FP32_PARTS", args.pose_fp32_parts] if args.pose_fp32_parts is not None else []), config=args.config)
     if args.single_stream:
         model.two_streams = False
     # synthetic inputs resident in HBM: uint8-valued fp32 RGB, seeds 1000+pair
@@ -438,7 +447,7 @@ def rank_main(args):
     n_slots = max(1, args.inflight)
     # streams, pinned row buffers and events of the in-flight slots; the streams are picked by hardware queue (nopesac_amd/streams.py)
     shift = {"own": 0, "none": None}.get(args.streams, None if not args.streams.startswith("shift") else int(args.streams[5:]))
-    loop = runner.InflightLoop(n_slots, B, device, world, side_shift=shift)
+    loop = runner.InflightLoop(n_slots, B, device, world, side_shift=shift, gather_every=args.gather_every)
     if loop.stream_set is not None:
         loop.stream_set.bind(model)
     streams, host_bufs, done = loop.streams, loop.host_bufs, loop.done
@@ -702,7 +711,7 @@ def rank_main(args):
                       "pairs_per_gpu": B, "global_batch": world * B, "K": K, "parallelism": "pair-sharded dp%d" % world,
                       "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                       "pairs_per_s_per_gpu": round(pairs_per_s / world, 3),
-                      "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph,
+                      "batches_in_flight_per_gpu": n_slots, "hip_graph": use_graph, "steps_per_all_gather": loop.G,
                       "streams": dict(loop.stream_set.describe(), policy=args.streams) if loop.stream_set is not None else {"policy": "none"},
                       "replay": None if not use_graph else ("whole hipGraph" if args.whole_graph or "tape_counts" not in last else "launch tape"),
                       "tape_nodes": last.get("tape_counts"), "autotuned_shapes": tuned,

@@ -106,6 +106,20 @@ int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, con
                            int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* stream);
 
+/* The same kernel with STREAM-K work distribution (conv_igemm_p8_kernel<.., SK>; round 5): the K-tiles of each XCD's run of output tiles
+ * are cut evenly over that XCD's persistent workgroups, so a layer of 300 (150) tiles costs 1.17 (0.59) tile times on 256 CUs instead of
+ * 2 (1) rounds.  A tile whose K range is shared is completed by whichever contributor arrives LAST on the tile's counter (nobody waits for
+ * another workgroup); partial accumulators travel through `workspace` as f32 slabs and are summed in K order - results do not depend on
+ * the arrival order, and equal the plain kernel's up to the K-split's summation order.
+ * workspace: nopesac_conv2d_p8_sk_workspace_bytes() bytes, 16-byte aligned; its first 16 KB (arrival counters) must be ZERO on entry and
+ * are zero again on completion - one workspace serves all launches of ONE stream.  variant: as nopesac_conv2d_nhwc_p8 (24 not allowed).
+ * Replaces: the same reference convolutions as nopesac_conv2d_nhwc_p8. */
+int64_t nopesac_conv2d_p8_sk_workspace_bytes(void);
+int nopesac_conv2d_nhwc_p8_sk(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                              int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                              int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- a stack of Linear(+bias)(+activation) layers in ONE launch (csrc/mlp_chain.hip) --------------------------------------------
  * Replaces one nopesac_conv2d_nhwc launch per layer for the row-wise MLP stacks of the heads in bf16 mode (reference:
  * camera_net/camera_head.py:957-990 geo_encoder / geo_proj_s1 / decoder_rot / geo_proj_s2 / decoder_tran / decoder_rot2 /

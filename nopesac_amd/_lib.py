@@ -23,6 +23,8 @@ SIGNATURES = {
     "nopesac_conv2d_nhwc": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, P],
     "nopesac_conv2d_nhwc_bfrag": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],
     "nopesac_conv2d_nhwc_p8": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],
+    "nopesac_conv2d_nhwc_p8_sk": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P, L, P],
+    "nopesac_conv2d_p8_sk_workspace_bytes": [],
     "nopesac_conv2d_nhwc_ex": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, I, P],
     "nopesac_stem_fused_bf16": [P, P, P, P, P, I, I, I, P],
     "nopesac_stem_fused_raw_bf16": [P, P, P, P, P, P, P, I, I, I, P],
@@ -97,7 +99,8 @@ SIGNATURES = {
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],
 }
-_RESTYPE = {"nopesac_jpeg_prepare_scan": c_int64, "nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64}
+_RESTYPE = {"nopesac_jpeg_prepare_scan": c_int64, "nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64,
+            "nopesac_conv2d_p8_sk_workspace_bytes": c_int64}
 
 MLP_MAX_IN, MLP_MAX_WIDTH, MLP_MAX_LAYERS = 1280, 1024, 12       # NOPESAC_MLP_* of the header
 

@@ -25,6 +25,8 @@ struct ConvParams {
     int tiles_m, tiles_n;
     int dbg_tile;
     unsigned long long* dbg;   // tuning builds only: per-workgroup cycle stamps (nullptr in product launches)
+    void* sk_ws;               // conv_igemm_p8_kernel<.., SK>: stream-K workspace (arrival counters + partial-tile slabs)
+    int sk_ws_bytes;
 };
 
 template <typename T> struct Cfg;

@@ -50,7 +50,13 @@ constexpr int P8_EPI_ROWS = 64;                                    // pixel rows
 constexpr int P8_EPI_OFF = P8_STAGE;                               // the staging buffer sits ABOVE K-tile buffer 0
 constexpr int P8_EPI_BYTES = P8_EPI_ROWS * P8_ELD * 4;             // 65 KB
 constexpr int P8_TAB_OFF = (2 * P8_STAGE > P8_EPI_OFF + P8_EPI_BYTES) ? 2 * P8_STAGE : P8_EPI_OFF + P8_EPI_BYTES;   // row table above everything
-constexpr int P8_LDS = P8_TAB_OFF + P8_BM * 8;                     // 131 KB
+constexpr int P8_FLAG_OFF = P8_TAB_OFF + P8_BM * 8;                // stream-K: one word "value of the arrival counter" (thread 0 -> workgroup)
+constexpr int P8_LDS = P8_FLAG_OFF + 16;                           // 131 KB (ONE __shared__ object: a second one makes hipcc drain vmcnt before every ds_read)
+// ---- stream-K (conv_igemm_p8_kernel<.., SK = true>): the workspace = [P8_SK_MAX_TILES arrival counters][slabs]; a slab = one partial
+//      256 x 256 f32 accumulator tile in REGISTER order: 16-byte element (b * 4 + q) * 512 + tid, b = accumulator block i * 2 + j
+constexpr int P8_SK_MAX_TILES = 4096;
+constexpr int P8_SK_HDR = P8_SK_MAX_TILES * 4;
+constexpr int P8_SK_SLAB = P8_BM * P8_BN * 4;                      // 256 KB
 
 // LDS-only workgroup barrier: orders this wave's LDS accesses (lgkmcnt) and synchronises, WITHOUT the vmcnt(0) that
 // __syncthreads() carries - the epilogue's global stores must not be waited for.
@@ -417,7 +423,15 @@ __device__ __forceinline__ void p8_epilogue4(f32x16 (&acc)[4][2], unsigned char*
 }
 
 // STAMP: tuning build - per (workgroup, wave) cycle stamps of the first tile into p.dbg (prologue / K loop / epilogue split).
-template <bool STAMP, int EPI>
+// SK (stream-K, round 5): the K-tiles of an XCD's run of tiles form ONE line of units that is cut evenly over the XCD's workgroups, so
+// 300 tiles on 256 workgroups cost 1.17 tile times instead of 2.  A workgroup's range = [tail piece of a tile][whole tiles][head piece of
+// a tile]; a partial piece ends in an ARRIVAL on the tile's counter: whoever arrives last adds the other pieces' slabs to its registers
+// (in K order, whoever it is: the sum is the same bit pattern in every arrival order) and runs the epilogue, everybody else writes its
+// accumulators to its slab first.  Nobody ever waits for another workgroup (no co-residency assumption: with several streams in flight a
+// workgroup of this launch may not have started yet).  Publish protocol (cdna_hip_programming.md, in-launch split-K): write-through (sc1)
+// slab stores -> s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope fetch_add; the reducer reads the slabs with sc1 loads.  The last
+// arriver re-zeroes the counter: the workspace's counter block is zero between launches (the caller zeroes it once).
+template <bool STAMP, int EPI, bool SK = false>
 __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[P8_LDS];
@@ -436,8 +450,14 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
     const int run_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int run_end = run_begin + tq + (xcd < tr ? 1 : 0);
     const int stride = ((int)gridDim.x - xcd + 7) / 8;
-    int tile = run_begin + slot;
-    if (tile >= run_end) return;
+    const int nk = p.K / P8_BK;
+    // SK: this workgroup's units [ub, ue) of the XCD's line of (run_end - run_begin) * nk K-tile units; `cur` = next unit
+    const int sk_units = SK ? (run_end - run_begin) * nk : 0;
+    auto sk_begin = [&](int s_) { return (int)(((long long)sk_units * s_) / stride); };
+    const int ue = SK ? sk_begin(slot + 1) : 0;
+    int cur = SK ? sk_begin(slot) : 0;
+    int tile = SK ? run_begin + cur / nk : run_begin + slot;
+    if (SK ? cur >= ue : tile >= run_end) return;
 
     // ---- DMA sources.  One 1-KB DMA = 8 tile rows x 128 B, lane -> row (lane >> 3), physical 16-byte slot (lane & 7).
     //   A piece h (pixel half mi = h of BOTH wave rows): DMA j of wave w fills rows j*128 + h*64 + w*8 .. +7
@@ -453,6 +473,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         (void*)p.res, 0, EPI == 4 ? (int)((((long long)p.M - 1) * p.r_cs + p.N) * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         p.y, 0, EPI >= 1 ? (int)((((long long)p.M - 1) * p.y_cs + p.N) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws, 0, SK ? p.sk_ws_bytes : 0, 0x00020000);
     unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
     int m0 = 0, n0 = 0;
     // wave-uniform K-tile cursor of the NEXT tile to stage (tiles are staged strictly in order)
@@ -545,6 +566,15 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             }
         }
     };
+    auto set_cursor = [&](int kt) {                          // SK: cursor -> K-tile kt of the current tile (wave-uniform integer math)
+        int tap, c0;
+        if (p.force == 0) { const int per = p.Cin / P8_BK; tap = kt / per; c0 = (kt - tap * per) * P8_BK; }
+        else { const int cs = kt / ntaps; tap = kt - cs * ntaps; c0 = cs * P8_BK; }
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        cur_tap = tap; cur_kw = kw; cur_c0 = c0;
+        cur_tapoff = (unsigned)(kh * p.W + kw) * (unsigned)p.x_cs * 2u;
+        cur_k0b = (unsigned)(tap * p.Cin + c0) * 2u;
+    };
     auto stage_a = [&](unsigned char* buf, int h) {          // pixel-half piece h at the cursor's K-tile
         const unsigned soff = cur_tapoff + (unsigned)cur_c0 * 2u;
 #pragma unroll
@@ -566,7 +596,6 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         stage_a(lds, 1);
     };
 
-    const int nk = p.K / P8_BK;
     const int sw = (lane >> 1) & 7;
     const int a_row_off = (wr * 128 + (lane & 31)) * P8_ROWB;
     const int b_row_off = P8_A_BYTES + (wc * 64 + (lane & 31)) * P8_ROWB;
@@ -583,11 +612,18 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
     } while (0)
 
     set_tile(tile);
+    int kb = 0;                                              // SK: first K-tile of the current piece (only a range's first piece starts inside a tile)
+    if constexpr (SK) {
+        kb = cur - (tile - run_begin) * nk;
+        if (kb) set_cursor(kb);
+    }
     stage_first();
     bool first = true;
     int tile_no = 0;
     while (true) {
         const bool stamp_now = STAMP && tile_no == p.dbg_tile;
+        // K-tiles of this piece (SK: the rest of the tile or the rest of the range, whichever ends first)
+        const int nkl = SK ? ((nk - kb) < (ue - cur) ? (nk - kb) : (ue - cur)) : nk;
         // ---- on entry: the four pieces of this tile's K-tile 0 are issued (first tile) or landed (later tiles: waited for in the
         //      previous tile's epilogue); the cursor stands at K-tile 0
         f32x16 acc[4][2];
@@ -599,9 +635,9 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         bf16x8 af[2][2], bfr[2][4];
         advance();                                               // cursor -> K-tile 1
-        if (nk > 1) stage_a(lds + P8_STAGE, 0);                  // A0(1)
+        if (nkl > 1) stage_a(lds + P8_STAGE, 0);                 // A0(1)
         if (first) {                                             // A0(0), BL(0), BH(0) must have landed; A1(0) [, A0(1)] may fly
-            if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (nkl > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -619,7 +655,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
             constexpr int BUF = decltype(BUFC)::value;
             unsigned char* sb = lds + BUF * P8_STAGE;            // tile t (and tile t+2's A0 piece)
             unsigned char* nb = lds + (BUF ^ 1) * P8_STAGE;      // tile t+1
-            const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+            const bool has1 = t + 1 < nkl, has2 = t + 2 < nkl;
             const bool pst = STAMP && stamp_now && t == 10;      // per-phase stamps of one mid-loop K-tile (tuning build)
             auto mfma_phase = [&](auto MIC, auto KHC) {
                 constexpr int MI = decltype(MIC)::value, KH = decltype(KHC)::value;
@@ -696,11 +732,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         };
         {
             int t = 0;
-            for (; t + 1 < nk; t += 2) {
+            for (; t + 1 < nkl; t += 2) {
                 ktile(IC<0>{}, t);
                 ktile(IC<1>{}, t + 1);
             }
-            if (t < nk) ktile(IC<0>{}, t);
+            if (t < nkl) ktile(IC<0>{}, t);
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();               // pairs with the lagging group's last barrier
         else __builtin_amdgcn_s_setprio(0);
@@ -710,8 +746,92 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         }
         // ---- next tile's addresses and the DMAs of its K-tile 0 (buffer 0) BEFORE this tile's epilogue (staging above buffer 0)
         const int cur_m0 = m0, cur_n0 = n0;
-        const int next = tile + stride;
-        const bool more = next < run_end;
+        if constexpr (SK) cur += nkl;
+        const int next = SK ? tile + 1 : tile + stride;
+        const bool more = SK ? cur < ue : next < run_end;
+        if constexpr (SK) {
+            if (nkl < nk) {
+                // ---- a PARTIAL piece of tile `tile`: arrive.  Contributors = the XCD's workgroup slots whose ranges meet the tile's units
+                //      [a, b): s_lo = the first slot with end > a, s_hi = the last slot with begin < b (ranges: [floor(U s / S), floor(U (s + 1) / S)))
+                const long long ua = (long long)(tile - run_begin) * nk, ub_ = ua + nk;
+                const int s_lo = (int)(((ua + 1) * stride + sk_units - 1) / sk_units) - 1;
+                const int s_hi = (int)((ub_ * stride + sk_units - 1) / sk_units) - 1;
+                const int ncon = s_hi - s_lo + 1;
+                volatile int* flag = reinterpret_cast<volatile int*>(lds + P8_FLAG_OFF);
+                int* cnt = reinterpret_cast<int*>(p.sk_ws) + tile;
+                auto slab_of = [&](int s_) {                     // byte offset of slot s_'s slab for THIS tile: slab 0 = its range's first piece
+                    const int first_tile = run_begin + sk_begin(s_) / nk;
+                    return (unsigned)P8_SK_HDR + (unsigned)(((s_ * 8 + xcd) * 2 + (first_tile == tile ? 0 : 1))) * (unsigned)P8_SK_SLAB;
+                };
+                bool last = false;
+                if (kb == 0) {
+                    // the head piece is the LAST piece of this workgroup's range: the others (tail / middle pieces, done first in their
+                    // ranges) have normally arrived long ago - look before writing 256 KB nobody would read
+                    if (tid == 0) flag[0] = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    P8_LDS_SYNC();
+                    last = flag[0] == ncon - 1;
+                    P8_LDS_SYNC();
+                }
+                if (!last) {
+                    const unsigned so = slab_of(slot);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x16& a = acc[b >> 1][b & 1];
+                            const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rws, tid * 16, (int)(so + (unsigned)(b * 4 + q) * 8192u), 16);
+                        }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every slab store of this wave is written through
+                    P8_LDS_SYNC();                                           // ... of every wave
+                    if (tid == 0) flag[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    P8_LDS_SYNC();
+                    last = flag[0] == ncon - 1;
+                    P8_LDS_SYNC();
+                }
+                if (!last) {
+                    // somebody else finishes this tile.  Next piece (if any): its first DMAs, waited for at the loop top like a first tile's
+                    if (!more) break;
+                    tile = next; kb = 0; first = true; ++tile_no;
+                    set_tile(tile);
+                    stage_first();
+                    continue;
+                }
+                if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+                // ---- reduce: acc = sum over the contributors in K (= slot) order.  With this piece at position 0 or 1 of that order the
+                //      running sum can live in acc itself ((me + c1) + c2 ... and (c0 + me) + c2 ... are the canonical (c0 + c1) + c2 ...
+                //      with the first pair commuted); from position 2 on the pieces before it are summed separately first.
+                const int me = slot - s_lo;
+                auto add_slab = [&](int s_, auto COPYC) {
+                    constexpr bool COPY = decltype(COPYC)::value != 0;
+                    const unsigned so = slab_of(s_);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        u32x4 t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16, (int)(so + (unsigned)(g * 8 + e) * 8192u), 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int b = (g * 8 + e) >> 2, q = (g * 8 + e) & 3;
+                            const f32x4 v = __builtin_bit_cast(f32x4, t[e]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if constexpr (COPY) acc[b >> 1][b & 1][4 * q + r] = v[r];
+                                else acc[b >> 1][b & 1][4 * q + r] += v[r];
+                            }
+                        }
+                    }
+                };
+                if (me >= 2) {
+                    // (a piece at position >= 1 came through the fetch_add path: its own slab is in the workspace, bit for bit the registers)
+                    add_slab(s_lo, IC<1>{});
+                    for (int c = 1; c < ncon; ++c) add_slab(s_lo + c, IC<0>{});
+                } else {
+                    for (int c = 0; c < ncon; ++c)
+                        if (c != me) add_slab(s_lo + c, IC<0>{});
+                }
+            }
+        }
         constexpr bool EPI16 = EPI >= 1 && EPI <= 3;             // arithmetic in the accumulator layout + bf16 staging
         P8EpiRegs epr;
         P8EpiRegs16 epr16;
@@ -780,6 +900,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
         if (!more) break;
         tile = next;
         first = false;
+        if constexpr (SK) kb = 0;
         ++tile_no;
         if constexpr (STAMP) {
             if (tile_no == p.dbg_tile) ts[0] = __builtin_readcyclecounter();     // "prologue" of a later tile = from here to its first barrier
@@ -811,10 +932,12 @@ static int p8_num_cus() {
 
 // x [B,H,W,Cin] bf16 (pixel stride x_cstride), w [Cout][KH][KW][Cin] bf16 (plain K-contiguous rows - NOT fragment-major),
 // Cin % 64 == 0, Cout % 256 == 0; epilogue = nopesac_conv2d_nhwc's (scale / bias / residual / activation / output dtype).
-extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
-                                      int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride,
-                                      int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* stream) {
+// ws != nullptr: the stream-K build (nopesac_conv2d_nhwc_p8_sk).
+static int p8_launch(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride,
+                     int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* ws, int64_t ws_bytes, void* stream) {
     using namespace nps;
+    const bool sk = ws != nullptr;
     NPS_CHECK_ARG(x && w && y, "conv2d_p8: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_p8: bad dims");
     NPS_CHECK_ARG(Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 256 == 0, "conv2d_p8: needs Cin %% 64 == 0 and Cout %% 256 == 0");
@@ -823,7 +946,7 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     const int generic_epi = (variant >> 6) & 1; // + 64: force the generic (run-time decided) epilogue build
     const int grid_cap = variant >> 8;          // tuning aid: (cap << 8) limits the number of persistent workgroups
     variant &= 0x9f;
-    NPS_CHECK_ARG(variant == 0 || variant == 24, "conv2d_p8: variant must be 0 (+32: channel-major K order); 24 = cycle-stamp build");
+    NPS_CHECK_ARG(variant == 0 || (variant == 24 && !sk), "conv2d_p8: variant must be 0 (+32: channel-major K order); 24 = cycle-stamp build");
     NPS_CHECK_ARG(x_cstride >= Cin && x_cstride % 8 == 0 && y_cstride >= Cout && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0),
                   "conv2d_p8: strides / alignment");
     NPS_CHECK_ARG(!residual || (r_cstride >= Cout && out_dt != NPS_DT_FP8), "conv2d_p8: residual stride / residual with fp8 output");
@@ -860,7 +983,22 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     const int ntiles = p.tiles_m * p.tiles_n;
     int nwg = p8_num_cus();                        // persistent: one workgroup per CU (129 KB of LDS each)
     if (grid_cap > 0 && grid_cap < nwg) nwg = grid_cap;
-    if (ntiles < nwg) nwg = ntiles;
+    if (sk) {
+        // stream-K: every XCD's run of tiles must hold at least one K-tile unit per workgroup of that XCD (smallest run x K-tiles >= the
+        // largest per-XCD workgroup count), else fewer workgroups
+        const int nkt = p.K / P8_BK;
+        NPS_CHECK_ARG(ntiles <= P8_SK_MAX_TILES, "conv2d_p8_sk: more than %d tiles (use the plain kernel: nothing to balance)", P8_SK_MAX_TILES);
+        NPS_CHECK_ARG((uintptr_t)ws % 16 == 0, "conv2d_p8_sk: workspace alignment");
+        while (nwg > 1) {
+            const int nx = nwg < 8 ? nwg : 8;
+            if ((long long)(ntiles / nx) * nkt >= (nwg + 7) / 8 && ntiles >= nx) break;
+            --nwg;
+        }
+        const long long need = (long long)P8_SK_HDR + (long long)nwg * 2 * P8_SK_SLAB;
+        NPS_CHECK_ARG(ws_bytes >= need && need < (1ll << 31), "conv2d_p8_sk: workspace of %lld bytes, %lld needed", (long long)ws_bytes, need);
+        p.sk_ws = ws;
+        p.sk_ws_bytes = (int)need;
+    } else if (ntiles < nwg) nwg = ntiles;
     const dim3 grid(nwg);
     // epilogue specialisation (code size, see p8_epilogue): the common no-residual / bf16-output forms get their own build
     int epi = 0;
@@ -870,7 +1008,13 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     if (residual && out_dt == NPS_DT_BF16 && !res_after && act == NPS_ACT_RELU && scale && bias && off32) epi = 4;
     if (generic_epi) epi = 0;
     const hipStream_t st = (hipStream_t)stream;
-    if (variant == 24) {
+    if (sk) {
+        if (epi == 1) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 1, true>), grid, dim3(512), 0, st, p);
+        else if (epi == 2) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 2, true>), grid, dim3(512), 0, st, p);
+        else if (epi == 3) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 3, true>), grid, dim3(512), 0, st, p);
+        else if (epi == 4) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 4, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 0, true>), grid, dim3(512), 0, st, p);
+    } else if (variant == 24) {
         p.dbg = g_p8_dbg; p.dbg_tile = g_p8_dbg_tile;
         if (epi == 1) hipLaunchKernelGGL((conv_igemm_p8_kernel<true, 1>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_p8_kernel<true, 0>), grid, dim3(512), 0, st, p);
@@ -880,4 +1024,27 @@ extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float*
     else if (epi == 4) hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 4>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_igemm_p8_kernel<false, 0>), grid, dim3(512), 0, st, p);
     NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_conv2d_nhwc_p8(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                                      int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride,
+                                      int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* stream) {
+    return p8_launch(x, w, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, r_cstride, act, out_dt, variant,
+                     nullptr, 0, stream);
+}
+
+// Stream-K form (conv_igemm_p8_kernel<.., SK>): same arguments + a workspace of nopesac_conv2d_p8_sk_workspace_bytes() bytes whose first
+// 16 KB (the arrival counters) are ZERO on entry; they are zero again when the launch has completed, so one workspace serves every launch
+// of a stream (launches on different streams need different workspaces).
+extern "C" int64_t nopesac_conv2d_p8_sk_workspace_bytes(void) {
+    return (int64_t)nps::P8_SK_HDR + (int64_t)p8_num_cus() * 2 * nps::P8_SK_SLAB;
+}
+
+extern "C" int nopesac_conv2d_nhwc_p8_sk(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                                         int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride,
+                                         int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    NPS_CHECK_ARG(workspace, "conv2d_p8_sk: null workspace");
+    return p8_launch(x, w, scale, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, r_cstride, act, out_dt, variant,
+                     workspace, workspace_bytes, stream);
 }

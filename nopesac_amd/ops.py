@@ -144,6 +144,7 @@ TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
+CFG_P8_SK = 12                         # tuner-only: nopesac_conv2d_nhwc_p8_sk (the same kernel with stream-K work distribution, round 5)
 P8_VARIANT = [32]                      # variant handed to nopesac_conv2d_nhwc_p8: 32 = channel-major K order (better L2 reuse of the taps)
 # added to nopesac_conv2d_nhwc_bfrag's variant for stride-1 KxK convs: channel-major K order (round 4: same time in isolation, 95 instead
 # of 149 MB read from HBM per launch on res3's 3x3 layers; stride 2 measured slower and stays tap-major).  NOPESAC_BFRAG_KMAJOR=0: A/B runs
@@ -151,7 +152,23 @@ BFRAG_KMAJOR = [0 if os.environ.get("NOPESAC_BFRAG_KMAJOR") == "0" else 256]
 LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
-                   10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel"}
+                   10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel", 12: "conv_igemm_p8_kernel<stream-K>"}
+P8_SK_TUNABLE = [os.environ.get("NOPESAC_P8_SK", "1") != "0"]      # NOPESAC_P8_SK=0: the tuner never offers the stream-K form (A/B runs)
+_P8_SK_WS = {}                         # (device index, stream handle) -> workspace tensor of the stream-K conv
+
+
+def p8_sk_workspace(device) -> torch.Tensor:
+    """The stream-K conv's workspace for the CURRENT stream of `device` (arrival counters + partial-tile slabs, 128 MB): launches of one
+    stream are ordered, so they share one; every stream gets its own.  Zeroed once - the kernel leaves the counters zero.  Inside a
+    graph capture the allocation (and its zero fill, harmlessly replayed) belongs to the capture's private pool."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), torch.cuda.is_current_stream_capturing())
+    ws = _P8_SK_WS.get(key)
+    if ws is None:
+        n = int(_L().nopesac_conv2d_p8_sk_workspace_bytes())
+        ws = torch.empty(n, device=device, dtype=torch.uint8)
+        ws[:16384].zero_()
+        _P8_SK_WS[key] = ws
+    return ws
 
 
 def _frag_weights(w: torch.Tensor) -> torch.Tensor:
@@ -224,7 +241,16 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
              and (residual is None or (r_cs % (4 if out_dtype == torch.float32 else 8) == 0 and out_dtype != torch.float8_e4m3fn))
              and all(t is None or t.data_ptr() % 16 == 0 for t in (x, w, out, residual, scale, bias)))
 
+    # stream-K only where whole rounds leave CUs idle: a few tiles per CU and a K loop long enough to cut
+    p8_sk_ok = p8_ok and (-(-(B * OH * OW) // 256)) * (Cout // 256) <= 1024 and KH * KW * Cin >= 512
+
     def launch(cfg):
+        if cfg == CFG_P8_SK:
+            ws = p8_sk_workspace(x.device)
+            rc = _L().nopesac_conv2d_nhwc_p8_sk(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW, stride,
+                                                pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], P8_VARIANT[0], _p(ws), ws.numel(), _stream())
+            _lib.check(rc, "nopesac_conv2d_nhwc_p8_sk")
+            return
         if cfg == CFG_P8:
             rc = _L().nopesac_conv2d_nhwc_p8(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW, stride,
                                              pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], P8_VARIANT[0], _stream())
@@ -252,7 +278,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0,
                scale is not None, bias is not None, act, bfrag_ok, halo_ok, p8_ok)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ())
-                           + ((CFG_P8,) if p8_ok else ()))
+                           + ((CFG_P8,) if p8_ok else ()) + ((CFG_P8_SK,) if (p8_sk_ok and P8_SK_TUNABLE[0]) else ()))
     try:
         launch(cfg)
     except _lib.HipKernelError:

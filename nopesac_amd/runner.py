@@ -136,10 +136,18 @@ class InflightLoop:
     complete when its event has fired (checked before the slot is reused and by `drain`).  On a CPU (the gloo tests) the same
     control flow runs without streams / events."""
 
-    def __init__(self, n_slots: int, rows_per_rank: int, device=None, world: int = 1, side_shift: Optional[int] = 0, pace_s: float = 0.0):
+    def __init__(self, n_slots: int, rows_per_rank: int, device=None, world: int = 1, side_shift: Optional[int] = 0, pace_s: float = 0.0,
+                 gather_every: int = 1):
         """side_shift: see streams.StreamSet (which hardware queue a batch's pose-net side stream shares); None = plain
-        torch.cuda.Stream()s, whatever queues the runtime hands out."""
+        torch.cuda.Stream()s, whatever queues the runtime hands out.
+        gather_every = G > 1 (round 5): the rows of G consecutive steps are parked in a device buffer and travel in ONE all_gather of
+        [G * B, 16] rows, issued by the step that completes the group (the reference gathers once, at the end).  With one
+        collective per step every rank waits for the slowest rank every ~8 ms and an RCCL kernel competes with the persistent conv
+        workgroups every step; with G = 8 the ranks are coupled every ~70 ms.  `flush()` (called by `barrier`) gathers a partial group -
+        every rank has then run the same number of steps, so the collective sequence is identical everywhere."""
         self.n_slots = max(1, int(n_slots))
+        self.G = max(1, int(gather_every))
+        self.world, self.rows_per_rank = int(world), int(rows_per_rank)
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.stream_set = None
         if self.cuda and side_shift is not None:
@@ -152,6 +160,16 @@ class InflightLoop:
         if self.cuda:
             self.host_bufs = [b.pin_memory() for b in self.host_bufs]
         self.done = [None] * self.n_slots
+        if self.G > 1:                                         # two groups: one filling, one whose gather may still be in flight
+            dev = device if self.cuda else None
+            self.acc = [torch.zeros(self.G, rows_per_rank, METRIC_WIDTH, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.acc_ev = [[None] * self.G for _ in range(2)]
+            self.group_host = [torch.empty(world * self.G * rows_per_rank, METRIC_WIDTH, dtype=torch.float32) for _ in range(2)]
+            if self.cuda:
+                self.group_host = [b.pin_memory() for b in self.group_host]
+            self.group_done = [None, None]
+            self.group_idx, self.group_fill, self.latest = 0, 0, None
+            self.collectives = 0
         self.host_seconds = 0.0
         self.last = None
         self.pace_s = float(pace_s)                            # minimum time between two submissions (see step)
@@ -177,24 +195,87 @@ class InflightLoop:
         t0 = time.perf_counter()
         self._last_submit = t0
         ctx = torch.cuda.stream(self.streams[slot]) if self.cuda else contextlib.nullcontext()
+        host = None
         with torch.no_grad(), ctx:
             d, rows = device_step(slot)
-            allrows = gather_metrics(rows)                     # the only collective (RCCL all_gather, KBs)
-            self.host_bufs[slot].copy_(allrows, non_blocking=True)   # results leave the device once per step
+            if self.G == 1:
+                allrows = gather_metrics(rows)                 # the only collective (RCCL all_gather, KBs)
+                self.host_bufs[slot].copy_(allrows, non_blocking=True)   # results leave the device once per step
+                host = self.host_bufs[slot]
+            else:
+                g, pos = self.group_idx & 1, self.group_fill
+                if pos == 0 and self.group_done[g] is not None:
+                    self.group_done[g].synchronize()           # this buffer's previous gather (two groups ago) has reached the host
+                self.acc[g][pos].copy_(rows, non_blocking=True)
+                if self.cuda:
+                    self.acc_ev[g][pos] = torch.cuda.Event()
+                    self.acc_ev[g][pos].record()
+                self.group_fill += 1
+                if self.group_fill == self.G:
+                    self._gather_group()
             if self.cuda:
                 ev = torch.cuda.Event()
                 ev.record()
                 self.done[slot] = ev
         self.host_seconds += time.perf_counter() - t0
         self.last = (d, slot)
-        return d, self.host_bufs[slot]
+        return d, host
+
+    def _gather_group(self):
+        """ONE all_gather of the group's rows on the CURRENT stream (the stream of the step that completes the group), behind the
+        row writes of the group's other steps (their streams' events)."""
+        g, n = self.group_idx & 1, self.group_fill
+        if self.cuda:
+            cur = torch.cuda.current_stream()
+            for ev in self.acc_ev[g][:n]:
+                cur.wait_event(ev)
+        allrows = gather_metrics(self.acc[g][:n].reshape(n * self.rows_per_rank, METRIC_WIDTH))     # [world * n * B, 16], rank-major
+        self.collectives += 1
+        self.group_host[g][:allrows.shape[0]].copy_(allrows, non_blocking=True)
+        if self.cuda:
+            self.group_done[g] = torch.cuda.Event()
+            self.group_done[g].record()
+        self.latest = (g, n)
+        self.group_idx += 1
+        self.group_fill = 0
+
+    def flush(self):
+        """gather_every > 1: gather the steps since the last collective (a partial group).  COLLECTIVE: every rank calls it after the
+        same number of steps (barrier() does)."""
+        if self.G > 1 and self.group_fill > 0:
+            import contextlib
+            slot = self.last[1] if self.last is not None else 0
+            ctx = torch.cuda.stream(self.streams[slot]) if self.cuda else contextlib.nullcontext()
+            with torch.no_grad(), ctx:
+                self._gather_group()
+
+    def last_group_rows(self) -> Optional[torch.Tensor]:
+        """gather_every > 1: the most recent gathered group as [world, n steps, B, 16] (host; valid once its event has fired - after
+        drain() / barrier())."""
+        if self.G == 1 or self.latest is None:
+            return None
+        g, n = self.latest
+        return self.group_host[g][:self.world * n * self.rows_per_rank].view(self.world, n, self.rows_per_rank, METRIC_WIDTH)
+
+    def last_step_rows(self) -> Optional[torch.Tensor]:
+        """The gathered rows [world * B, 16] of the last step that has been gathered (rank-major), as step() returns them with
+        gather_every = 1."""
+        if self.G == 1:
+            return self.host_bufs[self.last[1]] if self.last is not None else None
+        grp = self.last_group_rows()
+        return None if grp is None else grp[:, -1].reshape(self.world * self.rows_per_rank, METRIC_WIDTH)
 
     def drain(self):
         for ev in self.done:
             if ev is not None:
                 ev.synchronize()
+        if self.G > 1:
+            for ev in self.group_done:
+                if ev is not None:
+                    ev.synchronize()
 
     def barrier(self):
+        self.flush()
         self.drain()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.barrier()

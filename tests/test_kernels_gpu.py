@@ -799,6 +799,86 @@ def test_conv2d_p8(device, case, variant):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("case", [(2, 30, 40, 256, 256, 3, 1, 1),      # 10 tiles x 36 K-tiles over 256 workgroups: every tile cut 26 ways
+                                  (3, 31, 29, 128, 256, 3, 2, 1),      # stride 2, M tail, 18 K-tiles
+                                  (2, 24, 32, 512, 512, 1, 1, 0),      # 1x1, two channel tiles, 8 K-tiles
+                                  (1, 15, 20, 64, 256, 3, 1, 1),       # 9 K-tiles (odd), Cin = 64
+                                  (2, 9, 7, 64, 256, 1, 1, 0),         # ONE K-tile: a single workgroup, nothing to cut
+                                  (1, 12, 20, 192, 256, 1, 1, 0),      # three K-tiles
+                                  (5, 60, 80, 64, 512, 3, 1, 1),       # 188 tiles x 9 K-tiles: 6.6 units per workgroup
+                                  (16, 30, 40, 256, 256, 3, 1, 1)])    # 75 tiles x 36: 10.5 units per workgroup, a tile has 3-4 contributors
+@pytest.mark.parametrize("variant", [0, 32, 32 | 64, 32 | (5 << 8), 0 | (19 << 8), 32 | (64 << 8)])     # + (n << 8): n persistent workgroups
+def test_conv2d_p8_stream_k(device, case, variant):
+    """Stream-K form of the 256x256-tile kernel (conv_igemm_p8_kernel<.., SK>): against F.conv2d (f32 output: only the summation order
+    differs), against the plain kernel, and bit for bit against ITSELF over repeated launches - which workgroup arrives last on a tile
+    changes from launch to launch, the K-ordered reduction must not.  Workgroup counts 5 / 19 / 64 / 256 give whole tiles + head / tail
+    pieces, ranges inside one tile, and tiles with many contributors; the arrival counters must be zero again after every launch."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    xd, rd = _nhwc(x).to(device, torch.bfloat16), _nhwc(res).to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    sd, bd = scale.to(device), bias.to(device)
+    ws = ops.p8_sk_workspace(device)
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device=device)
+        args = (xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, k, k, s, p, Cin, Cout,
+                Cout, ops.ACT_RELU, 0, variant)
+        if rep == 3:
+            rc = _lib.load().nopesac_conv2d_nhwc_p8(*args, torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = _lib.load().nopesac_conv2d_nhwc_p8_sk(*args, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    assert _rel(outs[0].permute(0, 3, 1, 2), ref) < 2e-5
+    assert _rel(outs[0], outs[3]) < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("act,residual", [("ACT_RELU", False), ("ACT_NONE", False), ("ACT_LEAKY", False), ("ACT_RELU", True)])
+def test_conv2d_p8_stream_k_specialised_epilogues(device, act, residual):
+    """bf16-output epilogue builds (EPI 1-4) of the stream-K kernel against the plain kernel: both round the same f32 sums up to the
+    K-split's summation order; next to a second stream that keeps the chip busy (arrival order and residency then vary)."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k = 16, 30, 40, 256, 512, 3
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)).to(device, torch.bfloat16)
+    sc, bi = (1 + 0.1 * torch.randn(Cout, generator=g)).to(device), (0.1 * torch.randn(Cout, generator=g)).to(device)
+    r = torch.randn(B, H, W, Cout, generator=g).to(device, torch.bfloat16) if residual else None
+    ws = ops.p8_sk_workspace(device)
+    side = torch.cuda.Stream(device=device)
+    big = torch.randn(4096, 4096, device=device)
+    outs = []
+    for rep in range(5):
+        y = torch.zeros(B, H, W, Cout, device=device, dtype=torch.bfloat16)
+        args = (x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), r.data_ptr() if residual else None, y.data_ptr(), B, H, W, Cin, Cout,
+                k, k, 1, 1, Cin, Cout, Cout if residual else 0, getattr(ops, act), 1, 32)
+        if rep in (1, 2):
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    big = big * 1.0001 + 0.5
+        if rep == 4:
+            rc = _lib.load().nopesac_conv2d_nhwc_p8(*args, torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = _lib.load().nopesac_conv2d_nhwc_p8_sk(*args, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert _rel(outs[0].float(), outs[4].float()) < 4e-3 and torch.isfinite(outs[0].float()).all()
+    assert (outs[0].float() - outs[4].float()).abs().max() <= 2.0 ** -6 * max(1.0, float(outs[4].float().abs().max()))
+
+
 def test_conv2d_p8_through_the_tuner_route(device, monkeypatch):
     """ops.conv2d routed to the p8 configuration (as the autotuner would): bf16 output, no residual."""
     from nopesac_amd import ops

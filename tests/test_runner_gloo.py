@@ -147,6 +147,58 @@ def test_bench_inflight_loop_world2(tmp_path):
         assert (a[i, :, 9] == 32).all()
 
 
+def _grouped_worker(rank, world, port, steps, slots, B, G, out_dir):
+    """InflightLoop(gather_every = G): the rows of G steps per all_gather, the last partial group inside barrier()."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nopesac_amd import runner
+    r, w, _ = runner.init_distributed("gloo")
+    loop = runner.InflightLoop(slots, B, None, w, gather_every=G)
+    groups, seen = [], 0
+
+    def device_step_for(i):
+        def device_step(slot):
+            t = torch.full((B, 3), float(i)) + torch.arange(B, dtype=torch.float32).view(-1, 1) / 100 + r * 1000.0
+            q = torch.nn.functional.normalize(torch.ones(B, 4), dim=-1)
+            return {"step": i}, runner.metric_rows(t, q, torch.full((B,), 5), torch.full((B,), 6), torch.full((B,), 32), r * B)
+        return device_step
+
+    for i in range(steps):
+        d, host = loop.step(i, device_step_for(i))
+        assert d == {"step": i} and host is None
+        if loop.collectives > seen:                       # this step completed a group
+            seen = loop.collectives
+            groups.append(loop.last_group_rows().clone())
+    loop.barrier()                                        # flush: the partial group
+    if loop.collectives > seen:
+        groups.append(loop.last_group_rows().clone())
+    assert loop.collectives == -(-steps // G)
+    last = loop.last_step_rows()
+    assert last.shape == (w * B, runner.METRIC_WIDTH) and last[:, 12].tolist() == [float(v) for v in range(w * B)]
+    np.save(os.path.join(out_dir, f"grouped_{r}.npy"), torch.cat(groups, dim=1).numpy())       # [world, steps, B, 16]
+    torch.distributed.destroy_process_group()
+
+
+def test_inflight_loop_gather_every_world2(tmp_path):
+    """SURVEY 8(e) / round-5 hardening: ranks are coupled once per G steps, not every step.  World 2 over gloo, 4 slots, 11 steps, G = 4:
+    three collectives (4 + 4 + 3 steps), every step's rows of both ranks arrive, in step order and rank-major, identical on both ranks."""
+    steps, slots, B, world, G = 11, 4, 3, 2, 4
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_grouped_worker, args=(r, world, port, steps, slots, B, G, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "rank did not finish (deadlock?)"
+    a, b = np.load(tmp_path / "grouped_0.npy"), np.load(tmp_path / "grouped_1.npy")
+    assert a.shape == (world, steps, B, 16)
+    np.testing.assert_array_equal(a, b)
+    for i in range(steps):
+        for rk in range(world):
+            np.testing.assert_allclose(a[rk, i, :, 0], 1000.0 * rk + i + np.arange(B) / 100, rtol=1e-6)
+            assert a[rk, i, :, 12].tolist() == list(range(rk * B, rk * B + B))
+
+
 def _run_bench(argv, env_extra=None, timeout=300):
     import json
     import subprocess
@@ -193,3 +245,4 @@ def test_bench_gpus8_global_batch_256_stub():
     assert r.returncode == 0, r.stderr[-2000:]
     assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8 and j["config"]["global_batch"] == 256
     assert j["rows_gathered"] == 256 and j["rows_in_rank_order"]
+    assert j["steps_per_all_gather"] == 8 and j["collectives_in_run"] == 2          # warm-up flush (2 steps) + the timed region's 6 steps
