@@ -769,7 +769,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                     // ranges) have normally arrived long ago - look before writing 256 KB nobody would read
                     if (tid == 0) flag[0] = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     P8_LDS_SYNC();
-                    last = flag[0] == ncon - 1;
+                    last = __builtin_amdgcn_readfirstlane(flag[0]) == ncon - 1;     // (uniform by construction - say so, or every loop bound downstream becomes a VGPR)
                     P8_LDS_SYNC();
                 }
                 if (!last) {
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvParams p) 
                     P8_LDS_SYNC();                                           // ... of every wave
                     if (tid == 0) flag[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     P8_LDS_SYNC();
-                    last = flag[0] == ncon - 1;
+                    last = __builtin_amdgcn_readfirstlane(flag[0]) == ncon - 1;     // (uniform by construction - say so, or every loop bound downstream becomes a VGPR)
                     P8_LDS_SYNC();
                 }
                 if (!last) {
