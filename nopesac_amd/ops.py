@@ -145,6 +145,8 @@ CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
 CFG_P8_SK = 12                         # tuner-only: nopesac_conv2d_nhwc_p8_sk (the same kernel with stream-K work distribution, round 5)
+# NOPESAC_P8_CAP_1X1=n (experiment, round 5): persistent workgroups of the p8 kernel on 1x1 layers (the HBM-bound ones) capped at n
+P8_CAP_1X1 = [int(os.environ.get("NOPESAC_P8_CAP_1X1", "0"))]
 P8_VARIANT = [32]                      # variant handed to nopesac_conv2d_nhwc_p8: 32 = channel-major K order (better L2 reuse of the taps)
 # added to nopesac_conv2d_nhwc_bfrag's variant for stride-1 KxK convs: channel-major K order (round 4: same time in isolation, 95 instead
 # of 149 MB read from HBM per launch on res3's 3x3 layers; stride 2 measured slower and stays tap-major).  NOPESAC_BFRAG_KMAJOR=0: A/B runs
@@ -153,7 +155,7 @@ LAST_CONV_CFG = [0]                    # kernel configuration of the most recent
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
                    10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel", 12: "conv_igemm_p8_kernel<stream-K>"}
-P8_SK_TUNABLE = [os.environ.get("NOPESAC_P8_SK", "1") != "0"]      # NOPESAC_P8_SK=0: the tuner never offers the stream-K form (A/B runs)
+P8_SK_TUNABLE = [os.environ.get("NOPESAC_P8_SK", "0") == "1"]      # NOPESAC_P8_SK=1: the tuner may pick the stream-K form (wins isolated launches, loses 1.2 % in the four-in-flight loop: profiles/r5_b_*)
 _P8_SK_WS = {}                         # (device index, stream handle) -> workspace tensor of the stream-K conv
 
 
@@ -253,7 +255,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
             return
         if cfg == CFG_P8:
             rc = _L().nopesac_conv2d_nhwc_p8(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW, stride,
-                                             pad, x_cs, y_cs, r_cs, act, _DT[out_dtype], P8_VARIANT[0], _stream())
+                                             pad, x_cs, y_cs, r_cs, act, _DT[out_dtype],
+                                             P8_VARIANT[0] | ((P8_CAP_1X1[0] << 8) if KH * KW == 1 else 0), _stream())
             _lib.check(rc, "nopesac_conv2d_nhwc_p8")
             return
         if cfg in (CFG_HALO16, CFG_HALO8):
