@@ -120,6 +120,17 @@ int nopesac_conv2d_nhwc_p8_sk(const void* x, const void* w, const float* scale, 
                               int64_t x_cstride, int64_t y_cstride, int64_t r_cstride, int act, int out_dt, int variant,
                               void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The 256 x 128-tile sibling for layers with Cout % 128 == 0 that the 256-wide kernel cannot take (csrc/conv_p8n.hip,
+ * conv_igemm_p8n_kernel; round 5): the 3x3 128 -> 128 convs of res3 and of the top-down / pose-net stacks.  Same structure (persistent
+ * 8-wave workgroups, LDS-DMA operands, counted vmcnt, staggered wave groups), two 8-MFMA phases per K-tile, a three-deep K-tile ring.
+ * bf16 in / bf16 out, y = act(conv * scale + bias) with act in {NPS_ACT_NONE, NPS_ACT_RELU, NPS_ACT_LEAKY}, no residual; scale / bias may
+ * be NULL; Cin % 64 == 0, x_cstride % 8 == 0, y_cstride % 8 == 0; variant: 0, + 32 = channel-major K order.
+ * Replaces: the same reference convolutions as nopesac_conv2d_nhwc (detectron2 BottleneckBlock conv2 + FrozenBN + ReLU, Base.yaml:2-12;
+ * camera_modules.py:271-321 pixel-decoder convs). */
+int nopesac_conv2d_nhwc_p8n(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
+                            int variant, void* stream);
+
 /* ---- a stack of Linear(+bias)(+activation) layers in ONE launch (csrc/mlp_chain.hip) --------------------------------------------
  * Replaces one nopesac_conv2d_nhwc launch per layer for the row-wise MLP stacks of the heads in bf16 mode (reference:
  * camera_net/camera_head.py:957-990 geo_encoder / geo_proj_s1 / decoder_rot / geo_proj_s2 / decoder_tran / decoder_rot2 /

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnopesac_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_p8.hip", "stem.hip", "conv3x3_c64.hip", "conv3x3_halo.hip", "pwchain.hip", "gnn_layer.hip", "enc_tail.hip", "mask_head.hip", "resize.hip", "rle.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_p8.hip", "conv_p8n.hip", "stem.hip", "conv3x3_c64.hip", "conv3x3_halo.hip", "pwchain.hip", "gnn_layer.hip", "enc_tail.hip", "mask_head.hip", "resize.hip", "rle.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
            "ransac.hip", "mlp_chain.hip", "tape.hip", "posenet_branch.hip", "jpeg.hip"]
 # -packed-fp32-ops: NO v_pk_{fma,mul,add}_f32 anywhere in the library.  Round-3 finding (scripts/lds_victim.py): a wave
 # executing packed-f32 VALU instructions gets the results of its lanes 48-63 corrupted when a wave of ANOTHER kernel issues MFMAs on the

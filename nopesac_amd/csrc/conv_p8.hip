@@ -930,6 +930,8 @@ static int p8_num_cus() {
     return cus[dev];
 }
 
+int nps_p8_num_cus() { return p8_num_cus(); }             // (conv_p8n.hip)
+
 // x [B,H,W,Cin] bf16 (pixel stride x_cstride), w [Cout][KH][KW][Cin] bf16 (plain K-contiguous rows - NOT fragment-major),
 // Cin % 64 == 0, Cout % 256 == 0; epilogue = nopesac_conv2d_nhwc's (scale / bias / residual / activation / output dtype).
 // ws != nullptr: the stream-K build (nopesac_conv2d_nhwc_p8_sk).

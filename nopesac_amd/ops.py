@@ -144,6 +144,7 @@ TUNER = ConvTuner()
 CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv2d_nhwc_bfrag, K-tile 64 / 32
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
+CFG_P8N, CFG_P8N_TAP = 13, 14          # tuner-only: nopesac_conv2d_nhwc_p8n (256x128 tiles: the Cout % 128 == 0 layers, round 5), channel- / tap-major K order
 CFG_P8_SK = 12                         # tuner-only: nopesac_conv2d_nhwc_p8_sk (the same kernel with stream-K work distribution, round 5)
 # NOPESAC_P8_CAP_1X1=n (experiment, round 5): persistent workgroups of the p8 kernel on 1x1 layers (the HBM-bound ones) capped at n
 P8_CAP_1X1 = [int(os.environ.get("NOPESAC_P8_CAP_1X1", "0"))]
@@ -154,7 +155,9 @@ BFRAG_KMAJOR = [0 if os.environ.get("NOPESAC_BFRAG_KMAJOR") == "0" else 256]
 LAST_CONV_CFG = [0]                    # kernel configuration of the most recent conv2d launch (0 = the library's heuristic)
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
-                   10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel", 12: "conv_igemm_p8_kernel<stream-K>"}
+                   10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel", 12: "conv_igemm_p8_kernel<stream-K>",
+                   13: "conv_igemm_p8n_kernel", 14: "conv_igemm_p8n_kernel<tap-major>"}
+P8N_TUNABLE = [os.environ.get("NOPESAC_P8N", "1") != "0"]           # NOPESAC_P8N=0: the tuner never offers the 256x128-tile kernel (A/B runs)
 P8_SK_TUNABLE = [os.environ.get("NOPESAC_P8_SK", "0") == "1"]      # NOPESAC_P8_SK=1: the tuner may pick the stream-K form (wins isolated launches, loses 1.2 % in the four-in-flight loop: profiles/r5_b_*)
 _P8_SK_WS = {}                         # (device index, stream handle) -> workspace tensor of the stream-K conv
 
@@ -246,7 +249,18 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
     # stream-K only where whole rounds leave CUs idle: a few tiles per CU and a K loop long enough to cut
     p8_sk_ok = p8_ok and (-(-(B * OH * OW) // 256)) * (Cout // 256) <= 1024 and KH * KW * Cin >= 512
 
+    p8n_ok = (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and not batched_weights and residual is None
+              and Cin % 64 == 0 and Cout % 128 == 0 and x_cs % 8 == 0 and y_cs % 8 == 0 and KH * KW <= 32 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY)
+              and (B * H * W + pad * W + pad) * x_cs * 2 < 2 ** 31 and B * H * W < 2 ** 23 and x_cs < 2 ** 24 and KH * KW * Cin < 2 ** 24
+              and Cout * KH * KW * Cin * 2 < 2 ** 31 and (B * OH * OW + 256) * y_cs * 2 < 2 ** 31
+              and all(t is None or t.data_ptr() % 16 == 0 for t in (x, w, out, scale, bias)))
+
     def launch(cfg):
+        if cfg in (CFG_P8N, CFG_P8N_TAP):
+            rc = _L().nopesac_conv2d_nhwc_p8n(_p(x), _p(w), _p(scale), _p(bias), _p(out), B, H, W, Cin, Cout, KH, KW, stride, pad, x_cs, y_cs,
+                                              act, 32 if cfg == CFG_P8N else 0, _stream())
+            _lib.check(rc, "nopesac_conv2d_nhwc_p8n")
+            return
         if cfg == CFG_P8_SK:
             ws = p8_sk_workspace(x.device)
             rc = _L().nopesac_conv2d_nhwc_p8_sk(_p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, KH, KW, stride,
@@ -281,7 +295,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
         key = (x.dtype, w.dtype, out_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, residual is not None, x_cs, y_cs, w_bs != 0,
                scale is not None, bias is not None, act, bfrag_ok, halo_ok, p8_ok)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ())
-                           + ((CFG_P8,) if p8_ok else ()) + ((CFG_P8_SK,) if (p8_sk_ok and P8_SK_TUNABLE[0]) else ()))
+                           + ((CFG_P8,) if p8_ok else ()) + ((CFG_P8_SK,) if (p8_sk_ok and P8_SK_TUNABLE[0]) else ())
+                           + (((CFG_P8N,) + ((CFG_P8N_TAP,) if KH * KW > 1 else ())) if (p8n_ok and P8N_TUNABLE[0]) else ()))
     try:
         launch(cfg)
     except _lib.HipKernelError:

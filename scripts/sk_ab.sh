@@ -3,7 +3,7 @@
 # stream-K entry turned back into the plain p8 kernel (routing B), then the headline loop on A, B, A, B on the same box.
 O=gpurun_out; mkdir -p $O
 F="--no-cpu-baseline --no-boundary --no-fp32-path --no-accuracy --no-other-configs --no-tape --steps 40 --warmup 8"
-python bench.py $F --retune --routing $O/routing_sk_A.json > $O/sk_ab_tune.json 2> $O/sk_ab.err
+NOPESAC_P8_SK=1 python bench.py $F --retune --routing $O/routing_sk_A.json > $O/sk_ab_tune.json 2> $O/sk_ab.err
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/routing_sk_A.json'))

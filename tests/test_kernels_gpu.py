@@ -879,6 +879,69 @@ def test_conv2d_p8_stream_k_specialised_epilogues(device, act, residual):
     assert (outs[0].float() - outs[4].float()).abs().max() <= 2.0 ** -6 * max(1.0, float(outs[4].float().abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 30, 40, 128, 128, 3, 1, 1),      # 10 tiles, 18 K-tiles (a multiple of the ring depth)
+                                  (3, 31, 29, 128, 128, 3, 2, 1),      # stride 2, M tail (720 rows = 2.8 tiles)
+                                  (2, 24, 32, 512, 256, 1, 1, 0),      # 1x1, two channel tiles, 8 K-tiles (3 + 3 + 2)
+                                  (1, 15, 20, 64, 128, 3, 1, 1),       # 9 K-tiles, Cin = 64: every K-tile is another tap
+                                  (2, 9, 7, 64, 128, 1, 1, 0),         # ONE K-tile, 126 rows (half-empty tile)
+                                  (1, 17, 16, 128, 128, 1, 1, 0),      # two K-tiles
+                                  (1, 12, 20, 192, 128, 1, 1, 0),      # three K-tiles
+                                  (1, 12, 20, 256, 128, 1, 1, 0),      # four K-tiles
+                                  (1, 12, 20, 320, 384, 1, 1, 0),      # five K-tiles, three channel tiles
+                                  (5, 60, 80, 64, 256, 3, 1, 1),       # 188 tiles in two channel columns
+                                  (1, 15, 20, 2048, 128, 3, 1, 1)])    # pose-net layer_3's K: 288 K-tiles
+@pytest.mark.parametrize("variant", [0, 32, 0 | (3 << 8), 32 | (1 << 8)])     # + 32: channel-major K order; 3 / 1 persistent workgroups
+@pytest.mark.parametrize("act", ["ACT_RELU", "ACT_NONE", "ACT_LEAKY"])
+def test_conv2d_p8n(device, case, variant, act):
+    """256x128-tile kernel (csrc/conv_p8n.hip) vs F.conv2d on bf16-rounded operands (bf16 output: one rounding) and bit for bit vs the
+    library's generic bf16 kernel family is NOT expected (another summation order) - so: within bf16 rounding of the f64-accurate result,
+    and repeated launches identical (a DMA / LDS race of the three-deep ring would show up as run-to-run differences).  K loops of
+    1, 2, 3, 4, 5, 8, 9, 18, 288 K-tiles walk every prologue / tail branch of the counted-vmcnt schedule."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p = case
+    if variant >> 8 and B * H * W * Cin * Cout * k * k > 3e10:
+        pytest.skip("one workgroup on the long-K case: covered by the uncapped variants")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, s, p) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)
+    ref = {"ACT_RELU": F.relu, "ACT_NONE": lambda t: t, "ACT_LEAKY": lambda t: F.leaky_relu(t, 0.01)}[act](ref)
+    xd = _nhwc(x).to(device, torch.bfloat16)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    sd, bd = scale.to(device), bias.to(device)
+    outs = []
+    for rep in range(3):
+        y = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device=device, dtype=torch.bfloat16)
+        rc = _lib.load().nopesac_conv2d_nhwc_p8n(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, k, k,
+                                                  s, p, Cin, Cout, getattr(ops, act), variant, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    got = outs[0].float().permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-4 * (1 + math.sqrt(Cin * k * k) * 0.01)).all()), float(err.max())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_conv2d_p8n_through_the_tuner_route(device, monkeypatch):
+    """ops.conv2d routed to the 256x128-tile configuration: strided output view (a channel slice of a wider buffer), no scale."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, H, W, Cin, Cout = 2, 60, 80, 128, 128
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).to(device, torch.bfloat16)
+    bi = (0.1 * torch.randn(Cout, generator=g)).to(device)
+    ref = ops.conv2d(x, w, None, bi, pad=1, act=ops.ACT_RELU)
+    monkeypatch.setattr(ops.TUNER, "measuring", True)
+    monkeypatch.setattr(ops.TUNER, "choose", lambda key, launch, extra=(): ops.CFG_P8N if ops.CFG_P8N in extra else 0)
+    wide = torch.zeros(B, H, W, 2 * Cout, device=device, dtype=torch.bfloat16)
+    y = ops.conv2d(x, w, None, bi, pad=1, act=ops.ACT_RELU, out=wide[..., Cout:])
+    assert ops.LAST_CONV_CFG[0] == ops.CFG_P8N
+    assert _rel(y.float(), ref.float()) < 1e-2 and float(wide[..., :Cout].abs().max()) == 0.0
+
+
 def test_conv2d_p8_through_the_tuner_route(device, monkeypatch):
     """ops.conv2d routed to the p8 configuration (as the autotuner would): bf16 output, no residual."""
     from nopesac_amd import ops
