@@ -745,6 +745,10 @@ def rank_main(args):
             out["boundary"]["jpeg_decode"] = jpeg_decode_rate(device, 2 * B)
         except Exception as e:                                  # (no Pillow on the box: the frames are encoded with it)
             out["boundary"]["jpeg_decode"] = {"skipped": repr(e)}
+        try:
+            out["boundary"]["png_decode"] = png_decode_rate(2 * B)
+        except Exception as e:
+            out["boundary"]["png_decode"] = {"skipped": repr(e)}
     if (rank == 0 and world == 1 and not args.no_other_configs and args.dtype == "bfloat16" and not args.fp8 and args.config == "mp3d"
             and K == 32 and not args.ablate):
         del model
@@ -1028,6 +1032,60 @@ def jpeg_decode_rate(device, n_images=64, rounds=3, in_flight=4):
             "batches_in_flight": in_flight, "frame": "968x1296, 4:2:0, q90, %d KB, no restart markers" % (len(base[0]) // 1024),
             "bit_exact_vs_pillow": bool(exact), "settled_by_the_parallel_decoder": int(st["par_done"].sum()) if st else 0,
             "pillow_ms_per_image_one_core": round(pil_ms, 2)}
+
+
+def png_decode_rate(n_images=64, rounds=3):
+    """The mp3d split's input path (planercnn_transforms.py:210-227 `call_mp3d` -> utils.read_image): its frames are
+    480 x 640 PNG files, whose inflate stream is serial per file - they are decoded on host threads; there is NO GPU path for them.
+    data.read_image sends PNGs through the library's host decoder (csrc/png_host.hip: zlib + row filters, interpreter lock released, bit
+    for bit PIL's pixels); PIL itself holds the lock while it decodes a PNG and does not scale with threads (`pil_all_cores`).  Measured
+    here: the same synthetic picture content as the JPEG leg, PNG-encoded by Pillow (default compression), decoded by (a) cores / 8
+    threads = one rank's share of this host on a full 8-GPU node, (b) all cores."""
+    import io
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from PIL import Image
+    from nopesac_amd import data
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = {"frame": "480x640 RGB PNG (Pillow default compression)", "host_cores": cores}
+    with tempfile.TemporaryDirectory() as td:
+        paths, sizes = [], []
+        for i in range(8):
+            a = np.stack([128 + 90 * np.sin(xx / (20 + i) + yy / 45), 128 + 70 * np.cos(yy / (17 + i)) * np.sin(xx / 70), 120 + 100 * ((xx // 80 + yy // 60) % 2)], -1)
+            pth = os.path.join(td, "f%d.png" % i)
+            Image.fromarray(np.clip(a + rng.normal(0, 3.0, a.shape), 0, 255).astype(np.uint8)).save(pth, format="PNG")
+            paths.append(pth)
+            sizes.append(os.path.getsize(pth))
+        files = [paths[i % len(paths)] for i in range(n_images)]
+        t0 = time.perf_counter()
+        for f in files[:8]:
+            data.read_image(f, "BGR")
+        out["ms_per_image_one_core"] = round(1e3 * (time.perf_counter() - t0) / 8, 2)
+        out["png_kbytes"] = int(np.mean(sizes) // 1024)
+        for label, nthr in (("one_rank_of_8", max(1, cores // 8)), ("all_cores", cores)):
+            with ThreadPoolExecutor(max_workers=nthr) as pool:
+                list(pool.map(lambda f: data.read_image(f, "BGR"), files[:nthr]))          # warm the pool
+                t0 = time.perf_counter()
+                for _ in range(rounds):
+                    list(pool.map(lambda f: data.read_image(f, "BGR"), files))
+                el = time.perf_counter() - t0
+            rate = rounds * len(files) / el
+            out[label] = {"threads": nthr, "images_per_s": round(rate, 0), "pairs_per_s": round(rate / 2, 0)}
+        os.environ["NOPESAC_PNG_NATIVE"] = "0"             # the reference's decoder (PIL) on all cores, for comparison
+        try:
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                t0 = time.perf_counter()
+                list(pool.map(lambda f: data.read_image(f, "BGR"), files))
+                rate = len(files) / (time.perf_counter() - t0)
+            out["pil_all_cores"] = {"threads": cores, "images_per_s": round(rate, 0), "pairs_per_s": round(rate / 2, 0)}
+        finally:
+            os.environ.pop("NOPESAC_PNG_NATIVE", None)
+    out["note"] = ("host-bound: the PNG split feeds one GPU at `one_rank_of_8.pairs_per_s` when all eight ranks of a node share this host - compare with "
+                   "`value` (the model's rate per GPU)")
+    return out
 
 
 def fp32_path_throughput(m32, raw, forced, B, steps=4):

@@ -688,6 +688,17 @@ long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long 
 int nopesac_posenet_branch_tail_bf16(const void* x_trans, const void* x_rots, const void* const* w10, const float* const* scale10,
                                      const float* const* bias10, float* y_trans, float* y_rots, int B, int H, int W, int C, void* stream);
 
+/* ---- host-side PNG decode for the data mapper (csrc/png_host.hip; no kernel) ---------------------------------------------------------
+ * The mp3d split stores 480 x 640 PNG frames (reference: data/planercnn_transforms.py:210-227 -> detectron2 utils.read_image -> PIL).
+ * PIL decodes PNGs with the interpreter lock held; these entry points are called through ctypes with the lock released, so the reader
+ * threads scale with the host's cores.  nopesac_png_info_host: 0 + geometry (*supported = 1 if the decoder below takes the file), negative
+ * if the bytes are not a PNG.  nopesac_png_decode_host: the file's samples as interleaved RGB (bgr = 0) / BGR (bgr = 1) in out
+ * [H * W * 3], converted like PIL's convert("RGB") (grey replicated, palette looked up, alpha dropped); 0, or -1 not a PNG, -2
+ * unsupported (16-bit / sub-byte / interlaced: the caller falls back to PIL), -3 truncated / corrupt (CRC, inflate, filter type), -4 out
+ * too small, -100 built without zlib. */
+int nopesac_png_info_host(const unsigned char* data, int64_t n, int* height, int* width, int* channels, int* supported);
+int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,8 @@ SIGNATURES = {
     "nopesac_jpeg_prepare_scan": [P, L, I, P, L, P, P, P, L, P],
     "nopesac_jpeg_idct": [P, P, P, I, I, P, P, P],
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
+    "nopesac_png_info_host": [P, L, P, P, P, P],
+    "nopesac_png_decode_host": [P, L, P, L, I],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

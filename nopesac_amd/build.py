@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnopesac_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv_p8.hip", "conv_p8n.hip", "stem.hip", "conv3x3_c64.hip", "conv3x3_halo.hip", "pwchain.hip", "gnn_layer.hip", "enc_tail.hip", "mask_head.hip", "resize.hip", "rle.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
-           "ransac.hip", "mlp_chain.hip", "tape.hip", "posenet_branch.hip", "jpeg.hip"]
+           "ransac.hip", "mlp_chain.hip", "tape.hip", "posenet_branch.hip", "jpeg.hip", "png_host.hip"]
 # -packed-fp32-ops: NO v_pk_{fma,mul,add}_f32 anywhere in the library.  Round-3 finding (scripts/lds_victim.py): a wave
 # executing packed-f32 VALU instructions gets the results of its lanes 48-63 corrupted when a wave of ANOTHER kernel issues MFMAs on the
 # same SIMD - ransac_score_maps_kernel (whose f32 math the SLP vectoriser had packed) returned different scores on identical inputs in
@@ -62,7 +62,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    # (-lz: png_host.hip inflates the mp3d split's PNG frames on the host; without zlib headers that file compiles to a stub)
+    zlib = ["-lz"] if os.path.exists("/usr/include/zlib.h") else []
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, *zlib], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])
     with open(stamp, "w") as f:

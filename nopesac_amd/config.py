@@ -282,9 +282,12 @@ def add_amd_defaults(cfg) -> CfgNode:
         BACKBONE_FP8=False,           # BASELINE config 5: the 3x3 convs of the res3-res5 bottlenecks (44 % of the backbone FLOPs, its
                                       # MFMA-bound layers) on the fp8 (e4m3fn) K = 64 MFMA: per-output-channel weight scales, static
                                       # per-layer activation scales (PlaneTR_NopeSAC.calibrate_fp8); needs COMPUTE_DTYPE bfloat16
-        POSE_FP32_PARTS="",           # bfloat16 mode: stages of the camera head that keep f32 operands, space / comma separated, of
+        POSE_FP32_PARTS="aim",        # bfloat16 mode: stages of the camera head that keep f32 operands, space / comma separated, of
                                       # "decoder branches fc aim refine" (scripts/bf16_attribution.py tables what each one contributes
-                                      # to the bf16 pose error against the fp32 path)
+                                      # to the bf16 pose error against the fp32 path).  Default "aim" (round 5): the two re-embedding
+                                      # MLPs take a 4- / 3-vector - rounding a unit quaternion to bf16 alone is up to 0.45 deg - and
+                                      # cost nothing measurable in f32 (8 tiny launches per step): camera_initRec R 1.70 / 4.13 ->
+                                      # 1.41 / 3.61 deg mean / max on the benchmark workload, same pairs/s (profiles/r5_c_aim_fp32_ab.txt)
     ))
     return cfg
 

@@ -1,0 +1,156 @@
+// Host-side PNG decode for the data mapper (no kernel in this file): the mp3d split - the headline configuration's dataset - stores its
+// frames as 480 x 640 PNG files (reference: data/planercnn_transforms.py:210-227 `call_mp3d` -> detectron2 utils.read_image -> PIL).
+// PIL decodes a PNG with the interpreter lock HELD (measured round 5: 85 images/s with one thread, 92 with eight), so the reader threads
+// of data.LazyPairs could not scale: 45 pairs/s per process against 3800 pairs/s of model.  This decoder is called through ctypes (lock
+// released): chunk walk (PNG spec, ISO/IEC 15948 section 5), zlib inflate of the concatenated IDAT stream, the five row filters of
+// section 9 (None / Sub / Up / Average / Paeth), and the colour conversion PIL's `convert("RGB")` applies to the stored mode (grey ->
+// replicated, palette -> table lookup, alpha dropped).  Lossless format: the result is the file's samples, bit for bit what PIL returns
+// (tests/test_host_cpu.py compares on every supported colour type).  Not handled (-> negative return, the caller falls back to PIL):
+// 16-bit samples, sub-byte depths, Adam7 interlacing.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+#if __has_include(<zlib.h>)
+#include <zlib.h>
+#define NPS_HAVE_ZLIB 1
+#else
+#define NPS_HAVE_ZLIB 0
+#endif
+
+namespace {
+
+inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+
+inline int paeth(int a, int b, int c) {                      // p = a + b - c: |p - a| = |b - c|, |p - b| = |a - c|, |p - c| = |a + b - 2c|
+    const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+    const int bc = pb <= pc ? b : c;
+    return (pa <= pb && pa <= pc) ? a : bc;
+}
+
+// one row, bytes-per-pixel known at compile time (BPP independent dependency chains: the left neighbour is BPP bytes back)
+template <int BPP>
+inline int unfilter_row(unsigned char* row, const unsigned char* up, int64_t stride, int ftype) {
+    switch (ftype) {
+        case 0: return 0;
+        case 1:
+            for (int64_t i = BPP; i < stride; ++i) row[i] = (unsigned char)(row[i] + row[i - BPP]);
+            return 0;
+        case 2:
+            if (up) for (int64_t i = 0; i < stride; ++i) row[i] = (unsigned char)(row[i] + up[i]);
+            return 0;
+        case 3:
+            for (int64_t i = 0; i < BPP && i < stride; ++i) row[i] = (unsigned char)(row[i] + ((up ? up[i] : 0) >> 1));
+            if (up) for (int64_t i = BPP; i < stride; ++i) row[i] = (unsigned char)(row[i] + ((row[i - BPP] + up[i]) >> 1));
+            else for (int64_t i = BPP; i < stride; ++i) row[i] = (unsigned char)(row[i] + (row[i - BPP] >> 1));
+            return 0;
+        case 4:
+            if (!up) {                                           // first row: b = c = 0 -> the predictor is a
+                for (int64_t i = BPP; i < stride; ++i) row[i] = (unsigned char)(row[i] + row[i - BPP]);
+                return 0;
+            }
+            for (int64_t i = 0; i < BPP && i < stride; ++i) row[i] = (unsigned char)(row[i] + up[i]);       // a = c = 0 -> b
+            for (int64_t i = BPP; i < stride; ++i) row[i] = (unsigned char)(row[i] + paeth(row[i - BPP], up[i], up[i - BPP]));
+            return 0;
+        default: return -3;
+    }
+}
+
+}  // namespace
+
+// Geometry of a PNG file without decoding it: 0 and *height / *width / *channels (samples per pixel as stored) / *supported (1 if
+// nopesac_png_decode_host can decode it); negative if the bytes are not a PNG header.
+extern "C" int nopesac_png_info_host(const unsigned char* data, int64_t n, int* height, int* width, int* channels, int* supported) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (!data || n < 33 || memcmp(data, sig, 8) != 0 || be32(data + 8) != 13 || memcmp(data + 12, "IHDR", 4) != 0) return -1;
+    const uint32_t w = be32(data + 16), h = be32(data + 20);
+    const int depth = data[24], ctype = data[25], comp = data[26], filt = data[27], inter = data[28];
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (height) *height = (int)h;
+    if (width) *width = (int)w;
+    if (channels) *channels = ch;
+    if (supported) *supported = (NPS_HAVE_ZLIB && ch && depth == 8 && comp == 0 && filt == 0 && inter == 0 && w > 0 && h > 0 && w < (1u << 15) && h < (1u << 15)) ? 1 : 0;
+    return 0;
+}
+
+// data[n] = the file; out = H * W * 3 bytes, RGB (bgr = 0) or BGR (bgr = 1) interleaved.  Returns 0, or: -1 not a PNG, -2 unsupported
+// variant (16-bit / sub-byte / interlaced), -3 truncated or corrupt (chunk structure, CRC, inflate, filter byte), -4 out too small,
+// -100 the library was built without zlib.  Thread-safe, no global state.
+extern "C" int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr) {
+#if !NPS_HAVE_ZLIB
+    (void)data; (void)n; (void)out; (void)out_bytes; (void)bgr;
+    return -100;
+#else
+    int H = 0, W = 0, ch = 0, ok = 0;
+    if (nopesac_png_info_host(data, n, &H, &W, &ch, &ok) != 0) return -1;
+    if (!ok) return -2;
+    if (!out || out_bytes < (int64_t)H * W * 3) return -4;
+    const int ctype = data[25];
+    unsigned char pal[256 * 3];
+    memset(pal, 0, sizeof(pal));
+    const int64_t stride = (int64_t)W * ch, raw_bytes = (stride + 1) * H;
+    unsigned char* raw = (unsigned char*)malloc((size_t)raw_bytes + 8);
+    if (!raw) return -3;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) { free(raw); return -3; }
+    zs.next_out = raw;
+    zs.avail_out = (uInt)raw_bytes;
+    int rc = 0, zend = 0, have_plte = 0;
+    int64_t p = 8;
+    while (true) {
+        if (p + 12 > n) { rc = -3; break; }
+        const uint32_t L = be32(data + p);
+        const unsigned char* type = data + p + 4;
+        if ((int64_t)L > n - p - 12) { rc = -3; break; }
+        const unsigned char* body = data + p + 8;
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, L + 4) != be32(body + L)) { rc = -3; break; }
+        if (memcmp(type, "IDAT", 4) == 0) {
+            if (!zend && L) {
+                zs.next_in = (Bytef*)body;
+                zs.avail_in = L;
+                const int r = inflate(&zs, Z_NO_FLUSH);
+                if (r == Z_STREAM_END) zend = 1;
+                else if (r != Z_OK && !(r == Z_BUF_ERROR && zs.avail_out == 0)) { rc = -3; break; }
+            }
+        } else if (memcmp(type, "PLTE", 4) == 0) {
+            if (L % 3 != 0 || L > 768) { rc = -3; break; }
+            memcpy(pal, body, L);
+            have_plte = 1;
+        } else if (memcmp(type, "IEND", 4) == 0) {
+            break;
+        }
+        p += 12 + (int64_t)L;
+    }
+    const int64_t got = raw_bytes - (int64_t)zs.avail_out;
+    inflateEnd(&zs);
+    if (rc == 0 && (got != raw_bytes || (ctype == 3 && !have_plte))) rc = -3;
+    if (rc != 0) { free(raw); return rc; }
+    // ---- row filters (in place: a row's reconstructed samples are the next row's "up" samples)
+    for (int y = 0; y < H && rc == 0; ++y) {
+        unsigned char* row = raw + (int64_t)y * (stride + 1) + 1;
+        const unsigned char* up = y ? row - (stride + 1) : nullptr;
+        const int ft = row[-1];
+        rc = ch == 3 ? unfilter_row<3>(row, up, stride, ft) : ch == 4 ? unfilter_row<4>(row, up, stride, ft)
+           : ch == 1 ? unfilter_row<1>(row, up, stride, ft) : unfilter_row<2>(row, up, stride, ft);
+    }
+    if (rc != 0) { free(raw); return rc; }
+    // ---- stored mode -> RGB / BGR (what PIL's convert("RGB") gives: grey replicated, palette looked up, alpha dropped)
+    const int r0 = bgr ? 2 : 0, b0 = bgr ? 0 : 2;
+    for (int y = 0; y < H; ++y) {
+        const unsigned char* row = raw + (int64_t)y * (stride + 1) + 1;
+        unsigned char* o = out + (int64_t)y * W * 3;
+        if (ctype == 2 || ctype == 6) {
+            for (int x = 0; x < W; ++x) { o[3 * x + r0] = row[ch * x]; o[3 * x + 1] = row[ch * x + 1]; o[3 * x + b0] = row[ch * x + 2]; }
+        } else if (ctype == 0 || ctype == 4) {
+            for (int x = 0; x < W; ++x) { const unsigned char v = row[ch * x]; o[3 * x] = v; o[3 * x + 1] = v; o[3 * x + 2] = v; }
+        } else {
+            for (int x = 0; x < W; ++x) { const unsigned char* c = pal + 3 * row[x]; o[3 * x + r0] = c[0]; o[3 * x + 1] = c[1]; o[3 * x + b0] = c[2]; }
+        }
+    }
+    free(raw);
+    return 0;
+#endif
+}

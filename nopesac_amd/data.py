@@ -46,8 +46,36 @@ def load_pairs_json(json_file: str) -> List[dict]:
     return summary["data"]
 
 
+def read_png_native(blob: bytes, fmt: str = "BGR"):
+    """A PNG file's pixels as uint8 [H,W,3] through the library's host decoder (csrc/png_host.hip: zlib inflate + row filters + the
+    mode conversion of PIL's convert("RGB"); called with the interpreter lock RELEASED - PIL holds it while it decodes a PNG, which capped
+    the reader threads at ~90 images/s whatever their number).  None when the file is a variant the decoder leaves to PIL (16-bit,
+    sub-byte, interlaced), is corrupt, or the library is not built."""
+    import ctypes
+    try:
+        from . import _lib
+        L = _lib.load()
+    except (RuntimeError, OSError, AttributeError):
+        return None
+    h, w, ch, ok = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if L.nopesac_png_info_host(blob, len(blob), ctypes.byref(h), ctypes.byref(w), ctypes.byref(ch), ctypes.byref(ok)) != 0 or not ok.value:
+        return None
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = L.nopesac_png_decode_host(blob, len(blob), out.ctypes.data, out.size, 1 if fmt == "BGR" else 0)
+    return out if rc == 0 else None
+
+
 def read_image(path: str, fmt: str = "BGR") -> np.ndarray:
-    """detectron2 `utils.read_image`: uint8 [H,W,3] in `fmt` order (PIL decode, EXIF orientation ignored like d2 v0.4)."""
+    """detectron2 `utils.read_image`: uint8 [H,W,3] in `fmt` order (EXIF orientation ignored like d2 v0.4).  PNG files (the mp3d
+    split) go through `read_png_native` when it takes them (bit-identical pixels: tests/test_host_cpu.py); everything else through PIL."""
+    if fmt not in ("BGR", "RGB"):
+        raise ValueError(f"unsupported INPUT.FORMAT {fmt!r}")
+    if path.lower().endswith(".png") and os.environ.get("NOPESAC_PNG_NATIVE", "1") != "0":
+        with open(path, "rb") as f:
+            blob = f.read()
+        arr = read_png_native(blob, fmt)
+        if arr is not None:
+            return arr
     from PIL import Image
     with Image.open(path) as im:
         arr = np.asarray(im.convert("RGB"))

@@ -143,13 +143,14 @@ def test_bench_configuration_bf16_forced_k32_b32(device):
     assert err["m_bf16"] == [K] * B and err["m_fp32"] == [K] * B
     assert err["finite"] and err["max_quat_norm_dev"] < 1e-3
     cam, ini, rec = err["camera"], err["camera_init"], err["camera_initRec"]
-    # bounds = 1.5 x the maxima measured on MI355X in round 4 with the normalisation folded into the stem (exact bf16 input operand):
-    # camera R 0.44-0.47 deg / T 0.069-0.087 at |t| = 11.1; camera_init R 1.65-2.24 deg / T 0.0066; camera_initRec R 4.1-4.7 deg (routed
-    # kernels of the bench line / the library's heuristics of this test; round 3: 0.62 / 3.6 / 7.1 deg).  Where the error comes from:
-    # profiles/r3_a_bf16_attribution.json, profiles/r4_bf16_attribution_stem.json (the stem's operand rounding carried the maxima).
-    assert cam["R_err_deg_max"] < 0.71 and cam["T_err_max"] < 0.0117 * cam["mean_abs_t"], cam
-    assert ini["R_err_deg_max"] < 3.4 and ini["T_err_max"] < 0.0105, ini
-    assert rec["R_err_deg_max"] < 7.1, rec
+    # FIXED bounds (round 5; rounds 2-4 used 1.5 x whatever had been measured): refined camera R <= 1 deg, pixel pose R <= 2.5 deg,
+    # its re-embedding R <= 4.5 deg.  Measured on MI355X with the AIM on f32 operands (MODEL.AMD.POSE_FP32_PARTS default "aim"):
+    # camera 0.43 / camera_init 2.03 / camera_initRec 3.61 deg max (profiles/r5_c_aim_fp32_ab.txt).  The re-embedding cannot be held to
+    # 3 deg by its own precision: with f32 operands it still maps the pixel pose's 0.80 deg mean / 2.03 max error to 1.41 / 3.61 - the
+    # AIM of the synthetic checkpoint amplifies an input perturbation 1.8x whatever arithmetic evaluates it.
+    assert cam["R_err_deg_max"] < 1.0 and cam["T_err_max"] < 0.0117 * cam["mean_abs_t"], cam
+    assert ini["R_err_deg_max"] < 2.5 and ini["T_err_max"] < 0.0105, ini
+    assert rec["R_err_deg_max"] < 4.5, rec
 
 
 def test_e2e_scannet_config_nq64(device):

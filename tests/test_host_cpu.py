@@ -293,3 +293,46 @@ def test_training_twin_argument_checks_without_a_gpu():
     assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 16 + 4, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()
     assert lib.nopesac_ransac_soft_vote(*([None] * 21), 1, 50, 32, *([None] * 6), None) != 0 and "ransac_soft_vote" in err()
     assert lib.nopesac_camera_pose_loss(None, None, None, 7, None, 7, 4, 0.0, 1.0, None, None) != 0 and "camera_pose_loss" in err()
+
+
+def test_png_host_decoder_matches_pillow(tmp_path):
+    """csrc/png_host.hip (the mp3d split's frames; called with the interpreter lock released) against PIL - the reference's decoder
+    (planercnn_transforms.py:210-227 -> utils.read_image) - on every colour type it takes, both channel orders, Pillow's default and
+    `optimize` encodings (other filter / zlib choices), a multi-IDAT file; variants it leaves to PIL (16-bit, interlaced-free check via
+    the header, sub-byte palette) and damaged files must return None, and data.read_image must give PIL's pixels either way."""
+    import numpy as np
+    from PIL import Image
+    from nopesac_amd import data
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:97, 0:131].astype(np.float32)
+    a = np.clip(np.stack([128 + 90 * np.sin(xx / 9 + yy / 14), 128 + 70 * np.cos(yy / 7) * np.sin(xx / 20), 120 + 100 * ((xx // 16 + yy // 12) % 2)], -1)
+                + rng.normal(0, 4.0, (97, 131, 3)), 0, 255).astype(np.uint8)
+    modes = {"RGB": Image.fromarray(a), "RGBA": Image.fromarray(np.concatenate([a, a[..., :1]], -1), "RGBA"), "L": Image.fromarray(a[..., 0]),
+             "LA": Image.fromarray(np.ascontiguousarray(a[..., :2]), "LA"), "P": Image.fromarray(a).quantize(200)}
+    for m, im in modes.items():
+        for opt in (False, True):
+            p = tmp_path / f"{m}_{opt}.png"
+            im.save(p, optimize=opt)
+            ref = np.asarray(Image.open(p).convert("RGB"))
+            blob = p.read_bytes()
+            for fmt in ("RGB", "BGR"):
+                got = data.read_png_native(blob, fmt)
+                assert got is not None and np.array_equal(got, ref if fmt == "RGB" else ref[..., ::-1]), (m, opt, fmt)
+            assert np.array_equal(data.read_image(str(p), "BGR"), ref[..., ::-1])
+    big = np.clip(rng.normal(128, 60, (300, 400, 3)), 0, 255).astype(np.uint8)          # incompressible: Pillow splits it into many IDAT chunks
+    p = tmp_path / "noise.png"
+    Image.fromarray(big).save(p)
+    assert p.read_bytes().count(b"IDAT") > 1 and np.array_equal(data.read_png_native(p.read_bytes(), "RGB"), big)
+    # left to PIL: 16-bit samples, 1-bit palette; damaged: a flipped byte inside the compressed data (CRC), a truncated file
+    p16 = tmp_path / "g16.png"
+    Image.fromarray((a[..., 0].astype(np.uint16) * 257)).save(p16)
+    assert data.read_png_native(p16.read_bytes(), "RGB") is None
+    p1 = tmp_path / "bw.png"
+    Image.fromarray(a[..., 0] > 128).save(p1)
+    assert data.read_png_native(p1.read_bytes(), "RGB") is None
+    assert np.array_equal(data.read_image(str(p1), "RGB"), np.asarray(Image.open(p1).convert("RGB")))
+    blob = bytearray((tmp_path / "RGB_False.png").read_bytes())
+    blob[len(blob) // 2] ^= 0x55
+    assert data.read_png_native(bytes(blob), "RGB") is None
+    assert data.read_png_native((tmp_path / "RGB_False.png").read_bytes()[:-40], "RGB") is None
+    assert data.read_png_native(b"not a png at all, but long enough to hold a header....", "RGB") is None
