@@ -273,6 +273,10 @@ def add_amd_defaults(cfg) -> CfgNode:
         TWO_STREAMS=True,             # pixel pose net on a side HIP stream, overlapped with the plane head
         CHECK_FINITE=True,            # count Inf / NaN in the returned poses / plane parameters on the device; `model(...)` raises
                                       # FloatingPointError when the results are fetched (the reference drops into pdb instead)
+        CPU_AFFINITY=True,            # runner with more than one rank on a host: pin rank r to the r-th of WORLD_SIZE equal shares of the
+                                      # cores this process may use (contiguous ids - on the usual two-socket node the GPUs 0-3 / 4-7 and
+                                      # the low / high core ids share a socket) and size the decode-thread pool to that share; without it
+                                      # eight ranks each start min(32, cores) decoder threads on the same cores.  Unmeasured on hardware
         AUTOTUNE=True,                # runner (nopesac_amd/run.py), bfloat16 mode: before the first batch, time the library's equivalent
                                       # kernel configurations for every conv / GEMM shape of a (pairs-per-batch, 480, 640) forward and
                                       # keep the fastest (PlaneTR_NopeSAC.autotune: a few seconds; +10-15 % throughput, same results up

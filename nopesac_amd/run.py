@@ -53,6 +53,9 @@ def default_argument_parser():
     ap.add_argument("--eval-matchings", action="store_true", help="plane-matching precision / recall / F-score (mp3d_evaluation.py:746-849): "
                     "needs pairs with `gt_corrs` and RLE `annotations` (the dataset json's own fields)")
     ap.add_argument("--dump-dir", default="", help="write NopeSAC_instances_predictions.pth + continuous.pkl here (eval_full_scene)")
+    ap.add_argument("--stub-model", action="store_true", help="TEST ONLY (results are marked invalid): the CLI's sharding, batch loop, evaluator "
+                    "gather and dumps around a stub that fabricates result dicts instead of running the model - what the gloo CPU tests drive at "
+                    "world sizes no box offers")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides")
     return ap
 
@@ -92,7 +95,11 @@ def load_pairs(args, cfg=None):
     n = args.synthetic_pairs or 8
     pairs = []
     for i in range(n):
-        p = synth_pair(i, structured=args.structured)
+        if args.stub_model:      # no pixels needed: tiny images, a ground-truth pose so that the evaluator's error tables are exercised
+            p = synth_pair(i, 8, 8)
+            p["rel_pose"] = {"position": [float(i), 0.5, -0.25], "rotation": [1.0, 0.0, 0.0, 0.0]}
+        else:
+            p = synth_pair(i, structured=args.structured)
         pairs.append(p)
     return pairs
 
@@ -182,6 +189,34 @@ def inference_on_dataset(model, pairs, evaluator, pairs_per_batch: int, keep_out
     return {"pairs": n_done, "total_s": total, "compute_s": t_compute, "s_per_pair": t_compute / max(n_done, 1), "batches_in_flight": depth}
 
 
+class _StubModel(torch.nn.Module):
+    """--stub-model: result dicts of the reference's shape, fabricated from the inputs (pose = ground truth + an offset that depends on
+    the pair's image ids, so that every rank's rows are distinguishable after the gather).  No kernel runs."""
+
+    def __init__(self):
+        super().__init__()
+        self.anchor = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.infer_iter = 0
+
+    def forward(self, batch):
+        import numpy as np
+        import zlib
+        out = []
+        for inp in batch:
+            gt = inp.get("rel_pose") or {"position": [0.0, 0.0, 0.0], "rotation": [1.0, 0.0, 0.0, 0.0]}
+            h = zlib.crc32((str(inp["0"].get("image_id")) + "|" + str(inp["1"].get("image_id"))).encode()) % 1000
+            t = np.asarray(gt["position"], np.float32) + np.float32(1e-3 * h)
+            q = np.asarray(gt["rotation"], np.float32)
+            cam = {"tran": t, "rot": q}
+            res = {v: {"image_id": inp[v].get("image_id"), "file_name": inp[v].get("file_name"), "instances": [],
+                       "pred_plane": torch.zeros(1 + h % 3, 3)} for v in "01"}
+            res.update({k: dict(cam) for k in ("camera", "camera_init", "camera_initRec", "camera_avgRef0", "camera_softRef0")})
+            res.update(pred_aff=None, depth={"0": None, "1": None}, matched_num=float(h % 7),
+                       pred_assignment=torch.zeros(1, 1 + h % 3, 1 + h % 3))
+            out.append(res)
+        return out
+
+
 def tune_kernels(model, cfg, pairs_per_batch: int, rank: int = 0) -> int:
     """MODEL.AMD.AUTOTUNE / ROUTING_FILE: load-time kernel selection for the shapes of a `pairs_per_batch` forward (bfloat16 mode on a
     GPU only; the fp32 parity path keeps the built-in heuristic).  Returns the number of shapes measured now."""
@@ -224,9 +259,20 @@ def _main_rank(args):
     cfg = setup(args)
     if cfg.MODEL.DEVICE == "cuda" and torch.cuda.is_available():
         torch.cuda.set_device(local)
-    model = build_model(cfg)
-    src = load_checkpoint(model, cfg, args.synthetic_weights)
-    tune_kernels(model, cfg, args.pairs_per_batch, rank)
+    # one rank's share of the host: cores (MODEL.AMD.CPU_AFFINITY) and, from them, the decode-thread budget - eight ranks that each
+    # start min(32, cores) decoder threads would oversubscribe the host eightfold
+    from .config import amd_options
+    ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    my_cores = runner.pin_rank_to_cores(local, ranks_here) if (world > 1 and amd_options(cfg).CPU_AFFINITY) else None
+    n_cores = len(my_cores) if my_cores is not None else max(1, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)) // max(1, ranks_here))
+    if not args.decode_workers:
+        args.decode_workers = max(1, min(32, n_cores - (1 if n_cores > 2 else 0)))      # (one core stays with the thread that launches kernels)
+    if args.stub_model:
+        model, src = _StubModel(), "stub (no model: fabricated results)"
+    else:
+        model = build_model(cfg)
+        src = load_checkpoint(model, cfg, args.synthetic_weights)
+        tune_kernels(model, cfg, args.pairs_per_batch, rank)
     import gc
     gc.collect()
     gc.freeze()          # model, packed weights and caches leave the cyclic GC's generations: a gen-2 pass over them cost 30-50 ms every few batches
@@ -254,7 +300,10 @@ def _main_rank(args):
                 logger.info("Plane metrics (%s):\n%s", k, create_small_table({kk: float(vv) for kk, vv in v.items()}))
         elif rank == 0:
             logger.warning("--eval-matchings: no pair carries gt_corrs / annotations; nothing to evaluate")
+    timing.update(decode_threads=args.decode_workers, cores_of_this_rank=n_cores, pinned=my_cores is not None)
     results["timing(rank0)"] = timing
+    if args.stub_model:
+        results["INVALID_stub_model"] = True
     if args.dump_dir:            # eval_full_scene dumps (mp3d_evaluation.py:330-341)
         files = dump_predictions(evaluator._predictions, args.dump_dir)
         if rank == 0:

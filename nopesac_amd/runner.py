@@ -67,6 +67,24 @@ def launch(main_func, num_gpus_per_machine: int, args=()):
     return None
 
 
+def pin_rank_to_cores(local_rank: int, ranks_on_host: int) -> List[int]:
+    """Restrict this process (and the threads it starts later) to the local_rank-th of `ranks_on_host` equal, contiguous shares of
+    the cores it is allowed to use; returns the cores it now owns (unchanged set when the share would be empty or the platform has no
+    sched_setaffinity).  MODEL.AMD.CPU_AFFINITY."""
+    if not hasattr(os, "sched_setaffinity") or ranks_on_host <= 1:
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // ranks_on_host
+    if per < 1:
+        return cores
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return cores
+    return mine
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of rank `rank` (InferenceSampler semantics: ceil(N/W) per rank)."""
     per = int(math.ceil(n_items / world))

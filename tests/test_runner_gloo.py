@@ -246,3 +246,37 @@ def test_bench_gpus8_global_batch_256_stub():
     assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8 and j["config"]["global_batch"] == 256
     assert j["rows_gathered"] == 256 and j["rows_in_rank_order"]
     assert j["steps_per_all_gather"] == 8 and j["collectives_in_run"] == 2          # warm-up flush (2 steps) + the timed region's 6 steps
+
+
+def _run_cli(argv, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, "-m", "nopesac_amd.run"] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_cli_world8_stub_matches_single_rank(tmp_path):
+    """`python -m nopesac_amd.run --num-gpus 8` itself (not bench.py) at the world size of BASELINE configs[3], on CPU over gloo with the
+    stub model: its own launcher, the contiguous shards (19 pairs over 8 ranks: 3 each, one rank with a single pair, one with NONE),
+    the batch loop, the evaluator's padded all_gather and rank 0's summary must give exactly the single-rank run's tables; every rank
+    is pinned to its share of the cores and sizes its decode pool from it (MODEL.AMD.CPU_AFFINITY).  Unmeasured on hardware."""
+    import json
+    common = ["--stub-model", "--synthetic-pairs", "19", "--pairs-per-batch", "2", "MODEL.DEVICE", "cpu"]
+    r8 = _run_cli(["--num-gpus", "8", "--output", str(tmp_path / "w8.json")] + common)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    r1 = _run_cli(["--num-gpus", "1", "--output", str(tmp_path / "w1.json")] + common)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a, b = json.load(open(tmp_path / "w8.json")), json.load(open(tmp_path / "w1.json"))
+    assert a["INVALID_stub_model"] and a["pairs"]["count"] == 19 == b["pairs"]["count"]
+    for k in ("pairs", "camera", "camera_init", "camera_initRec", "camera_avgRef0", "camera_softRef0"):
+        assert a[k].keys() == b[k].keys()
+        for kk in a[k]:
+            assert abs(a[k][kk] - b[k][kk]) < 1e-5, (k, kk, a[k][kk], b[k][kk])
+    t = a["timing(rank0)"]
+    assert t["pairs"] == 3 and t["pinned"] and t["decode_threads"] >= 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if cores >= 8:
+        assert t["cores_of_this_rank"] == cores // 8
+    assert not b["timing(rank0)"]["pinned"]
