@@ -688,6 +688,49 @@ long long nopesac_rle_compress_batch_host(const uint32_t* positions, const long 
 int nopesac_posenet_branch_tail_bf16(const void* x_trans, const void* x_rots, const void* const* w10, const float* const* scale10,
                                      const float* const* bias10, float* y_trans, float* y_rots, int B, int H, int W, int C, void* stream);
 
+/* ---- backward kernels of the camera head's training-side twin (csrc/refine_bwd.hip) ----------------------------
+ * Vector-Jacobian products of nopesac_plane_cam_ref_losses, nopesac_ransac_soft_vote (mode | 16) and nopesac_ransac_score_maps - the
+ * forward of the reference's __forward_PlaneCamRefHead (camera_net/camera_head.py:737-923; CameraPoseLoss camera_modules.py:355-365).
+ * All f32, [B, ...] layouts exactly as the forward kernels'; no atomics: parameter gradients of the vote kernel are written PER PAIR
+ * (pb_* = [B, size of the parameter]) and summed over the pairs by nopesac_col_sum_f32.  The Linear / MLP stacks in between are
+ * differentiated with nopesac_conv2d_nhwc (f32): dX = dY W, dW = dY^T X, plus the helpers below (nopesac_amd/training.py).
+ *  losses_backward:     g_loss [7] (d total / d each loss of nopesac_plane_cam_ref_losses) -> gradients of the four poses ([B,4] / [B,3],
+ *                       with respect to the NORMALISED quaternions the vote kernel returns), of the scores [B,nq+1] (the hypothesis the
+ *                       index losses pick is a constant, as in autograd) and of l2_dist [B,nq+1,nq] (its diagonal entries).
+ *  vote_backward:       -> gradients of the score features [B,nq+1,64] x 2, the initial pose features [B,256] x 2, the per-plane features
+ *                       [B,nq,256] x 2 and, per pair, of rots / trans weights + biases and of the two score regressors.
+ *  score_maps_backward: gradients of normal_score / param_score / l2_dist [B,nq+1,nq] -> rot_raw [B,nq,4] (through its normalisation),
+ *                       trans_raw [B,nq,3], init_rot [B,4], init_trans [B,3]. */
+int nopesac_refine_losses_backward(const float* pred_rot, const float* pred_trans, const float* avg_rot, const float* avg_trans,
+                                   const float* rots_all, const float* trans_all, const float* score_rot, const float* score_trans,
+                                   const int32_t* m, const float* gt_pose, const float* g_loss, int B, int nq, float weight,
+                                   float* g_pred_rot, float* g_pred_trans, float* g_avg_rot, float* g_avg_trans, float* g_score_rot,
+                                   float* g_score_trans, float* g_l2_dist, void* stream);
+int nopesac_refine_vote_backward(const float* sf_rot, const float* sf_trans, const float* reg_rot_w, const float* reg_rot_b,
+                                 const float* reg_trans_w, const float* reg_trans_b, const float* init_rot_feat,
+                                 const float* init_trans_feat, const float* fused_rot, const float* fused_trans, const float* rots_w,
+                                 const float* rots_b, const float* trans_w, const float* trans_b, const int32_t* m, int B, int nq,
+                                 const float* g_pred_rot, const float* g_pred_trans, const float* g_avg_rot, const float* g_avg_trans,
+                                 const float* g_score_rot, const float* g_score_trans, float* g_sf_rot, float* g_sf_trans,
+                                 float* g_init_rot_feat, float* g_init_trans_feat, float* g_fused_rot, float* g_fused_trans,
+                                 float* pb_rots_w, float* pb_rots_b, float* pb_trans_w, float* pb_trans_b, float* pb_reg_rot_w,
+                                 float* pb_reg_rot_b, float* pb_reg_trans_w, float* pb_reg_trans_b, void* stream);
+int nopesac_refine_score_maps_backward(const float* geo_local, const float* rot_raw, const float* trans_raw, const float* init_rot,
+                                       const float* init_trans, const int32_t* m, int B, int nq, const float* g_normal_score,
+                                       const float* g_param_score, const float* g_l2_dist, float* g_rot_raw, float* g_trans_raw,
+                                       float* g_init_rot, float* g_init_trans, void* stream);
+/* helpers of the Linear backward and the optimiser (f32): y [cols,rows] = x^T (x rows strided by x_ld); out [cols] = column sums (fixed
+ * summation order); out = y > 0 ? g : 0; J^T g of row-wise x / max(|x|, 1e-12) (D <= 4); torch.optim.AdamW / SGD(momentum) updates of one
+ * tensor (train_NopeSAC.py:150-157). */
+int nopesac_transpose_f32(const float* x, int rows, int cols, int64_t x_ld, float* y, void* stream);
+int nopesac_col_sum_f32(const float* x, int rows, int cols, int64_t x_ld, float* out, void* stream);
+int nopesac_relu_backward_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
+int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, float* out, void* stream);
+int nopesac_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, void* stream);
+int nopesac_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                     int first_step, void* stream);
+
 /* ---- host-side PNG decode for the data mapper (csrc/png_host.hip; no kernel) ---------------------------------------------------------
  * The mp3d split stores 480 x 640 PNG frames (reference: data/planercnn_transforms.py:210-227 -> detectron2 utils.read_image -> PIL).
  * PIL decodes PNGs with the interpreter lock held; these entry points are called through ctypes with the lock released, so the reader

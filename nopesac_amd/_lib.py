@@ -98,6 +98,15 @@ SIGNATURES = {
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_png_info_host": [P, L, P, P, P, P],
     "nopesac_png_decode_host": [P, L, P, L, I],
+    "nopesac_refine_losses_backward": [P] * 11 + [I, I, F] + [P] * 7 + [P],
+    "nopesac_refine_vote_backward": [P] * 15 + [I, I] + [P] * 20 + [P],
+    "nopesac_refine_score_maps_backward": [P] * 6 + [I, I] + [P] * 7 + [P],
+    "nopesac_transpose_f32": [P, I, I, L, P, P],
+    "nopesac_col_sum_f32": [P, I, I, L, P, P],
+    "nopesac_relu_backward_f32": [P, P, L, P, P],
+    "nopesac_normalize_rows_backward": [P, P, I, I, P, P],
+    "nopesac_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P],
+    "nopesac_sgd_step": [P, P, P, L, F, F, F, I, P],
     "nopesac_mlp_padded_k": [I, I],
     "nopesac_mlp_packed_elems": [I, I],
     "nopesac_mlp_chain_bf16": [P, P],

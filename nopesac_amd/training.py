@@ -1,0 +1,303 @@
+"""Training step of the camera head's refinement stage on MI355X (reference: `__forward_PlaneCamRefHead`,
+camera_net/camera_head.py:737-923; losses camera_modules.py:355-365; optimiser groups train_NopeSAC.py:88-169) - round 5.
+
+Forward = the kernels of the training-side twin (ops.geo_sequence, ops.ransac_score_maps, ops.ransac_soft_vote mode | 16,
+ops.plane_cam_ref_losses) with the MLP stacks as one f32 GEMM launch per layer (every layer output is kept for the backward pass);
+backward = the hand-written vector-Jacobian kernels of csrc/refine_bwd.hip (losses, scoring + aggregation + pose heads, hypothesis x
+plane geometry) and, for every Linear layer, dgrad = dY W and wgrad = dY^T X on the library's f32 GEMM kernel + column sums for the
+bias + the ReLU mask.  `torch.autograd.Function` only does the bookkeeping (which gradient goes where); concatenations and the
+broadcast of the initial-pose features are torch views / a [B, nq, 256] sum.  Everything is f32 and deterministic.
+
+What this is NOT: a trainer for the whole network.  The backbone, the plane head, the matcher and the pixel pose net have no backward
+kernels here - their outputs (the initial pose, its 256-d features, the plane sets and the assignment) are inputs of this stage, as they
+are of the reference function, and receive no gradient beyond `input_grads`.  Gated against torch.autograd on the oracle
+(tests/test_training_gpu.py)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+
+PREFIX = "camera_head_list.0."
+MLPS = ("geo_encoder", "geo_proj_s1", "decoder_rot", "geo_proj_s2", "decoder_tran", "decoder_rot2", "decoder_tran2", "normal_score_proj",
+        "param_score_proj")
+LINEARS = ("rots", "trans", "rot_score_reg", "trans_score_reg")
+
+
+def _L():
+    return _lib.load()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """[rows, cols] f32 (rows may be strided) -> contiguous [cols, rows]."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    y = torch.empty(x.shape[1], x.shape[0], device=x.device, dtype=torch.float32)
+    _lib.check(_L().nopesac_transpose_f32(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(y), _st()), "nopesac_transpose_f32")
+    return y
+
+
+def col_sum(x: torch.Tensor) -> torch.Tensor:
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    _lib.check(_L().nopesac_col_sum_f32(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _st()), "nopesac_col_sum_f32")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) on the exact-f32 GEMM kernel; backward: dX = dY W, dW = dY^T X (the same kernel), db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu: bool):
+        x = x.contiguous()
+        y = ops.linear(x, w, b, act=ops.ACT_RELU if relu else ops.ACT_NONE)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            gm = torch.empty_like(g)
+            _lib.check(_L().nopesac_relu_backward_f32(_p(g), _p(y), g.numel(), _p(gm), _st()), "nopesac_relu_backward_f32")
+            g = gm
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear(g, transpose(w))                      # [rows, N] x [N, K]
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear(transpose(g), transpose(x))           # [N, rows] x [rows, K]
+        if ctx.needs_input_grad[2]:
+            gb = col_sum(g)
+        return gx, gw, gb, None
+
+
+class _ScoreMaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geo_local, rot_raw, trans_raw, init_rot, init_trans, m):
+        out = ops.ransac_score_maps(geo_local, rot_raw.contiguous(), trans_raw.contiguous(), init_rot, init_trans, m, diagnostics=True)
+        ctx.save_for_backward(geo_local, rot_raw, trans_raw, init_rot, init_trans, m)
+        # (rots_all / trans_all only pick the hypothesis of the index losses; the row sums feed the inference-only 'min-cost' mode)
+        ctx.mark_non_differentiable(out["rots_all"], out["trans_all"], out["dn_sum"], out["dl2_sum"])
+        return out["normal_score"], out["param_score"], out["l2_dist"], out["rots_all"], out["trans_all"], out["dn_sum"], out["dl2_sum"]
+
+    @staticmethod
+    def backward(ctx, g_ns, g_ps, g_l2, _a, _b, _c, _d):
+        geo_local, rot_raw, trans_raw, init_rot, init_trans, m = ctx.saved_tensors
+        B, nq, _ = geo_local.shape
+        z = lambda t, ref: torch.zeros_like(ref) if t is None else t.contiguous()
+        ref = torch.empty(B, nq + 1, nq, device=geo_local.device, dtype=torch.float32)
+        g_ns, g_ps, g_l2 = (z(t, ref) for t in (g_ns, g_ps, g_l2))
+        g_rot, g_tr = torch.empty_like(rot_raw), torch.empty_like(trans_raw)
+        g_ir, g_it = torch.empty_like(init_rot), torch.empty_like(init_trans)
+        rc = _L().nopesac_refine_score_maps_backward(_p(geo_local), _p(rot_raw.contiguous()), _p(trans_raw.contiguous()), _p(init_rot), _p(init_trans),
+                                                     _p(m), B, nq, _p(g_ns), _p(g_ps), _p(g_l2), _p(g_rot), _p(g_tr), _p(g_ir), _p(g_it), _st())
+        _lib.check(rc, "nopesac_refine_score_maps_backward")
+        return None, g_rot, g_tr, g_ir, g_it, None
+
+
+class _Vote(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot, fused_trans,
+                rots_w, rots_b, trans_w, trans_b, rots_all, trans_all, dn_sum, dl2_sum, init_rot, init_trans, m):
+        args = [t.contiguous() for t in (sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot,
+                                         fused_trans, rots_w, rots_b, trans_w, trans_b)]
+        maps = {"rots_all": rots_all, "trans_all": trans_all, "dn_sum": dn_sum, "dl2_sum": dl2_sum}
+        out = ops.ransac_soft_vote(*args, maps, init_rot, init_trans, m, 16)
+        ctx.save_for_backward(*args, m)
+        return out["pred_rot"], out["pred_trans"], out["avg_rot"], out["avg_trans"], out["score_rot"], out["score_trans"]
+
+    @staticmethod
+    def backward(ctx, g_pr, g_pt, g_ar, g_at, g_sr, g_st):
+        (sf_rot, sf_trans, reg_rot_w, reg_rot_b, reg_trans_w, reg_trans_b, init_rot_feat, init_trans_feat, fused_rot, fused_trans, rots_w, rots_b,
+         trans_w, trans_b, m) = ctx.saved_tensors
+        B, NH, _ = sf_rot.shape
+        nq = NH - 1
+        dev = sf_rot.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        zl = lambda t, shape: torch.zeros(shape, **f32) if t is None else t.contiguous()
+        g_pr, g_ar = zl(g_pr, (B, 4)), zl(g_ar, (B, 4))
+        g_pt, g_at = zl(g_pt, (B, 3)), zl(g_at, (B, 3))
+        g_sr, g_st = zl(g_sr, (B, NH)), zl(g_st, (B, NH))
+        o = {"g_sf_rot": torch.empty_like(sf_rot), "g_sf_trans": torch.empty_like(sf_trans), "g_irf": torch.empty_like(init_rot_feat),
+             "g_itf": torch.empty_like(init_trans_feat), "g_fr": torch.empty_like(fused_rot), "g_ft": torch.empty_like(fused_trans),
+             "pb_rw": torch.empty(B, 4 * 256, **f32), "pb_rb": torch.empty(B, 4, **f32), "pb_tw": torch.empty(B, 3 * 256, **f32),
+             "pb_tb": torch.empty(B, 3, **f32), "pb_rrw": torch.empty(B, 64, **f32), "pb_rrb": torch.empty(B, 1, **f32),
+             "pb_rtw": torch.empty(B, 64, **f32), "pb_rtb": torch.empty(B, 1, **f32)}
+        rc = _L().nopesac_refine_vote_backward(
+            _p(sf_rot), _p(sf_trans), _p(reg_rot_w), _p(reg_rot_b), _p(reg_trans_w), _p(reg_trans_b), _p(init_rot_feat), _p(init_trans_feat), _p(fused_rot),
+            _p(fused_trans), _p(rots_w), _p(rots_b), _p(trans_w), _p(trans_b), _p(m), B, nq, _p(g_pr), _p(g_pt), _p(g_ar), _p(g_at), _p(g_sr), _p(g_st),
+            _p(o["g_sf_rot"]), _p(o["g_sf_trans"]), _p(o["g_irf"]), _p(o["g_itf"]), _p(o["g_fr"]), _p(o["g_ft"]), _p(o["pb_rw"]), _p(o["pb_rb"]),
+            _p(o["pb_tw"]), _p(o["pb_tb"]), _p(o["pb_rrw"]), _p(o["pb_rrb"]), _p(o["pb_rtw"]), _p(o["pb_rtb"]), _st())
+        _lib.check(rc, "nopesac_refine_vote_backward")
+        red = lambda t, like: col_sum(t).view_as(like)              # per-pair partials -> the parameter's gradient (fixed order)
+        return (o["g_sf_rot"], o["g_sf_trans"], red(o["pb_rrw"], reg_rot_w), red(o["pb_rrb"], reg_rot_b), red(o["pb_rtw"], reg_trans_w),
+                red(o["pb_rtb"], reg_trans_b), o["g_irf"], o["g_itf"], o["g_fr"], o["g_ft"], red(o["pb_rw"], rots_w), red(o["pb_rb"], rots_b),
+                red(o["pb_tw"], trans_w), red(o["pb_tb"], trans_b), None, None, None, None, None, None, None)
+
+
+class _Losses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_rot, pred_trans, avg_rot, avg_trans, score_rot, score_trans, l2_dist, rots_all, trans_all, m, gt_pose, weight: float):
+        vote = {"pred_rot": pred_rot.contiguous(), "pred_trans": pred_trans.contiguous(), "avg_rot": avg_rot.contiguous(), "avg_trans": avg_trans.contiguous(),
+                "score_rot": score_rot.contiguous(), "score_trans": score_trans.contiguous()}
+        maps = {"rots_all": rots_all, "trans_all": trans_all, "l2_dist": l2_dist.contiguous()}
+        ctx.weight = float(weight)
+        ctx.save_for_backward(vote["pred_rot"], vote["pred_trans"], vote["avg_rot"], vote["avg_trans"], vote["score_rot"], vote["score_trans"], rots_all,
+                              trans_all, m, gt_pose)
+        ctx.l2_shape = tuple(l2_dist.shape)
+        return ops.plane_cam_ref_losses(vote, maps, m, gt_pose, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        pr, pt, ar, at, sr, st, rots_all, trans_all, m, gt = ctx.saved_tensors
+        B, NH = sr.shape
+        dev = sr.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        o = [torch.empty(B, 4, **f32), torch.empty(B, 3, **f32), torch.empty(B, 4, **f32), torch.empty(B, 3, **f32), torch.empty(B, NH, **f32),
+             torch.empty(B, NH, **f32), torch.empty(ctx.l2_shape, **f32)]
+        rc = _L().nopesac_refine_losses_backward(_p(pr), _p(pt), _p(ar), _p(at), _p(rots_all), _p(trans_all), _p(sr), _p(st), _p(m), _p(gt),
+                                                 _p(g.contiguous()), B, NH - 1, ctx.weight, *[_p(t) for t in o], _st())
+        _lib.check(rc, "nopesac_refine_losses_backward")
+        return o[0], o[1], o[2], o[3], o[4], o[5], o[6], None, None, None, None, None
+
+
+class RefineTrainer:
+    """The refinement head's parameters as f32 leaf tensors + forward / backward / optimiser step.
+
+        tr = RefineTrainer.from_state_dict(sd, nq, device)             # or .from_head(model.camera_head_list[0])
+        losses = tr.losses(A, planes1, planes2, n1, n2, init_trans, init_rot, init_trans_feat, init_rot_feat, gt_pose, suffix, weight)
+        grads = tr.backward(losses)                                     # {state-dict key: gradient}; tr.input_grads for the feature inputs
+        tr.step(lr=1e-4)                                                # AdamW (train_NopeSAC.py:150-153) on the device
+        tr.write_back(head)                                             # into the inference model's packed weights
+    """
+
+    def __init__(self, params: Dict[str, torch.Tensor], nq: int, warp_in_ref: bool = True):
+        self.nq, self.warp_in_ref = int(nq), bool(warp_in_ref)
+        self.params = {k: v.detach().clone().float().contiguous().requires_grad_(True) for k, v in params.items()}
+        self.state: Dict[str, dict] = {}
+        self.steps = 0
+        self.input_grads: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def parameter_names(sd_keys) -> List[str]:
+        out = []
+        for k in sd_keys:
+            if not k.startswith(PREFIX):
+                continue
+            r = k[len(PREFIX):]
+            if r.split(".")[0] in MLPS + LINEARS:
+                out.append(k)
+        return sorted(out)
+
+    @classmethod
+    def from_state_dict(cls, sd: dict, nq: int, device, warp_in_ref: bool = True) -> "RefineTrainer":
+        return cls({k: sd[k].to(device) for k in cls.parameter_names(sd.keys())}, nq, warp_in_ref)
+
+    @classmethod
+    def from_head(cls, head) -> "RefineTrainer":
+        names = cls.parameter_names(PREFIX + k for k in head.spec)
+        return cls({k: head.raw(k[len(PREFIX):]) for k in names}, head.num_queries, head.warp_plane_in_cam_ref_on)
+
+    # ---- forward
+    def _mlp(self, x, name: str, final_relu: bool = False):
+        i = 0
+        while f"{PREFIX}{name}.layers.{i + 1}.weight" in self.params:
+            x = _Linear.apply(x, self.params[f"{PREFIX}{name}.layers.{i}.weight"], self.params[f"{PREFIX}{name}.layers.{i}.bias"], True)
+            i += 1
+        return _Linear.apply(x, self.params[f"{PREFIX}{name}.layers.{i}.weight"], self.params[f"{PREFIX}{name}.layers.{i}.bias"], final_relu)
+
+    def _lin(self, x, name: str):
+        return _Linear.apply(x, self.params[f"{PREFIX}{name}.weight"], self.params[f"{PREFIX}{name}.bias"], False)
+
+    def losses(self, A0, planes1, planes2, n1, n2, init_trans, init_rot, init_trans_feat, init_rot_feat, gt_pose, suffix: str = "",
+               weight: float = 1.0) -> Dict[str, torch.Tensor]:
+        """The seven losses of __forward_PlaneCamRefHead (camera_head.py:883-921) with the autograd tape attached.  The feature / pose inputs
+        may require grad (their gradients land in `input_grads` after backward())."""
+        P, nq = self.params, self.nq
+        B = A0.shape[0]
+        with torch.no_grad():
+            geo_local, _gg, _sig, geo_enc, m = ops.geo_sequence(A0, planes1, planes2, n1, n2, init_trans.detach(), init_rot.detach(), self.warp_in_ref)
+        rows = B * nq
+        geo = self._mlp(geo_enc.view(rows, 8), "geo_encoder")
+        s1 = self._mlp(geo, "geo_proj_s1")
+        f_rot = self._mlp(s1, "decoder_rot")
+        s2 = self._mlp(torch.cat([s1, f_rot], dim=1), "geo_proj_s2")
+        f_tran = self._mlp(s2, "decoder_tran")
+        bc = lambda f: f.unsqueeze(1).expand(B, nq, f.shape[1]).reshape(rows, f.shape[1])
+        fused_rot = self._mlp(torch.cat([bc(init_rot_feat), f_rot], dim=1), "decoder_rot2", final_relu=True)       # :980-983 (+ F.relu)
+        fused_tran = self._mlp(torch.cat([bc(init_trans_feat), f_tran], dim=1), "decoder_tran2", final_relu=True)
+        rot_raw = self._lin(fused_rot, "rots").view(B, nq, 4)
+        trans_raw = self._lin(fused_tran, "trans").view(B, nq, 3)
+        ns, ps, l2, rots_all, trans_all, dn_sum, dl2_sum = _ScoreMaps.apply(geo_local, rot_raw, trans_raw, init_rot, init_trans, m)
+        NH = nq + 1
+        sf_rot = self._mlp(ns.view(B * NH, nq), "normal_score_proj").view(B, NH, 64)
+        sf_tran = self._mlp(ps.view(B * NH, nq), "param_score_proj").view(B, NH, 64)
+        w = lambda n: P[f"{PREFIX}{n}.weight"]
+        bb = lambda n: P[f"{PREFIX}{n}.bias"]
+        pr, pt, ar, at, sr, st = _Vote.apply(sf_rot, sf_tran, w("rot_score_reg").view(-1), bb("rot_score_reg"), w("trans_score_reg").view(-1),
+                                             bb("trans_score_reg"), init_rot_feat, init_trans_feat, fused_rot.view(B, nq, 256),
+                                             fused_tran.view(B, nq, 256), w("rots"), bb("rots"), w("trans"), bb("trans"), rots_all, trans_all,
+                                             dn_sum, dl2_sum, init_rot.detach(), init_trans.detach(), m)
+        lv = _Losses.apply(pr, pt, ar, at, sr, st, l2, rots_all, trans_all, m, gt_pose, float(weight))
+        self._inputs = {"init_trans_feat": init_trans_feat, "init_rot_feat": init_rot_feat, "init_trans": init_trans, "init_rot": init_rot}
+        self.last = {"pred_rot": pr, "pred_trans": pt, "avg_rot": ar, "avg_trans": at, "score_rot": sr, "score_trans": st, "m": m}
+        return {"%s_%s" % (nm, suffix): lv[i] for i, nm in enumerate(ops.PLANE_CAM_REF_LOSS_NAMES)}
+
+    # ---- backward
+    def backward(self, losses: Dict[str, torch.Tensor], loss_weights: Optional[Dict[str, float]] = None) -> Dict[str, torch.Tensor]:
+        """d (sum of the losses, optionally weighted) / d parameters -> {state-dict key: gradient}."""
+        for p in self.params.values():
+            p.grad = None
+        for t in self._inputs.values():
+            if t.requires_grad:
+                t.grad = None
+        total = None
+        for k, v in losses.items():
+            term = v * float(loss_weights.get(k, 1.0)) if loss_weights else v
+            total = term if total is None else total + term
+        total.backward()
+        self.input_grads = {k: t.grad for k, t in self._inputs.items() if t.requires_grad and t.grad is not None}
+        return {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in self.params.items()}
+
+    # ---- optimiser (train_NopeSAC.py:88-169: AdamW / SGD over per-parameter groups; norm / embedding groups do not occur in this head)
+    def step(self, lr: float = 1e-4, optimizer: str = "ADAMW", weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8,
+             momentum: float = 0.9):
+        self.steps += 1
+        for k, p in self.params.items():
+            if p.grad is None:
+                continue
+            g = p.grad.contiguous()
+            st = self.state.setdefault(k, {})
+            with torch.no_grad():
+                if optimizer.upper() == "ADAMW":
+                    if not st:
+                        st["m1"], st["m2"] = torch.zeros_like(p), torch.zeros_like(p)
+                    rc = _L().nopesac_adamw_step(_p(p), _p(g), _p(st["m1"]), _p(st["m2"]), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                                 float(eps), float(weight_decay), self.steps, _st())
+                    _lib.check(rc, "nopesac_adamw_step")
+                elif optimizer.upper() == "SGD":
+                    first = "mom" not in st
+                    if first:
+                        st["mom"] = torch.zeros_like(p)
+                    rc = _L().nopesac_sgd_step(_p(p), _p(g), _p(st["mom"]), p.numel(), float(lr), float(momentum), float(weight_decay), int(first), _st())
+                    _lib.check(rc, "nopesac_sgd_step")
+                else:
+                    raise NotImplementedError(f"no optimizer type {optimizer}")           # train_NopeSAC.py:158
+
+    def write_back(self, head):
+        """Copy the trained parameters into the inference head (its packed / bf16 copies are rebuilt on the next forward)."""
+        with torch.no_grad():
+            for k, p in self.params.items():
+                head.raw(k[len(PREFIX):]).copy_(p)
+        head.invalidate()
