@@ -206,7 +206,7 @@ class RefineTrainer:
 
     @classmethod
     def from_head(cls, head) -> "RefineTrainer":
-        names = cls.parameter_names(PREFIX + k for k in head.spec)
+        names = cls.parameter_names(PREFIX + k for k in head._spec_keys)
         return cls({k: head.raw(k[len(PREFIX):]) for k in names}, head.num_queries, head.warp_plane_in_cam_ref_on)
 
     # ---- forward
