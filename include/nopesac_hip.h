@@ -719,13 +719,19 @@ int nopesac_refine_score_maps_backward(const float* geo_local, const float* rot_
                                        const float* init_trans, const int32_t* m, int B, int nq, const float* g_normal_score,
                                        const float* g_param_score, const float* g_l2_dist, float* g_rot_raw, float* g_trans_raw,
                                        float* g_init_rot, float* g_init_trans, void* stream);
+/* backward of nopesac_camera_pose_loss (CameraPoseLoss camera_modules.py:355-365 and the AIM's reconstruction losses camera_head.py:700-705,
+ * :725-731): g_out [2] -> gradients of BOTH pose arguments ([B,3] / [B,4] dense; the "ground truth" of a reconstruction loss is the pixel
+ * pose, an output of trainable layers). */
+int nopesac_camera_pose_loss_backward(const float* est_trans, const float* est_rot, const float* gt_trans, int gt_trans_stride,
+                                      const float* gt_rot, int gt_rot_stride, int B, float trans_eps, float weight, const float* g_out,
+                                      float* g_est_trans, float* g_est_rot, float* g_gt_trans, float* g_gt_rot, void* stream);
 /* helpers of the Linear backward and the optimiser (f32): y [cols,rows] = x^T (x rows strided by x_ld); out [cols] = column sums (fixed
- * summation order); out = y > 0 ? g : 0; J^T g of row-wise x / max(|x|, 1e-12) (D <= 4); torch.optim.AdamW / SGD(momentum) updates of one
+ * summation order); out = y > 0 ? g : 0; J^T g of row-wise x / max(|x|, 1e-12) (D <= 4; canonical_sign: the forward also flipped rows with x[0] < 0); torch.optim.AdamW / SGD(momentum) updates of one
  * tensor (train_NopeSAC.py:150-157). */
 int nopesac_transpose_f32(const float* x, int rows, int cols, int64_t x_ld, float* y, void* stream);
 int nopesac_col_sum_f32(const float* x, int rows, int cols, int64_t x_ld, float* out, void* stream);
 int nopesac_relu_backward_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
-int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, float* out, void* stream);
+int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, int canonical_sign, float* out, void* stream);
 int nopesac_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                        float eps, float weight_decay, int step, void* stream);
 int nopesac_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,

@@ -111,6 +111,50 @@ __global__ __launch_bounds__(64) void refine_losses_bwd_kernel(
     for (int j = 0; j < nq; ++j) g_l2_dist[((long long)b * NH + 1 + j) * nq + j] = gd;
 }
 
+// (1b) CameraPoseLoss / the AIM's reconstruction losses (camera_pose_loss_kernel): out[0] = w mean_b |gt_t + eps - est_t|,
+// out[1] = w mean_b |n(gt_q) - n(est_q)|.  Both sides get a gradient: in the reconstruction losses the "ground truth" is the pixel
+// pose, an output of trainable layers.
+__global__ __launch_bounds__(64) void camera_pose_loss_bwd_kernel(const float* __restrict__ est_trans, const float* __restrict__ est_rot,
+                                                                  const float* __restrict__ gt_trans, int gt_trans_stride, const float* __restrict__ gt_rot,
+                                                                  int gt_rot_stride, int B, float trans_eps, float weight, const float* __restrict__ g_out,
+                                                                  float* __restrict__ g_est_trans, float* __restrict__ g_est_rot,
+                                                                  float* __restrict__ g_gt_trans, float* __restrict__ g_gt_rot) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float k = weight / (float)B;
+    {
+        const float* gt = gt_trans + (long long)b * gt_trans_stride;
+        float e[3], n2 = 0.f;
+        for (int d = 0; d < 3; ++d) { e[d] = est_trans[3 * b + d] - (gt[d] + trans_eps); n2 += e[d] * e[d]; }
+        const float n = sqrtf(n2);
+        for (int d = 0; d < 3; ++d) {
+            const float v = n > 0.f ? g_out[0] * k * e[d] / n : 0.f;
+            g_est_trans[3 * b + d] = v;
+            g_gt_trans[3 * b + d] = -v;
+        }
+    }
+    {
+        const float* gq = gt_rot + (long long)b * gt_rot_stride;
+        const float* eq = est_rot + 4 * b;
+        float gn = 0.f, en = 0.f;
+        for (int d = 0; d < 4; ++d) { gn += gq[d] * gq[d]; en += eq[d] * eq[d]; }
+        gn = fmaxf(sqrtf(gn), 1e-12f); en = fmaxf(sqrtf(en), 1e-12f);
+        float diff[4], l2 = 0.f;
+        for (int d = 0; d < 4; ++d) { diff[d] = eq[d] / en - gq[d] / gn; l2 += diff[d] * diff[d]; }
+        const float l = sqrtf(l2);
+        float ge[4], gg[4], xe[4], xg[4];
+        for (int d = 0; d < 4; ++d) {
+            ge[d] = l > 0.f ? g_out[1] * k * diff[d] / l : 0.f;
+            gg[d] = -ge[d];
+            xe[d] = eq[d]; xg[d] = gq[d];
+        }
+        float oe[4], og[4];
+        normalize_bwd(xe, ge, 4, oe);
+        normalize_bwd(xg, gg, 4, og);
+        for (int d = 0; d < 4; ++d) { g_est_rot[4 * b + d] = oe[d]; g_gt_rot[4 * b + d] = og[d]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // (2) scoring + aggregation + pose heads (ransac_soft_vote_kernel, mode | 16).  One workgroup per pair, thread = feature dim.
 // Parameter gradients are written PER PAIR ([B, ...]) and reduced over the pairs afterwards (nopesac_col_sum_f32).
@@ -391,11 +435,14 @@ __global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float* __restri
     if (i < n) out[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int rows, int D, float* __restrict__ out) {
+// canonical: the forward was y = sign * x / |x| with sign = -1 where x[0] < 0 (ops.normalize_rows(canonical_sign=True), camera_head.py:695-696)
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int rows, int D, int canonical,
+                                                                 float* __restrict__ out) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     float xv[4], gv[4], o[4];
-    for (int d = 0; d < D; ++d) { xv[d] = x[(long long)r * D + d]; gv[d] = g[(long long)r * D + d]; }
+    const float sg = (canonical && x[(long long)r * D] < 0.f) ? -1.f : 1.f;
+    for (int d = 0; d < D; ++d) { xv[d] = x[(long long)r * D + d]; gv[d] = sg * g[(long long)r * D + d]; }
     normalize_bwd(xv, gv, D, o);
     for (int d = 0; d < D; ++d) out[(long long)r * D + d] = o[d];
 }
@@ -484,6 +531,18 @@ extern "C" int nopesac_refine_score_maps_backward(const float* geo_local, const 
     NPS_LAUNCH_RET();
 }
 
+extern "C" int nopesac_camera_pose_loss_backward(const float* est_trans, const float* est_rot, const float* gt_trans, int gt_trans_stride,
+                                                 const float* gt_rot, int gt_rot_stride, int B, float trans_eps, float weight, const float* g_out,
+                                                 float* g_est_trans, float* g_est_rot, float* g_gt_trans, float* g_gt_rot, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(est_trans && est_rot && gt_trans && gt_rot && g_out && g_est_trans && g_est_rot && g_gt_trans && g_gt_rot,
+                  "camera_pose_loss_backward: null pointer");
+    NPS_CHECK_ARG(B > 0 && gt_trans_stride >= 3 && gt_rot_stride >= 4, "camera_pose_loss_backward: bad dims / strides");
+    hipLaunchKernelGGL(camera_pose_loss_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, est_trans, est_rot, gt_trans, gt_trans_stride,
+                       gt_rot, gt_rot_stride, B, trans_eps, weight, g_out, g_est_trans, g_est_rot, g_gt_trans, g_gt_rot);
+    NPS_LAUNCH_RET();
+}
+
 extern "C" int nopesac_transpose_f32(const float* x, int rows, int cols, int64_t x_ld, float* y, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && y && rows > 0 && cols > 0 && x_ld >= cols, "transpose_f32: bad arguments");
@@ -505,10 +564,10 @@ extern "C" int nopesac_relu_backward_f32(const float* g, const float* y, int64_t
     NPS_LAUNCH_RET();
 }
 
-extern "C" int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, float* out, void* stream) {
+extern "C" int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, int canonical_sign, float* out, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && g && out && rows > 0 && D >= 1 && D <= 4, "normalize_rows_backward: bad arguments (D <= 4)");
-    hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, g, rows, D, out);
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, g, rows, D, canonical_sign, out);
     NPS_LAUNCH_RET();
 }
 

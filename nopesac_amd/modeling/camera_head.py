@@ -92,7 +92,7 @@ class PlaneCameraHead(ParamModule):
         return ops.groupnorm(x, self.raw(f"pixel_decoder.{nm}.norm.weight"), self.raw(f"pixel_decoder.{nm}.norm.bias"), 32, 1e-5, act)
 
     # ---------------------------------------------------------------- (i) pixel pose net
-    def pixel_pose_net(self, feats: dict, B: int, canonical_sign: bool = True):
+    def pixel_pose_net(self, feats: dict, B: int, canonical_sign: bool = True, features_only: bool = False):
         """feats: NHWC res3..res5 for 2B images (view-1 images first) -> trans0 [B,3], rot0 [B,4] (unit, w>=0),
         trans_feat, rots_feat [B,256].  `canonical_sign=False`: the training forward keeps the regressed sign (:667)."""
         P, gd = self.packed, self._gd("decoder")
@@ -139,20 +139,22 @@ class PlaneCameraHead(ParamModule):
             # FC + ReLU, then the regressor on top of it (one launch in bf16 GEMM mode)
             return run_stacks(t.reshape(B, -1), [([P[fc]], ops.ACT_RELU, True), ([P[reg]], ops.ACT_NONE, True)], self._gd("fc"))
 
-        def branch(name, fc, reg):
+        def branch(name):
             t = conv0(name)
             for i in range(1, 6):
                 t = cv(t, f"{name}.{i}", 1, 2 if i % 2 == 1 else 1, ops.ACT_LEAKY, out_dtype=torch.float32 if i == 5 else None)
-            return head(t, fc, reg)
+            return t
 
         if self.fused_branch_tail and act_dt == torch.bfloat16 and (h, w) == (15, 20):
             # layers 1..5 of BOTH branches in one launch, activations resident in LDS (csrc/posenet_branch.hip): 3 launches instead of 12
             if "branch_tail" not in P:
                 P["branch_tail"] = ops.PoseBranchTail([P[f"convs_trans.{i}"] for i in range(1, 6)], [P[f"convs_rots.{i}"] for i in range(1, 6)])
             yt, yr = ops.posenet_branch_tail(conv0("convs_trans"), conv0("convs_rots"), P["branch_tail"])
-            (trans_feat, trans0), (rots_feat, rot_raw) = head(yt, "fc_trans", "trans"), head(yr, "fc_rots", "rots")
         else:
-            (trans_feat, trans0), (rots_feat, rot_raw) = branch("convs_trans", "fc_trans", "trans"), branch("convs_rots", "fc_rots", "rots")
+            yt, yr = branch("convs_trans"), branch("convs_rots")
+        if features_only:                                    # training.CameraHeadTrainer: the conv stacks' outputs [B, 2*3*128] (NHWC order)
+            return yt.reshape(B, -1), yr.reshape(B, -1)
+        (trans_feat, trans0), (rots_feat, rot_raw) = head(yt, "fc_trans", "trans"), head(yr, "fc_rots", "rots")
         rot0 = ops.normalize_rows(rot_raw, canonical_sign=canonical_sign)                         # :667, :436-437
         return trans0, rot0, trans_feat, rots_feat
 

@@ -172,6 +172,45 @@ class _Losses(torch.autograd.Function):
         return o[0], o[1], o[2], o[3], o[4], o[5], o[6], None, None, None, None, None
 
 
+class _Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, canonical: bool):
+        x = x.contiguous()
+        ctx.canonical = bool(canonical)
+        ctx.save_for_backward(x)
+        return ops.normalize_rows(x, canonical_sign=ctx.canonical)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        out = torch.empty_like(x)
+        D = x.shape[-1]
+        rc = _L().nopesac_normalize_rows_backward(_p(x), _p(g.contiguous()), x.numel() // D, D, int(ctx.canonical), _p(out), _st())
+        _lib.check(rc, "nopesac_normalize_rows_backward")
+        return out, None
+
+
+class _PoseLoss(torch.autograd.Function):
+    """CameraPoseLoss / the AIM's reconstruction losses (ops.camera_pose_loss) -> f32[2] = (l_x, l_q) * weight."""
+
+    @staticmethod
+    def forward(ctx, est_t, est_q, gt_t, gt_q, weight: float, trans_eps: float):
+        est_t, est_q, gt_t, gt_q = (t.contiguous() for t in (est_t, est_q, gt_t, gt_q))
+        ctx.weight, ctx.eps = float(weight), float(trans_eps)
+        ctx.save_for_backward(est_t, est_q, gt_t, gt_q)
+        return ops.camera_pose_loss(est_t, est_q, gt_t, gt_q, weight, trans_eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        est_t, est_q, gt_t, gt_q = ctx.saved_tensors
+        B = est_t.shape[0]
+        o = [torch.empty_like(est_t), torch.empty_like(est_q), torch.empty_like(gt_t), torch.empty_like(gt_q)]
+        rc = _L().nopesac_camera_pose_loss_backward(_p(est_t), _p(est_q), _p(gt_t), 3, _p(gt_q), 4, B, ctx.eps, ctx.weight, _p(g.contiguous()),
+                                                    *[_p(t) for t in o], _st())
+        _lib.check(rc, "nopesac_camera_pose_loss_backward")
+        return o[0], o[1], o[2], o[3], None, None
+
+
 class RefineTrainer:
     """The refinement head's parameters as f32 leaf tensors + forward / backward / optimiser step.
 
@@ -301,3 +340,81 @@ class RefineTrainer:
             for k, p in self.params.items():
                 head.raw(k[len(PREFIX):]).copy_(p)
         head.invalidate()
+
+
+class CameraHeadTrainer(RefineTrainer):
+    """The camera head in TRAINING mode (reference PlaneCameraHead.forward, camera_head.py:140-344) with every Linear layer trainable:
+    the pixel pose net's FC layers + pose regressors (fc_trans / fc_rots / trans / rots), the AIM (rot_emb_proj / trans_emb_proj) and the
+    refinement head - 92 tensors.  The pixel pose net's CONVOLUTIONS (pixel decoder, correlation stack) have no backward kernels: their
+    output features [B, 768] are computed by the inference kernels and enter as constants, i.e. those layers are frozen.
+    Detach points as in the reference: the AIM re-embeds a detached copy of the pixel pose (:694, :723); the geometry sequences are built
+    from detached initial poses (:354-365)."""
+
+    EXTRA_MLPS = ("rot_emb_proj", "trans_emb_proj")
+    EXTRA_LINEARS = ("fc_trans", "fc_rots")
+
+    @staticmethod
+    def parameter_names(sd_keys) -> List[str]:
+        out = []
+        for k in sd_keys:
+            if not k.startswith(PREFIX):
+                continue
+            if k[len(PREFIX):].split(".")[0] in MLPS + LINEARS + CameraHeadTrainer.EXTRA_MLPS + CameraHeadTrainer.EXTRA_LINEARS:
+                out.append(k)
+        return sorted(out)
+
+    def pixel_pose(self, yt: torch.Tensor, yr: torch.Tensor):
+        """The FC layers + regressors on the conv features yt / yr [B, 768] in the REFERENCE's flatten order (channel-major: c * 6 + hw)."""
+        trans_feat = self._lin_relu(yt, "fc_trans")
+        rots_feat = self._lin_relu(yr, "fc_rots")
+        trans0 = self._lin(trans_feat, "trans")
+        rot0 = _Normalize.apply(self._lin(rots_feat, "rots"), False)
+        return trans0, rot0, trans_feat, rots_feat
+
+    def _lin_relu(self, x, name: str):
+        return _Linear.apply(x, self.params[f"{PREFIX}{name}.weight"], self.params[f"{PREFIX}{name}.bias"], True)
+
+    def aim(self, trans_in: torch.Tensor, rot_in: torch.Tensor):
+        """__forward_RotRecHead / __forward_TransRecHead (:685-735) on DETACHED inputs; returns (rec_trans, rec_rot, trans_feat, rot_feat,
+        the canonical-sign input rotation, the shifted input translation)."""
+        rot_c = ops.normalize_rows(rot_in.detach().contiguous(), canonical_sign=True)
+        tr_in = (trans_in.detach() + 1e-10).contiguous()
+        rot_feat = self._mlp(rot_c, "rot_emb_proj", final_relu=True)
+        rec_rot = _Normalize.apply(self._lin(rot_feat, "rots"), False)
+        trans_feat = self._mlp(tr_in, "trans_emb_proj", final_relu=True)
+        rec_trans = self._lin(trans_feat, "trans")
+        return rec_trans, rec_rot, trans_feat, rot_feat, rot_c, tr_in
+
+    def camera_head_losses(self, head, feats: dict, B: int, gt_planes1, gt_planes2, gt_n1, gt_n2, gt_assignment, gt_pose, planes1=None, planes2=None,
+                           n1=None, n2=None, assignment=None, rand_rot=None, rand_trans=None) -> Dict[str, torch.Tensor]:
+        """All losses of the training-mode forward (the 34 of PlaneCameraHead.forward_train) with the autograd tape attached."""
+        with torch.no_grad():
+            yt, yr = head.pixel_pose_net(feats, B, features_only=True)          # [B, hw * 128 + c]: the inference kernels' NHWC order
+            to_ref = lambda y: y.view(B, 6, 128).transpose(1, 2).reshape(B, 768).contiguous().float()
+            yt, yr = to_ref(yt), to_ref(yr)
+        losses: Dict[str, torch.Tensor] = {}
+        trans0, rot0, tf0, rf0 = self.pixel_pose(yt, yr)
+        lp = _PoseLoss.apply(trans0, rot0, gt_pose[:, 0:3], gt_pose[:, 3:7], head.initial_cam_weight, 0.0)
+        losses["loss_tran_pixelReg"], losses["loss_rot_pixelReg"] = lp[0], lp[1]
+
+        def rec(trans_in, rot_in, suffix):
+            rec_t, rec_r, rec_tf, rec_rf, rot_c, tr_in = self.aim(trans_in, rot_in)
+            lr = _PoseLoss.apply(rec_t, rec_r, tr_in, rot_c, 1.0, 0.0)           # (tr_in already carries the + 1e-10)
+            losses["loss_rot" + suffix], losses["loss_trans" + suffix] = lr[1], lr[0]
+            return rec_t, rec_r, rec_tf, rec_rf
+
+        rec_t, rec_r, rec_tf, rec_rf = rec(trans0, rot0, "_initCamRec")
+        passes = [("", gt_planes1, gt_planes2, gt_n1, gt_n2, gt_assignment, head.plane_cam_weight)]
+        if assignment is not None:
+            passes.append(("_Aux", planes1, planes2, n1, n2, assignment, head.plane_cam_weight_predplane))
+        self.recorded = {"trans": [trans0, rec_t], "rot": [rot0, rec_r]}
+        inputs = {}
+        for sfx, pl1, pl2, c1, c2, A, w in passes:
+            for name, it, ir, itf, irf in (("initCamRef", trans0, rot0, tf0, rf0), ("initRecCamRef", rec_t, rec_r, rec_tf, rec_rf)):
+                losses.update(self.losses(A, pl1, pl2, c1, c2, it, ir, itf, irf, gt_pose, suffix=name + sfx, weight=w))
+                self.recorded["trans"] += [self.last["avg_trans"], self.last["pred_trans"]]
+                self.recorded["rot"] += [self.last["avg_rot"], self.last["pred_rot"]]
+        if rand_rot is not None:
+            rec(rand_trans, rand_rot, "_randCamRecLBS_N1")
+        self._inputs = inputs
+        return losses

@@ -208,3 +208,90 @@ def test_trained_parameters_reach_the_inference_head(device):
     tr.write_back(head)
     k = "geo_encoder.layers.0.weight"
     assert torch.equal(head.raw(k), tr.params["camera_head_list.0." + k].detach())
+
+
+def _oracle_camera_head_train_like_the_reference(sd, c, nq, head, names):
+    """The oracle's training-mode camera head with the reference's DETACH points (camera_head.py:694, :723 the AIM re-embeds detached poses;
+    :354-365 the geometry sequences come from detached initial poses) - oracle.camera_head_train keeps those paths differentiable, which is
+    irrelevant for its (forward-only) use but not for a gradient oracle.  float64, autograd."""
+    from oracle import nopesac_oracle as O
+    p = "camera_head_list.0"
+    cfg = O.OracleConfig(num_queries=nq)
+    sdg = {k: (v.clone().double().requires_grad_(True) if k in names else v.double()) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
+    dd = lambda t: t.double()
+    f1 = {k: dd(v) for k, v in c["feats1"].items()}
+    f2 = {k: dd(v) for k, v in c["feats2"].items()}
+    gt = dd(c["gt_pose"])
+    losses = {}
+    trans0, rot0, tf0, rf0, _ = O.pixel_pose_net(sdg, f1, f2, p)
+    l_t, l_r = O.camera_pose_loss(torch.cat((trans0, rot0), -1), gt)
+    losses["loss_tran_pixelReg"], losses["loss_rot_pixelReg"] = l_t * head.initial_cam_weight, l_r * head.initial_cam_weight
+
+    def rec(trans_in, rot_in, suffix):
+        trans_in, rot_in = trans_in.detach(), rot_in.detach()
+        sig = ((rot_in[:, 0:1] >= 0.0).double() - 0.5) * 2.0
+        rec_t, rec_r, rec_tf, rec_rf = O.aim_reembed(sdg, trans_in, rot_in, p)
+        losses["loss_rot" + suffix] = (torch.nn.functional.normalize(rot_in * sig, dim=1) - rec_r).norm(dim=1).mean()
+        losses["loss_trans" + suffix] = ((trans_in + 1e-10) - rec_t).norm(dim=1).mean()
+        return rec_t, rec_r, rec_tf, rec_rf
+
+    rec_t, rec_r, rec_tf, rec_rf = rec(trans0, rot0, "_initCamRec")
+    B = gt.shape[0]
+    for sfx, pl1, pl2, AA, w in (("", c["gt_planes1"], c["gt_planes2"], c["gt_A"], head.plane_cam_weight),
+                                 ("_Aux", c["planes1"], c["planes2"], c["A"], head.plane_cam_weight_predplane)):
+        for name, it, ir, itf, irf in (("initCamRef", trans0, rot0, tf0, rf0), ("initRecCamRef", rec_t, rec_r, rec_tf, rec_rf)):
+            gl, gg, sg, ms = [], [], [], []
+            for b in range(B):
+                l, m = O.geo_sequence(dd(pl1[b]), dd(pl2[b]), dd(AA[b]), nq)
+                g_, _ = O.geo_sequence(dd(pl1[b]), dd(pl2[b]), dd(AA[b]), nq, ir[b].detach(), it[b].detach())
+                a_, _ = O.geo_sequence(dd(pl1[b]), dd(pl2[b]), dd(AA[b]), nq, ir[b].detach(), torch.zeros(3, dtype=torch.float64))
+                gl.append(l); gg.append(g_); ms.append(m)
+                sg.append((((g_[:, 0:1] * a_[:, 0:1]) >= 0).double() - 0.5) * 2.0)
+            ls, _ = O.ransac_refine_train(sdg, itf, irf, torch.stack(gg), torch.stack(gl), torch.stack(sg), ms, it, ir, gt, cfg, suffix=name + sfx, weight=w, p=p)
+            losses.update(ls)
+    rec(dd(c["rand_trans"]), dd(c["rand_rot"]), "_randCamRecLBS_N1")
+    total = sum(losses.values())
+    total.backward()
+    return losses, {k: sdg[k].grad for k in names}
+
+
+def test_camera_head_training_gradients(device):
+    """The whole training-mode camera head (34 losses: pixel pose, AIM reconstruction x 2, four refinement passes) differentiated with
+    respect to every Linear layer of the head (92 tensors: FC + regressors of the pixel pose net, AIM, refinement head) - the shared
+    `rots` / `trans` regressors collect gradients from eleven call sites - against float64 autograd on the oracle with the reference's
+    detach points.  The conv stacks of the pixel pose net are constants here (no backward kernels)."""
+    from nopesac_amd.synth import synth_state_dict
+    from nopesac_amd.training import CameraHeadTrainer
+    from tests.util import make_model, nhwc
+    nq, ms = 50, (7, 2, 19)
+    c = GI.camera_train_case(nq, ms, 80)
+    B = len(ms)
+    sd = synth_state_dict(nq)
+    model = make_model(device)
+    head = model.camera_head_list[0]
+    tr = CameraHeadTrainer.from_head(head)
+    names = list(tr.params)
+    assert len(names) == 92
+    feats = {k: torch.cat([nhwc(c["feats1"][k]), nhwc(c["feats2"][k])]).to(device) for k in ("res3", "res4", "res5")}
+    d = lambda k: c[k].to(device)
+    losses = tr.camera_head_losses(head, feats, B, d("gt_planes1"), d("gt_planes2"), d("n1"), d("n2"), d("gt_A"), d("gt_pose"), d("planes1"), d("planes2"),
+                                   d("n1"), d("n2"), d("A"), d("rand_rot"), d("rand_trans"))
+    grads = tr.backward(losses)
+    o_loss, o_grads = _oracle_camera_head_train_like_the_reference(sd, c, nq, head, names)
+    assert set(losses) == set(o_loss) and len(losses) == 34
+    for k in o_loss:
+        assert rel_err(losses[k].detach(), o_loss[k].float().detach()) < 3e-4, (k, float(losses[k]), float(o_loss[k]))
+    gmax = max(float(o_grads[k].abs().max()) for k in names)
+    report = []
+    for k in names:
+        ref = o_grads[k].float()
+        assert torch.isfinite(grads[k]).all(), k
+        report.append((float((grads[k].cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4 * gmax), k))
+    report.sort(reverse=True)
+    assert report[0][0] < 3e-3, report[:6]
+    tr.step(lr=1e-4)
+    tr.write_back(head)
+    with torch.no_grad():
+        l2, _, _ = head.forward_train(feats, B, d("gt_planes1"), d("gt_planes2"), d("n1"), d("n2"), d("gt_A"), d("gt_pose"), d("planes1"), d("planes2"),
+                                      d("n1"), d("n2"), d("A"), d("rand_rot"), d("rand_trans"))
+    assert all(torch.isfinite(v) for v in l2.values()) and float(sum(l2.values())) != float(sum(v.detach() for v in losses.values()))
