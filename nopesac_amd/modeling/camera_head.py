@@ -206,8 +206,9 @@ class PlaneCameraHead(ParamModule):
         prediction, and the seven refinement losses (:883-921) in one launch (nopesac_plane_cam_ref_losses).  The matched-plane
         sequence is given as in `refine` - an assignment matrix over the two plane sets (GT correspondences over GT planes for the
         'initCamRef' / 'initRecCamRef' calls :452-474, the predicted assignment for 'initCamRef_Aux' :480-500); every pair needs
-        m >= 1 matches, as in the reference.  No gradient kernels exist: the losses are values (validation curves, loss parity),
-        not a training step.  Returns (losses, pred_cam) with the reference's keys; pred_cam's per-hypothesis entries describe pair 0."""
+        m >= 1 matches, as in the reference.  This method returns loss VALUES; the differentiable form of the same function - gradients of
+        all its parameters from hand-written backward kernels, and an optimiser step - is nopesac_amd.training.RefineTrainer (round 5).
+        Returns (losses, pred_cam) with the reference's keys; pred_cam's per-hypothesis entries describe pair 0."""
         out = self.refine(A0, planes1, planes2, n1, n2, initial_trans, initial_rot, initial_trans_feat, initial_rot_feat,
                           diagnostics=True, train=True)
         maps, m = out["maps"], out["m"]
@@ -230,8 +231,9 @@ class PlaneCameraHead(ParamModule):
         assignment are given, over those ('..._Aux', weight PLANE_CAM_WEIGHT_PREDPLANE), and the AIM's losses on caller-provided
         random poses (the reference draws them, :687-690, :718).  Planes are [B,nq,3] zero-padded with counts int32[B]; assignments
         [B,nq,nq]; gt_pose [B,7].  BatchNorm / GroupNorm layers run with their stored statistics: this evaluates the losses of a
-        checkpoint (validation curves, loss parity); there are no gradient kernels, so it is not an optimiser step.
-        Returns (losses, trans_list, rot_list) as the reference does."""
+        checkpoint (validation curves, loss parity).  The training step over the same losses - backward kernels for every Linear layer
+        of the head (pixel-pose FC + regressors, AIM, refinement head; the conv stacks stay frozen) + AdamW / SGD - is
+        nopesac_amd.training.CameraHeadTrainer (round 5).  Returns (losses, trans_list, rot_list) as the reference does."""
         losses = {}
         trans0, rot0, tf0, rf0 = self.pixel_pose_net(feats, B, canonical_sign=False)
         lp = ops.camera_pose_loss(trans0, rot0, gt_pose[:, 0:3], gt_pose[:, 3:7], self.initial_cam_weight)

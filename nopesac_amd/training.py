@@ -345,7 +345,7 @@ class RefineTrainer:
 class CameraHeadTrainer(RefineTrainer):
     """The camera head in TRAINING mode (reference PlaneCameraHead.forward, camera_head.py:140-344) with every Linear layer trainable:
     the pixel pose net's FC layers + pose regressors (fc_trans / fc_rots / trans / rots), the AIM (rot_emb_proj / trans_emb_proj) and the
-    refinement head - 92 tensors.  The pixel pose net's CONVOLUTIONS (pixel decoder, correlation stack) have no backward kernels: their
+    refinement head - 108 tensors.  The pixel pose net's CONVOLUTIONS (pixel decoder, correlation stack) have no backward kernels: their
     output features [B, 768] are computed by the inference kernels and enter as constants, i.e. those layers are frozen.
     Detach points as in the reference: the AIM re-embeds a detached copy of the pixel pose (:694, :723); the geometry sequences are built
     from detached initial poses (:354-365)."""
@@ -392,6 +392,7 @@ class CameraHeadTrainer(RefineTrainer):
             yt, yr = head.pixel_pose_net(feats, B, features_only=True)          # [B, hw * 128 + c]: the inference kernels' NHWC order
             to_ref = lambda y: y.view(B, 6, 128).transpose(1, 2).reshape(B, 768).contiguous().float()
             yt, yr = to_ref(yt), to_ref(yr)
+        self.conv_feats = (yt, yr)                                # (what the frozen conv stacks handed to the trainable layers)
         losses: Dict[str, torch.Tensor] = {}
         trans0, rot0, tf0, rf0 = self.pixel_pose(yt, yr)
         lp = _PoseLoss.apply(trans0, rot0, gt_pose[:, 0:3], gt_pose[:, 3:7], head.initial_cam_weight, 0.0)
