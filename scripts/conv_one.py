@@ -9,7 +9,7 @@ from nopesac_amd import ops  # noqa: E402
 
 B, H, W, Cin, Cout, k, s = [int(v) for v in sys.argv[1:8]]
 mode = sys.argv[8] if len(sys.argv) > 8 else ""
-if mode and mode != "auto" and not mode.startswith("bfrag") and not mode.startswith("p8"):
+if mode and mode != "auto" and not mode.startswith("bfrag") and not mode.startswith("p8"):     # (p8<variant>, p8n<variant>, p8sk<variant>: below)
     os.environ["NOPESAC_CONV_FORCE"] = mode
 dev = torch.device("cuda:0")
 x = torch.randn(B, H, W, Cin, device=dev).bfloat16()
@@ -33,7 +33,24 @@ if mode.startswith("bfrag"):
         assert rc == 0
         return yb
     ops.conv2d = _bfrag
-if mode.startswith("p8"):
+if mode.startswith("p8n") or mode.startswith("p8sk"):
+    from nopesac_amd import _lib
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    yb = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)
+    ws = ops.p8_sk_workspace(dev) if mode.startswith("p8sk") else None
+
+    def _p8x(x, w, sc, bi, res, stride=1, pad=0, act=0):
+        if mode.startswith("p8n"):
+            rc = _lib.load().nopesac_conv2d_nhwc_p8n(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), yb.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad,
+                                                      Cin, Cout, act, int(mode[3:] or 0), torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = _lib.load().nopesac_conv2d_nhwc_p8_sk(x.data_ptr(), w.data_ptr(), sc.data_ptr(), bi.data_ptr(), res.data_ptr() if res is not None else None,
+                                                        yb.data_ptr(), B, H, W, Cin, Cout, k, k, stride, pad, Cin, Cout, Cout if res is not None else 0,
+                                                        act, 1, int(mode[4:] or 0), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return yb
+    ops.conv2d = _p8x
+elif mode.startswith("p8"):
     from nopesac_amd import _lib
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     yb = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=torch.bfloat16)

@@ -27,3 +27,19 @@ export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${P}_stats -o bench -- python $R/bench.py --steps 32 --warmup 5 --no-cpu-baseline --no-accuracy --no-boundary --no-other-configs --no-tape --no-fp32-path --routing $ROUT > $R/$O/${P}_stats.log 2>&1
 cd $R; cp $(find $O/prof_${P}_stats -name "*kernel_stats.csv" | head -1) $O/${P}_kernel_stats.csv; head -4 $O/${P}_kernel_stats.csv | cut -c1-200
 bash scripts/pmc_bench.sh --routing $ROUT > $O/${P}_pmc_bench.log 2>&1; cp $O/pmc_traffic.json $O/${P}_pmc_traffic.json; tail -3 $O/${P}_pmc_bench.log
+# PMC summaries of the dominant kernel and of this round's new kernels (counters only, separate passes)
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8.json conv_igemm_p8 conv_one.py 64 60 80 256 256 3 1 p832 > /dev/null 2>&1
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_res4_3x3.json conv_igemm_p8 conv_one.py 64 30 40 256 256 3 1 p832 > /dev/null 2>&1
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_sk_res4_3x3.json conv_igemm_p8 conv_one.py 64 30 40 256 256 3 1 p8sk32 > /dev/null 2>&1
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8n_res3_3x3.json conv_igemm_p8n conv_one.py 64 60 80 128 128 3 1 p8n0 > /dev/null 2>&1
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8n_res3_s2.json conv_igemm_p8n conv_one.py 64 120 160 128 128 3 2 p8n32 > /dev/null 2>&1
+bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_res4_expand.json conv_igemm_p8 conv_one.py 64 30 40 256 1024 1 1 p832 res > /dev/null 2>&1
+python - <<PY
+import json
+for f in ('conv_p8','conv_p8_res4_3x3','conv_p8_sk_res4_3x3','conv_p8n_res3_3x3','conv_p8n_res3_s2','conv_p8_res4_expand'):
+    try:
+        d=json.load(open('$O/r${RND}_pmc_'+f+'.json'))
+        for k,v in d['kernels'].items(): print(f, k[:44], d['unprofiled_run'], {a:b for a,b in v.items() if a not in ('counters','wave_cycle_shares')})
+    except Exception as e: print(f, 'failed', e)
+PY
+python scripts/parity_report.py > $O/${P}_parity_report.json 2> $O/${P}_parity.err; tail -c 400 $O/${P}_parity_report.json
