@@ -13,7 +13,8 @@ if [ -z "$ROUTING" ]; then ROUTING=$R/profiles/routing_r5.json; ARGS+=(--routing
 export PMC_ROUTING_FILE=$ROUTING
 set -- "${ARGS[@]}"
 cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
+[ -n "$PMC_SKIP_COLLECT" ] && set --          # (re-summarise the CSVs of an earlier collection)
+for c in $([ -n "$PMC_SKIP_COLLECT" ] || echo FETCH_SIZE WRITE_SIZE); do
   rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench/$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-accuracy --no-fp32-path --no-boundary --no-other-configs --no-tape "$@" > $R/gpurun_out/pmc_bench_$c.log 2>&1
 done
 cd $R
@@ -41,7 +42,9 @@ rows.sort(reverse=True)
 print("per step: kernel, launches, HBM read GB (2x FETCH_SIZE), write GB")
 for t,k,rd,wr,n in rows[:16]:
     print("%-80s %6.1f  %7.3f  %7.3f"%(k,n,rd/1e9,wr/1e9))
-fam=[r for r in rows if any(s in r[1] for s in ("conv_igemm", "pw_chain", "stem_fused", "conv3x3_halo", "conv3x3_c64")) and "float" not in r[1]]
+# the family bench.py's per-launch timer sees (`roofline.conv_family`): every bf16 conv2d / bottleneck-tail launch - NOT the fused stem and the
+# res2 3x3 kernel, which are separate entry points
+fam=[r for r in rows if any(s in r[1] for s in ("conv_igemm", "pw_chain", "conv3x3_halo")) and "float" not in r[1]]
 import os
 out={"routing_file": os.path.relpath(os.environ["PMC_ROUTING_FILE"]),
      "note": "HBM bytes per forward pass of 32 pairs (bench.py --inflight 1, kernel routing from the routing file, the 6 forward passes after the tuning), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
