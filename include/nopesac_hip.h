@@ -732,6 +732,11 @@ int nopesac_transpose_f32(const float* x, int rows, int cols, int64_t x_ld, floa
 int nopesac_col_sum_f32(const float* x, int rows, int cols, int64_t x_ld, float* out, void* stream);
 int nopesac_relu_backward_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
 int nopesac_normalize_rows_backward(const float* x, const float* g, int rows, int D, int canonical_sign, float* out, void* stream);
+/* full-model gradient clipping (train_NopeSAC.py:139-148 -> torch.nn.utils.clip_grad_norm_): out[0] += sum x^2 (one launch per tensor on the
+ * same accumulator, fixed order); coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); x *= coef[0]. */
+int nopesac_sumsq_accumulate_f32(const float* x, int64_t n, float* out, void* stream);
+int nopesac_clip_coefficient(const float* sumsq, float max_norm, float* coef, void* stream);
+int nopesac_scale_by_f32(float* x, int64_t n, const float* coef, void* stream);
 int nopesac_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                        float eps, float weight_decay, int step, void* stream);
 int nopesac_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float weight_decay,

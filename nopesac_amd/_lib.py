@@ -106,6 +106,9 @@ SIGNATURES = {
     "nopesac_relu_backward_f32": [P, P, L, P, P],
     "nopesac_normalize_rows_backward": [P, P, I, I, I, P, P],
     "nopesac_camera_pose_loss_backward": [P, P, P, I, P, I, I, F, F, P, P, P, P, P, P],
+    "nopesac_sumsq_accumulate_f32": [P, L, P, P],
+    "nopesac_clip_coefficient": [P, F, P, P],
+    "nopesac_scale_by_f32": [P, L, P, P],
     "nopesac_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, P],
     "nopesac_sgd_step": [P, P, P, L, F, F, F, I, P],
     "nopesac_mlp_padded_k": [I, I],

@@ -447,6 +447,28 @@ __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __
     for (int d = 0; d < D; ++d) out[(long long)r * D + d] = o[d];
 }
 
+// sum of squares of one tensor -> out[0] += (accumulated across tensors by launching on the same `out`; ONE workgroup, fixed order: the
+// global gradient norm of torch.nn.utils.clip_grad_norm_ is deterministic) ; scale: x *= s[0]
+__global__ __launch_bounds__(256) void sumsq_accum_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    __shared__ float sh4[4];
+    float a = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) a += x[i] * x[i];
+    a = rb_block_sum_256(a, sh4);
+    if (threadIdx.x == 0) out[0] += a;
+}
+
+// clip coefficient of clip_grad_norm_: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) -> coef[0]
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
+    const float total = sqrtf(sumsq[0]);
+    const float c = max_norm / (total + 1e-6f);
+    coef[0] = c < 1.f ? c : 1.f;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, long long n, const float* __restrict__ coef) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= coef[0];
+}
+
 // AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias-corrected moments) / SGD with momentum, one launch per tensor
 __global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                                                          long long n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
@@ -568,6 +590,27 @@ extern "C" int nopesac_normalize_rows_backward(const float* x, const float* g, i
     using namespace nps;
     NPS_CHECK_ARG(x && g && out && rows > 0 && D >= 1 && D <= 4, "normalize_rows_backward: bad arguments (D <= 4)");
     hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, g, rows, D, canonical_sign, out);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_sumsq_accumulate_f32(const float* x, int64_t n, float* out, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && out && n > 0, "sumsq_accumulate_f32: bad arguments");
+    hipLaunchKernelGGL(sumsq_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_clip_coefficient(const float* sumsq, float max_norm, float* coef, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(sumsq && coef && max_norm > 0.f, "clip_coefficient: bad arguments");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef);
+    NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_scale_by_f32(float* x, int64_t n, const float* coef, void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(x && coef && n > 0, "scale_by_f32: bad arguments");
+    hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, coef);
     NPS_LAUNCH_RET();
 }
 

@@ -334,6 +334,35 @@ class RefineTrainer:
                 else:
                     raise NotImplementedError(f"no optimizer type {optimizer}")           # train_NopeSAC.py:158
 
+    def clip_grad_norm(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ over ALL parameters of this trainer (the reference's FullModelGradientClippingOptimizer,
+        train_NopeSAC.py:139-148), on the device: returns the clip coefficient (f32[1]; 1 = not clipped) without a host sync."""
+        grads = [p.grad for p in self.params.values() if p.grad is not None]
+        acc = torch.zeros(1, device=grads[0].device, dtype=torch.float32)
+        coef = torch.empty(1, device=grads[0].device, dtype=torch.float32)
+        for g in grads:
+            _lib.check(_L().nopesac_sumsq_accumulate_f32(_p(g.contiguous()), g.numel(), _p(acc), _st()), "nopesac_sumsq_accumulate_f32")
+        _lib.check(_L().nopesac_clip_coefficient(_p(acc), float(max_norm), _p(coef), _st()), "nopesac_clip_coefficient")
+        for p in self.params.values():
+            if p.grad is not None:
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                _lib.check(_L().nopesac_scale_by_f32(_p(p.grad), p.grad.numel(), _p(coef), _st()), "nopesac_scale_by_f32")
+        return coef
+
+    def step_from_cfg(self, cfg):
+        """One optimiser step with the reference's solver settings (Trainer.build_optimizer, train_NopeSAC.py:88-169): SOLVER.OPTIMIZER
+        (ADAMW / SGD), BASE_LR, WEIGHT_DECAY, MOMENTUM, CLIP_GRADIENTS (CLIP_TYPE "full_model": global-norm clipping in front of the
+        step).  The per-module multipliers (BACKBONE / SEM_SEG_HEAD / PLANE_MATCHER_HEAD) and the norm / embedding weight decays apply
+        to modules this trainer does not hold; every camera-head parameter uses the defaults, as in the reference."""
+        S = cfg.SOLVER
+        cg = S.CLIP_GRADIENTS
+        if cg.ENABLED and cg.CLIP_TYPE == "full_model" and cg.CLIP_VALUE > 0.0:
+            self.clip_grad_norm(float(cg.CLIP_VALUE))
+        elif cg.ENABLED:
+            raise NotImplementedError("SOLVER.CLIP_GRADIENTS.CLIP_TYPE %r (the reference's configs use full_model)" % (cg.CLIP_TYPE,))
+        self.step(lr=float(S.BASE_LR), optimizer=str(S.OPTIMIZER), weight_decay=float(S.WEIGHT_DECAY), momentum=float(S.MOMENTUM))
+
     def write_back(self, head):
         """Copy the trained parameters into the inference head (its packed / bf16 copies are rebuilt on the next forward)."""
         with torch.no_grad():

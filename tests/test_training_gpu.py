@@ -317,3 +317,38 @@ def test_camera_head_training_gradients(device):
         assert all(torch.isfinite(v) for v in l2.values()) and float(sum(l2.values())) != float(sum(v.detach() for v in losses.values()))
     finally:                                                  # (tests/util.make_model caches the model: hand it back with its checkpoint)
         model.load_state_dict(sd)
+
+
+def test_full_model_gradient_clipping_and_solver_step(device):
+    """RefineTrainer.clip_grad_norm = torch.nn.utils.clip_grad_norm_ (the reference's FullModelGradientClippingOptimizer), and
+    step_from_cfg reads the solver keys of the reference's config (OPTIMIZER / BASE_LR / WEIGHT_DECAY / CLIP_GRADIENTS)."""
+    from nopesac_amd.config import get_cfg
+    from nopesac_amd.training import RefineTrainer
+    g = torch.Generator().manual_seed(9)
+    p0 = {"camera_head_list.0.rots.weight": torch.randn(4, 256, generator=g), "camera_head_list.0.trans.weight": torch.randn(3, 256, generator=g)}
+    grads = {k: torch.randn(v.shape, generator=g) * 3 for k, v in p0.items()}
+    for max_norm in (0.5, 1e6):
+        tr = RefineTrainer({k: v.to(device) for k, v in p0.items()}, 50)
+        ref = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        for k in p0:
+            tr.params[k].grad = grads[k].to(device)
+            ref[k].grad = grads[k].clone()
+        coef = tr.clip_grad_norm(max_norm)
+        total = torch.nn.utils.clip_grad_norm_(list(ref.values()), max_norm)
+        assert abs(float(coef) - min(1.0, max_norm / (float(total) + 1e-6))) < 1e-6
+        for k in p0:
+            assert rel_err(tr.params[k].grad.cpu(), ref[k].grad) < 1e-5
+    cfg = get_cfg()
+    cfg.merge_from_list(["SOLVER.OPTIMIZER", "ADAMW", "SOLVER.BASE_LR", 0.001, "SOLVER.WEIGHT_DECAY", 0.05, "SOLVER.CLIP_GRADIENTS.ENABLED", True,
+                         "SOLVER.CLIP_GRADIENTS.CLIP_TYPE", "full_model", "SOLVER.CLIP_GRADIENTS.CLIP_VALUE", 0.01])
+    tr = RefineTrainer({k: v.to(device) for k, v in p0.items()}, 50)
+    ref = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    opt = torch.optim.AdamW(list(ref.values()), lr=0.001, weight_decay=0.05)
+    for k in p0:
+        tr.params[k].grad = grads[k].to(device)
+        ref[k].grad = grads[k].clone()
+    tr.step_from_cfg(cfg)
+    torch.nn.utils.clip_grad_norm_(list(ref.values()), 0.01)
+    opt.step()
+    for k in p0:
+        assert float((tr.params[k].detach().cpu() - ref[k].detach()).abs().max()) < 2e-6
