@@ -1007,8 +1007,9 @@ struct PwRt8 {
     static_assert(BYTES <= 160 * 1024, "LDS");
 };
 
+// (C = 256 - the res4 form, round 5 experiment - holds 16 + 8 weight fragments per lane: one workgroup per CU, 256 registers)
 template <int C, int C4, int CN, int C2>
-__global__ __launch_bounds__(512, 2) void pw_chain_rt8_kernel(const PwArgs p) {
+__global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(const PwArgs p) {
     typedef PwRt8<C, C4, CN, C2> S;
     constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, A_LD = S::A_LD, A2_LD = S::A2_LD, Y_LD = S::Y_LD, O_LD = S::O_LD;
     constexpr int KF1 = S::KF1, KF1S = S::KF1S, KF2 = S::KF2, NR2 = S::NR2;
@@ -1315,6 +1316,11 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
     PW_CASE(64, 256, 64, 0, 64) PW_CASE(64, 256, 128, 0, 64) PW_CASE(64, 256, 64, 64, 64) PW_CASE(64, 256, 0, 0, 64) PW_CASE(64, 256, 0, 64, 64)
     PW_CASE(128, 512, 128, 0, 32) PW_CASE(128, 512, 256, 0, 32) PW_CASE(128, 512, 128, 256, 32) PW_CASE(128, 512, 0, 0, 32) PW_CASE(128, 512, 0, 256, 32)
 #undef PW_CASE
+    // res4 identity blocks on the eight-wave 128-pixel chunked form (round-5 experiment, NOPESAC_TAIL_RT8_WIDE=1)
+    if (!x2 && a.M % 128 == 0 && C == 256 && C4 == 1024 && CN == 256 && getenv("NOPESAC_TAIL_RT8_WIDE")) {
+        pw_launch_rt8<256, 1024, 256, 0>(a, st);
+        NPS_LAUNCH_RET();
+    }
     // identity blocks of res4 / res5: chunk-streaming kernel (weights shared by 128 / 64 pixels)
     if (!x2 && !getenv("NOPESAC_TAIL_NO_STREAM")) {
         if (C == 256 && C4 == 1024 && CN == 256) { pw_launch_stream<256, 1024, 256, 64>(a, st); NPS_LAUNCH_RET(); }
