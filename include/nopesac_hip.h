@@ -586,7 +586,8 @@ int nopesac_gnn_layer_bf16_pf(const float* x, int x_off, const float* src, int s
  * c1 [B,H,W,256], t1 [B,H/2,W/2,256] bf16; w_lateral [256][256] and mask_w [B][NQP][256] (rows >= nq zero) bf16 in MFMA
  * fragment-major order; mask_b f32 [B][NQP]; NQP = 64 for nq <= 64, 128 for nq <= 128; prob f32 [B,H,W,nq] (nq even, <= 128);
  * p1_out optional bf16 [B,H,W,256].
- * H*W must be a multiple of 128.  apply_sigmoid: bit 0 = apply the sigmoid, bit 1 = write prob planar, [B,nq,H,W]. */
+ * H*W must be a multiple of 128.  apply_sigmoid: bit 0 = apply the sigmoid, bit 1 = write prob planar, [B,nq,H,W], bit 2 = tuning
+ * aid / test: one pixel per item in the bilinear phase (default: four consecutive pixels share their eight taps; identical results). */
 int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                            const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
                            int apply_sigmoid, void* stream);

@@ -19,6 +19,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 
+#ifndef MH_ABLATE
+#define MH_ABLATE 0          // tuning builds (NOPESAC_HIPCC_EXTRA=-DMH_ABLATE=n, WRONG results): 1 no bilinear tap loads, 2 no lateral MFMAs,
+#endif                       // 3 no probability store, 4 no c1 load, 5 no mask-GEMM MFMAs + sigmoid
 constexpr int MH_C = 256, MH_LD = MH_C + 8, MH_BM = 128, MH_RT = MH_BM / 32, MH_NQP_MAX = 128;
 constexpr size_t MH_LDS_BYTES = (size_t)(2 * MH_BM * MH_LD);      // ONE 128 x 264 bf16 tile (67.6 KB): c1 rows -> p1 -> f32 output staging
 constexpr int MH_RING = 8;                                          // weight fragments in flight per wave (rolling ring)
@@ -30,6 +33,7 @@ struct MaskHeadArgs {
     const bf16_t* mw; const float* mb;           // [B][NQP][256] fragment-major per image (rows >= nq zero), [B][NQP]; NQP = 64 or 128
     float* prob; bf16_t* p1;                     // [B][H][W][nq] f32; optional [B][H][W][256] bf16
     int B, H, W, nq, apply_sigmoid, planar;      // planar: prob is [B][nq][H][W] (one 512-byte run per plane and workgroup)
+    int taps1;                                   // tuning aid / test: one pixel per bilinear item (the form of rounds 1-4)
 };
 
 // Two workgroups per CU (67.6 KB LDS, <= 128 registers): while one is in its load / bilinear / store phase the other one's MFMAs
@@ -65,7 +69,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
 #pragma unroll
     for (int i = 0; i < MH_BM * 32 / 512; ++i) {
         const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+#if MH_ABLATE != 4
         *reinterpret_cast<us8*>(At + r * MH_LD + col) = *reinterpret_cast<const us8*>(p.c1 + (m0 + r) * MH_C + col);
+#endif
     }
     __syncthreads();
 
@@ -80,8 +86,10 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
         for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
             for (int r = 0; r < MH_RT; ++r) {
+#if MH_ABLATE != 2
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc[r], 0, 0, 0);
+#endif
             }
             if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wlp + (kk + MH_RING) * 512);
             else ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING - 16) * 512);     // mask GEMM k-steps 0..7
@@ -107,29 +115,24 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
     }
     __syncthreads();
 
-    // ---- p1 = lateral + relu(bilinear_2x(t1)): thread = (pixel, 8-channel chunk); F.interpolate align_corners=False
+    // ---- p1 = lateral + relu(bilinear_2x(t1)); F.interpolate align_corners=False.
+    // Round 5: thread = (FOUR consecutive output pixels, 8-channel chunk).  Under exact 2x up-sampling the pixels 4j .. 4j+3 of an output
+    // row tap the source columns 2j-1, 2j, 2j+1, 2j+2 of the same two source rows: 8 loads of 16 bytes per four outputs instead of 16
+    // (the tap loads were a quarter of the kernel's time: ablation build MH_ABLATE=1).  Same arithmetic per pixel - the pairs
+    // (x0, x1) are the generic formula's columns (or the same DATA at the clamped borders) and lx / ly are the generic weights - so
+    // the result is bit-identical.  W % 4 == 0 (a group never straddles two output rows); otherwise one pixel per item as before.
     {
         const int H2 = p.H >> 1, W2 = p.W >> 1;
         const int oh0 = pix0 / p.W, ow0 = pix0 - oh0 * p.W;       // workgroup-uniform
         const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
-#pragma unroll 2
-        for (int i = 0; i < MH_BM * 32 / 512; ++i) {
-            const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
-            int oh = oh0, ow = ow0 + r;                      // (pix0 + r) / W, % W without a per-item division
-            while (ow >= p.W) { ow -= p.W; ++oh; }
-            const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
-            const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H2 - 1), x1 = min(x0 + 1, W2 - 1);
-            const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            const u32x4_t v00 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x0) * MH_C + col);
-            const u32x4_t v01 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
-            const u32x4_t v10 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
-            const u32x4_t v11 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        auto unpack = [](unsigned int wd) { return f32x2_t{__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)}; };
+        auto blend_store = [&](int r, int col, const u32x4_t& v00, const u32x4_t& v01, const u32x4_t& v10, const u32x4_t& v11, float lx, float ly) {
+            const float hy = 1.f - ly, hx = 1.f - lx;
             const u32x4_t lw = *reinterpret_cast<const u32x4_t*>(At + r * MH_LD + col);
             u32x4_t ow4;
-            // two channels per step on float2 (v_pk_mul_f32 / v_pk_add_f32); a bf16 pair unpacks with one shift and one mask
-            auto unpack = [](unsigned int wd) { return f32x2_t{__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)}; };
+            // two channels per step on float2; a bf16 pair unpacks with one shift and one mask
             const f32x2_t hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -143,6 +146,50 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             const us8 l8 = __builtin_bit_cast(us8, ow4);
             *reinterpret_cast<us8*>(At + r * MH_LD + col) = l8;
             if (p.p1) *reinterpret_cast<us8*>(p.p1 + (m0 + r) * MH_C + col) = l8;
+        };
+        if ((p.W & 3) == 0 && !p.taps1) {
+#pragma unroll 1
+            for (int i = 0; i < MH_BM * 8 / 512; ++i) {          // 32 pixel groups x 32 chunks = 1024 items
+                const int c = tid + i * 512, gq = c >> 5, col = (c & 31) * 8;
+                const int r0 = gq * 4;
+                int oh = oh0, ow = ow0 + r0;                     // (pix0 % 4 == 0 and W % 4 == 0: the four pixels share a row)
+                while (ow >= p.W) { ow -= p.W; ++oh; }
+                const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f);
+                const int y0 = (int)sy, y1 = min(y0 + 1, H2 - 1);
+                const float ly = sy - y0;
+                const int j2 = ow >> 1;                           // = 2j
+                const int ca = max(j2 - 1, 0), cb = j2, cc = min(j2 + 1, W2 - 1), cd = min(j2 + 2, W2 - 1);
+                const bf16_t* r0p = tb + (long long)y0 * W2 * MH_C + col;
+                const bf16_t* r1p = tb + (long long)y1 * W2 * MH_C + col;
+#if MH_ABLATE == 1
+                const u32x4_t a0 = {(unsigned)y0, 0u, 0u, 0u}, b0 = {(unsigned)ca, 0u, 0u, 0u}, c0 = {(unsigned)y1, 0u, 0u, 0u}, d0 = a0, a1 = b0, b1 = c0, c1v = a0, d1 = b0;
+#else
+                const u32x4_t a0 = *reinterpret_cast<const u32x4_t*>(r0p + ca * MH_C), b0 = *reinterpret_cast<const u32x4_t*>(r0p + cb * MH_C);
+                const u32x4_t c0 = *reinterpret_cast<const u32x4_t*>(r0p + cc * MH_C), d0 = *reinterpret_cast<const u32x4_t*>(r0p + cd * MH_C);
+                const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(r1p + ca * MH_C), b1 = *reinterpret_cast<const u32x4_t*>(r1p + cb * MH_C);
+                const u32x4_t c1v = *reinterpret_cast<const u32x4_t*>(r1p + cc * MH_C), d1 = *reinterpret_cast<const u32x4_t*>(r1p + cd * MH_C);
+#endif
+                // generic horizontal weights of the four pixels: sx = max(0.5 (ow + 0.5) - 0.5, 0), lx = sx - floor(sx)
+                auto lx_of = [](int o) { const float sx = fmaxf(0.5f * (o + 0.5f) - 0.5f, 0.f); return sx - (float)(int)sx; };
+                blend_store(r0, col, a0, b0, a1, b1, lx_of(ow), ly);             // x0 = 2j-1 (ow = 0: lx = 0 and a == b's data)
+                blend_store(r0 + 1, col, b0, c0, b1, c1v, lx_of(ow + 1), ly);    // x0 = 2j
+                blend_store(r0 + 2, col, b0, c0, b1, c1v, lx_of(ow + 2), ly);    // x0 = 2j
+                blend_store(r0 + 3, col, c0, d0, c1v, d1, lx_of(ow + 3), ly);    // x0 = 2j+1 (right border: d clamps to c's column)
+            }
+        } else {
+#pragma unroll 2
+            for (int i = 0; i < MH_BM * 32 / 512; ++i) {
+                const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+                int oh = oh0, ow = ow0 + r;                      // (pix0 + r) / W, % W without a per-item division
+                while (ow >= p.W) { ow -= p.W; ++oh; }
+                const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ow + 0.5f) - 0.5f, 0.f);
+                const int y0 = (int)sy, x0 = (int)sx, y1 = min(y0 + 1, H2 - 1), x1 = min(x0 + 1, W2 - 1);
+                const u32x4_t v00 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x0) * MH_C + col);
+                const u32x4_t v01 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y0 * W2 + x1) * MH_C + col);
+                const u32x4_t v10 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x0) * MH_C + col);
+                const u32x4_t v11 = *reinterpret_cast<const u32x4_t*>(tb + ((long long)y1 * W2 + x1) * MH_C + col);
+                blend_store(r, col, v00, v01, v10, v11, sx - x0, sy - y0);
+            }
         }
     }
     __syncthreads();
@@ -157,8 +204,10 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             for (int e = 0; e < 16; ++e) acc[ps][e] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
+#if MH_ABLATE != 5
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
                 acc[ps] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc[ps], 0, 0, 0);
+#endif
                 if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)ps * 32 + kk + MH_RING) * 512);
                 else if (ps + 1 < NPASS) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)(ps + 1) * 32 + kk + MH_RING - 16) * 512);
             }
@@ -176,7 +225,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
                 for (int e = 0; e < 4; ++e) {
                     if (n + e < p.nq) {
                         float v = acc[ps][4 * q + e] + mbv[e];
+#if MH_ABLATE != 5
                         if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+#endif
                         if (p.planar) St[(n + e) * MH_BM + r * 32 + l31] = v;
                         else St[(r * 32 + l31) * p.nq + n + e] = v;
                     }
@@ -194,7 +245,11 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             for (int i = tid; i < total4; i += 512)
                 *reinterpret_cast<f32x4*>(ob + (long long)(i >> 5) * per + (i & 31) * 4) = *reinterpret_cast<const f32x4*>(St + 4 * i);
         } else {
+#if MH_ABLATE != 3
             for (int i = tid; i < total4; i += 512) *reinterpret_cast<f32x4*>(og + 4 * i) = *reinterpret_cast<const f32x4*>(St + 4 * i);
+#else
+            if (tid == 0 && St[0] == 123456.f) og[0] = St[1];
+#endif
         }
     }
 }
@@ -247,6 +302,7 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
     a.c1 = (const bf16_t*)c1; a.t1 = (const bf16_t*)t1; a.wc = (const bf16_t*)w_lateral; a.sc = scale; a.bc = bias;
     a.mw = (const bf16_t*)mask_w; a.mb = mask_b; a.prob = prob; a.p1 = (bf16_t*)p1_out;
     a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid & 1; a.planar = (apply_sigmoid >> 1) & 1;
+    a.taps1 = (apply_sigmoid >> 2) & 1;           // + 4: one pixel per bilinear item (tests: both forms must agree bit for bit)
     const long long blocks = (long long)B * H * W / MH_BM;
     if (nq <= 64) {
         NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<64>);

@@ -1192,6 +1192,24 @@ def test_score_maps_reproducible_next_to_mfma_kernels(device):
     assert bad == 0, "%d of 96 launches differ from the idle-GPU result" % bad
 
 
+def test_mask_head_shared_taps_equal_the_per_pixel_form(device):
+    """Round 5: the bilinear phase of the fused mask head loads the eight taps of four consecutive output pixels once (half the tap loads);
+    the result - probabilities and the optional p1 map - must equal the one-pixel-per-item form bit for bit, image borders included
+    (first / last rows and columns: clamped taps), for several images and both plane paddings."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for B, H, W, nq in ((2, 120, 160, 50), (1, 16, 32, 50), (1, 8, 64, 128)):
+        c1 = (0.5 * torch.randn(B, H, W, 256, generator=g)).to(device, torch.bfloat16)
+        t1 = (0.5 * torch.randn(B, H // 2, W // 2, 256, generator=g)).to(device, torch.bfloat16)
+        wl = ops.mfma_fragment_major((torch.randn(256, 256, generator=g) / 16).to(device, torch.bfloat16))
+        sc, bi = (1 + 0.1 * torch.randn(256, generator=g)).to(device), (0.1 * torch.randn(256, generator=g)).to(device)
+        mw, mb = (torch.randn(B, nq, 256, generator=g) / 16).to(device), torch.randn(B, nq, generator=g).to(device)
+        a, pa = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, want_p1=True)
+        b, pb = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, want_p1=True, taps1=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(a, b), (B, H, W, nq)
+
+
 def test_stream_set_places_streams_by_hardware_queue(device):
     """streams.StreamSet: the probe (a tiny kernel behind another stream's spin kernel) sorts candidate streams into hardware-queue
     classes; the batch streams it hands out are pairwise on DIFFERENT queues (as long as there are queues left), side stream i shares
