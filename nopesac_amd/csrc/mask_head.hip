@@ -9,6 +9,8 @@
 // LDS, the lateral GEMM streams W_c1 fragment-major from L2 (pwchain.hip), the up-sampling term is added cooperatively
 // (16-byte channel chunks, 4 taps from the L2-resident low-resolution map), p1 stays in LDS as the A operand of the mask GEMM,
 // and the 128 x 50 probabilities leave as one contiguous 25 KB run.  HBM: 629 MB in + 246 MB out.
+#include <type_traits>
+
 #include "common.h"
 
 namespace nps {
@@ -254,6 +256,269 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: PERSISTENT, software-pipelined form (an experiment that LOST - kept, tested bit-identical, off by default; see the launcher).
+// The phase ablation of mask_head_kernel shows its phases
+// ADD - c1 load 56 + lateral GEMM 139 + bilinear taps 136 + mask GEMM / sigmoid 84 + store 31 of 555 us: the two workgroups of a CU do
+// not hide each other's memory phases.  Here ONE 8-wave workgroup per CU walks its XCD's run of 128-pixel tiles and overlaps the memory
+// phases of a tile with its own MFMA phases:
+//   * the c1 rows of tile i+1 arrive by LDS-DMA (`buffer_load ... lds`: no registers) into a second, UNPADDED operand tile (512-byte
+//     rows, 16-byte chunks XOR-swizzled with row & 15 on the source address and on the fragment reads) while tile i runs its mask GEMM,
+//     sigmoid and store;
+//   * the 16 bilinear tap vectors of a thread (two items of four pixels x eight taps) are requested BEFORE the lateral GEMM of the
+//     same tile into 64 registers (one workgroup per CU: 256 registers per lane) and are consumed after it;
+//   * the probability store goes through a bounds-checked buffer descriptor (always four stores per thread), so the wait for the next
+//     tile's DMAs at the top of the loop is a counted one that never waits for the stores.
+// Same arithmetic and rounding points as mask_head_kernel: bit-identical output (tests).
+constexpr int MHP_C1_BYTES = MH_BM * MH_C * 2;                                     // 64 KB, unpadded, swizzled
+constexpr int MHP_VEC_BYTES = (256 + 256 + MH_NQP_MAX) * 4;                        // folded BN scale / bias of the lateral conv, mask bias
+constexpr size_t MHP_LDS_BYTES = (size_t)MHP_C1_BYTES + MH_LDS_BYTES + MHP_VEC_BYTES;   // + the working tile: 134.1 KB
+
+// LDS-only workgroup barrier: with an LDS-DMA in flight __syncthreads() would drain vmcnt(0) - the next tile's rows AND the stores
+#define MHP_SYNC()                                             \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    } while (0)
+
+template <int NQP>
+__global__ __launch_bounds__(512, 1) void mask_head_pipe_kernel(const MaskHeadArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NPASS = NQP / 64, NTILES = NQP / 32;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char mh_smem[];
+    unsigned char* C1t = mh_smem;                                                  // [128][256] bf16, chunk c of row r at (c ^ (r & 15)) * 16
+    bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem + MHP_C1_BYTES);               // [128][264]: lateral -> p1 -> f32 staging
+    float* SCl = reinterpret_cast<float*>(mh_smem + MHP_C1_BYTES + MH_LDS_BYTES);  // [256] scale, [256] bias, [NQP] mask bias of the tile's image:
+    float* BCl = SCl + 256;                                                        // read from LDS so that no epilogue waits on vmcnt
+    float* MBl = BCl + 256;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = p.H * p.W;
+    const int ntile = (int)((long long)p.B * per / MH_BM);
+    // XCD x owns a contiguous run of tiles (its L2 then holds only the t1 rows its own tiles tap); its workgroups walk the run with stride
+    const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int tq = ntile / nx, tr = ntile % nx;
+    const int run_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int run_end = run_begin + tq + (xcd < tr ? 1 : 0);
+    const int stride = ((int)gridDim.x - xcd + 7) / 8;
+    int tile = run_begin + slot;
+    if (tile >= run_end) return;
+
+    const __amdgpu_buffer_rsrc_t c1src = __builtin_amdgcn_make_buffer_rsrc((void*)p.c1, 0, (int)((long long)p.B * per * MH_C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t probr = __builtin_amdgcn_make_buffer_rsrc((void*)p.prob, 0, (int)((long long)p.B * per * p.nq * 4), 0x00020000);
+    // DMA d of wave w fills rows 2 (8 w + d), + 1: lane -> row 2 (8 w + d) + (lane >> 5), PHYSICAL chunk lane & 31 <- logical chunk (lane & 31) ^ (row & 15)
+    // (row & 15 = 2 d + half: the swizzle of DMA d is one XOR away from that of DMA 0)
+    // ALWAYS eight DMAs (`on` = false: out of the descriptor's range, nothing is fetched): a conditional DMA would make the compiler's own
+    // counted waits for the mask-weight registers assume the path without DMAs - and drain them
+    auto stage_c1 = [&](int t, int l31, int half, bool on) {
+        const unsigned x0 = (unsigned)((l31 ^ half) * 16), r0b = (unsigned)((wave * 16 + half) * MH_C * 2);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const unsigned vo = on ? r0b + (x0 ^ (unsigned)(d * 32)) : 0x7FFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c1src, (__attribute__((address_space(3))) void*)(C1t + (wave * 8 + d) * 1024), 16, vo,
+                                                     (unsigned)t * (unsigned)(MH_BM * MH_C * 2) + (unsigned)(d * 1024), 0, 0);
+        }
+    };
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    auto unpack = [](unsigned int wd) { return f32x2_t{__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)}; };
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+
+    if (tid < 256) { SCl[tid] = p.sc[tid]; BCl[tid] = p.bc[tid]; }              // (visible behind the first barrier; waited for before the DMAs start)
+    float mb_in = p.mb[(long long)((long long)tile * MH_BM / per) * NQP + (tid & (NQP - 1))];     // mask bias of the first tile's image
+    stage_c1(tile, tid & 31, (tid >> 5) & 1, true);
+    bf16x8 ring[MH_RING], mwf[MH_RING];
+    bool first = true;
+    while (true) {
+        // Every per-thread quantity of a tile is derived from an OPAQUE copy of the thread index: left to itself the compiler hoists the
+        // thread-dependent halves of all addresses out of the tile loop - dozens of registers that live across it, spill, and whose
+        // reloads (scratch loads count in vmcnt like any load) would turn the counted waits below into full drains.
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int lane = tl & 63, l31 = lane & 31, half = lane >> 5;
+        const long long m0 = (long long)tile * MH_BM;
+        const int b = (int)(m0 / per), pix0 = (int)(m0 % per);
+        const bf16_t* wlp = p.wc + ((long long)wave * 16 * 64 + lane) * 8;
+        const bf16_t* wmp = p.mw + (((long long)b * NTILES + (wave & 1)) * 16) * 512 + lane * 8;
+        // ---- requests of this tile: lateral weights (ring), bilinear taps (two items of four pixels: 16 vectors)
+#pragma unroll
+        for (int s = 0; s < MH_RING; ++s) ring[s] = *reinterpret_cast<const bf16x8*>(wlp + s * 512);
+        u32x4_t tap[2][8];
+        float lyv[2];
+        int owv[2];
+        const int oh0 = pix0 / p.W, ow0 = pix0 - oh0 * p.W;
+        const bf16_t* tb = p.t1 + (long long)b * H2 * W2 * MH_C;
+        auto request_taps = [&](auto IC_) {
+            constexpr int i = decltype(IC_)::value;
+            const int c = tl + i * 512, gq = c >> 5, col = (c & 31) * 8;
+            int oh = oh0, ow = ow0 + gq * 4;
+            while (ow >= p.W) { ow -= p.W; ++oh; }
+            const float sy = fmaxf(0.5f * (oh + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)sy, y1 = min(y0 + 1, H2 - 1);
+            lyv[i] = sy - y0; owv[i] = ow;
+            const int j2 = ow >> 1;
+            const int ca = max(j2 - 1, 0), cb = j2, cc = min(j2 + 1, W2 - 1), cd = min(j2 + 2, W2 - 1);
+            const bf16_t* r0p = tb + (long long)y0 * W2 * MH_C + col;
+            const bf16_t* r1p = tb + (long long)y1 * W2 * MH_C + col;
+            tap[i][0] = *reinterpret_cast<const u32x4_t*>(r0p + ca * MH_C); tap[i][1] = *reinterpret_cast<const u32x4_t*>(r0p + cb * MH_C);
+            tap[i][2] = *reinterpret_cast<const u32x4_t*>(r0p + cc * MH_C); tap[i][3] = *reinterpret_cast<const u32x4_t*>(r0p + cd * MH_C);
+            tap[i][4] = *reinterpret_cast<const u32x4_t*>(r1p + ca * MH_C); tap[i][5] = *reinterpret_cast<const u32x4_t*>(r1p + cb * MH_C);
+            tap[i][6] = *reinterpret_cast<const u32x4_t*>(r1p + cc * MH_C); tap[i][7] = *reinterpret_cast<const u32x4_t*>(r1p + cd * MH_C);
+        };
+        request_taps(std::integral_constant<int, 0>{});          // item 0 flies under the lateral GEMM; item 1 is requested behind its MFMAs
+        // ---- the c1 rows of this tile: 8 DMAs per wave issued one tile ago (or above).  vmcnt retires in issue order; younger than the
+        //      DMAs are the 8 + 8 loads just requested and, except for the first tile, the previous tile's NQP / 16 probability stores -
+        //      a counted wait that leaves exactly those in flight (the stores are never waited for)
+        if (first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (NQP == 64) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (tl < NQP) MBl[tl] = mb_in;                          // (requested BEFORE the DMAs: arrived; read behind three more barriers)
+        MHP_SYNC();
+        // ---- lateral = relu(bn(W_c1 c1)): wave owns channels wave*32 .. +32 of all four 32-pixel row tiles
+        {
+            f32x16 acc[MH_RT];
+#pragma unroll
+            for (int r = 0; r < MH_RT; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+                for (int r = 0; r < MH_RT; ++r) {
+                    const int row = r * 32 + l31;
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(C1t + row * 512 + (((kk * 2 + half) ^ (l31 & 15)) * 16));
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[kk % MH_RING], af, acc[r], 0, 0, 0);
+                }
+                if (kk + MH_RING < 16) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wlp + (kk + MH_RING) * 512);
+                else ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING - 16) * 512);     // mask GEMM k-steps 0..7
+                if ((kk & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            request_taps(std::integral_constant<int, 1>{});
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = wave * 32 + 8 * q + 4 * half;
+                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(SCl + n), bb = *reinterpret_cast<const f32x4*>(BCl + n);
+#pragma unroll
+                for (int r = 0; r < MH_RT; ++r) {
+                    us4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[r][4 * q + e] * sc4[e];
+                        v += bb[e];
+                        o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                    *reinterpret_cast<us4*>(At + (r * 32 + l31) * MH_LD + n) = o;
+                }
+            }
+        }
+        MHP_SYNC();                                               // lateral complete in At; every wave is done reading the c1 tile
+        // ---- p1 = lateral + relu(bilinear_2x(t1)) from the tap registers
+        {
+            auto blend_store = [&](int r, int col, const u32x4_t& v00, const u32x4_t& v01, const u32x4_t& v10, const u32x4_t& v11, float lx, float ly) {
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const u32x4_t lw = *reinterpret_cast<const u32x4_t*>(At + r * MH_LD + col);
+                u32x4_t ow4;
+                const f32x2_t hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2_t top = hx2 * unpack(v00[e]) + lx2 * unpack(v01[e]), bot = hx2 * unpack(v10[e]) + lx2 * unpack(v11[e]);
+                    f32x2_t u = hy2 * top + ly2 * bot;
+                    u.x = u.x > 0.f ? u.x : 0.f;
+                    u.y = u.y > 0.f ? u.y : 0.f;
+                    u = u + unpack(lw[e]);
+                    ow4[e] = f32x2_to_bf16x2(u.x, u.y);
+                }
+                const us8 l8 = __builtin_bit_cast(us8, ow4);
+                *reinterpret_cast<us8*>(At + r * MH_LD + col) = l8;
+                if (p.p1) *reinterpret_cast<us8*>(p.p1 + (m0 + r) * MH_C + col) = l8;
+            };
+            auto lx_of = [](int o) { const float sx = fmaxf(0.5f * (o + 0.5f) - 0.5f, 0.f); return sx - (float)(int)sx; };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tl + i * 512, r0 = (c >> 5) * 4, col = (c & 31) * 8;
+                const int ow = owv[i];
+                blend_store(r0, col, tap[i][0], tap[i][1], tap[i][4], tap[i][5], lx_of(ow), lyv[i]);
+                blend_store(r0 + 1, col, tap[i][1], tap[i][2], tap[i][5], tap[i][6], lx_of(ow + 1), lyv[i]);
+                blend_store(r0 + 2, col, tap[i][1], tap[i][2], tap[i][5], tap[i][6], lx_of(ow + 2), lyv[i]);
+                blend_store(r0 + 3, col, tap[i][2], tap[i][3], tap[i][6], tap[i][7], lx_of(ow + 3), lyv[i]);
+            }
+        }
+        MHP_SYNC();
+        // ---- everything the rest of the tile consumes from global memory is requested BEFORE the next tile's DMAs (a consumed load that
+        //      is younger than a DMA makes its wait a wait for the DMA: vmcnt retires in order): mask weights k-steps 8..15
+        const int mr = wave >> 1;
+#pragma unroll
+        for (int s2 = 0; s2 < MH_RING; ++s2) mwf[s2] = *reinterpret_cast<const bf16x8*>(wmp + (s2 + MH_RING) * 512);
+        // ---- the next tile's c1 rows: the c1 tile is dead since the barrier behind the lateral GEMM
+        const int next = tile + stride;
+        const bool more = next < run_end;
+        if (more) mb_in = p.mb[(long long)((long long)next * MH_BM / per) * NQP + (tl & (NQP - 1))];
+        stage_c1(next, l31, half, more);
+        // ---- mask logits: NQP (padded) planes = NQP/32 column tiles x 4 row tiles = 8 * NPASS (tile, rows) pairs, NPASS per wave
+        {
+            const int r = mr;
+            f32x16 acc[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ps][e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + (r * 32 + l31) * MH_LD + kk * 16 + half * 8);
+                    acc[ps] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kk < MH_RING ? ring[kk] : mwf[kk - MH_RING], af, acc[ps], 0, 0, 0);
+                    // (NQP = 128 only: the second column tile's fragments are requested behind the DMAs - their wait includes the DMAs')
+                    if (ps + 1 < NPASS) {
+                        if (kk < MH_RING) ring[kk] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)(ps + 1) * 32 + kk) * 512);
+                        else mwf[kk - MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)(ps + 1) * 32 + kk) * 512);
+                    }
+                }
+            }
+            MHP_SYNC();                                           // p1 is dead: the tile becomes the [128][nq] f32 staging buffer
+            float* St = reinterpret_cast<float*>(At);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int nt = (wave & 1) + 2 * ps;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nt * 32 + 8 * q + 4 * half;
+                    const f32x4 mb4 = *reinterpret_cast<const f32x4*>(MBl + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.nq) {
+                            float v = acc[ps][4 * q + e] + mb4[e];
+                            if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+                            St[(r * 32 + l31) * p.nq + n + e] = v;
+                        }
+                    }
+                }
+            }
+        }
+        MHP_SYNC();
+        {
+            // 128 * nq floats, contiguous; NQP / 16 16-byte stores per thread whatever nq (<= NQP: NQP * 32 vectors; the vectors >= total4
+            // are pointed out of the descriptor's range, where the bounds check drops them - the count of stores in flight is fixed)
+            const float* St = reinterpret_cast<const float*>(At);
+            const int total4 = MH_BM * p.nq / 4;
+            const unsigned base = (unsigned)((m0 * p.nq) * 4);
+#pragma unroll
+            for (int k = 0; k < NQP / 16; ++k) {
+                const int i = tl + k * 512;
+                const bool on = i < total4;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(St + 4 * (on ? i : 0));
+                __builtin_amdgcn_raw_buffer_store_b128(v, probr, on ? (int)(base + (unsigned)i * 16u) : (int)0x7FFFFFF0, 0, 0);
+            }
+        }
+        MHP_SYNC();                                               // staging reads done before the next tile's lateral epilogue rewrites At
+        if (!more) break;
+        tile = next;
+        first = false;
+    }
+#endif
+}
+
 }  // namespace nps
 
 // The mask GEMM's per-image operands from the folded plane embeddings (plane_head.py: `fold` f32 [B * nq][ld], columns 0..255 = mask
@@ -304,6 +569,27 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
     a.B = B; a.H = H; a.W = W; a.nq = nq; a.apply_sigmoid = apply_sigmoid & 1; a.planar = (apply_sigmoid >> 1) & 1;
     a.taps1 = (apply_sigmoid >> 2) & 1;           // + 4: one pixel per bilinear item (tests: both forms must agree bit for bit)
     const long long blocks = (long long)B * H * W / MH_BM;
+    // round 5: the persistent software-pipelined form (row-major probabilities, W % 4 == 0, everything within 32-bit byte offsets) runs
+    // only on request - flag bit 3 (+ 8) or NOPESAC_MASK_HEAD_PIPE=1: measured 590 us against 460 us of the two-workgroups-per-CU form
+    // at the headline shape (a tile costs the SUM of its HBM, LDS, vector-memory, MFMA and VALU times in one
+    // workgroup whatever is prefetched; two workgroups per CU overlap those resources, one does not)
+    static const bool pipe_on = getenv("NOPESAC_MASK_HEAD_PIPE") && atoi(getenv("NOPESAC_MASK_HEAD_PIPE")) == 1;
+    if ((pipe_on || ((apply_sigmoid >> 3) & 1)) && !a.planar && !a.taps1 && W % 4 == 0 && (long long)B * H * W * 256 * 2 < (1ll << 31) &&
+        (long long)B * H * W * nq * 4 < (1ll << 31) - (1 << 20)) {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        const int grid = (int)(blocks < cus ? blocks : cus);
+        if (nq <= 64) {
+            NPS_ENSURE_LDS((int)MHP_LDS_BYTES, mask_head_pipe_kernel<64>);
+            hipLaunchKernelGGL(mask_head_pipe_kernel<64>, dim3(grid), dim3(512), MHP_LDS_BYTES, (hipStream_t)stream, a);
+        } else {
+            NPS_ENSURE_LDS((int)MHP_LDS_BYTES, mask_head_pipe_kernel<128>);
+            hipLaunchKernelGGL(mask_head_pipe_kernel<128>, dim3(grid), dim3(512), MHP_LDS_BYTES, (hipStream_t)stream, a);
+        }
+        NPS_LAUNCH_RET();
+    }
     if (nq <= 64) {
         NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<64>);
         hipLaunchKernelGGL(mask_head_kernel<64>, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);

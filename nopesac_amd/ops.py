@@ -1130,9 +1130,11 @@ def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tenso
 
 
 def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scale, bias, mask_w: torch.Tensor, mask_b: torch.Tensor,
-              sigmoid: bool = True, want_p1: bool = False, planar: bool = False, fold: Optional[torch.Tensor] = None, taps1: bool = False):
+              sigmoid: bool = True, want_p1: bool = False, planar: bool = False, fold: Optional[torch.Tensor] = None, taps1: bool = False,
+              pipe: bool = False):
     """Fused lateral conv + bilinear add + per-image mask GEMM (csrc/mask_head.hip).  c1 [B,H,W,256] / t1 [B,H/2,W/2,256] bf16;
-    mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] ([B,nq,H,W] when `planar`) (and p1 bf16 if asked)."""
+    mask_w [B,nq,256] (any float dtype), mask_b [B,nq] f32 -> prob f32 [B,H,W,nq] ([B,nq,H,W] when `planar`) (and p1 bf16 if asked).
+    `pipe`: the persistent software-pipelined kernel (round-5 experiment, slower; bit-identical) instead of two workgroups per CU."""
     _chk(c1, torch.bfloat16); _chk(t1, torch.bfloat16); _chk(w_lat_frag, torch.bfloat16)
     B, H, W, C = c1.shape
     nq = mask_w.shape[1] if fold is None else fold.shape[0] // B
@@ -1154,7 +1156,7 @@ def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scal
     prob = torch.empty((B, nq, H, W) if planar else (B, H, W, nq), device=c1.device, dtype=torch.float32)
     p1 = torch.empty(B, H, W, 256, device=c1.device, dtype=torch.bfloat16) if want_p1 else None
     rc = _L().nopesac_mask_head_bf16(_p(c1), _p(t1), _p(w_lat_frag), _p(scale), _p(bias), _p(mw), _p(mb), _p(prob), _p(p1), B, H, W, nq,
-                                     int(sigmoid) | (2 if planar else 0) | (4 if taps1 else 0), _stream())
+                                     int(sigmoid) | (2 if planar else 0) | (4 if taps1 else 0) | (8 if pipe else 0), _stream())
     _lib.check(rc, "nopesac_mask_head_bf16")
     return (prob, p1) if want_p1 else prob
 

@@ -10,13 +10,14 @@ t1 = (0.5 * torch.randn(B, 60, 80, 256, device=dev)).bfloat16()
 wl = ops.mfma_fragment_major((torch.randn(256, 256, device=dev) / 16).bfloat16())
 sc, bi = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 mw, mb = torch.randn(B, nq, 256, device=dev) / 16, torch.randn(B, nq, device=dev)
-for _ in range(3):
-    y = ops.mask_head(c1, t1, wl, sc, bi, mw, mb)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10):
-    y = ops.mask_head(c1, t1, wl, sc, bi, mw, mb)
-e1.record()
-torch.cuda.synchronize()
-print("mask_head: %.1f us" % (e0.elapsed_time(e1) * 1000 / 10))
+for pipe in (True, False):
+    for _ in range(3):
+        y = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, pipe=pipe)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        y = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, pipe=pipe)
+    e1.record()
+    torch.cuda.synchronize()
+    print("mask_head (%s): %.1f us" % ("persistent pipeline" if pipe else "two workgroups per CU", e0.elapsed_time(e1) * 1000 / 10))

@@ -1210,6 +1210,35 @@ def test_mask_head_shared_taps_equal_the_per_pixel_form(device):
         assert torch.equal(pa, pb) and torch.equal(a, b), (B, H, W, nq)
 
 
+def test_mask_head_persistent_pipeline_equals_the_two_workgroup_form(device):
+    """Round 5: the persistent, software-pipelined mask head (one workgroup per CU walking its XCD's run of tiles; c1 by LDS-DMA one tile
+    ahead, taps prefetched under the lateral GEMM, descriptor-checked stores; off by default - it measured slower) must give the bits of
+    the two-workgroups-per-CU kernel:
+    fewer tiles than CUs, many tiles per CU (several images: the per-image mask operands change inside a workgroup's walk), tile counts
+    that do not divide by 8 XCDs, both plane paddings, nq that leaves the last store vectors of a tile out of range, logits and p1."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(22)
+    for B, H, W, nq, sig in ((1, 16, 32, 50, True), (3, 120, 160, 50, True), (5, 24, 48, 20, False), (2, 48, 64, 128, True), (9, 40, 32, 66, True),
+                             (16, 120, 160, 50, True)):
+        c1 = (0.5 * torch.randn(B, H, W, 256, generator=g)).to(device, torch.bfloat16)
+        t1 = (0.5 * torch.randn(B, H // 2, W // 2, 256, generator=g)).to(device, torch.bfloat16)
+        wl = ops.mfma_fragment_major((torch.randn(256, 256, generator=g) / 16).to(device, torch.bfloat16))
+        sc, bi = (1 + 0.1 * torch.randn(256, generator=g)).to(device), (0.1 * torch.randn(256, generator=g)).to(device)
+        mw, mb = (torch.randn(B, nq, 256, generator=g) / 16).to(device), torch.randn(B, nq, generator=g).to(device)
+        for want_p1 in (False, True):
+            a = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, sigmoid=sig, want_p1=want_p1, pipe=True)
+            b = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, sigmoid=sig, want_p1=want_p1)
+            torch.cuda.synchronize()
+            if want_p1:
+                assert torch.equal(a[1], b[1]), ("p1", B, H, W, nq)
+                a, b = a[0], b[0]
+            assert torch.equal(a, b), (B, H, W, nq, want_p1, (a != b).sum().item())
+        for _ in range(3):                                            # back to back on one stream: a launch must not see its predecessor's LDS / tiles
+            a2 = ops.mask_head(c1, t1, wl, sc, bi, mw, mb, sigmoid=sig, pipe=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a2, b), (B, H, W, nq, "repeat")
+
+
 def test_stream_set_places_streams_by_hardware_queue(device):
     """streams.StreamSet: the probe (a tiny kernel behind another stream's spin kernel) sorts candidate streams into hardware-queue
     classes; the batch streams it hands out are pairwise on DIFFERENT queues (as long as there are queues left), side stream i shares
