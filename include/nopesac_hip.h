@@ -753,6 +753,13 @@ int nopesac_sgd_step(float* param, const float* grad, float* momentum_buf, int64
  * too small, -100 built without zlib. */
 int nopesac_png_info_host(const unsigned char* data, int64_t n, int* height, int* width, int* channels, int* supported);
 int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr);
+/* A batch of PNG FILES on `threads` threads of the call itself (replaces the per-image Python of the reference mapper,
+ * planercnn_transforms.py:210-227, whose open / read / array / transpose steps hold the interpreter lock): file paths[i] -> out + i *
+ * image_stride, H x W x 3 interleaved or (flags bit 1) 3 x H x W channel-major - the mapper's CHW layout - in RGB or (flags bit 0) BGR
+ * order.  status[i] = 0, a code of nopesac_png_decode_host, -5 geometry is not H x W, -6 unreadable file.  Returns the number of files
+ * with a non-zero status (the caller hands those to PIL), negative on bad arguments. */
+int nopesac_png_decode_files_host(const char* const* paths, int n, unsigned char* out, int64_t image_stride, int H, int W, int flags,
+                                  int threads, int* status);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_png_info_host": [P, L, P, P, P, P],
     "nopesac_png_decode_host": [P, L, P, L, I],
+    "nopesac_png_decode_files_host": [P, I, P, L, I, I, I, I, P],
     "nopesac_refine_losses_backward": [P] * 11 + [I, I, F] + [P] * 7 + [P],
     "nopesac_refine_vote_backward": [P] * 15 + [I, I] + [P] * 20 + [P],
     "nopesac_refine_score_maps_backward": [P] * 6 + [I, I] + [P] * 7 + [P],

@@ -12,7 +12,6 @@ file.  Ground-truth masks / depth / k-means pose classes are not read: nothing o
 """
 from __future__ import annotations
 
-import copy
 import json
 import os
 from typing import List
@@ -65,6 +64,32 @@ def read_png_native(blob: bytes, fmt: str = "BGR"):
     return out if rc == 0 else None
 
 
+def read_png_files(paths: List[str], fmt: str = "BGR", height: int = 480, width: int = 640, chw: bool = True, threads: int = 4, out: torch.Tensor = None):
+    """A batch of PNG files decoded by ONE library call on `threads` threads of its own (csrc/png_host.hip
+    nopesac_png_decode_files_host: no per-image interpreter work - with one ctypes call per image the open / read / allocate / transpose
+    steps around it, interpreter lock held, capped 32 reader threads at 6.1 k images/s on cores that inflate 11 k).  Returns (uint8 tensor
+    [n, 3, H, W] (chw) or [n, H, W, 3], status list): status[i] != 0 -> image i was NOT written (another geometry, a variant the decoder
+    leaves to PIL, unreadable) and the caller reads that file itself.  `out`: a (pinned) uint8 buffer of that shape to decode into."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    n = len(paths)
+    shape = (n, 3, height, width) if chw else (n, height, width, 3)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8)
+    if tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_contiguous() or out.device.type != "cpu":
+        raise ValueError("read_png_files: out must be a contiguous host uint8 tensor of shape %r" % (shape,))
+    if n == 0:
+        return out, []
+    status = (ctypes.c_int * max(1, n))()
+    arr = (ctypes.c_char_p * max(1, n))(*[os.fsencode(p) for p in paths])
+    rc = L.nopesac_png_decode_files_host(arr, n, out.data_ptr(), 3 * height * width, height, width, (1 if fmt == "BGR" else 0) | (2 if chw else 0),
+                                         max(1, int(threads)), status)
+    if rc < 0:
+        raise RuntimeError("nopesac_png_decode_files_host: bad arguments")
+    return out, list(status[:n])
+
+
 def read_image(path: str, fmt: str = "BGR") -> np.ndarray:
     """detectron2 `utils.read_image`: uint8 [H,W,3] in `fmt` order (EXIF orientation ignored like d2 v0.4).  PNG files (the mp3d
     split) go through `read_png_native` when it takes them (bit-identical pixels: tests/test_host_cpu.py); everything else through PIL."""
@@ -84,6 +109,14 @@ def read_image(path: str, fmt: str = "BGR") -> np.ndarray:
     elif fmt != "RGB":
         raise ValueError(f"unsupported INPUT.FORMAT {fmt!r}")
     return np.ascontiguousarray(arr)
+
+
+def _png_batch_available() -> bool:
+    try:
+        from . import _lib
+        return hasattr(_lib.load(), "nopesac_png_decode_files_host")
+    except (RuntimeError, OSError, AttributeError):
+        return False
 
 
 def is_jpeg_path(path: str) -> bool:
@@ -183,7 +216,12 @@ class PairMapper:
 
     def __call__(self, dataset_dict: dict, images: List[torch.Tensor] = None) -> dict:
         """images: the two decoded images when the caller decoded a whole batch at once (map_batch)"""
-        d = copy.deepcopy(dataset_dict)
+        # (the reference mapper deep-copies the dict because it edits the annotations; here only these four keys of the two view dicts are
+        #  set, so the view dicts are copied and everything below them - the annotation lists of a pair are kilobytes - is shared: a deep
+        #  copy per pair is interpreter time the loader threads take from the thread that launches the model)
+        d = dict(dataset_dict)
+        for v in "01":
+            d[v] = dict(dataset_dict[v])
         for vi, v in enumerate("01"):
             if not self.scannet and self.root_dir:
                 d[v]["file_name"] = d[v]["file_name"].replace(MP3D_ORIGINAL_ROOT, self.root_dir)
@@ -216,8 +254,10 @@ class LazyPairs:
     shards), iteration and iter_batches() in order."""
 
     def __init__(self, entries: List[dict], mapper: "PairMapper", workers: int = 4, prefetch: int = 64):
+        import threading
         self.entries, self.mapper = entries, mapper
         self.workers, self.prefetch = max(1, int(workers)), max(1, int(prefetch))
+        self._decode_lock = threading.Lock()
 
     def __len__(self) -> int:
         return len(self.entries)
@@ -294,9 +334,53 @@ class LazyPairs:
                 ev.synchronize()
                 yield items
 
+    def _png_batch(self, entries: List[dict]):
+        """batch thread: every image of the batch through ONE native call (read_png_files, `workers` threads), files it does not take
+        through read_image; the mapped dicts hold views of the batch tensor (uint8 CHW) or of its float32 copy."""
+        m = self.mapper
+        paths = [n for e in entries for n in m.file_names(e)]
+        H, W = int(entries[0]["0"].get("height", 480)), int(entries[0]["0"].get("width", 640))          # (files of another size: status -5)
+        # The batch buffer comes from torch's PINNED host allocator when there is a GPU: it caches freed blocks, so after the first few
+        # batches a buffer is a recycled one - already faulted in (decoding into fresh pageable memory is bound by its page faults:
+        # measured 2.2 k images/s on 32 threads against 9.9 k into a buffer that has been touched before), the H2D copy of its images is a
+        # DMA, and the allocator itself keeps a block from being reused while such a copy is in flight.
+        pin = torch.cuda.is_available()
+        buf = torch.empty((len(paths), 3, H, W), dtype=torch.uint8, pin_memory=pin)
+        with self._decode_lock:                                   # one decode at a time, on all of this loader's threads; the mapping of
+            buf, status = read_png_files(paths, m.img_format, H, W, chw=True, threads=self.workers, out=buf)      # the batch before overlaps it
+        imgs = [None] * len(paths)
+        for i, st in enumerate(status):
+            if st != 0:                                           # another size / colour depth / not a PNG after all: the general reader
+                imgs[i] = m._image_host(paths[i])
+        batch = buf if m.uint8 else torch.empty(buf.shape, dtype=torch.float32, pin_memory=pin).copy_(buf)
+        if m.device is not None:
+            batch = batch.to(m.device, non_blocking=False)
+        for i in range(len(paths)):
+            if imgs[i] is None:
+                imgs[i] = batch[i]
+        return [m(e, images=imgs[2 * i:2 * i + 2]) for i, e in enumerate(entries)]
+
+    def _iter_batches_png(self, pairs_per_batch: int, ahead: int = 2):
+        """PNG splits (mp3d): whole batches decoded `ahead` of the consumer, each by one native call that runs on `workers` threads
+        without the interpreter (two batch threads: one batch's mapping overlaps the next one's decode)."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        chunks = [self.entries[i:i + pairs_per_batch] for i in range(0, len(self.entries), pairs_per_batch)]
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            pending, nxt = deque(), 0
+            while nxt < len(chunks) or pending:
+                while nxt < len(chunks) and len(pending) < ahead + 1:
+                    pending.append(pool.submit(self._png_batch, chunks[nxt]))
+                    nxt += 1
+                yield pending.popleft().result()
+
     def iter_batches(self, pairs_per_batch: int):
         if self.mapper._use_gpu_jpeg() and self.entries and is_jpeg_path(self.mapper.file_names(self.entries[0])[0]):
             yield from self._iter_batches_gpu(pairs_per_batch)
+            return
+        if (self.entries and not self.mapper.scannet and self.mapper.file_names(self.entries[0])[0].lower().endswith(".png")
+                and os.environ.get("NOPESAC_PNG_NATIVE", "1") != "0" and _png_batch_available()):
+            yield from self._iter_batches_png(pairs_per_batch)
             return
         batch = []
         for item in self:

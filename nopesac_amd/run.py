@@ -90,7 +90,7 @@ def load_pairs(args, cfg=None):
         if args.dataset or os.path.exists(data.dataset_json(name, args.datasets_dir)):
             lazy = data.build_inference_pairs(cfg, name, args.datasets_dir, args.limit, uint8=args.uint8_images, lazy=True,
                                               prefetch=max(64, 3 * args.pairs_per_batch))
-            lazy.workers = args.decode_workers or max(lazy.workers, min(32, os.cpu_count() or 4))
+            lazy.workers = args.decode_workers or max(lazy.workers, min(32, runner.cpu_budget()))
             return lazy
     n = args.synthetic_pairs or 8
     pairs = []
@@ -264,7 +264,7 @@ def _main_rank(args):
     from .config import amd_options
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     my_cores = runner.pin_rank_to_cores(local, ranks_here) if (world > 1 and amd_options(cfg).CPU_AFFINITY) else None
-    n_cores = len(my_cores) if my_cores is not None else max(1, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)) // max(1, ranks_here))
+    n_cores = min(len(my_cores), max(1, runner.cpu_budget() // max(1, ranks_here))) if my_cores is not None else max(1, runner.cpu_budget() // max(1, ranks_here))
     if not args.decode_workers:
         args.decode_workers = max(1, min(32, n_cores - (1 if n_cores > 2 else 0)))      # (one core stays with the thread that launches kernels)
     if args.stub_model:

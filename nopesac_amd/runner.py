@@ -67,6 +67,33 @@ def launch(main_func, num_gpus_per_machine: int, args=()):
     return None
 
 
+def cpu_budget() -> int:
+    """CPUs this process can actually keep busy: the cores it may run on (sched_getaffinity) capped by its cgroup's CPU quota
+    (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  A container that SEES 256 hardware threads under a 16-CPU quota
+    (the MI355X boxes of this build) runs 32 busy threads for half of every 100 ms period and parks ALL of them for the other half -
+    measured as 40 ms stalls of every decoder thread at once; thread pools are sized from this number, not from os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(math.ceil(quota))))
+    return max(1, n)
+
+
 def pin_rank_to_cores(local_rank: int, ranks_on_host: int) -> List[int]:
     """Restrict this process (and the threads it starts later) to the local_rank-th of `ranks_on_host` equal, contiguous shares of
     the cores it is allowed to use; returns the cores it now owns (unchanged set when the share would be empty or the platform has no

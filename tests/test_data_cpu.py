@@ -117,3 +117,21 @@ def test_lazy_pairs_decode_ahead_in_order(tmp_path):
         ref = mapper(entries[k])
         assert p["0"]["image_id"] == f"h_{k}_0" and torch.equal(p["0"]["image"], ref["0"]["image"]) and torch.equal(p["1"]["image"], ref["1"]["image"])
     assert [p["0"]["image_id"] for p in lazy[5:]] == ["h_5_0", "h_6_0"]
+    # the batch path (one native call per batch, csrc/png_host.hip) against the per-image path it replaces, float32 hand-over and BGR too;
+    # a palette file and a 16-bit file inside a batch (the second is left to PIL: status -2 -> the general reader)
+    Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)).quantize(64).save(entries[4]["1"]["file_name"])
+    Image.fromarray(rng.integers(0, 65535, (480, 640), dtype=np.uint16)).save(entries[2]["0"]["file_name"])
+    for overrides, u8 in (([], False), (["INPUT.FORMAT", "BGR"], True)):
+        m2 = data.PairMapper(_cfg(overrides), "mp3d_test", uint8=u8)
+        lz = data.LazyPairs(entries, m2, workers=4, prefetch=4)
+        batched = [p for b in lz.iter_batches(4) for p in b]
+        os.environ["NOPESAC_PNG_NATIVE"] = "0"
+        try:
+            plain = [p for b in lz.iter_batches(4) for p in b]
+        finally:
+            os.environ.pop("NOPESAC_PNG_NATIVE")
+        assert len(batched) == len(plain) == 7
+        for a, b in zip(batched, plain):
+            for v in "01":
+                assert a[v]["image"].dtype == b[v]["image"].dtype and torch.equal(a[v]["image"], b[v]["image"]), (overrides, a[v]["image_id"])
+    assert "image" not in entries[0]["0"]                                                # the json entries are never written to

@@ -336,3 +336,27 @@ def test_png_host_decoder_matches_pillow(tmp_path):
     assert data.read_png_native(bytes(blob), "RGB") is None
     assert data.read_png_native((tmp_path / "RGB_False.png").read_bytes()[:-40], "RGB") is None
     assert data.read_png_native(b"not a png at all, but long enough to hold a header....", "RGB") is None
+    # the batch entry point (one call, its own threads): every file above at the batch's geometry decodes into its slot, channel-major or
+    # interleaved, either channel order; other sizes (-5), variants left to PIL (-2), damaged (-3) and missing (-6) files report a status
+    # and leave their slot untouched
+    (tmp_path / "broken.png").write_bytes(bytes(blob))
+    good = [str(tmp_path / f"{m}_{opt}.png") for m in modes for opt in (False, True)]
+    paths = good[:3] + [str(p), str(p16), str(tmp_path / "broken.png"), str(tmp_path / "missing.png")] + good[3:]
+    want = [0, 0, 0, -5, -2, -3, -6] + [0] * (len(good) - 3)
+    for chw in (True, False):
+        for fmt in ("RGB", "BGR"):
+            for thr in (1, 5):
+                pre = torch.full((len(paths), 3, 97, 131) if chw else (len(paths), 97, 131, 3), 7, dtype=torch.uint8)
+                out, st = data.read_png_files(paths, fmt, 97, 131, chw=chw, threads=thr, out=pre)
+                assert st == want and out.data_ptr() == pre.data_ptr()
+                for i, (f, s_) in enumerate(zip(paths, st)):
+                    if s_ != 0:
+                        assert int(out[i].min()) == 7 and int(out[i].max()) == 7
+                        continue
+                    ref = np.asarray(Image.open(f).convert("RGB"))
+                    ref = ref if fmt == "RGB" else ref[..., ::-1]
+                    got = out[i].numpy()
+                    assert np.array_equal(got.transpose(1, 2, 0) if chw else got, ref), (f, chw, fmt, thr)
+    out16, st16 = data.read_png_files([str(p16)], "RGB", 97, 131)
+    assert st16 == [-2]
+    assert data.read_png_files([], "RGB", 97, 131)[1] == []
