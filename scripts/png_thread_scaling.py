@@ -1,3 +1,4 @@
+"""Thread scaling of the batch PNG decoder (data.read_png_files) into a reused and into a fresh output buffer (page faults)."""
 import os, sys, time, tempfile
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

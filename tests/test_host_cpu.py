@@ -360,3 +360,27 @@ def test_png_host_decoder_matches_pillow(tmp_path):
     out16, st16 = data.read_png_files([str(p16)], "RGB", 97, 131)
     assert st16 == [-2]
     assert data.read_png_files([], "RGB", 97, 131)[1] == []
+
+
+def test_cpu_budget_respects_affinity_and_quota(monkeypatch, tmp_path):
+    """runner.cpu_budget: thread pools are sized from what the container may keep busy - the affinity mask capped by the cgroup CPU quota
+    (cpu.max "1600000 100000" = 16 CPUs on a host that shows 256 hardware threads), never from os.cpu_count()."""
+    import builtins
+    import os
+    from nopesac_amd import runner
+    n = runner.cpu_budget()
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    assert 1 <= n <= aff
+    real_open = builtins.open
+    for text, want in (("1600000 100000\n", min(aff, 16)), ("max 100000\n", aff), ("150000 100000\n", min(aff, 2)), ("garbage", aff)):
+        def fake_open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(text)
+                return real_open(f, *a, **k)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise OSError("no v1 hierarchy")
+            return real_open(path, *a, **k)
+        monkeypatch.setattr(builtins, "open", fake_open)
+        assert runner.cpu_budget() == want, text
+        monkeypatch.setattr(builtins, "open", real_open)
