@@ -513,8 +513,21 @@ def rank_main(args):
         re-issued as plain launches by a C loop, side-stream structure kept) or, with --whole-graph, by hipGraphLaunch.  One replay
         per slot is checked against the slot's last eager results."""
         nonlocal graphs
+
+        def rows_of_every_slot():
+            # one step per slot, each followed by a barrier: with --gather-every G > 1 the rows travel in groups and barrier() flushes the
+            # partial group, so last_step_rows() is this step's [world * B, 16] whatever G is (round 5: the check used to read
+            # loop.host_bufs, which a grouped loop never writes - uninitialised pinned memory, NaN != NaN, and the tape leg was skipped)
+            out = []
+            for i in range(n_slots):
+                step(i)
+                barrier()
+                out.append(loop.last_step_rows().clone())
+            return out
         try:
             from nopesac_amd.tape import LaunchTape, TapeUnsupported
+            eager_rows = rows_of_every_slot()                  # eager results of each slot (same static inputs)
+            captured = [None] * n_slots
             for slot in range(n_slots):
                 g = torch.cuda.CUDAGraph(keep_graph=not args.whole_graph)
                 with torch.no_grad(), torch.cuda.graph(g, stream=streams[slot]):
@@ -526,12 +539,10 @@ def rank_main(args):
                     except TapeUnsupported as e:
                         print("launch tape unavailable (%s): whole-graph replay" % (e,), file=sys.stderr)
                         g.instantiate()
-                graphs[slot] = g
+                captured[slot] = g
+            graphs = captured
             barrier()
-            eager_rows = [hb.clone() for hb in host_bufs]      # last eager results of each slot (same static inputs)
-            for i in range(n_slots):                           # one replay per slot outside the timed region
-                step(i)
-            barrier()
+            host_bufs = rows_of_every_slot()                   # one replay per slot outside the timed region
             if not all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(eager_rows, host_bufs)):
                 diff = [[round(float(x), 6) for x in (a - b).abs().amax(dim=0)[:7]] for a, b in zip(eager_rows, host_bufs)]
                 # (every slot holds the same images: which side is the odd one out?)

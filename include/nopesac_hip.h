@@ -760,6 +760,9 @@ int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char*
  * with a non-zero status (the caller hands those to PIL), negative on bad arguments. */
 int nopesac_png_decode_files_host(const char* const* paths, int n, unsigned char* out, int64_t image_stride, int H, int W, int flags,
                                   int threads, int* status);
+/* The decoder's own inflate (csrc/inflate_host.h: a whole RFC 1950 / 1951 stream in memory -> a buffer of known size; replaces zlib's
+ * streaming inflate, the floor of the PNG path) on its own, for tests: bytes written, or -1 on any malformed stream / overflow. */
+int64_t nopesac_inflate_zlib_host(const unsigned char* in, int64_t n, unsigned char* out, int64_t out_cap);
 
 #ifdef __cplusplus
 }

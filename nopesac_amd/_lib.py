@@ -99,6 +99,7 @@ SIGNATURES = {
     "nopesac_png_info_host": [P, L, P, P, P, P],
     "nopesac_png_decode_host": [P, L, P, L, I],
     "nopesac_png_decode_files_host": [P, I, P, L, I, I, I, I, P],
+    "nopesac_inflate_zlib_host": [P, L, P, L],
     "nopesac_refine_losses_backward": [P] * 11 + [I, I, F] + [P] * 7 + [P],
     "nopesac_refine_vote_backward": [P] * 15 + [I, I] + [P] * 20 + [P],
     "nopesac_refine_score_maps_backward": [P] * 6 + [I, I] + [P] * 7 + [P],
@@ -117,7 +118,7 @@ SIGNATURES = {
     "nopesac_mlp_chain_bf16": [P, P],
 }
 _RESTYPE = {"nopesac_jpeg_prepare_scan": c_int64, "nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64,
-            "nopesac_conv2d_p8_sk_workspace_bytes": c_int64}
+            "nopesac_conv2d_p8_sk_workspace_bytes": c_int64, "nopesac_inflate_zlib_host": c_int64}
 
 MLP_MAX_IN, MLP_MAX_WIDTH, MLP_MAX_LAYERS = 1280, 1024, 12       # NOPESAC_MLP_* of the header
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "inflate_host.h"
 
 #if __has_include(<zlib.h>)
 #include <zlib.h>
@@ -36,13 +37,14 @@ namespace {
 // what one decode needs besides its input and output: the inflated scanlines and the inflate state.  The batch entry point keeps one per
 // pool thread (a fresh 900 KB block and a fresh 40 KB inflate state per image are malloc / mmap traffic from dozens of threads at once)
 struct PngScratch {
-    std::vector<unsigned char> raw, file;
+    std::vector<unsigned char> raw, file, idat;
+    nps_inflate::Tables tables;
     z_stream zs;
     bool zinit = false;
     ~PngScratch() { if (zinit) inflateEnd(&zs); }
 };
 #else
-struct PngScratch { std::vector<unsigned char> raw, file; };
+struct PngScratch { std::vector<unsigned char> raw, file, idat; nps_inflate::Tables tables; };
 #endif
 
 inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
@@ -114,18 +116,26 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
     unsigned char pal[256 * 3];
     memset(pal, 0, sizeof(pal));
     const int64_t stride = (int64_t)W * ch, raw_bytes = (stride + 1) * H;
-    if ((int64_t)sc.raw.size() < raw_bytes + 8) sc.raw.resize((size_t)raw_bytes + 8);
+    if ((int64_t)sc.raw.size() < raw_bytes + 64) sc.raw.resize((size_t)raw_bytes + 64);
     unsigned char* raw = sc.raw.data();
+    // The IDAT payloads (CRC-checked chunk by chunk) are gathered into one buffer and inflated in one go by csrc/inflate_host.h;
+    // NOPESAC_PNG_ZLIB_INFLATE=1 keeps zlib's streaming inflate (the first round-5 form; A/B and a way out).
+    static const bool use_zlib = getenv("NOPESAC_PNG_ZLIB_INFLATE") && atoi(getenv("NOPESAC_PNG_ZLIB_INFLATE")) == 1;
     z_stream& zs = sc.zs;
-    if (!sc.zinit) {
-        memset(&zs, 0, sizeof(zs));
-        if (inflateInit(&zs) != Z_OK) return -3;
-        sc.zinit = true;
-    } else if (inflateReset(&zs) != Z_OK) {
-        return -3;
+    if (use_zlib) {
+        if (!sc.zinit) {
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit(&zs) != Z_OK) return -3;
+            sc.zinit = true;
+        } else if (inflateReset(&zs) != Z_OK) {
+            return -3;
+        }
+        zs.next_out = raw;
+        zs.avail_out = (uInt)raw_bytes;
+    } else if ((int64_t)sc.idat.size() < n + 16) {
+        sc.idat.resize((size_t)n + 16);
     }
-    zs.next_out = raw;
-    zs.avail_out = (uInt)raw_bytes;
+    int64_t idat_len = 0;
     int rc = 0, zend = 0, have_plte = 0;
     int64_t p = 8;
     while (true) {
@@ -136,7 +146,10 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
         const unsigned char* body = data + p + 8;
         if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, L + 4) != be32(body + L)) { rc = -3; break; }
         if (memcmp(type, "IDAT", 4) == 0) {
-            if (!zend && L) {
+            if (!use_zlib) {
+                memcpy(sc.idat.data() + idat_len, body, L);
+                idat_len += L;
+            } else if (!zend && L) {
                 zs.next_in = (Bytef*)body;
                 zs.avail_in = L;
                 const int r = inflate(&zs, Z_NO_FLUSH);
@@ -152,7 +165,13 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
         }
         p += 12 + (int64_t)L;
     }
-    const int64_t got = raw_bytes - (int64_t)zs.avail_out;
+    int64_t got;
+    if (use_zlib) {
+        got = raw_bytes - (int64_t)zs.avail_out;
+    } else {
+        memset(sc.idat.data() + idat_len, 0, 16);
+        got = rc == 0 ? nps_inflate::inflate_zlib(sc.idat.data(), idat_len, raw, raw_bytes, sc.tables) : -1;
+    }
     if (rc == 0 && (got != raw_bytes || (ctype == 3 && !have_plte))) rc = -3;
     if (rc != 0) return rc;
     // ---- row filters (in place: a row's reconstructed samples are the next row's "up" samples)
@@ -298,4 +317,17 @@ extern "C" int nopesac_png_decode_files_host(const char* const* paths, int n, un
     if (T <= 1) work(mine);
     else png_pool().run(T - 1, work, mine);
     return failed.load();
+}
+
+// The inflate of csrc/inflate_host.h on its own (tests: against zlib on every block type, level and strategy, and on damaged streams):
+// a whole zlib stream in[n] -> out[out_cap]; returns the number of bytes written or -1.  No slack is required of the caller's buffers.
+extern "C" int64_t nopesac_inflate_zlib_host(const unsigned char* in, int64_t n, unsigned char* out, int64_t out_cap) {
+    if (!in || n < 0 || (!out && out_cap > 0) || out_cap < 0) return -1;
+    std::vector<unsigned char> src((size_t)n + 16, 0), dst((size_t)out_cap + 16);
+    memcpy(src.data(), in, (size_t)n);
+    PngScratch* sc = new PngScratch();
+    const int64_t got = nps_inflate::inflate_zlib(src.data(), n, dst.data(), out_cap, sc->tables);
+    delete sc;
+    if (got > 0) memcpy(out, dst.data(), (size_t)got);
+    return got;
 }

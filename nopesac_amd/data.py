@@ -338,7 +338,9 @@ class LazyPairs:
         """batch thread: every image of the batch through ONE native call (read_png_files, `workers` threads), files it does not take
         through read_image; the mapped dicts hold views of the batch tensor (uint8 CHW) or of its float32 copy."""
         m = self.mapper
-        paths = [n for e in entries for n in m.file_names(e)]
+        names = [m.file_names(e) for e in entries]
+        paths = [n[0] for n in names] + [n[1] for n in names]     # the model's batch order: every pair's view 0, then every pair's view 1 -
+        B = len(entries)                                          # its H2D copy of the batch is then ONE transfer of this buffer
         H, W = int(entries[0]["0"].get("height", 480)), int(entries[0]["0"].get("width", 640))          # (files of another size: status -5)
         # The batch buffer comes from torch's PINNED host allocator when there is a GPU: it caches freed blocks, so after the first few
         # batches a buffer is a recycled one - already faulted in (decoding into fresh pageable memory is bound by its page faults:
@@ -358,7 +360,7 @@ class LazyPairs:
         for i in range(len(paths)):
             if imgs[i] is None:
                 imgs[i] = batch[i]
-        return [m(e, images=imgs[2 * i:2 * i + 2]) for i, e in enumerate(entries)]
+        return [m(e, images=[imgs[i], imgs[B + i]]) for i, e in enumerate(entries)]
 
     def _iter_batches_png(self, pairs_per_batch: int, ahead: int = 2):
         """PNG splits (mp3d): whole batches decoded `ahead` of the consumer, each by one native call that runs on `workers` threads

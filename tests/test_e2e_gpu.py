@@ -338,9 +338,11 @@ def test_cli_runner_rows_match_the_oracle(device, tmp_path, sd50):
     assert np.isfinite(te).all()
 
 
-def test_cli_runner_on_a_dataset_split_from_disk(device, tmp_path):
+def test_cli_runner_on_a_dataset_split_from_disk(device, tmp_path, monkeypatch):
     """The runner on a (tiny) Matterport3D-style split on disk: json -> LazyPairs (decoder threads running ahead) -> uint8 images ->
-    batches in flight -> evaluator; 5 pairs, 2 per batch (ragged last batch), pose rows for every pair with a rel_pose."""
+    batches in flight -> evaluator; 5 pairs, 2 per batch (ragged last batch), pose rows for every pair with a rel_pose.  The PNG frames
+    go through the library's batch decoder into one pinned buffer per batch that crosses PCIe in one transfer (round 5); the same run with
+    NOPESAC_PNG_NATIVE=0 (PIL per image, one tensor and one transfer per image - the reference's decode) must give the same rows."""
     import json
     import os
     from PIL import Image
@@ -358,10 +360,31 @@ def test_cli_runner_on_a_dataset_split_from_disk(device, tmp_path):
             pair[v] = {"file_name": str(f), "image_id": f"house_{k}_{v}", "height": 480, "width": 640}
         entries.append(pair)
     json.dump({"categories": [], "data": entries}, open(root / "mp3d_planercnn_json" / "cached_set_test.json", "w"))
-    res = run.main(["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights",
-                    "--dataset", "mp3d_test", "--datasets-dir", str(tmp_path / "datasets"), "--pairs-per-batch", "2", "--uint8-images",
-                    "--inflight", "2", "MODEL.DEVICE", str(device), "MODEL.AMD.AUTOTUNE", False])
+    argv = ["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights",
+            "--dataset", "mp3d_test", "--datasets-dir", str(tmp_path / "datasets"), "--pairs-per-batch", "2", "--uint8-images", "--inflight", "2"]
+    opts = ["MODEL.DEVICE", str(device), "MODEL.AMD.AUTOTUNE", False]
+    res = run.main(argv + ["--output", str(tmp_path / "native.json")] + opts)
     assert res["pairs"]["count"] == 5 and res["timing(rank0)"]["pairs"] == 5 and res["timing(rank0)"]["batches_in_flight"] == 2
+    monkeypatch.setenv("NOPESAC_PNG_NATIVE", "0")
+    ref = run.main(argv + ["--output", str(tmp_path / "pil.json")] + opts)
+    assert ref["pairs"]["count"] == 5
+    ja, jb = json.load(open(tmp_path / "native.json")), json.load(open(tmp_path / "pil.json"))
+    seen = []
+
+    def same(x, y, path):
+        if isinstance(x, dict):
+            assert sorted(x) == sorted(y), path
+            for k in x:
+                same(x[k], y[k], path + "/" + k)
+        elif isinstance(x, list):
+            assert len(x) == len(y), path
+            for i, (p, q) in enumerate(zip(x, y)):
+                same(p, q, path + "/%d" % i)
+        elif isinstance(x, float):
+            assert x == y, (path, x, y)
+            seen.append(path)
+    same(ja["pairs"], jb["pairs"], "pairs")
+    assert len(seen) >= 2, seen
 
 
 def test_cli_runner_on_a_scannet_style_jpeg_split(device, tmp_path, monkeypatch):

@@ -384,3 +384,82 @@ def test_cpu_budget_respects_affinity_and_quota(monkeypatch, tmp_path):
         monkeypatch.setattr(builtins, "open", fake_open)
         assert runner.cpu_budget() == want, text
         monkeypatch.setattr(builtins, "open", real_open)
+
+
+def test_images_lying_back_to_back_become_one_transfer():
+    """PlaneTR_NopeSAC._as_one_host_batch: the images data.LazyPairs yields are views of one batch buffer in the model's order (all view-0
+    images, then all view-1 images) - they are recognised and copied to the device as ONE tensor; anything else (separate tensors, another
+    order, a gap, mixed dtypes) keeps the per-image copies."""
+    import torch
+    from nopesac_amd.modeling.meta_arch import PlaneTR_NopeSAC as M
+    buf = torch.arange(6 * 3 * 4 * 5, dtype=torch.uint8).view(6, 3, 4, 5)
+    imgs = [buf[i] for i in range(6)]
+    whole = M._as_one_host_batch(imgs)
+    assert whole is not None and whole.shape == buf.shape and whole.data_ptr() == buf.data_ptr() and torch.equal(whole, buf)
+    sub = M._as_one_host_batch(imgs[2:5])
+    assert sub is not None and torch.equal(sub, buf[2:5]) and sub.data_ptr() == buf[2].data_ptr()
+    assert M._as_one_host_batch([b.clone() for b in imgs]) is None
+    assert M._as_one_host_batch([imgs[1], imgs[0], imgs[2]]) is None
+    assert M._as_one_host_batch([imgs[0], imgs[2], imgs[4]]) is None
+    assert M._as_one_host_batch([imgs[0], imgs[1].float()]) is None
+    assert M._as_one_host_batch([buf[0, :, :2], buf[0, :, 2:]]) is None and M._as_one_host_batch(imgs[:1]) is None
+
+
+def test_own_inflate_matches_zlib():
+    """csrc/inflate_host.h (the PNG decoder's inflate: whole stream in memory, 11-bit primary table with two-literal entries, branch-free
+    refill) against zlib - the decoder the reference's PIL uses - on every block type (stored / fixed / dynamic), compression level and
+    strategy, small windows, flush points, far and short-period matches; malformed streams (truncated, bad header, flipped bits, an output
+    buffer one byte short) must be refused or decode to what zlib decodes, never crash."""
+    import ctypes
+    import random
+    import zlib
+    import numpy as np
+    from nopesac_amd import _lib
+    L = _lib.load()
+
+    def inf(comp, n, cap=None):
+        cap = n if cap is None else cap
+        out = ctypes.create_string_buffer(max(1, cap))
+        got = L.nopesac_inflate_zlib_host(comp, len(comp), out, cap)
+        return got, out.raw[:max(0, got)]
+    rng = np.random.default_rng(0)
+    cases = {
+        "empty": b"", "one": b"a", "zeros": bytes(70000), "rand": rng.integers(0, 256, 60000, dtype=np.uint8).tobytes(),
+        "text": b"the quick brown fox jumps over the lazy dog " * 2000, "lowent": rng.integers(0, 4, 90000, dtype=np.uint8).tobytes(),
+        "rgbflat": bytes([10, 20, 30]) * 30000, "period5": bytes([1, 2, 3, 4, 5]) * 9000 + bytes([7, 7, 9, 9, 9, 9, 9]) * 3000,
+        "mixed": b"".join(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes() + bytes(int(rng.integers(0, 2000))) for _ in range(120)),
+        "far": (lambda a: a + bytes(32768 - len(a) - 300) + a * 3)(rng.integers(0, 256, 300, dtype=np.uint8).tobytes()),
+        "skew": bytes(np.minimum(255, rng.geometric(0.02, 120000)).astype(np.uint8)),          # long codes: second-level tables
+    }
+    for name, data in cases.items():
+        for level in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                for wbits in (15, 9):
+                    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strat)
+                    comp = c.compress(data) + c.flush()
+                    got, out = inf(comp, len(data))
+                    assert got == len(data) and out == data, (name, level, strat, wbits, got)
+    c = zlib.compressobj(6)
+    parts = [rng.integers(0, 50, 5000, dtype=np.uint8).tobytes() for _ in range(12)]
+    comp = b"".join(c.compress(p) + c.flush(zlib.Z_SYNC_FLUSH if i % 2 else zlib.Z_FULL_FLUSH) for i, p in enumerate(parts)) + c.flush()
+    assert inf(comp, 60000) == (60000, b"".join(parts))
+    data = cases["text"]
+    comp = zlib.compress(data, 6)
+    assert inf(comp, len(data), len(data) - 1)[0] == -1 and inf(comp, len(data), len(data) + 100) == (len(data), data)
+    assert all(inf(comp[:k], len(data))[0] == -1 for k in (0, 1, 2, 5, 10, len(comp) // 2, len(comp) - 5))
+    assert inf(b"\x79" + comp[1:], len(data))[0] == -1 and inf(comp[:1] + b"\x00" + comp[2:], len(data))[0] == -1
+    random.seed(1)
+    refused = 0
+    for name in ("text", "mixed", "skew", "rand"):
+        data = cases[name]
+        comp = bytearray(zlib.compress(data, 6))
+        for _ in range(400):
+            b = bytearray(comp)
+            for _ in range(random.randint(1, 3)):
+                b[random.randrange(2, len(b))] ^= 1 << random.randrange(8)
+            got, out = inf(bytes(b), len(data))
+            refused += got < 0
+            if got > 0:                                       # accepted: then zlib's raw inflate yields the same bytes (raw: the Adler-32
+                ref = zlib.decompressobj(-15).decompress(bytes(b)[2:], got)          # trailer is not checked here - a PNG chunk's CRC
+                assert out == ref, name                                              # stands in for it)
+    assert refused > 100
