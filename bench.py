@@ -863,6 +863,8 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
     mk = lambda h: [{"0": {"image": h[i], "image_id": "a%d" % i, "file_name": ""}, "1": {"image": h[B + i], "image_id": "b%d" % i, "file_name": ""}}
                     for i in range(B)]
     inputs_by_dtype = {"float32_images": mk(host), "uint8_images": mk(host8)}
+    if os.environ.get("NOPESAC_BD_DEVICE_IMAGES"):        # analysis: the same loop without the PCIe transfers (images already in HBM)
+        inputs_by_dtype = {"float32_images": mk(host.cuda()), "uint8_images": mk(host8.cuda())}
     cur = [inputs_by_dtype["float32_images"]]             # the input list the closures below work on
     rle_saved, graph_saved, model.output_rle = model.output_rle, model.use_hip_graph, True
     gc.collect()
@@ -903,8 +905,12 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
                 ev.record()
                 return slot, d, ev
 
+        tw = [0.0]
+
         def finish(h):
+            a = time.perf_counter()
             h[2].synchronize()                                                  # the batch's forward is complete
+            tw[0] += time.perf_counter() - a
             with torch.no_grad(), torch.cuda.stream(streams[h[0]]):
                 return model.package(cur[0], h[1])
 
@@ -932,7 +938,8 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
             finish(pending.pop(0))
         torch.cuda.synchronize()
         if os.environ.get("NOPESAC_BD_DEBUG"):
-            print("pipelined depth %d n %d: %.2f ms/step, submit %.2f finish %.2f" % (depth, n, 1e3 * (time.perf_counter() - t0) / n, 1e3 * ts / n, 1e3 * tf / n), file=sys.stderr)
+            print("pipelined depth %d n %d: %.2f ms/step, submit %.2f finish %.2f (of which waiting for the batch %.2f)"
+                  % (depth, n, 1e3 * (time.perf_counter() - t0) / n, 1e3 * ts / n, 1e3 * tf / n, 1e3 * tw[0] / n), file=sys.stderr)
         return (time.perf_counter() - t0) / n
 
     out = {}
@@ -949,8 +956,15 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
                 pipelined(4)
                 pipelined(8, 4)
                 el, t_pack = serial(steps)
-                el2 = pipelined(2 * steps)
-                el4 = pipelined(4 * steps, 4)
+                # (as many steps as the headline's default timed region: a pipeline of depth d pays ~d - 1 batches of fill and drain, which
+                #  16 steps - the count until round 5 - turned into 8-10 % of the figure and 40 steps into 3 %)
+                el2 = pipelined(5 * steps)
+                el4 = pipelined(10 * steps, 4)
+                for dep in [int(v) for v in os.environ.get("NOPESAC_BD_DEPTHS", "").split(",") if v]:      # analysis: deeper pipelines
+                    model.graph_slots = max(4, dep)
+                    pipelined(2 * dep, dep)
+                    print("boundary %s %s depth %d: %.1f pairs/s" % (dt_name, mode, dep, B / pipelined(4 * steps, dep)), file=sys.stderr)
+                model.graph_slots = 4
                 out[dt_name][mode] = {"four_in_flight": {"value": round(B / el4, 2), "ms_per_step": round(1e3 * el4, 2)},
                                       "two_in_flight": {"value": round(B / el2, 2), "ms_per_step": round(1e3 * el2, 2)},
                                       "one_batch_at_a_time": {"value": round(B / el, 2), "ms_per_step": round(1e3 * el, 2),
@@ -963,7 +977,7 @@ def boundary_rate(model, raw, forced, B, steps=4, streams=None):
     best = max(((m, f) for m in ref for f in ("two_in_flight", "four_in_flight")), key=lambda k: ref[k[0]][k[1]]["value"])
     return {"value": ref[best[0]][best[1]]["value"], "unit": "pairs/s", "ms_per_step": ref[best[0]][best[1]]["ms_per_step"],
             "configuration": "float32 host images (the reference mapper's format), %s, %s" % best,
-            "steps": 4 * steps, "pairs_per_step": B, "rle_instances_per_step": n_rle[0],
+            "steps": 10 * steps, "pairs_per_step": B, "rle_instances_per_step": n_rle[0],
             "h2d_bytes_per_step": {"float32_images": int(host.numel() * 4), "uint8_images": int(host8.numel())},
             "float32_images": out["float32_images"], "uint8_images": out["uint8_images"],
             "note": "model(list[dict]) -> list[dict]: HOST images in, H2D + forward + package() + COCO RLE instances of every kept plane; "
