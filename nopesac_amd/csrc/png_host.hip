@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -271,8 +272,19 @@ struct PngPool {
     }
 };
 
+// (a forked child inherits the pool object but none of its threads: it gets a fresh pool - the old one is leaked, its mutexes may have
+//  been held at the moment of the fork)
+std::atomic<PngPool*> g_png_pool{nullptr};
+std::once_flag g_png_atfork;
+
 PngPool& png_pool() {
-    static PngPool* p = new PngPool();
+    std::call_once(g_png_atfork, [] { pthread_atfork(nullptr, nullptr, [] { g_png_pool.store(nullptr); }); });
+    PngPool* p = g_png_pool.load();
+    if (!p) {
+        PngPool* fresh = new PngPool();
+        if (g_png_pool.compare_exchange_strong(p, fresh)) p = fresh;
+        else delete fresh;
+    }
     return *p;
 }
 }  // namespace

@@ -359,6 +359,32 @@ def test_png_host_decoder_matches_pillow(tmp_path):
                     assert np.array_equal(got.transpose(1, 2, 0) if chw else got, ref), (f, chw, fmt, thr)
     out16, st16 = data.read_png_files([str(p16)], "RGB", 97, 131)
     assert st16 == [-2]
+    # the decoder's parked threads do not survive a fork: a child (a forked DataLoader worker) must get its own pool, not wait for threads
+    # it does not have
+    import os
+    import signal
+    import time
+    want_px = data.read_png_files(good, "RGB", 97, 131, threads=4)[0].numpy().copy()
+    child_out = torch.empty(len(good), 3, 97, 131, dtype=torch.uint8)           # (allocated here: the child does no torch work of its own -
+    pid = os.fork()                                                             #  torch's OpenMP pool does not survive a fork either)
+    if pid == 0:
+        code = 4
+        try:
+            _, st_c = data.read_png_files(good, "RGB", 97, 131, threads=4, out=child_out)
+            code = 0 if (not any(st_c) and np.array_equal(child_out.numpy(), want_px)) else 3
+        finally:
+            os._exit(code)
+    t0, status = time.time(), None
+    while time.time() - t0 < 60:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, signal.SIGKILL)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child did not finish: it waits for pool threads it does not have")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     assert data.read_png_files([], "RGB", 97, 131)[1] == []
 
 
