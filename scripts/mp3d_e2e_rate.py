@@ -1,0 +1,50 @@
+"""End-to-end rate of the CLI on a Matterport3D-style split ON DISK (PNG frames): json -> data.LazyPairs (batch PNG decode on the host,
+pinned batch buffers) -> uint8 images -> four batches in flight (bf16) -> package() -> evaluator.  The split is synthetic (16 distinct
+480 x 640 frames, Pillow-encoded, referenced by N pairs; random-init weights): what is measured is the pipeline, two runs of different
+length so that start-up (model build, routing file, the first batch's full synchronisation) cancels.
+usage: python scripts/mp3d_e2e_rate.py [pairs_short=512] [pairs_long=4096]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from PIL import Image  # noqa: E402
+
+from nopesac_amd import run, runner  # noqa: E402
+
+n_short = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+n_long = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+rng = np.random.default_rng(5)
+yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+with tempfile.TemporaryDirectory() as td:
+    root = os.path.join(td, "datasets", "mp3d_dataset")
+    os.makedirs(os.path.join(root, "mp3d_planercnn_json"))
+    files = []
+    for i in range(16):
+        a = np.stack([128 + 90 * np.sin(xx / (20 + i) + yy / 45), 128 + 70 * np.cos(yy / (17 + i)) * np.sin(xx / 70), 120 + 100 * ((xx // 80 + yy // 60) % 2)], -1)
+        f = os.path.join(root, "frame_%02d.png" % i)
+        Image.fromarray(np.clip(a + rng.normal(0, 3.0, a.shape), 0, 255).astype(np.uint8)).save(f)
+        files.append(f)
+    entries = [{"rel_pose": {"position": [0.1, 0.2, 0.3], "rotation": [1.0, 0.0, 0.0, 0.0]},
+                "0": {"file_name": files[(2 * k) % 16], "image_id": "h_%d_0" % k, "height": 480, "width": 640},
+                "1": {"file_name": files[(2 * k + 1) % 16], "image_id": "h_%d_1" % k, "height": 480, "width": 640}} for k in range(n_long)]
+    json.dump({"categories": [], "data": entries}, open(os.path.join(root, "mp3d_planercnn_json", "cached_set_test.json"), "w"))
+    out = {"cpu_budget": runner.cpu_budget(), "png_kbytes": os.path.getsize(files[0]) // 1024}
+    res = {}
+    for label, n in (("warm-up", 64), ("short", n_short), ("long", n_long)):
+        t0 = time.perf_counter()
+        r = run.main(["--config-file", os.path.join(ROOT, "configs", "inference_mp3d.yaml"), "--eval-only", "--synthetic-weights", "--dataset", "mp3d_test",
+                      "--datasets-dir", os.path.join(td, "datasets"), "--limit", str(n), "--pairs-per-batch", "32", "--inflight", "4", "--uint8-images",
+                      "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r5.json"), "MODEL.AMD.AUTOTUNE", False])
+        res[label] = {"pairs": r["timing(rank0)"]["pairs"], "loop_s": round(r["timing(rank0)"]["total_s"], 3), "wall_s": round(time.perf_counter() - t0, 2)}
+    d_pairs = res["long"]["pairs"] - res["short"]["pairs"]
+    d_t = res["long"]["loop_s"] - res["short"]["loop_s"]
+    out.update(res)
+    out["steady_pairs_per_s"] = round(d_pairs / d_t, 1)
+    out["note"] = "steady rate = (pairs_long - pairs_short) / (loop seconds long - short): inference_on_dataset's own clock around its batch loop"
+    print(json.dumps(out, indent=1))
