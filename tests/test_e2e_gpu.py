@@ -612,3 +612,26 @@ def test_steps_in_flight_are_bit_identical(device):
     assert len(blocks) == steps
     off = [i for i, b in enumerate(blocks) if not torch.equal(b, blocks[0])]
     assert not off, "steps whose rows differ from step 0: %s" % off
+
+
+def test_bench_line_carries_the_launch_tape_leg(device):
+    """`python bench.py` (the driver's command, shortened): the JSON line must carry the contract's keys, `roofline`, and the `launch_tape`
+    leg - whose capture check compares a replay of every in-flight slot with the slot's eager rows.  With the grouped gather (--gather-every
+    > 1, the default) that check once read buffers the loop never writes and the leg was silently skipped: both gather modes are run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    for gather in ("8", "1"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--pairs", "8", "--gather-every", gather,
+                            "--no-cpu-baseline", "--no-boundary", "--no-fp32-path", "--no-accuracy", "--no-other-configs", "--no-autotune"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "capture failed" not in r.stderr, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in line, k
+        assert line["steps"] == 6 and line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["steps_per_all_gather"] == int(gather)
+        tape = line.get("launch_tape")
+        assert tape and tape["value"] > 0 and tape["replay"] == "launch tape", tape
