@@ -1117,6 +1117,37 @@ def png_decode_rate(n_images=64, min_s=1.0):
         r = rate_of(batch_call, len(files))
         assert not any(status)
         out["batch_call"] = {"threads": cores, "images_per_batch": len(files), "images_per_s": round(r, 0), "pairs_per_s": round(r / 2, 0)}
+        # the same frames with EVERY row Paeth-filtered (libpng-style encoders use it far more than Pillow's, whose files above are 90 % "Up"
+        # rows): the serial-per-channel filter then costs about as much as the inflate - the input path's worst case
+        import struct
+        import zlib
+
+        def all_paeth(img):
+            H, W, C = img.shape
+            rows, prev, raw = img.reshape(H, W * C).astype(np.int32), np.zeros(W * C, np.int32), bytearray()
+            for y in range(H):
+                cur = rows[y]
+                left, ul = np.concatenate([np.zeros(C, np.int32), cur[:-C]]), np.concatenate([np.zeros(C, np.int32), prev[:-C]])
+                pp = left + prev - ul
+                pa, pb, pc = abs(pp - left), abs(pp - prev), abs(pp - ul)
+                raw.append(4)
+                raw += ((cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))) & 255).astype(np.uint8).tobytes()
+                prev = cur
+            chunk = lambda t, b: struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+            return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b"")
+        pfiles = []
+        for i, pth in enumerate(paths):
+            q = os.path.join(td, "paeth%d.png" % i)
+            with open(q, "wb") as f:
+                f.write(all_paeth(np.asarray(Image.open(pth).convert("RGB"))))
+            pfiles.append(q)
+        pf = [pfiles[i % len(pfiles)] for i in range(n_images)]
+
+        def batch_call_paeth():
+            status[:] = data.read_png_files(pf, "BGR", 480, 640, threads=cores, out=pre)[1]
+        r = rate_of(batch_call_paeth, len(pf))
+        assert not any(status)
+        out["batch_call_all_paeth_rows"] = {"threads": cores, "png_kbytes": os.path.getsize(pfiles[0]) // 1024, "images_per_s": round(r, 0), "pairs_per_s": round(r / 2, 0)}
         # ... and through the loader itself (LazyPairs.iter_batches: decode + mapped dicts, uint8 hand-over, two batches ahead)
         cfgl = NS(INPUT=NS(FORMAT="BGR"), DATASETS=NS(ROOT_DIR="", TEST=("mp3d_test",)), DATALOADER=NS(NUM_WORKERS=cores))
         entries = [{v: {"file_name": files[(2 * k + int(v)) % len(files)], "height": 480, "width": 640, "image_id": "%d_%s" % (k, v)} for v in "01"}

@@ -336,6 +336,47 @@ def test_png_host_decoder_matches_pillow(tmp_path):
     assert data.read_png_native(bytes(blob), "RGB") is None
     assert data.read_png_native((tmp_path / "RGB_False.png").read_bytes()[:-40], "RGB") is None
     assert data.read_png_native(b"not a png at all, but long enough to hold a header....", "RGB") is None
+    # every row filter on every row (Pillow's encoder mostly picks Up and Paeth): files written here with ONE filter type each, three and
+    # four bytes per pixel (the SSE2 Paeth path), one and two (its scalar form), odd widths - against PIL's decode of the same file
+    import struct
+    import zlib
+
+    def png_with_filter(img, ftype, ctype):
+        H, W, C = img.shape
+        rows = img.reshape(H, W * C).astype(np.int32)
+        out, prev = bytearray(), np.zeros(W * C, np.int32)
+        for y in range(H):
+            cur = rows[y]
+            left = np.concatenate([np.zeros(C, np.int32), cur[:-C]])
+            ul = np.concatenate([np.zeros(C, np.int32), prev[:-C]])
+            if ftype == 0:
+                f = cur
+            elif ftype == 1:
+                f = cur - left
+            elif ftype == 2:
+                f = cur - prev
+            elif ftype == 3:
+                f = cur - ((left + prev) >> 1)
+            else:
+                pp = left + prev - ul
+                pa, pb, pc = abs(pp - left), abs(pp - prev), abs(pp - ul)
+                f = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            out.append(ftype)
+            out += (f & 255).astype(np.uint8).tobytes()
+            prev = cur
+        chunk = lambda t, b: struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(out), 6))
+                + chunk(b"IEND", b""))
+    import io
+    for C, ctype in ((3, 2), (4, 6), (1, 0), (2, 4)):
+        for Wd in (131, 4, 1):
+            pix = rng.integers(0, 256, (23, Wd, C), dtype=np.uint8)
+            pix[5:9] = pix[4:5]                                   # some exact repeats: ties between the Paeth candidates
+            for ftype in range(5):
+                blob_f = png_with_filter(pix, ftype, ctype)
+                want_f = np.asarray(Image.open(io.BytesIO(blob_f)).convert("RGB"))
+                got_f = data.read_png_native(blob_f, "RGB")
+                assert got_f is not None and np.array_equal(got_f, want_f), (C, Wd, ftype)
     # the batch entry point (one call, its own threads): every file above at the batch's geometry decodes into its slot, channel-major or
     # interleaved, either channel order; other sizes (-5), variants left to PIL (-2), damaged (-3) and missing (-6) files report a status
     # and leave their slot untouched
