@@ -118,6 +118,37 @@ __attribute__((noinline)) void unfilter_avg(unsigned char* __restrict__ row, con
     for (; i < stride; ++i) row[i] = (unsigned char)(row[i] + ((row[i - BPP] + up[i]) >> 1));
 }
 
+// the same pixel step with SSSE3 / SSE4.1 instructions (abs in one instruction, the two selections as blends): 9 instead of 12 dependent
+// operations per pixel; chosen at run time.  Returns the first byte index it did not process.
+template <int BPP>
+__attribute__((target("sse4.1"), noinline)) int64_t unfilter_paeth_sse41(unsigned char* __restrict__ row, const unsigned char* __restrict__ up, int64_t stride) {
+    const __m128i zero = _mm_setzero_si128(), lo8 = _mm_set1_epi16(0x00ff);
+#define NPS_LOAD4(p) ([&] { int v_; memcpy(&v_, (p), 4); return v_; }())        /* (a lambda does not inherit the target attribute) */
+    __m128i a = _mm_cvtepu8_epi16(_mm_cvtsi32_si128(NPS_LOAD4(row))), c = _mm_cvtepu8_epi16(_mm_cvtsi32_si128(NPS_LOAD4(up)));
+    int64_t i = BPP;
+    for (; i + BPP <= stride; i += BPP) {
+        const __m128i b = _mm_cvtepu8_epi16(_mm_cvtsi32_si128(NPS_LOAD4(up + i))), x = _mm_cvtepu8_epi16(_mm_cvtsi32_si128(NPS_LOAD4(row + i)));
+        const __m128i dbc = _mm_sub_epi16(b, c), dac = _mm_sub_epi16(a, c);
+        const __m128i pa = _mm_abs_epi16(dbc), pb = _mm_abs_epi16(dac), pc = _mm_abs_epi16(_mm_add_epi16(dbc, dac));
+        const __m128i smallest = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+        const __m128i bc = _mm_blendv_epi8(c, b, _mm_cmpeq_epi16(smallest, pb));
+        const __m128i pred = _mm_blendv_epi8(bc, a, _mm_cmpeq_epi16(smallest, pa));                      // ties: a, then b, then c
+        a = _mm_and_si128(_mm_add_epi16(x, pred), lo8);
+        c = b;
+        const int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
+        if (BPP == 3) {
+            const unsigned short lo = (unsigned short)out;
+            memcpy(row + i, &lo, 2);
+            row[i + 2] = (unsigned char)(out >> 16);
+        } else {
+            memcpy(row + i, &out, 4);
+        }
+    }
+#undef NPS_LOAD4
+    (void)zero;
+    return i;
+}
+
 template <int BPP>
 __attribute__((noinline)) void unfilter_paeth(unsigned char* __restrict__ row, const unsigned char* __restrict__ up, int64_t stride) {
     for (int64_t i = 0; i < BPP && i < stride; ++i) row[i] = (unsigned char)(row[i] + up[i]);       // a = c = 0 -> the predictor is b
@@ -125,9 +156,12 @@ __attribute__((noinline)) void unfilter_paeth(unsigned char* __restrict__ row, c
     if constexpr (BPP == 3 || BPP == 4) {
         // one PIXEL per step in 16-bit SSE2 lanes (x86-64 baseline): the channels' chains run side by side in one register, and the code
         // is the same whatever the compiler makes of the scalar form (clang's took 2.9 ms per all-Paeth 480 x 640 frame).  |b - c| does not
-        // depend on the left pixel and leaves the chain.  Four bytes are read and written per pixel: for BPP = 3 the fourth is the next
-        // pixel's first (still filtered) byte, read from the scanline buffer (slack behind its end) and written back unchanged.
-        if (stride >= 2 * BPP) {
+        // depend on the left pixel and leaves the chain.  Four bytes are READ per pixel (BPP = 3: the fourth is the next pixel's first byte or the
+        // slack behind the scanline buffer's end) and BPP bytes written.
+        static const bool sse41 = __builtin_cpu_supports("sse4.1");
+        if (stride >= 2 * BPP && sse41) {
+            i = unfilter_paeth_sse41<BPP>(row, up, stride);
+        } else if (stride >= 2 * BPP) {
             const __m128i zero = _mm_setzero_si128(), lo8 = _mm_set1_epi16(0x00ff);
             auto load4 = [&](const unsigned char* p) { int v; memcpy(&v, p, 4); return _mm_unpacklo_epi8(_mm_cvtsi32_si128(v), zero); };
             __m128i a = load4(row), c = load4(up);
@@ -144,9 +178,14 @@ __attribute__((noinline)) void unfilter_paeth(unsigned char* __restrict__ row, c
                 const __m128i pred = _mm_or_si128(_mm_and_si128(ma, a), _mm_andnot_si128(ma, bc));
                 a = _mm_and_si128(_mm_add_epi16(x, pred), lo8);
                 c = b;
-                int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
-                if (BPP == 3) out = (out & 0x00ffffff) | (xin & (int)0xff000000);
-                memcpy(row + i, &out, 4);
+                const int out = _mm_cvtsi128_si32(_mm_packus_epi16(a, a));
+                if (BPP == 3) {                                  // exactly three bytes: a four-byte store would overlap the next pixel's
+                    const unsigned short lo = (unsigned short)out;               // four-byte load by one byte - a store-forwarding stall per
+                    memcpy(row + i, &lo, 2);                                      // pixel, in the middle of the chain
+                    row[i + 2] = (unsigned char)(out >> 16);
+                } else {
+                    memcpy(row + i, &out, 4);
+                }
             }
         }
     } else if (stride >= 2 * BPP) {
