@@ -609,6 +609,10 @@ int nopesac_encoder_tail_bf16(const void* attn, const float* src, const void* wo
 /* cv2.resize(img, (OW, OH)) with the default INTER_LINEAR on uint8 HWC images (the ScanNet input path,
  * data/planercnn_transforms.py:314): OpenCV's 11-bit fixed-point algorithm (csrc/resize.hip). src [H][W][C], dst [OH][OW][C]. */
 int nopesac_resize_bilinear_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int OH, int OW, void* stream);
+/* The same for n images of one size that lie src_stride bytes apart (the GPU JPEG decoder's output buffer), one launch; chw = 1: dst is
+ * [n][C][OH][OW] (the mapper's CHW tensors: the reference's transpose after cv2.resize, planercnn_transforms.py:314-320), else [n][OH][OW][C]. */
+int nopesac_resize_bilinear_u8_batch(const uint8_t* src, int n, int64_t src_stride, int H, int W, int C, uint8_t* dst, int OH, int OW, int chw,
+                                     void* stream);
 
 /* Pre-norm counterpart for the decoder layers (transformer/transformer.py:293-322, after the cross-attention), same kernel:
  *   s = tgt + attn . wo^T + bo;  u = s + relu(LN3(s) . w1^T + b1) . w2^T + b2;  n = LN_next(u)

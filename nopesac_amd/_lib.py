@@ -37,6 +37,7 @@ SIGNATURES = {
     "nopesac_gnn_layer_bf16_pf": [P, I, P, I, P, I, I, I, P, P] + [P] * 10 + [P, I, P],
     "nopesac_encoder_tail_bf16": [P] * 13 + [I] + [P] * 3 + [I, P],
     "nopesac_resize_bilinear_u8": [P, I, I, I, P, I, I, P],
+    "nopesac_resize_bilinear_u8_batch": [P, I, L, I, I, I, P, I, I, I, P],
     "nopesac_mask_head_bf16": [P] * 9 + [I] * 5 + [P],
     "nopesac_mask_operands": [P, I, P, P, I, I, I, P],
     "nopesac_decoder_tail_bf16": [P] * 13 + [I] + [P] * 4 + [I, P],

@@ -36,7 +36,38 @@ __global__ void resize_bilinear_u8_kernel(const uint8_t* __restrict__ src, int H
     dst[idx] = (uint8_t)min(max(v, 0), 255);
 }
 
+// n images of one size, `src_stride` bytes apart (the GPU JPEG decoder's output buffer), in ONE launch; chw = 1 writes [n][C][OH][OW] -
+// the data mapper's layout - instead of [n][OH][OW][C] (the per-image path: resize, permute, contiguous = three launches per image).
+// Element for element the arithmetic of resize_bilinear_u8_kernel.
+__global__ void resize_bilinear_u8_batch_kernel(const uint8_t* __restrict__ src, long long src_stride, int H, int W, int C, uint8_t* __restrict__ dst,
+                                                int OH, int OW, int chw, float scale_y, float scale_x) {
+    const long long per = (long long)OH * OW * C;
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= per) return;
+    const uint8_t* s = src + (long long)blockIdx.y * src_stride;
+    int c, dx, dy;
+    if (chw) { dx = (int)(idx % OW); dy = (int)((idx / OW) % OH); c = (int)(idx / ((long long)OW * OH)); }
+    else { c = (int)(idx % C); dx = (int)((idx / C) % OW); dy = (int)(idx / ((long long)C * OW)); }
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    resize_coef(dx, scale_x, W, x0, x1, a0, a1);
+    resize_coef(dy, scale_y, H, y0, y1, b0, b1);
+    const int r0 = (int)s[((long long)y0 * W + x0) * C + c] * a0 + (int)s[((long long)y0 * W + x1) * C + c] * a1;
+    const int r1 = (int)s[((long long)y1 * W + x0) * C + c] * a0 + (int)s[((long long)y1 * W + x1) * C + c] * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    dst[(long long)blockIdx.y * per + idx] = (uint8_t)min(max(v, 0), 255);
+}
+
 }  // namespace nps
+
+extern "C" int nopesac_resize_bilinear_u8_batch(const uint8_t* src, int n, int64_t src_stride, int H, int W, int C, uint8_t* dst, int OH, int OW, int chw,
+                                                void* stream) {
+    using namespace nps;
+    NPS_CHECK_ARG(src && dst && n > 0 && n <= 65535 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && src_stride >= (int64_t)H * W * C, "resize_batch: bad args");
+    const long long per = (long long)OH * OW * C;
+    hipLaunchKernelGGL(resize_bilinear_u8_batch_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_stride, H, W, C, dst, OH, OW, chw ? 1 : 0, (float)((double)H / OH), (float)((double)W / OW));
+    NPS_LAUNCH_RET();
+}
 
 extern "C" int nopesac_resize_bilinear_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int OH, int OW, void* stream) {
     using namespace nps;

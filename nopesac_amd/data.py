@@ -149,16 +149,35 @@ class PairMapper:
             self.gpu_jpeg = self._resize_device is not None and os.environ.get("NOPESAC_GPU_JPEG", "1") != "0"
         return bool(self.gpu_jpeg) and self._resize_device is not None
 
-    def _finish_device_image(self, img_t: torch.Tensor) -> torch.Tensor:
+    def _finish_device_image(self, img_t: torch.Tensor, keep_device: bool = False) -> torch.Tensor:
         """uint8 [H,W,3] on the GPU (cfg.INPUT.FORMAT order) -> what _image returns (resized for ScanNet, CHW, uint8 / float32, on
         self.device or the host)"""
         if self.scannet and tuple(img_t.shape[:2]) != (480, 640):
             from . import ops
             img_t = ops.resize_bilinear_u8(img_t.contiguous(), 480, 640)
         t = img_t.permute(2, 0, 1).contiguous() if self.uint8 else img_t.permute(2, 0, 1).float()
-        return t if self.device is not None else t.cpu()
+        return t if (self.device is not None or keep_device) else t.cpu()
 
-    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None, sync: bool = True) -> List[torch.Tensor]:
+    def _finish_device_batch(self, imgs: List[torch.Tensor], keep_device: bool) -> List[torch.Tensor]:
+        """_finish_device_image for the images of one decode_batch call.  When they share one size (a ScanNet batch: 968 x 1296) the
+        resize + CHW transpose of the WHOLE batch is one launch (per image: resize, permute, contiguous = three; 192 launches per batch of 32
+        pairs on the thread that also launches the model); the results are views of one [n,3,480,640] tensor.  keep_device: GPU-decoded
+        images stay in HBM although the mapper was built without a device (LazyPairs' GPU path: the model reads them in place - the host
+        round trip `.cpu()` + the model's own H2D copy was 17 of the 22 ms a batch took to map)."""
+        from . import ops
+        batch = None
+        if len(imgs) > 1 and len({tuple(t.shape) for t in imgs}) == 1:
+            if self.scannet and tuple(imgs[0].shape[:2]) != (480, 640):
+                batch = ops.resize_bilinear_u8_batch(imgs, 480, 640, chw=True)
+        if batch is None:
+            return [self._finish_device_image(t, keep_device) for t in imgs]
+        if not self.uint8:
+            batch = batch.float()
+        if self.device is None and not keep_device:
+            batch = batch.cpu()
+        return [batch[i] for i in range(len(imgs))]
+
+    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False) -> List[torch.Tensor]:
         """The images of `paths` as _image() returns them, the JPEG files among them decoded in ONE launch chain on the GPU (all
         restart intervals / images of the batch in flight together).  blobs / infos: file contents and jpeg.parse results when the
         caller (LazyPairs' reader threads) has them already.  sync (default): device tensors are COMPLETE when this returns - the
@@ -186,9 +205,9 @@ class PairMapper:
         if gpu_idx:
             with torch.cuda.device(dev):
                 dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
-                for i, t in zip(gpu_idx, dec):
-                    out[i] = self._finish_device_image(t)
-                if sync and self.device is not None:          # (device = None: .cpu() above has synchronised already)
+                for i, t in zip(gpu_idx, self._finish_device_batch(dec, keep_device)):
+                    out[i] = t
+                if sync and (self.device is not None or keep_device):          # (host hand-over: .cpu() above has synchronised already)
                     torch.cuda.current_stream(dev).synchronize()
         for i, p in enumerate(paths):
             if out[i] is None:
@@ -239,11 +258,18 @@ class PairMapper:
             names = [n.replace(MP3D_ORIGINAL_ROOT, self.root_dir) for n in names]
         return names
 
-    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None, sync: bool = True) -> List[dict]:
-        """The mapped dicts of a batch of pairs with all 2 * len(entries) images decoded together (decode_files)."""
-        paths = [n for e in entries for n in self.file_names(e)]
-        imgs = self.decode_files(paths, blobs, infos, sync=sync)
-        return [self(e, images=imgs[2 * i:2 * i + 2]) for i, e in enumerate(entries)]
+    def batch_paths(self, entries: List[dict]) -> List[str]:
+        """The 2 * len(entries) files of a batch in the MODEL's order - every pair's view 0, then every pair's view 1: images decoded
+        into one buffer in this order reach the model's input tensor in one copy (PlaneTR_NopeSAC._as_one_batch)."""
+        names = [self.file_names(e) for e in entries]
+        return [n[0] for n in names] + [n[1] for n in names]
+
+    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False) -> List[dict]:
+        """The mapped dicts of a batch of pairs with all 2 * len(entries) images decoded together (decode_files; blobs / infos in
+        batch_paths order)."""
+        B = len(entries)
+        imgs = self.decode_files(self.batch_paths(entries), blobs, infos, sync=sync, keep_device=keep_device)
+        return [self(e, images=[imgs[i], imgs[B + i]]) for i, e in enumerate(entries)]
 
 
 class LazyPairs:
@@ -287,7 +313,7 @@ class LazyPairs:
     def _read_batch(self, entries: List[dict]):
         """reader thread: file contents + marker walk of a batch's JPEG files (host work only)"""
         from . import jpeg
-        paths = [n for e in entries for n in self.mapper.file_names(e)]
+        paths = self.mapper.batch_paths(entries)
         blobs, infos = [None] * len(paths), [None] * len(paths)
         for i, p in enumerate(paths):
             if is_jpeg_path(p):
@@ -299,14 +325,17 @@ class LazyPairs:
                     infos[i] = False
         return entries, blobs, infos
 
-    def _iter_batches_gpu(self, pairs_per_batch: int, ahead: int = 3):
+    def _iter_batches_gpu(self, pairs_per_batch: int, ahead: int = 0):
         """JPEG splits with a GPU: reader threads load and parse the files of whole batches ahead of the consumer; this thread
         launches each batch's decode (one chain for its 2 * pairs_per_batch images) on one of `ahead` decode streams, up to `ahead`
-        batches before the consumer needs them - the serial Huffman chains of different batches run next to each other and next to
+        batches (default 6, NOPESAC_JPEG_AHEAD: under the model's four batches in flight a decode chain waits its turn on the GPU for
+        tens of milliseconds - measured end to end on 968 x 1296 frames: 2060 / 2430 / 2170 pairs/s with 3 / 6 / 10 ahead)
+        before the consumer needs them - the serial Huffman chains of different batches run next to each other and next to
         the model; the consumer's stream waits for the batch's event."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         dev = self.mapper._resize_device
+        ahead = ahead or max(1, int(os.environ.get("NOPESAC_JPEG_AHEAD", "6")))
         chunks = [self.entries[i:i + pairs_per_batch] for i in range(0, len(self.entries), pairs_per_batch)]
         with torch.cuda.device(dev):
             streams = [torch.cuda.Stream(device=dev) for _ in range(ahead)]
@@ -322,7 +351,7 @@ class LazyPairs:
                     st = streams[k % ahead]
                     k += 1
                     with torch.cuda.device(dev), torch.cuda.stream(st):
-                        items = self.mapper.map_batch(entries, blobs, infos, sync=False)
+                        items = self.mapper.map_batch(entries, blobs, infos, sync=False, keep_device=True)
                         ev = torch.cuda.Event()
                         ev.record()
                     decoding.append((items, ev, st))
@@ -338,9 +367,8 @@ class LazyPairs:
         """batch thread: every image of the batch through ONE native call (read_png_files, `workers` threads), files it does not take
         through read_image; the mapped dicts hold views of the batch tensor (uint8 CHW) or of its float32 copy."""
         m = self.mapper
-        names = [m.file_names(e) for e in entries]
-        paths = [n[0] for n in names] + [n[1] for n in names]     # the model's batch order: every pair's view 0, then every pair's view 1 -
-        B = len(entries)                                          # its H2D copy of the batch is then ONE transfer of this buffer
+        paths = m.batch_paths(entries)                            # the model's batch order: its H2D copy of the batch is then ONE
+        B = len(entries)                                          # transfer of this buffer
         H, W = int(entries[0]["0"].get("height", 480)), int(entries[0]["0"].get("width", 640))          # (files of another size: status -5)
         # The batch buffer comes from torch's PINNED host allocator when there is a GPU: it caches freed blocks, so after the first few
         # batches a buffer is a recycled one - already faulted in (decoding into fresh pageable memory is bound by its page faults:

@@ -129,8 +129,10 @@ class PlaneTR_NopeSAC(nn.Module):
             for im in imgs:                                   # device images decoded on another stream (data.LazyPairs): their memory
                 if im.is_cuda:                                # must not be recycled there while this stream still reads it
                     im.record_stream(cur)
-        whole = self._as_one_host_batch(imgs)                 # data.LazyPairs hands out views of ONE (pinned) batch buffer, in this order:
-        if imgs[0].dtype == torch.uint8 and self.device.type == "cuda":         # one DMA instead of 2B (each ~15 us of launch-thread time)
+        whole = self._as_one_batch(imgs)                      # data.LazyPairs hands out views of ONE batch buffer (pinned host memory for
+        if imgs[0].dtype == torch.uint8 and self.device.type == "cuda":         # PNG splits, HBM for GPU-decoded JPEG splits), in this order:
+            if whole is not None and whole.is_cuda and staging is None:         # one copy instead of 2B (each ~15 us of launch-thread time) -
+                return ops.u8_to_f32(whole, out)                                # or none at all when the bytes are in HBM already
             u8 = staging if staging is not None else torch.empty(out.shape, device=self.device, dtype=torch.uint8)
             if whole is not None:
                 u8.copy_(whole, non_blocking=True)
@@ -146,15 +148,15 @@ class PlaneTR_NopeSAC(nn.Module):
         return out
 
     @staticmethod
-    def _as_one_host_batch(imgs):
-        """[n, ...] view over `imgs` when they are host tensors lying back to back, in order, in one storage (what data.LazyPairs yields);
-        None otherwise."""
+    def _as_one_batch(imgs):
+        """[n, ...] view over `imgs` when they are tensors of one device lying back to back, in order, in one storage (what data.LazyPairs
+        yields); None otherwise."""
         a = imgs[0]
-        if a.is_cuda or not a.is_contiguous() or len(imgs) < 2:
+        if not a.is_contiguous() or len(imgs) < 2:
             return None
         nb, base, st = a.numel() * a.element_size(), a.data_ptr(), a.untyped_storage().data_ptr()
         for k, im in enumerate(imgs):
-            if (im.is_cuda or im.dtype != a.dtype or im.shape != a.shape or not im.is_contiguous() or im.data_ptr() != base + k * nb
+            if (im.device != a.device or im.dtype != a.dtype or im.shape != a.shape or not im.is_contiguous() or im.data_ptr() != base + k * nb
                     or im.untyped_storage().data_ptr() != st):
                 return None
         return torch.as_strided(a, (len(imgs),) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))

@@ -1129,6 +1129,24 @@ def resize_bilinear_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tenso
     return out
 
 
+def resize_bilinear_u8_batch(imgs, out_h: int, out_w: int, chw: bool = True) -> torch.Tensor:
+    """n uint8 [H,W,C] device images of ONE size lying evenly spaced in one buffer (views of jpeg.decode_batch's output) -> uint8
+    [n,C,out_h,out_w] (chw) or [n,out_h,out_w,C], one launch; None if the images are not laid out like that."""
+    a = imgs[0]
+    _chk(a, torch.uint8)
+    H, W, C = a.shape
+    n = len(imgs)
+    stride = (imgs[1].data_ptr() - a.data_ptr()) if n > 1 else H * W * C
+    st = a.untyped_storage().data_ptr()
+    if stride < H * W * C or any(im.shape != a.shape or not im.is_contiguous() or im.data_ptr() != a.data_ptr() + k * stride
+                                 or im.untyped_storage().data_ptr() != st for k, im in enumerate(imgs)):
+        return None
+    out = torch.empty((n, C, out_h, out_w) if chw else (n, out_h, out_w, C), device=a.device, dtype=torch.uint8)
+    _lib.check(_L().nopesac_resize_bilinear_u8_batch(_p(a), n, stride, H, W, C, _p(out), out_h, out_w, 1 if chw else 0, _stream()),
+               "nopesac_resize_bilinear_u8_batch")
+    return out
+
+
 def mask_head(c1: torch.Tensor, t1: torch.Tensor, w_lat_frag: torch.Tensor, scale, bias, mask_w: torch.Tensor, mask_b: torch.Tensor,
               sigmoid: bool = True, want_p1: bool = False, planar: bool = False, fold: Optional[torch.Tensor] = None, taps1: bool = False,
               pipe: bool = False):

@@ -454,22 +454,22 @@ def test_cpu_budget_respects_affinity_and_quota(monkeypatch, tmp_path):
 
 
 def test_images_lying_back_to_back_become_one_transfer():
-    """PlaneTR_NopeSAC._as_one_host_batch: the images data.LazyPairs yields are views of one batch buffer in the model's order (all view-0
+    """PlaneTR_NopeSAC._as_one_batch: the images data.LazyPairs yields are views of one batch buffer in the model's order (all view-0
     images, then all view-1 images) - they are recognised and copied to the device as ONE tensor; anything else (separate tensors, another
     order, a gap, mixed dtypes) keeps the per-image copies."""
     import torch
     from nopesac_amd.modeling.meta_arch import PlaneTR_NopeSAC as M
     buf = torch.arange(6 * 3 * 4 * 5, dtype=torch.uint8).view(6, 3, 4, 5)
     imgs = [buf[i] for i in range(6)]
-    whole = M._as_one_host_batch(imgs)
+    whole = M._as_one_batch(imgs)
     assert whole is not None and whole.shape == buf.shape and whole.data_ptr() == buf.data_ptr() and torch.equal(whole, buf)
-    sub = M._as_one_host_batch(imgs[2:5])
+    sub = M._as_one_batch(imgs[2:5])
     assert sub is not None and torch.equal(sub, buf[2:5]) and sub.data_ptr() == buf[2].data_ptr()
-    assert M._as_one_host_batch([b.clone() for b in imgs]) is None
-    assert M._as_one_host_batch([imgs[1], imgs[0], imgs[2]]) is None
-    assert M._as_one_host_batch([imgs[0], imgs[2], imgs[4]]) is None
-    assert M._as_one_host_batch([imgs[0], imgs[1].float()]) is None
-    assert M._as_one_host_batch([buf[0, :, :2], buf[0, :, 2:]]) is None and M._as_one_host_batch(imgs[:1]) is None
+    assert M._as_one_batch([b.clone() for b in imgs]) is None
+    assert M._as_one_batch([imgs[1], imgs[0], imgs[2]]) is None
+    assert M._as_one_batch([imgs[0], imgs[2], imgs[4]]) is None
+    assert M._as_one_batch([imgs[0], imgs[1].float()]) is None
+    assert M._as_one_batch([buf[0, :, :2], buf[0, :, 2:]]) is None and M._as_one_batch(imgs[:1]) is None
 
 
 def test_own_inflate_matches_zlib():

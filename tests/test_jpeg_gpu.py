@@ -137,6 +137,51 @@ def test_lazy_pairs_decode_batches_ahead_on_the_gpu(device, tmp_path):
             assert g[v]["image_id"] == r[v]["image_id"] and g[v]["image"].is_cuda and torch.equal(g[v]["image"].cpu(), r[v]["image"])
 
 
+def test_same_size_batch_is_resized_in_one_launch_and_stays_in_hbm(device, tmp_path):
+    """A ScanNet batch (all frames one size): LazyPairs' GPU path resizes and transposes the whole batch in ONE launch
+    (nopesac_resize_bilinear_u8_batch) into one [n,3,480,640] tensor in the model's order (view 0 of every pair, then view 1), hands out
+    views of it that STAY on the device even for a mapper built without one (the host round trip was most of a batch's mapping time),
+    and the model takes the batch without a copy - same pixels as the host path (PIL decode + per-image resize), uint8 and float32."""
+    from PIL import Image
+    from nopesac_amd import data, ops
+    from nopesac_amd.modeling.meta_arch import PlaneTR_NopeSAC as M
+    cfg = _scannet_cfg()
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:242, 0:324].astype(np.float32)
+    entries = []
+    for i in range(5):
+        pair = {}
+        for v in "01":
+            a = np.stack([128 + 90 * np.sin(xx / (9 + i) + yy / 14), 128 + 70 * np.cos(yy / (7 + int(v))) * np.sin(xx / 20), 120 + 100 * ((xx // 16 + yy // 12) % 2)], -1)
+            f = tmp_path / ("%d_%s.jpg" % (i, v))
+            Image.fromarray(np.clip(a + rng.normal(0, 4.0, a.shape), 0, 255).astype(np.uint8)).save(f, format="JPEG", quality=88, subsampling=2)
+            pair[v] = {"file_name": str(f), "image_id": "%d-%s" % (i, v)}
+        entries.append(pair)
+    for uint8 in (True, False):
+        host = data.PairMapper(cfg, "scannet_test", uint8=uint8, gpu_jpeg=False)
+        ref = [host(e) for e in entries]
+        lazy = data.LazyPairs(entries, data.PairMapper(cfg, "scannet_test", uint8=uint8), workers=2, prefetch=8)
+        batches = list(lazy.iter_batches(3))
+        assert [len(b) for b in batches] == [3, 2]
+        k = 0
+        for b in batches:
+            imgs = [p["0"]["image"] for p in b] + [p["1"]["image"] for p in b]
+            assert all(t.is_cuda and t.shape == (3, 480, 640) for t in imgs)
+            whole = M._as_one_batch(imgs)
+            assert whole is not None and whole.shape == (2 * len(b), 3, 480, 640)
+            for p in b:
+                for v in "01":
+                    assert p[v]["image_id"] == ref[k][v]["image_id"] and torch.equal(p[v]["image"].cpu(), ref[k][v]["image"]), (uint8, k, v)
+                k += 1
+    # the batched kernel against the per-image one, both layouts
+    dec = [torch.from_numpy(rng.integers(0, 256, (5, 37, 53, 3), dtype=np.uint8)).to(device)]
+    views = [dec[0][i] for i in range(5)]
+    one = torch.stack([ops.resize_bilinear_u8(v, 24, 40) for v in views])
+    assert torch.equal(ops.resize_bilinear_u8_batch(views, 24, 40, chw=False), one)
+    assert torch.equal(ops.resize_bilinear_u8_batch(views, 24, 40, chw=True), one.permute(0, 3, 1, 2).contiguous())
+    assert ops.resize_bilinear_u8_batch([views[1], views[0]], 24, 40) is None
+
+
 def test_self_synchronising_decoder_settles_and_matches_the_serial_kernel(device):
     """restart-free files of >= 4 KB go through nopesac_jpeg_huffman_parallel: every image must settle (par_done) and give the bytes the
     one-wave-per-interval kernel gives (parallel=False)"""
