@@ -177,7 +177,8 @@ class PairMapper:
             batch = batch.cpu()
         return [batch[i] for i in range(len(imgs))]
 
-    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False) -> List[torch.Tensor]:
+    def decode_files(self, paths: List[str], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False,
+                     host=None) -> List[torch.Tensor]:
         """The images of `paths` as _image() returns them, the JPEG files among them decoded in ONE launch chain on the GPU (all
         restart intervals / images of the batch in flight together).  blobs / infos: file contents and jpeg.parse results when the
         caller (LazyPairs' reader threads) has them already.  sync (default): device tensors are COMPLETE when this returns - the
@@ -204,7 +205,10 @@ class PairMapper:
         out = [None] * len(paths)
         if gpu_idx:
             with torch.cuda.device(dev):
-                dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
+                if host is not None and len(gpu_idx) == len(paths) and host.n == len(paths):       # prepared by the reader thread (every file)
+                    dec = jpeg.decode_batch(None, dev, bgr=(self.img_format == "BGR"), host=host)
+                else:
+                    dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
                 for i, t in zip(gpu_idx, self._finish_device_batch(dec, keep_device)):
                     out[i] = t
                 if sync and (self.device is not None or keep_device):          # (host hand-over: .cpu() above has synchronised already)
@@ -264,11 +268,12 @@ class PairMapper:
         names = [self.file_names(e) for e in entries]
         return [n[0] for n in names] + [n[1] for n in names]
 
-    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False) -> List[dict]:
+    def map_batch(self, entries: List[dict], blobs: List[bytes] = None, infos: list = None, sync: bool = True, keep_device: bool = False,
+                  host=None) -> List[dict]:
         """The mapped dicts of a batch of pairs with all 2 * len(entries) images decoded together (decode_files; blobs / infos in
         batch_paths order)."""
         B = len(entries)
-        imgs = self.decode_files(self.batch_paths(entries), blobs, infos, sync=sync, keep_device=keep_device)
+        imgs = self.decode_files(self.batch_paths(entries), blobs, infos, sync=sync, keep_device=keep_device, host=host)
         return [self(e, images=[imgs[i], imgs[B + i]]) for i, e in enumerate(entries)]
 
 
@@ -323,7 +328,10 @@ class LazyPairs:
                     infos[i] = jpeg.parse(blobs[i])
                 except jpeg.JpegUnsupported:
                     infos[i] = False
-        return entries, blobs, infos
+        # every file one the GPU decoder takes: the batch's launch arguments are assembled HERE (pinned arrays), the consumer's thread -
+        # which also launches the model - only launches
+        host = jpeg.prepare_batch(infos) if (infos and all(infos)) else None
+        return entries, blobs, infos, host
 
     def _iter_batches_gpu(self, pairs_per_batch: int, ahead: int = 0):
         """JPEG splits with a GPU: reader threads load and parse the files of whole batches ahead of the consumer; this thread
@@ -347,11 +355,11 @@ class LazyPairs:
                     reading.append(pool.submit(self._read_batch, chunks[nxt]))
                     nxt += 1
                 while reading and len(decoding) < ahead:
-                    entries, blobs, infos = reading.popleft().result()
+                    entries, blobs, infos, host = reading.popleft().result()
                     st = streams[k % ahead]
                     k += 1
                     with torch.cuda.device(dev), torch.cuda.stream(st):
-                        items = self.mapper.map_batch(entries, blobs, infos, sync=False, keep_device=True)
+                        items = self.mapper.map_batch(entries, blobs, infos, sync=False, keep_device=True, host=host)
                         ev = torch.cuda.Event()
                         ev.record()
                     decoding.append((items, ev, st))
