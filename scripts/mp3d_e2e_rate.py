@@ -17,6 +17,7 @@ from PIL import Image  # noqa: E402
 
 from nopesac_amd import run, runner  # noqa: E402
 
+tape = "--tape" in sys.argv                 # MODEL.AMD.USE_HIP_GRAPH: every batch's forward replayed through the launch tape
 scannet = "--scannet" in sys.argv           # 968 x 1296 JPEG frames (GPU decode + GPU resize) instead of 480 x 640 PNG frames (host decode)
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_short = int(argv[0]) if len(argv) > 0 else 512
@@ -50,10 +51,12 @@ with tempfile.TemporaryDirectory() as td:
         r = run.main(["--config-file", os.path.join(ROOT, "configs", "inference_scannet.yaml" if scannet else "inference_mp3d.yaml"), "--eval-only",
                       "--synthetic-weights", "--dataset", "scannet_test" if scannet else "mp3d_test",
                       "--datasets-dir", os.path.join(td, "datasets"), "--limit", str(n), "--pairs-per-batch", "32", "--inflight", "4", "--uint8-images",
-                      "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r5.json"), "MODEL.AMD.AUTOTUNE", False])
+                      "MODEL.AMD.COMPUTE_DTYPE", "bfloat16", "MODEL.AMD.ROUTING_FILE", os.path.join(ROOT, "profiles", "routing_r5.json"), "MODEL.AMD.AUTOTUNE", False,
+                      "MODEL.AMD.USE_HIP_GRAPH", str(bool(tape))])
         res[label] = {"pairs": r["timing(rank0)"]["pairs"], "loop_s": round(r["timing(rank0)"]["total_s"], 3), "wall_s": round(time.perf_counter() - t0, 2)}
     d_pairs = res["long"]["pairs"] - res["short"]["pairs"]
     d_t = res["long"]["loop_s"] - res["short"]["loop_s"]
+    out["launch_tape"] = tape
     out.update(res)
     out["steady_pairs_per_s"] = round(d_pairs / d_t, 1)
     out["note"] = "steady rate = (pairs_long - pairs_short) / (loop seconds long - short): inference_on_dataset's own clock around its batch loop"
