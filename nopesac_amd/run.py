@@ -267,6 +267,8 @@ def _main_rank(args):
     n_cores = min(len(my_cores), max(1, runner.cpu_budget() // max(1, ranks_here))) if my_cores is not None else max(1, runner.cpu_budget() // max(1, ranks_here))
     if not args.decode_workers:
         args.decode_workers = max(1, min(32, n_cores - (1 if n_cores > 2 else 0)))      # (one core stays with the thread that launches kernels)
+    # torch's own CPU thread pool (dtype conversions of host batches, the evaluator's small ops) defaults to every hardware thread it sees
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), n_cores)))
     if args.stub_model:
         model, src = _StubModel(), "stub (no model: fabricated results)"
     else:
