@@ -14,6 +14,7 @@ Supported: SOF0 / SOF1 (baseline / extended sequential Huffman), 8-bit, ONE scan
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 import struct
 import threading
@@ -273,17 +274,23 @@ def _words(intervals: Sequence[bytes]):
 
 
 class HostBatch:
-    """The host half of decode_batch for one batch of parsed files: every array the launch chain needs, in pinned memory when there is a GPU
-    (the H2D copies are then asynchronous DMAs), built WITHOUT touching the device - data.LazyPairs' reader threads build it next to the
-    file reads, so that the thread which launches the model only launches (the concatenation of a batch's 13 MB of scan words and seven
-    synchronous pageable-memory copies were ~3 ms per batch of 32 ScanNet pairs on that thread)."""
+    """The host half of decode_batch for one batch of parsed files: every array the launch chain needs, built WITHOUT touching the device -
+    data.LazyPairs' reader threads build it next to the file reads, so that the thread which launches the model only copies and launches
+    (the per-image table filling and the concatenation of a batch's 13 MB of scan words were ~2 ms per batch of 32 ScanNet pairs on that
+    thread)."""
     __slots__ = ("infos", "img32", "img64", "tables", "seg32", "seg64", "words", "lane_img", "n", "n_lanes", "n_blocks", "max_px", "coef_off", "plane_off",
                  "out_off", "n_seg")
 
 
+# NOPESAC_JPEG_PINNED=1: the batch's host arrays in pinned memory (asynchronous H2D DMAs).  Off by default: every pinned block that is not in
+# torch's cache yet is a hipHostMalloc, which waits for the whole device - with several batches in flight the first rounds of a run (and every
+# short run: bench.py's jpeg_decode leg, three rounds) serialise on it (measured: 68 instead of 11 ms per round of four batches).
+_PIN = os.environ.get("NOPESAC_JPEG_PINNED", "0") == "1"
+
+
 def _pinned(arr: np.ndarray) -> torch.Tensor:
     t = torch.from_numpy(np.ascontiguousarray(arr))
-    if torch.cuda.is_available():
+    if _PIN and torch.cuda.is_available():
         p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         p.copy_(t)
         return p
@@ -343,7 +350,7 @@ def prepare_batch(infos: Sequence[JpegInfo], parallel: bool = True) -> HostBatch
     hb.img32, hb.img64, hb.tables = _pinned(img32), _pinned(img64), _pinned(tables)
     hb.seg32, hb.seg64 = _pinned(np.asarray(seg32, np.int32).reshape(-1, 4)), _pinned(np.asarray(seg64, np.int64).reshape(-1, 2))
     hb.n_seg = len(seg32)
-    if torch.cuda.is_available():                          # the words of every file straight into ONE pinned buffer
+    if _PIN and torch.cuda.is_available():                 # the words of every file straight into ONE pinned buffer
         wt = torch.empty(word_off, dtype=torch.int32, pin_memory=True)
         wn, o = wt.numpy().view(np.uint32), 0
         for w in words:
