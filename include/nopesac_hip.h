@@ -540,8 +540,22 @@ int nopesac_jpeg_huffman(const int32_t* img32, const int64_t* img64, const uint8
  * ends the scan like any other marker: has_restart = 0.) */
 int64_t nopesac_jpeg_prepare_scan(const uint8_t* data, int64_t n, int has_restart, uint32_t* words, int64_t words_cap, int64_t* seg_off,
                                   int64_t* seg_cnt, int64_t* seg_bytes, int64_t max_segs, int64_t* consumed);
-#define NOPESAC_JPEG_SUB_WORDS 256
-#define NOPESAC_JPEG_SYNC_PASSES 6
+/* HOST functions: the whole host side of a BATCH of JPEG files on the library's own threads (csrc/jpeg_host.hip) - file read, marker walk,
+ * supported-subset checks, nopesac_jpeg_prepare_scan, derived Huffman tables and the launch arrays above; replaces the per-file Python of
+ * nopesac_amd/jpeg.py (parse_markers / prepare_batch), i.e. the reference's per-image utils.read_image call (planercnn_transforms.py:306-314),
+ * which held the interpreter lock next to the thread that launches the model.
+ *   scan:  status[n] = 0 or why file i keeps the batch off this path (-1 not a JPEG, -2 unsupported, -3 malformed, -6 unreadable);
+ *          totals[8] = words, restart intervals, lanes, 8x8 blocks, largest image (pixels), coef / plane / output elements of the batch;
+ *          returns an opaque batch (NULL on bad arguments);
+ *   fill:  only if every status is 0: img32 [n][32], img64 [n][8], tables [n][TABLES_BYTES], seg32 [segs][4], seg64 [segs][2], words,
+ *          lane_img [lanes] (NULL if none), geometry [n][2] = (height, width); 0, -1 bad arguments, -2 bad Huffman table;
+ *   free:  always. */
+void* nopesac_jpeg_batch_scan_host(const char* const* paths, int n, int threads, int parallel, int* status, int64_t* totals);
+int nopesac_jpeg_batch_fill_host(void* batch, int32_t* img32, int64_t* img64, uint8_t* tables, int32_t* seg32, int64_t* seg64, uint32_t* words,
+                                 int32_t* lane_img, int32_t* geometry);
+void nopesac_jpeg_batch_free_host(void* batch);
+#define NOPESAC_JPEG_SUB_WORDS 64
+#define NOPESAC_JPEG_SYNC_PASSES 12
 int nopesac_jpeg_huffman_parallel(const int32_t* img32, const int64_t* img64, const uint8_t* tables, int n_images, const int32_t* lane_img,
                                   int64_t n_lanes, const uint32_t* words, int64_t n_words, int64_t* exit_state, int64_t* entry_used,
                                   int32_t* n_blk, int64_t* first_block, int32_t* changed, int32_t* par_done, int16_t* coef, void* stream);

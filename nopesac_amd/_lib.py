@@ -95,6 +95,9 @@ SIGNATURES = {
     "nopesac_jpeg_huffman": [P, P, P, P, P, I, P, L, P, P, P],
     "nopesac_jpeg_huffman_parallel": [P, P, P, I, P, L, P, L, P, P, P, P, P, P, P, P],
     "nopesac_jpeg_prepare_scan": [P, L, I, P, L, P, P, P, L, P],
+    "nopesac_jpeg_batch_scan_host": [P, I, I, I, P, P],
+    "nopesac_jpeg_batch_fill_host": [P, P, P, P, P, P, P, P, P],
+    "nopesac_jpeg_batch_free_host": [P],
     "nopesac_jpeg_idct": [P, P, P, I, I, P, P, P],
     "nopesac_jpeg_color": [P, P, I, I, P, P, I, P],
     "nopesac_png_info_host": [P, L, P, P, P, P],
@@ -119,7 +122,7 @@ SIGNATURES = {
     "nopesac_mlp_chain_bf16": [P, P],
 }
 _RESTYPE = {"nopesac_jpeg_prepare_scan": c_int64, "nopesac_last_error": c_char_p, "nopesac_rle_compress_batch_host": c_int64, "nopesac_mlp_packed_elems": c_int64,
-            "nopesac_conv2d_p8_sk_workspace_bytes": c_int64, "nopesac_inflate_zlib_host": c_int64}
+            "nopesac_conv2d_p8_sk_workspace_bytes": c_int64, "nopesac_inflate_zlib_host": c_int64, "nopesac_jpeg_batch_scan_host": c_void_p, "nopesac_jpeg_batch_free_host": None}
 
 MLP_MAX_IN, MLP_MAX_WIDTH, MLP_MAX_LAYERS = 1280, 1024, 12       # NOPESAC_MLP_* of the header
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnopesac_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv_p8.hip", "conv_p8n.hip", "stem.hip", "conv3x3_c64.hip", "conv3x3_halo.hip", "pwchain.hip", "gnn_layer.hip", "enc_tail.hip", "mask_head.hip", "resize.hip", "rle.hip", "elementwise.hip", "attention.hip", "postselect.hip", "matcher.hip",
-           "ransac.hip", "refine_bwd.hip", "mlp_chain.hip", "tape.hip", "posenet_branch.hip", "jpeg.hip", "png_host.hip"]
+           "ransac.hip", "refine_bwd.hip", "mlp_chain.hip", "tape.hip", "posenet_branch.hip", "jpeg.hip", "jpeg_host.hip", "png_host.hip"]
 # -packed-fp32-ops: NO v_pk_{fma,mul,add}_f32 anywhere in the library.  Round-3 finding (scripts/lds_victim.py): a wave
 # executing packed-f32 VALU instructions gets the results of its lanes 48-63 corrupted when a wave of ANOTHER kernel issues MFMAs on the
 # same SIMD - ransac_score_maps_kernel (whose f32 math the SLP vectoriser had packed) returned different scores on identical inputs in

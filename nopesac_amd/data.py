@@ -186,6 +186,13 @@ class PairMapper:
         for a caller that records its own event behind the decode (LazyPairs._iter_batches_gpu)."""
         from . import jpeg
         dev = self._resize_device
+        if host is not None and host.n == len(paths) and self._use_gpu_jpeg():       # the whole batch prepared already (reader thread, natively)
+            with torch.cuda.device(dev):
+                dec = jpeg.decode_batch(None, dev, bgr=(self.img_format == "BGR"), host=host)
+                out = self._finish_device_batch(dec, keep_device)
+                if sync and (self.device is not None or keep_device):
+                    torch.cuda.current_stream(dev).synchronize()
+            return out
         blobs = list(blobs) if blobs is not None else [None] * len(paths)
         infos = list(infos) if infos is not None else [None] * len(paths)
         gpu_idx = []
@@ -205,10 +212,7 @@ class PairMapper:
         out = [None] * len(paths)
         if gpu_idx:
             with torch.cuda.device(dev):
-                if host is not None and len(gpu_idx) == len(paths) and host.n == len(paths):       # prepared by the reader thread (every file)
-                    dec = jpeg.decode_batch(None, dev, bgr=(self.img_format == "BGR"), host=host)
-                else:
-                    dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
+                dec = jpeg.decode_batch([blobs[i] for i in gpu_idx], dev, bgr=(self.img_format == "BGR"), infos=[infos[i] for i in gpu_idx])
                 for i, t in zip(gpu_idx, self._finish_device_batch(dec, keep_device)):
                     out[i] = t
                 if sync and (self.device is not None or keep_device):          # (host hand-over: .cpu() above has synchronised already)
@@ -316,9 +320,15 @@ class LazyPairs:
                 yield item
 
     def _read_batch(self, entries: List[dict]):
-        """reader thread: file contents + marker walk of a batch's JPEG files (host work only)"""
+        """reader thread: the host side of a batch's JPEG files.  Fast path: ONE library call (jpeg.prepare_files, csrc/jpeg_host.hip: read,
+        marker walk, stuffing removal, tables, launch arrays on a few threads of its own, no interpreter).  If it reports a file it does not
+        take: file contents + jpeg.parse per file in Python, which sorts out what PIL must decode."""
         from . import jpeg
         paths = self.mapper.batch_paths(entries)
+        if paths and all(is_jpeg_path(p) for p in paths) and os.environ.get("NOPESAC_JPEG_NATIVE_PREPARE", "1") != "0":
+            host, status = jpeg.prepare_files(paths, threads=max(1, self.workers // 4))
+            if host is not None:
+                return entries, None, None, host
         blobs, infos = [None] * len(paths), [None] * len(paths)
         for i, p in enumerate(paths):
             if is_jpeg_path(p):
@@ -328,8 +338,6 @@ class LazyPairs:
                     infos[i] = jpeg.parse(blobs[i])
                 except jpeg.JpegUnsupported:
                     infos[i] = False
-        # every file one the GPU decoder takes: the batch's launch arguments are assembled HERE (pinned arrays), the consumer's thread -
-        # which also launches the model - only launches
         host = jpeg.prepare_batch(infos) if (infos and all(infos)) else None
         return entries, blobs, infos, host
 

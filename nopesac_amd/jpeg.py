@@ -34,7 +34,7 @@ LOOK_BITS = 9
 HUFF_BYTES = 1536                 # one Huffman table: look u16[512] | maxcode i32[18] | valoffset i32[18] | huffval u8[256] | pad
 TABLES_BYTES = 4 * HUFF_BYTES + 3 * 128          # DC0, DC1, AC0, AC1, then three quantisation tables u16[64] (natural order)
 IMG_I32, IMG_I64, SEG_I32, SEG_I64 = 32, 8, 4, 2
-SUB_WORDS, SYNC_PASSES = 256, 6                # NOPESAC_JPEG_SUB_WORDS / NOPESAC_JPEG_SYNC_PASSES
+SUB_WORDS, SYNC_PASSES = 64, 12                # NOPESAC_JPEG_SUB_WORDS / NOPESAC_JPEG_SYNC_PASSES
 PARALLEL_MIN_BYTES = 4 * SUB_WORDS * 4         # shorter restart-free streams stay on the one-wave-per-interval kernel
 
 
@@ -362,6 +362,53 @@ def prepare_batch(infos: Sequence[JpegInfo], parallel: bool = True) -> HostBatch
     hb.lane_img = _pinned(np.concatenate(lane_img)) if n_lanes else None
     hb.n_lanes, hb.n_blocks, hb.max_px, hb.coef_off, hb.plane_off, hb.out_off = n_lanes, n_blocks, max_px, coef_off, plane_off, out_off
     return hb
+
+
+class _Geometry:
+    """what decode_batch needs of a file a HostBatch was built for natively"""
+    __slots__ = ("width", "height")
+
+    def __init__(self, height, width):
+        self.height, self.width = int(height), int(width)
+
+
+def prepare_files(paths: Sequence[str], threads: int = 4, parallel: bool = True):
+    """The HostBatch of a batch of JPEG FILES built by ONE library call on `threads` threads of its own (csrc/jpeg_host.hip: read, marker
+    walk, checks, stuffing removal, tables, launch arrays - parse() + prepare_batch() without the interpreter).  Returns (HostBatch, None)
+    or (None, status list) when a file is outside what that path takes (the caller falls back to parse() per file, which decides what
+    PIL must decode)."""
+    L = _lib.load()
+    n = len(paths)
+    if n == 0:
+        return None, []
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    status = (ctypes.c_int * n)()
+    totals = (ctypes.c_int64 * 8)()
+    h = L.nopesac_jpeg_batch_scan_host(arr, n, max(1, int(threads)), 1 if parallel else 0, status, totals)
+    if not h:
+        return None, [-1] * n
+    try:
+        if any(status):
+            return None, list(status)
+        n_words, n_segs, n_lanes, n_blocks, max_px, coef_off, plane_off, out_off = [int(v) for v in totals]
+        hb = HostBatch()
+        hb.n = n
+        hb.img32, hb.img64 = torch.empty((n, IMG_I32), dtype=torch.int32), torch.empty((n, IMG_I64), dtype=torch.int64)
+        hb.tables = torch.empty((n, TABLES_BYTES), dtype=torch.uint8)
+        hb.seg32, hb.seg64 = torch.empty((n_segs, 4), dtype=torch.int32), torch.empty((n_segs, 2), dtype=torch.int64)
+        hb.words = torch.empty(n_words, dtype=torch.int32)
+        hb.lane_img = torch.empty(n_lanes, dtype=torch.int32) if n_lanes else None
+        geo = torch.empty((n, 2), dtype=torch.int32)
+        rc = L.nopesac_jpeg_batch_fill_host(h, hb.img32.data_ptr(), hb.img64.data_ptr(), hb.tables.data_ptr(), hb.seg32.data_ptr(), hb.seg64.data_ptr(),
+                                            hb.words.data_ptr(), hb.lane_img.data_ptr() if n_lanes else None, geo.data_ptr())
+        if rc != 0:
+            return None, [rc] * n
+        hb.infos = [_Geometry(hh, ww) for hh, ww in geo.tolist()]
+        hb.n_seg, hb.n_lanes, hb.n_blocks, hb.max_px = n_segs, n_lanes, n_blocks, max_px
+        hb.coef_off, hb.plane_off, hb.out_off = coef_off, plane_off, out_off
+        return hb, None
+    finally:
+        L.nopesac_jpeg_batch_free_host(h)
 
 
 def decode_batch(files: Sequence[bytes], device, bgr: bool = False, infos: Sequence[JpegInfo] = None, parallel: bool = True,

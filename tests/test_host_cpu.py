@@ -530,3 +530,56 @@ def test_own_inflate_matches_zlib():
                 ref = zlib.decompressobj(-15).decompress(bytes(b)[2:], got)          # trailer is not checked here - a PNG chunk's CRC
                 assert out == ref, name                                              # stands in for it)
     assert refused > 100
+
+
+def test_native_jpeg_batch_prepare_equals_the_python_form(tmp_path):
+    """csrc/jpeg_host.hip (one call per batch: file read, marker walk, checks, stuffing removal, derived Huffman tables, launch arrays) against
+    jpeg.py's parse() + prepare_batch() - the per-file Python it replaces on the loader's reader threads - array for array, on every committed
+    fixture the GPU decoder takes (all sampling modes, grey, restart markers, a 16-bit quantisation table if present) in mixed batches, one and
+    several threads; files it must leave alone (progressive, not a JPEG, missing, truncated) are reported per file and fail the batch's fast
+    path without touching the rest."""
+    import glob
+    import os
+    import numpy as np
+    import torch
+    from PIL import Image
+    from nopesac_amd import jpeg
+    from tests.util import ROOT
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "jpeg", "*.jpg")))
+    good, bad = [], []
+    for f in files:
+        try:
+            jpeg.parse(open(f, "rb").read())
+            good.append(f)
+        except jpeg.JpegUnsupported:
+            bad.append(f)
+    assert len(good) >= 8 and len(bad) >= 1
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:200, 0:264].astype(np.float32)
+    big = tmp_path / "big.jpg"                                # long enough for the self-synchronising decoder's lanes
+    Image.fromarray(np.clip(np.stack([128 + 90 * np.sin(xx / 9 + yy / 14), 128 + 70 * np.cos(yy / 7), 120 + 100 * ((xx // 16 + yy // 12) % 2)], -1)
+                            + rng.normal(0, 6.0, (200, 264, 3)), 0, 255).astype(np.uint8)).save(big, format="JPEG", quality=95, subsampling=2)
+    good = good + [str(big)]
+    for order in (good, good[::-1], [good[-1]] * 3 + good[:2]):
+        for parallel in (True, False):
+            want = jpeg.prepare_batch([jpeg.parse(open(f, "rb").read()) for f in order], parallel)
+            for thr in (1, 4):
+                got, st = jpeg.prepare_files(order, threads=thr, parallel=parallel)
+                assert st is None and got is not None and got.n == want.n
+                for name in ("img32", "img64", "tables", "seg32", "seg64", "words"):
+                    a, b = getattr(got, name), getattr(want, name)
+                    assert a.shape == b.shape and torch.equal(a.view(torch.uint8) if a.dtype != b.dtype else a, b.view(torch.uint8) if a.dtype != b.dtype else b), (name, parallel, thr)
+                assert (got.lane_img is None) == (want.lane_img is None) and (got.lane_img is None or torch.equal(got.lane_img, want.lane_img))
+                assert (got.n_seg, got.n_lanes, got.n_blocks, got.max_px, got.coef_off, got.plane_off, got.out_off) == (
+                    want.n_seg, want.n_lanes, want.n_blocks, want.max_px, want.coef_off, want.plane_off, want.out_off)
+                assert [(g.height, g.width) for g in got.infos] == [(w.height, w.width) for w in want.infos]
+    assert want.n_lanes == 0 and jpeg.prepare_batch([jpeg.parse(open(str(big), "rb").read())], True).n_lanes > 0
+    # files the fast path leaves alone
+    notjpg = tmp_path / "x.jpg"
+    notjpg.write_bytes(b"\x89PNG not a jpeg at all")
+    trunc = tmp_path / "t.jpg"
+    trunc.write_bytes(open(good[0], "rb").read()[:-200])
+    mixed = [good[0], bad[0], str(notjpg), str(tmp_path / "missing.jpg"), str(trunc), good[1]]
+    got, st = jpeg.prepare_files(mixed, threads=3)
+    assert got is None and st[0] == 0 and st[5] == 0 and st[1] == -2 and st[2] == -1 and st[3] == -6 and st[4] in (-3, -2)
+    assert jpeg.prepare_files([], threads=2) == (None, [])
