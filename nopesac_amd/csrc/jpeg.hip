@@ -4,7 +4,7 @@
 // upsampling, RGB), host side in nopesac_amd/jpeg.py (marker walk, restart split, stuffing removal, table layout - no entropy decoding):
 //
 //   jpeg_sync_kernel<0|1|2>, jpeg_sync_scan_kernel, jpeg_dc_kernel
-//                        restart-free files: self-synchronising parallel Huffman decode, one lane per 8192-bit subsequence (further down)
+//                        restart-free files: self-synchronising parallel Huffman decode, one lane per 2048-bit subsequence (further down)
 //   jpeg_huffman_kernel  one WAVE per restart interval (per image when the file has none and the lanes above did not settle).  Entropy decoding is a serial chain per
 //                        interval (every code's position depends on all codes before it), so the wave runs it on the SCALAR unit:
 //                        all state is wave-uniform, the bit stream and the tables are read with scalar loads from the constant

@@ -3,7 +3,7 @@ libjpeg-turbo decode, NopeSAC_Net/data/planercnn_transforms.py:210-227 and :306-
 
 Host side (this file): marker walk, restart-interval split, removal of the byte stuffing, Huffman lookup tables - a few numpy calls
 per file, no entropy decoding.  Device side (csrc/jpeg.hip, include/nopesac_hip.h `nopesac_jpeg_*`): Huffman decode (restart-free
-files: self-synchronising, one lane per 8192-bit subsequence; files with restart markers and streams the lanes do not settle on: one
+files: self-synchronising, one lane per 2048-bit subsequence; files with restart markers and streams the lanes do not settle on: one
 wave per restart interval on the scalar unit), dequantisation + libjpeg's 13-bit "islow" inverse DCT,
 "fancy" (triangle) chroma upsampling and the 16-bit fixed-point YCbCr -> RGB conversion, bit for bit what libjpeg-turbo produces with
 its default decompression parameters (tests/test_jpeg_gpu.py against Pillow-decoded fixtures and oracle/jpeg_oracle.py).

@@ -37,7 +37,7 @@ for label, opt in (("no restart markers", dict(quality=90, subsampling=2)), ("re
     assert np.array_equal(outs[0].cpu().numpy(), ref)
     if st:
         print("   self-synchronising decoder: %d of %d images settled; lanes that moved per pass (all images): %s of %d lanes" % (
-            int(st["par_done"].sum()), N, st["changed"].sum(1).tolist(), sum(-(-i.seg_bytes[0] * 8 // 8192) for i in infos)), flush=True)
+            int(st["par_done"].sum()), N, st["changed"].sum(1).tolist(), sum(-(-i.seg_bytes[0] * 8 // (jpeg.SUB_WORDS * 32)) for i in infos)), flush=True)
     print("%s: %d KB per file; Pillow %.2f ms per image on one core; host parse + stuffing removal %.3f ms per image" % (label, len(base[0]) // 1024, pil_ms, parse_ms), flush=True)
     for n_streams in (1, 2, 4):
         streams = [torch.cuda.Stream() for _ in range(n_streams)]
