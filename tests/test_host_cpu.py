@@ -583,3 +583,32 @@ def test_native_jpeg_batch_prepare_equals_the_python_form(tmp_path):
     got, st = jpeg.prepare_files(mixed, threads=3)
     assert got is None and st[0] == 0 and st[5] == 0 and st[1] == -2 and st[2] == -1 and st[3] == -6 and st[4] in (-3, -2)
     assert jpeg.prepare_files([], threads=2) == (None, [])
+    # damaged files (bytes overwritten, inserted, cut off): the native walk never takes a file the Python walk refuses (it may be stricter:
+    # the batch then goes down the Python path), and where both take it the arrays are equal
+    import random
+    random.seed(3)
+    stricter = 0
+    for it in range(150):
+        b = bytearray(open(random.choice(good[:-1]), "rb").read())
+        mode = random.random()
+        if mode < 0.5:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode < 0.8:
+            b = b[:random.randrange(2, len(b))]
+        else:
+            i = random.randrange(len(b))
+            b[i:i] = bytes(random.randrange(256) for _ in range(random.randint(1, 8)))
+        pth = tmp_path / ("fuzz%d.jpg" % (it % 4))
+        pth.write_bytes(bytes(b))
+        try:
+            info = jpeg.parse(bytes(b))
+        except jpeg.JpegUnsupported:
+            info = None
+        hb, st = jpeg.prepare_files([str(pth)], threads=1)
+        assert not (hb is not None and info is None), it
+        if hb is not None:
+            want = jpeg.prepare_batch([info])
+            assert all(torch.equal(getattr(hb, k), getattr(want, k)) for k in ("img32", "img64", "tables", "seg32", "seg64", "words")), it
+        stricter += hb is None and info is not None
+    assert stricter < 30
