@@ -355,29 +355,78 @@ class LazyPairs:
         chunks = [self.entries[i:i + pairs_per_batch] for i in range(0, len(self.entries), pairs_per_batch)]
         with torch.cuda.device(dev):
             streams = [torch.cuda.Stream(device=dev) for _ in range(ahead)]
-        with ThreadPoolExecutor(max_workers=self.workers) as pool:
-            reading, decoding, nxt, k = deque(), deque(), 0, 0
-            depth = max(ahead + 1, self.prefetch // max(1, pairs_per_batch))
-            while nxt < len(chunks) or reading or decoding:
-                while nxt < len(chunks) and len(reading) + len(decoding) < depth:
-                    reading.append(pool.submit(self._read_batch, chunks[nxt]))
-                    nxt += 1
-                while reading and len(decoding) < ahead:
-                    entries, blobs, infos, host = reading.popleft().result()
-                    st = streams[k % ahead]
+        # A decode THREAD launches the chains (a dozen torch calls, seven host-to-device copies and ten kernel launches per batch: ~3 ms of
+        # wall time that the consumer's thread - which launches the model and packages its results - does not have); the consumer only
+        # waits for a finished batch.  NOPESAC_JPEG_DECODE_THREAD=0: launch from the consumer's thread (the round-4 form).
+        import queue
+        import threading
+        done_q: "queue.Queue" = queue.Queue(maxsize=ahead)
+        stop = threading.Event()
+        depth = max(ahead + 1, self.prefetch // max(1, pairs_per_batch))
+
+        def launch(k, res):
+            entries, blobs, infos, host = res
+            st = streams[k % ahead]
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                items = self.mapper.map_batch(entries, blobs, infos, sync=False, keep_device=True, host=host)
+                ev = torch.cuda.Event()
+                ev.record()
+            return items, ev
+
+        def put(x):                                             # (gives up when the consumer has gone away)
+            while not stop.is_set():
+                try:
+                    done_q.put(x, timeout=0.1)
+                    return
+                except queue.Full:
+                    pass
+
+        def decoder(pool):
+            try:
+                reading, nxt, k = deque(), 0, 0
+                while (nxt < len(chunks) or reading) and not stop.is_set():
+                    while nxt < len(chunks) and len(reading) < depth:
+                        reading.append(pool.submit(self._read_batch, chunks[nxt]))
+                        nxt += 1
+                    put(launch(k, reading.popleft().result()))
                     k += 1
-                    with torch.cuda.device(dev), torch.cuda.stream(st):
-                        items = self.mapper.map_batch(entries, blobs, infos, sync=False, keep_device=True, host=host)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    decoding.append((items, ev, st))
-                items, ev, st = decoding.popleft()
-                # The consumer picks its own stream AFTER next() returns (run.inference_on_dataset rotates side streams), so a
-                # wait_event on this thread's current stream would order nothing: the batch is handed out COMPLETE.  The decode was
-                # launched `ahead` batches ago - this wait is normally over already.  (Memory: the images were allocated on the decode
-                # stream; PlaneTR_NopeSAC._copy_images records the consumer's stream on every device image it reads.)
-                ev.synchronize()
-                yield items
+                put(None)
+            except BaseException as e:                          # surfaces in the consumer
+                put(e)
+
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            if os.environ.get("NOPESAC_JPEG_DECODE_THREAD", "1") == "0":
+                reading, decoding, nxt, k = deque(), deque(), 0, 0
+                while nxt < len(chunks) or reading or decoding:
+                    while nxt < len(chunks) and len(reading) + len(decoding) < depth:
+                        reading.append(pool.submit(self._read_batch, chunks[nxt]))
+                        nxt += 1
+                    while reading and len(decoding) < ahead:
+                        decoding.append(launch(k, reading.popleft().result()))
+                        k += 1
+                    items, ev = decoding.popleft()
+                    ev.synchronize()
+                    yield items
+                return
+            th = threading.Thread(target=decoder, args=(pool,), name="nopesac-jpeg-decode", daemon=True)
+            th.start()
+            try:
+                while True:
+                    item = done_q.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    items, ev = item
+                    # The consumer picks its own stream AFTER next() returns (run.inference_on_dataset rotates side streams), so a
+                    # wait_event on this thread's current stream would order nothing: the batch is handed out COMPLETE.  The decode was
+                    # launched up to `ahead` batches ago - this wait is normally over already.  (Memory: the images were allocated on the
+                    # decode stream; PlaneTR_NopeSAC._copy_images records the consumer's stream on every device image it reads.)
+                    ev.synchronize()
+                    yield items
+            finally:
+                stop.set()
+                th.join()
 
     def _png_batch(self, entries: List[dict]):
         """batch thread: every image of the batch through ONE native call (read_png_files, `workers` threads), files it does not take
