@@ -768,7 +768,7 @@ int nopesac_sgd_step(float* param, const float* grad, float* momentum_buf, int64
  * if the bytes are not a PNG.  nopesac_png_decode_host: the file's samples as interleaved RGB (bgr = 0) / BGR (bgr = 1) in out
  * [H * W * 3], converted like PIL's convert("RGB") (grey replicated, palette looked up, alpha dropped); 0, or -1 not a PNG, -2
  * unsupported (16-bit / sub-byte / interlaced: the caller falls back to PIL), -3 truncated / corrupt (CRC, inflate, filter type), -4 out
- * too small, -100 built without zlib. */
+ * too small.  (zlib is optional: only the NOPESAC_PNG_ZLIB_INFLATE=1 A/B path uses it; the default inflate is csrc/inflate_host.h.) */
 int nopesac_png_info_host(const unsigned char* data, int64_t n, int* height, int* width, int* channels, int* supported);
 int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr);
 /* A batch of PNG FILES on `threads` threads of the call itself (replaces the per-image Python of the reference mapper,

@@ -34,6 +34,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
+def _have_zlib(cc: str) -> bool:
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "z.cpp")
+        with open(src, "w") as f:
+            f.write("#include <zlib.h>\nint main() { z_stream s{}; return inflateInit(&s) == Z_OK ? inflateEnd(&s) : 1; }\n")
+        r = subprocess.run([cc, "-x", "c++", src, "-o", os.path.join(d, "z"), "-lz"], capture_output=True, text=True)
+        return r.returncode == 0
+
+
 def _digest() -> str:
     h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for name in sorted(os.listdir(CSRC)) + ["../../include/nopesac_hip.h"]:
@@ -51,10 +61,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     cc = _hipcc()
+    # zlib only serves png_host.hip's NOPESAC_PNG_ZLIB_INFLATE=1 A/B path (the decoder's own inflate needs nothing).  Decided ONCE, here, by a
+    # test compile + link, and handed to the compiler and the linker together: -DNPS_HAVE_ZLIB=1 exactly when -lz is on the link line.
+    have_zlib = _have_zlib(cc)
+    per_build = {"png_host.hip": ["-DNPS_HAVE_ZLIB=%d" % int(have_zlib)]}       # (not part of the digest: a property of the box, not of the sources)
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), *per_build.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
@@ -62,8 +76,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    # (-lz: png_host.hip inflates the mp3d split's PNG frames on the host; without zlib headers that file compiles to a stub)
-    zlib = ["-lz"] if os.path.exists("/usr/include/zlib.h") else []
+    zlib = ["-lz"] if have_zlib else []
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, *zlib], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])

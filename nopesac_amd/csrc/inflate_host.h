@@ -5,11 +5,14 @@
 // second-level tables behind long codes), emit up to three literals per refill and copy matches in 8-byte steps into an output buffer with
 // slack.  Written from the RFCs; the table layout and the loop are this file's own.
 //
-// Contract: `in` must be readable for 16 bytes past `in_len` (the caller concatenates the IDAT payloads into scratch with zeroed slack);
+// Contract: `in` must be readable for 24 bytes (NPS_INFLATE_IN_SLACK) past `in_len` (the caller concatenates the IDAT payloads into scratch
+// with zeroed slack: the loop lets ip reach in_end + 8 before a refill, the refill advances it by up to 7, and the second refill in front of a
+// distance code then loads the 8 bytes at in_end + 15 .. + 23);
 // `out` must be writable for 16 bytes past `out_cap` (match copies run up to 7 bytes over their end, never past out_cap + 8).  Returns the
 // number of bytes written, or -1 on any malformed input (bad header, invalid / over-subscribed / incomplete code, distance too far back,
 // output overflow, input exhausted).  The Adler-32 trailer is NOT checked here: a PNG chunk's CRC-32 has covered the same bytes already.
 #pragma once
+#define NPS_INFLATE_IN_SLACK 24
 #include <cstdint>
 #include <cstring>
 
@@ -146,7 +149,7 @@ inline int64_t inflate_zlib(const unsigned char* in, int64_t in_len, unsigned ch
     if (in_len < 6) return -1;
     if ((in[0] & 15) != 8 || (in[0] >> 4) > 7 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 32)) return -1;   // CM = 8, window <= 32 K, FCHECK, no preset dictionary
     const unsigned char* const in_end = in + in_len;
-    const unsigned char* const in_limit = in_end + 8;           // reads stay inside the 16 bytes of slack
+    const unsigned char* const in_limit = in_end + 8;           // reads stay inside NPS_INFLATE_IN_SLACK bytes past in_end
     const unsigned char* ip = in + 2;
     unsigned char* op = out;
     unsigned char* const out_end = out + out_cap;

@@ -58,6 +58,9 @@ bool derived_table(const std::vector<uint8_t>& spec, uint8_t* out) {
     int code = 0, k = 0;
     for (int ln = 1; ln <= 16; ++ln) {
         const int cnt = spec[ln - 1];
+        // Kraft check BEFORE any table write: code + cnt codes of this length must fit ln bits (a crafted BITS such as {255, 0, ...}
+        // passes the total == nval test and would otherwise index look[] far past its 512 entries)
+        if (code + cnt > (1 << ln)) return false;
         if (cnt) {
             valoff[ln] = k - code;
             for (int j = 0; j < cnt; ++j) {
@@ -116,7 +119,12 @@ void parse_file(const std::vector<uint8_t>& buf, FileInfo& f) {
                 if (s + 17 > sl) { f.status = -3; return; }
                 int cnt = 0;
                 for (int i = 0; i < 16; ++i) cnt += seg[s + 1 + i];
-                if (s + 17 + cnt > sl) { f.status = -3; return; }
+                if (s + 17 + cnt > sl || cnt > 256) { f.status = -3; return; }
+                for (int ln = 1, code = 0; ln <= 16; ++ln) {     // Kraft: the canonical codes of every length must fit that length
+                    code += seg[s + ln];
+                    if (code > (1 << ln)) { f.status = -3; return; }
+                    code <<= 1;
+                }
                 if (tc <= 1 && th <= 1) {
                     f.huff[tc][th].assign(seg + s + 1, seg + s + 17 + cnt);
                     f.have_huff[tc][th] = true;

@@ -27,11 +27,14 @@
 #include "common.h"
 #include "inflate_host.h"
 
-#if __has_include(<zlib.h>)
-#include <zlib.h>
-#define NPS_HAVE_ZLIB 1
-#else
+// zlib is OPTIONAL and only serves the NOPESAC_PNG_ZLIB_INFLATE=1 A/B path: the decoder's own inflate (inflate_host.h) needs nothing.
+// nopesac_amd/build.py decides once (a test compile + link against -lz) and passes -DNPS_HAVE_ZLIB=0/1 together with -lz, so the object
+// never references zlib symbols the link line does not provide (a bare __has_include also finds headers under conda / sysroot paths).
+#ifndef NPS_HAVE_ZLIB
 #define NPS_HAVE_ZLIB 0
+#endif
+#if NPS_HAVE_ZLIB
+#include <zlib.h>
 #endif
 
 namespace {
@@ -262,18 +265,14 @@ extern "C" int nopesac_png_info_host(const unsigned char* data, int64_t n, int* 
     if (height) *height = (int)h;
     if (width) *width = (int)w;
     if (channels) *channels = ch;
-    if (supported) *supported = (NPS_HAVE_ZLIB && ch && depth == 8 && comp == 0 && filt == 0 && inter == 0 && w > 0 && h > 0 && w < (1u << 15) && h < (1u << 15)) ? 1 : 0;
+    if (supported) *supported = (ch && depth == 8 && comp == 0 && filt == 0 && inter == 0 && w > 0 && h > 0 && w < (1u << 15) && h < (1u << 15)) ? 1 : 0;
     return 0;
 }
 
 // data[n] = the file; out = H * W * 3 bytes, RGB (bgr = 0) or BGR (bgr = 1) interleaved.  Returns 0, or: -1 not a PNG, -2 unsupported
 // variant (16-bit / sub-byte / interlaced), -3 truncated or corrupt (chunk structure, CRC, inflate, filter byte), -4 out too small,
-// -100 the library was built without zlib.  Thread-safe, no global state.
+// (-100 is no longer returned: the decoder's own inflate needs no zlib).  Thread-safe, no global state.
 static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr, int chw, PngScratch& sc) {
-#if !NPS_HAVE_ZLIB
-    (void)data; (void)n; (void)out; (void)out_bytes; (void)bgr; (void)chw; (void)sc;
-    return -100;
-#else
     int H = 0, W = 0, ch = 0, ok = 0;
     if (nopesac_png_info_host(data, n, &H, &W, &ch, &ok) != 0) return -1;
     if (!ok) return -2;
@@ -286,9 +285,14 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
     unsigned char* raw = sc.raw.data();
     // The IDAT payloads (CRC-checked chunk by chunk) are gathered into one buffer and inflated in one go by csrc/inflate_host.h;
     // NOPESAC_PNG_ZLIB_INFLATE=1 keeps zlib's streaming inflate (the first round-5 form; A/B and a way out).
+#if NPS_HAVE_ZLIB
     static const bool use_zlib = getenv("NOPESAC_PNG_ZLIB_INFLATE") && atoi(getenv("NOPESAC_PNG_ZLIB_INFLATE")) == 1;
     z_stream& zs = sc.zs;
+#else
+    constexpr bool use_zlib = false;                             // (built without zlib: the A/B switch has nothing to switch to)
+#endif
     if (use_zlib) {
+#if NPS_HAVE_ZLIB
         if (!sc.zinit) {
             memset(&zs, 0, sizeof(zs));
             if (inflateInit(&zs) != Z_OK) return -3;
@@ -298,8 +302,9 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
         }
         zs.next_out = raw;
         zs.avail_out = (uInt)raw_bytes;
-    } else if ((int64_t)sc.idat.size() < n + 16) {
-        sc.idat.resize((size_t)n + 16);
+#endif
+    } else if ((int64_t)sc.idat.size() < n + NPS_INFLATE_IN_SLACK) {
+        sc.idat.resize((size_t)n + NPS_INFLATE_IN_SLACK);
     }
     int64_t idat_len = 0;
     int rc = 0, zend = 0, have_plte = 0;
@@ -315,13 +320,16 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
             if (!use_zlib) {
                 memcpy(sc.idat.data() + idat_len, body, L);
                 idat_len += L;
-            } else if (!zend && L) {
+            }
+#if NPS_HAVE_ZLIB
+            else if (!zend && L) {
                 zs.next_in = (Bytef*)body;
                 zs.avail_in = L;
                 const int r = inflate(&zs, Z_NO_FLUSH);
                 if (r == Z_STREAM_END) zend = 1;
                 else if (r != Z_OK && !(r == Z_BUF_ERROR && zs.avail_out == 0)) { rc = -3; break; }
             }
+#endif
         } else if (memcmp(type, "PLTE", 4) == 0) {
             if (L % 3 != 0 || L > 768) { rc = -3; break; }
             memcpy(pal, body, L);
@@ -333,9 +341,13 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
     }
     int64_t got;
     if (use_zlib) {
+#if NPS_HAVE_ZLIB
         got = raw_bytes - (int64_t)zs.avail_out;
+#else
+        got = -1;
+#endif
     } else {
-        memset(sc.idat.data() + idat_len, 0, 16);
+        memset(sc.idat.data() + idat_len, 0, NPS_INFLATE_IN_SLACK);
         got = rc == 0 ? nps_inflate::inflate_zlib(sc.idat.data(), idat_len, raw, raw_bytes, sc.tables) : -1;
     }
     if (rc == 0 && (got != raw_bytes || (ctype == 3 && !have_plte))) rc = -3;
@@ -378,7 +390,6 @@ static int png_decode_impl(const unsigned char* data, int64_t n, unsigned char* 
         }
     }
     return 0;
-#endif
 }
 
 extern "C" int nopesac_png_decode_host(const unsigned char* data, int64_t n, unsigned char* out, int64_t out_bytes, int bgr) {
@@ -502,7 +513,7 @@ extern "C" int nopesac_png_decode_files_host(const char* const* paths, int n, un
 // a whole zlib stream in[n] -> out[out_cap]; returns the number of bytes written or -1.  No slack is required of the caller's buffers.
 extern "C" int64_t nopesac_inflate_zlib_host(const unsigned char* in, int64_t n, unsigned char* out, int64_t out_cap) {
     if (!in || n < 0 || (!out && out_cap > 0) || out_cap < 0) return -1;
-    std::vector<unsigned char> src((size_t)n + 16, 0), dst((size_t)out_cap + 16);
+    std::vector<unsigned char> src((size_t)n + NPS_INFLATE_IN_SLACK, 0), dst((size_t)out_cap + 16);
     memcpy(src.data(), in, (size_t)n);
     PngScratch* sc = new PngScratch();
     const int64_t got = nps_inflate::inflate_zlib(src.data(), n, dst.data(), out_cap, sc->tables);

@@ -457,6 +457,24 @@ __global__ __launch_bounds__(256) void sumsq_accum_kernel(const float* __restric
     if (threadIdx.x == 0) out[0] += a;
 }
 
+// large tensors (the 1024 x 1024 weights): two stages so that the whole chip reads the tensor - up to 256 workgroups each sum one contiguous
+// slice (stride-256 order inside the slice), then ONE workgroup adds the partial sums in index order.  Fixed slices, fixed order: still
+// bit-identical run to run (no atomics)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, long long chunk, float* __restrict__ partials) {
+    __shared__ float sh4[4];
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    float a = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) a += x[i] * x[i];
+    a = rb_block_sum_256(a, sh4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+    __shared__ float sh4[4];
+    float a = (int)threadIdx.x < nb ? partials[threadIdx.x] : 0.f;
+    a = rb_block_sum_256(a, sh4);
+    if (threadIdx.x == 0) out[0] += a;
+}
+
 // clip coefficient of clip_grad_norm_: c = min(1, max_norm / (sqrt(sumsq) + 1e-6)) -> coef[0]
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
     const float total = sqrtf(sumsq[0]);
@@ -596,7 +614,22 @@ extern "C" int nopesac_normalize_rows_backward(const float* x, const float* g, i
 extern "C" int nopesac_sumsq_accumulate_f32(const float* x, int64_t n, float* out, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && out && n > 0, "sumsq_accumulate_f32: bad arguments");
-    hipLaunchKernelGGL(sumsq_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    if (n <= 16384) {
+        hipLaunchKernelGGL(sumsq_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    } else {
+        // slices of a multiple of 4096 elements, at most 256 of them; the partial sums live in stream-ordered scratch
+        long long chunk = ((n + 255) / 256 + 4095) / 4096 * 4096;
+        const int nb = (int)((n + chunk - 1) / chunk);
+        float* partials = nullptr;
+        if (hipMallocAsync((void**)&partials, 256 * sizeof(float), (hipStream_t)stream) != hipSuccess || !partials) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(sumsq_accum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);   // (same value class, one CU)
+        } else {
+            hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n, chunk, partials);
+            hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, out);
+            (void)hipFreeAsync(partials, (hipStream_t)stream);
+        }
+    }
     NPS_LAUNCH_RET();
 }
 

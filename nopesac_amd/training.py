@@ -290,6 +290,9 @@ class RefineTrainer:
                                              dn_sum, dl2_sum, init_rot.detach(), init_trans.detach(), m)
         lv = _Losses.apply(pr, pt, ar, at, sr, st, l2, rots_all, trans_all, m, gt_pose, float(weight))
         self._inputs = {"init_trans_feat": init_trans_feat, "init_rot_feat": init_rot_feat, "init_trans": init_trans, "init_rot": init_rot}
+        for t in self._inputs.values():                    # a caller may chain its own graph in front (CameraHeadTrainer does): non-leaf
+            if t.requires_grad and not t.is_leaf:          # inputs keep their gradient only on request, and `input_grads` promises it
+                t.retain_grad()
         self.last = {"pred_rot": pr, "pred_trans": pt, "avg_rot": ar, "avg_trans": at, "score_rot": sr, "score_trans": st, "m": m}
         return {"%s_%s" % (nm, suffix): lv[i] for i, nm in enumerate(ops.PLANE_CAM_REF_LOSS_NAMES)}
 
@@ -299,7 +302,7 @@ class RefineTrainer:
         for p in self.params.values():
             p.grad = None
         for t in self._inputs.values():
-            if t.requires_grad:
+            if t.requires_grad and t.is_leaf:
                 t.grad = None
         total = None
         for k, v in losses.items():

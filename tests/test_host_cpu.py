@@ -612,3 +612,25 @@ def test_native_jpeg_batch_prepare_equals_the_python_form(tmp_path):
             assert all(torch.equal(getattr(hb, k), getattr(want, k)) for k in ("img32", "img64", "tables", "seg32", "seg64", "words")), it
         stricter += hb is None and info is not None
     assert stricter < 30
+    # crafted DHT (round-5 advisor finding): BITS = [255, 0, ...] with 255 values passes the "sum of BITS == number of values" test but is
+    # no prefix code; the derived-table builder used to index its 512-entry look-ahead table at ~65000 (heap overflow in the batch's
+    # `tables` tensor).  The native walk must refuse the file (status -3) and the Python walk must refuse it too.
+    b = open(good[0], "rb").read()
+    i = b.rfind(b"\xff\xc4")
+    L = (b[i + 2] << 8) | b[i + 3]
+    assert i > 0 and L > 19
+    seg = bytes([b[i + 4]]) + bytes([255] + [0] * 15) + bytes(range(255))
+    crafted = b[:i] + b"\xff\xc4" + bytes([(len(seg) + 2) >> 8, (len(seg) + 2) & 255]) + seg + b[i + 2 + L:]
+    cp = tmp_path / "crafted_dht.jpg"
+    cp.write_bytes(crafted)
+    for _ in range(3):
+        hb, st = jpeg.prepare_files([str(cp)] * 4, threads=2)
+        assert hb is None and st == [-3] * 4, st
+    with pytest.raises(jpeg.JpegUnsupported):
+        jpeg.prepare_batch([jpeg.parse(crafted)])
+    # a table that over-subscribes a LONGER length only (two 1-bit codes are fine, three 2-bit codes on top are not)
+    seg = bytes([b[i + 4]]) + bytes([2, 3] + [0] * 14) + bytes(range(5))
+    crafted = b[:i] + b"\xff\xc4" + bytes([0, len(seg) + 2]) + seg + b[i + 2 + L:]
+    cp.write_bytes(crafted)
+    hb, st = jpeg.prepare_files([str(cp)], threads=1)
+    assert hb is None and st == [-3], st
