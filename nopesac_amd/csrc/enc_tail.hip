@@ -577,9 +577,397 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 128-token form of the ENCODER tail (round 6).  Why: in the 64-token kernel every 1 KB weight fragment feeds TWO MFMAs, i.e. 16 cycles of
+// the CU's vector-memory path (64 B/clk) per 16 cycles of CU-level MFMA time (32 cycles on one of four SIMDs): the weight stream from L2
+// and the MFMAs need the SAME time, each wave waits for its own eight fragments with one K = 128 step of look-ahead, and the kernel sat
+// at 13 % MFMA-busy / 56 % of the wave cycles parked in s_waitcnt (profiles/r4_pmc_enc_tail.json).  Here a workgroup owns 128 tokens and
+// every fragment feeds FOUR MFMAs (row tiles 0..3): half the L2 -> CU bytes per FLOP (1.5 MB per 128 instead of per 64 tokens), 32
+// MFMAs (1024 SIMD cycles) of cover behind every weight step, 150 workgroups for the 19200 encoder tokens in ONE round instead of 300
+// in two.  What makes it fit (256 registers per wave, 160 KB of LDS):
+//   * the residual input is the accumulator's start value (acc = src + b_o, loaded straight into the accumulator registers while the
+//     attention rows and the first weight step are in flight), and linear2 accumulates on top of y1 + b2 in the registers that held y1 -
+//     no second copy of y1, no separate residual load behind the GEMM.  Sums: (src + b_o) + sum_k instead of (sum_k + b_o) + src, and
+//     (y1 + b2) + sum_k instead of (sum_k + b2) + y1: f32 roundings in a different order, not bit-identical to the 32- / 64-token kernels;
+//   * the 1024-wide hidden tile in four quarters of 256 = ONE column tile per wave and quarter, parked in the region that held the
+//     attention rows; linear1 of quarter q + 1 is computed into registers BEFORE the barrier that frees the hidden tile, so that barrier
+//     has a full linear2 + linear1 quarter (128 MFMAs per wave) between its arrivals;
+//   * the f32 residual stream leaves straight from the accumulators (four 32-byte pieces of a row per wave = one 128-byte line), only
+//     the bf16 operand tiles of the chained projections go back through LDS.
+// NR = row tiles of 32 tokens per workgroup: 4 (128 tokens, the form described above) or 3 (96 tokens: 200 workgroups for the 19200
+// encoder tokens - more CUs busy, three MFMAs per fragment)
+template <int NR> struct E8 {
+    static constexpr int BM = 32 * NR, A = BM * ET_LD, HALF = 16 * NR;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(2 * A) + 2 * 8 * BM * sizeof(float);
+    static_assert((size_t)HALF * ET_FLD * 4 <= 2 * (size_t)A, "half of the f32 rows must fit one bf16 tile region");
+};
+
+// acc[r] += A[r*32 + row][(koff + kk)*16 ..] * W over the 8 k-steps held in ring.f[BUF]; each fragment feeds four MFMAs
+template <int BUF, int NR>
+__device__ __forceinline__ void e8_gemm(const E6Ring& ring, const bf16_t* A, int koff, f32x16 (&acc)[NR], int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + (r * 32 + l31) * ET_LD + (koff + kk) * 16 + half * 8);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring.f[BUF][kk], af, acc[r], 0, 0, 0);
+        }
+}
+// LayerNorm over 256 channels spread over the 8 waves (32 each), four row tiles per wave.  Two passes like every LayerNorm of the library
+// (mean, then the sum of squared deviations), with the VALU work of a kernel whose LayerNorms cost 8 % of its cycles cut from 8 to 5
+// operations per value: the deviations REPLACE the values in pass 2 (one subtraction, one fused multiply-add into the sum) and the
+// affine step is (d * rstd) fused-multiply-added with gamma and beta.
+template <int NR>
+__device__ __forceinline__ void e8_layernorm(f32x16 (&acc)[NR], const float* __restrict__ gamma, const float* __restrict__ beta, float* red,
+                                             int wave, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    constexpr int BM = 32 * NR;
+    float mean[NR], rstd[NR];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* rp = red + pass * 8 * BM;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float s = 0.f;
+            if (pass == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += acc[r][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[r][e] -= mean[r];
+                    s = __builtin_fmaf(acc[r][e], acc[r][e], s);
+                }
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (half == 0) rp[wave * BM + r * 32 + l31] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += rp[w * BM + r * 32 + l31];
+            if (pass == 0) mean[r] = t / ET_D;
+            else rstd[r] = rsqrtf(t / ET_D + 1e-5f);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n), b = *reinterpret_cast<const f32x4*>(beta + n);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][4 * q + e] = __builtin_fmaf(acc[r][4 * q + e] * rstd[r], g[e], b[e]);
+    }
+}
+
+// STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into `dbg` [workgroups][8 waves][16] (scripts/enc_tail_stamps.py)
+template <bool STAMP, int NR>
+__global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p, unsigned long long* dbg) {
+    constexpr int E8_BM = E8<NR>::BM, E8_A = E8<NR>::A, HALF = E8<NR>::HALF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char et_smem[];
+    bf16_t* At = reinterpret_cast<bf16_t*>(et_smem);         // attention rows [128][264]; then the hidden quarter; later bf16(y + pos)
+    bf16_t* Yt = At + E8_A;                                  // bf16(y1) [128][264]; later bf16(y); last the projections' output staging
+    float* red = reinterpret_cast<float*>(Yt + E8_A);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * E8_BM;
+    E6Ring ring;
+    unsigned long long ts[16];
+    auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
+    stamp(0);
+
+    e6_issue<0>(ring, p.wo, 16, 0, wave, lane);                                   // out-proj tile `wave`, K 0..127
+    // ---- the attention rows first (GEMM 1 waits for them), the residual rows behind them (they land under GEMM 1)
+    // (rows behind M: the LAST row's data instead of a guarded load - a branch around a load is something the compiler's s_waitcnt
+    // pass cannot count across, so the ds_writes below waited for the residual rows as well; those rows' results are never stored)
+    const long long last = (long long)p.M - 1;
+    us8 av[E8_BM * 32 / 512];
+#pragma unroll
+    for (int i = 0; i < E8_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        const long long row = m0 + r < last ? m0 + r : last;
+        av[i] = *reinterpret_cast<const us8*>(p.attn + row * ET_D + col);
+    }
+    f32x4 sv[NR][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const long long row = m0 + r * 32 + l31 < last ? m0 + r * 32 + l31 : last;
+            sv[r][q] = *reinterpret_cast<const f32x4*>(p.src + row * ET_D + wave * 32 + 8 * q + 4 * half);
+        }
+#pragma unroll
+    for (int i = 0; i < E8_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        *reinterpret_cast<us8*>(At + r * ET_LD + col) = av[i];
+    }
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+    // ---- y1 = LN1(src + out_proj(attn))
+    f32x16 y[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) et_zero(y[r]);
+    e6_issue<1>(ring, p.wo, 16, 8, wave, lane);
+    e8_gemm<0, NR>(ring, At, 0, y, lane);
+    e6_issue<0>(ring, p.w1, 16, 0, wave, lane);                                   // linear1, quarter 0, tile `wave`, K 0..127
+    e8_gemm<1, NR>(ring, At, 8, y, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + wave * 32 + 8 * q + 4 * half);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[r][4 * q + e] = (y[r][4 * q + e] + b[e]) + sv[r][q][e];
+    }
+    stamp(3);
+    e8_layernorm<NR>(y, p.g1, p.be1, red, wave, lane);
+    stamp(4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            us4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = f32_to_bf16(y[r][4 * q + e]);
+                y[r][4 * q + e] += b[e];                                          // linear2 accumulates on top of y1 + b2
+            }
+            *reinterpret_cast<us4*>(Yt + (r * 32 + l31) * ET_LD + n) = o;
+        }
+    }
+    __syncthreads();                                          // bf16(y1) visible; every wave is done reading the attention rows
+    stamp(5);
+    // ---- the projection rounds that follow the FFN (needed here: the FFN's last quarter prefetches the first round's weights).
+    // tb <= 8 (the encoder's q|k + v projections: 16 + 8 tiles): the `proj` tiles FIRST, from bf16(y); that tile is then free and every
+    // round's outputs are staged in it and leave as whole rows.  Otherwise: tile nt = round * 8 + wave, stored straight from the accumulators.
+    const int ta = p.wpa ? p.npa / 32 : 0, tb = p.wpb ? p.npb / 32 : 0, tt = ta + tb;
+    const bool staged = tb <= 8;
+    const int b_rounds = (staged && tb > 0) ? 1 : 0;
+    const int nrounds = staged ? b_rounds + (ta + 7) / 8 : (tt + 7) / 8;
+    auto round_tile = [&](int i) -> int {                     // this wave's tile (index into [Wpa ; Wpb]) in round i, -1: none
+        if (i >= nrounds) return -1;
+        if (!staged) return i * 8 + wave < tt ? i * 8 + wave : -1;
+        if (b_rounds && i == 0) return wave < tb ? ta + wave : -1;
+        const int nt = (i - b_rounds) * 8 + wave;
+        return nt < ta ? nt : -1;
+    };
+    auto tile_w = [&](int nt) { return nt < ta ? p.wpa : p.wpb; };
+    const int nt0 = round_tile(0);
+    // ---- FFN in four quarters of 256 hidden channels: hidden_q = relu(linear1 tile 8q + wave), y += hidden_q W2[:, 256q ..]
+    auto quarter = [&](auto Q) {                              // on entry ring buffer 0 holds K 0..127 of linear1 tile 8q + wave
+        constexpr int q = decltype(Q)::value;
+        f32x16 hd[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) et_zero(hd[r]);
+        e6_issue<1>(ring, p.w1, 16, 8, 8 * q + wave, lane);
+        e8_gemm<0, NR>(ring, Yt, 0, hd, lane);
+        e6_issue<0>(ring, p.w2, 64, 16 * q, wave, lane);                          // linear2, K 256q .. +127
+        e8_gemm<1, NR>(ring, Yt, 8, hd, lane);
+        if constexpr (q > 0) __syncthreads();                 // every wave is done reading hidden quarter q - 1
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int nl = wave * 32 + 8 * qq + 4 * half;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + 256 * q + nl);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                us4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = hd[r][4 * qq + e] + b[e];
+                    o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                }
+                *reinterpret_cast<us4*>(At + (r * 32 + l31) * ET_LD + nl) = o;
+            }
+        }
+        __syncthreads();
+        e6_issue<1>(ring, p.w2, 64, 16 * q + 8, wave, lane);
+        e8_gemm<0, NR>(ring, At, 0, y, lane);
+        if constexpr (q < 3) e6_issue<0>(ring, p.w1, 16, 0, 8 * (q + 1) + wave, lane);
+        e8_gemm<1, NR>(ring, At, 8, y, lane);
+    };
+    quarter(std::integral_constant<int, 0>{});
+    stamp(6);
+    quarter(std::integral_constant<int, 1>{});
+    stamp(7);
+    quarter(std::integral_constant<int, 2>{});
+    stamp(8);
+    quarter(std::integral_constant<int, 3>{});
+    stamp(9);
+    // (every per-thread address below comes from an OPAQUE copy of the thread index: the compiler otherwise shares the row / column
+    // arithmetic of the prologue's residual loads with this phase and keeps ~80 registers of it alive - spilled - across the whole kernel)
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, l31b = lane2 & 31, half2 = lane2 >> 5;
+    e8_layernorm<NR>(y, p.g2, p.be2, red, wave, lane2);           // its barriers also retire every read of the hidden tile / bf16(y1)
+    stamp(10);
+    // ---- outputs.  The normalised rows go through LDS as f32 (the first half of the rows in the first tile region, the rest in the second) and are picked
+    // up again as 16-byte chunks of whole rows: the f32 residual stream leaves as 1 KB rows, the position rows arrive as whole rows, and
+    // the two bf16 operand tiles of the projections (y, y + pos) are formed in that chunk layout - the accumulators are free from here on
+    float* Yf0 = reinterpret_cast<float*>(At);
+    float* Yf1 = reinterpret_cast<float*>(Yt);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {y[r][4 * q], y[r][4 * q + 1], y[r][4 * q + 2], y[r][4 * q + 3]};
+            const int rl = r * 32 + l31b;
+            *reinterpret_cast<f32x4*>((rl < HALF ? Yf0 : Yf1) + (rl < HALF ? rl : rl - HALF) * ET_FLD + wave * 32 + 8 * q + 4 * half2) = v;
+        }
+    __syncthreads();
+    if (nt0 >= 0) {                                           // the first projection tile's weights: they land under the chunk pass below
+        e6_issue<0>(ring, tile_w(nt0), 16, 0, nt0 < ta ? nt0 : nt0 - ta, lane2);
+        e6_issue<1>(ring, tile_w(nt0), 16, 8, nt0 < ta ? nt0 : nt0 - ta, lane2);
+    }
+    constexpr int NCH = E8_BM * 64 / 512;                     // 16 chunks of 4 channels per thread: rows (tid >> 6) + 8 i
+    uint2 c16[NCH], cp16[NCH];
+    // the thread's position row advances by 8 per chunk: ONE modulo, then add-and-wrap (a 32-bit modulo is ~30 VALU operations)
+    const unsigned prow_n = p.pos ? (unsigned)p.pos_rows : 1u;
+    unsigned prow = (unsigned)((m0 + (tid2 >> 6)) % (long long)prow_n);
+    const unsigned pstep = 8u % prow_n;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid2 + i * 512, r = c >> 6, col = (c & 63) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>((r < HALF ? Yf0 : Yf1) + (r < HALF ? r : r - HALF) * ET_FLD + col);
+        if (p.y && m0 + r < p.M) *reinterpret_cast<f32x4*>(p.y + (m0 + r) * ET_D + col) = v;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (p.pos) pv = *reinterpret_cast<const f32x4*>(p.pos + (long long)prow * ET_D + col);    // (wave-uniform condition; rows behind M read a valid row)
+        prow += pstep;
+        prow = prow >= prow_n ? prow - prow_n : prow;
+        c16[i] = uint2{f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3])};
+        cp16[i] = uint2{f32x2_to_bf16x2(v[0] + pv[0], v[1] + pv[1]), f32x2_to_bf16x2(v[2] + pv[2], v[3] + pv[3])};
+    }
+    __syncthreads();                                          // every f32 chunk has been read: the regions become the bf16 tiles
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid2 + i * 512, r = c >> 6, col = (c & 63) * 4;
+        *reinterpret_cast<uint2*>(Yt + r * ET_LD + col) = c16[i];
+        *reinterpret_cast<uint2*>(At + r * ET_LD + col) = cp16[i];
+    }
+    stamp(11);
+    __syncthreads();
+    stamp(12);
+    if (p.y16 || p.ypos16) {
+#pragma unroll
+        for (int i = 0; i < E8_BM * 32 / 512; ++i) {
+            const int c = tid2 + i * 512, r = c >> 5, col = (c & 31) * 8;
+            if (m0 + r < p.M) {
+                if (p.y16) *reinterpret_cast<us8*>(p.y16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(Yt + r * ET_LD + col);
+                if (p.ypos16) *reinterpret_cast<us8*>(p.ypos16 + (m0 + r) * ET_D + col) = *reinterpret_cast<const us8*>(At + r * ET_LD + col);
+            }
+        }
+    }
+    // ---- the next attention's input projections from the two bf16 tiles (At = y + pos, Yt = y), K = 256 per tile
+    for (int i = 0; i < nrounds; ++i) {
+        const int nt = round_tile(i), nn = round_tile(i + 1);
+        const bool is_a = nt < ta;                            // (nt = -1: an idle wave of a partial round takes part in the barriers only)
+        const int ct = is_a ? nt : nt - ta;
+        f32x16 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) et_zero(acc[r]);
+        if (nt >= 0) {
+            e8_gemm<0, NR>(ring, is_a ? At : Yt, 0, acc, lane2);
+            if (nn >= 0) e6_issue<0>(ring, tile_w(nn), 16, 0, nn < ta ? nn : nn - ta, lane2);   // the next tile's fragments replace this one's
+            e8_gemm<1, NR>(ring, is_a ? At : Yt, 8, acc, lane2);
+            if (nn >= 0) e6_issue<1>(ring, tile_w(nn), 16, 8, nn < ta ? nn : nn - ta, lane2);
+        } else if (nn >= 0) {
+            e6_issue<0>(ring, tile_w(nn), 16, 0, nn < ta ? nn : nn - ta, lane2);
+            e6_issue<1>(ring, tile_w(nn), 16, 8, nn < ta ? nn : nn - ta, lane2);
+        }
+        const float* bias = nt >= 0 ? (is_a ? p.bpa : p.bpb) : nullptr;
+        if (!staged) {
+            if (nt >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 8 * q + 4 * half2;
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const long long row = m0 + r * 32 + l31b;
+                        us4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[r][4 * q + e] + b[e]);
+                        if (row < p.M) *reinterpret_cast<us4*>((is_a ? p.pa : p.pb) + row * (is_a ? p.npa : p.npb) + ct * 32 + n) = o;
+                    }
+                }
+            }
+            continue;
+        }
+        // staged: this round's [128][<= 256] output block goes through the bf16(y) tile (free once the `proj` round has read it) and
+        // leaves as 16-byte chunks of whole rows
+        const bool round_a = !(b_rounds && i == 0);
+        const int base = round_a ? (i - b_rounds) * 8 : 0, width = round_a ? (ta - base < 8 ? ta - base : 8) : tb;      // tiles in this round
+        __syncthreads();                                      // the previous round's chunks have left the tile / this round's reads of it are done
+        if (nt >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 8 * q + 4 * half2;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    us4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(acc[r][4 * q + e] + b[e]);
+                    *reinterpret_cast<us4*>(Yt + (r * 32 + l31b) * ET_LD + wave * 32 + n) = o;
+                }
+            }
+        }
+        __syncthreads();
+        bf16_t* outp = round_a ? p.pa + base * 32 : p.pb;
+        const int ldo = round_a ? p.npa : p.npb, cpr = width * 4;             // 16-byte chunks per row
+        int tid3 = tid2;                                      // (opaque per round: the chunk addresses are not loop-invariant values to keep alive - spilled - across the MFMAs)
+        asm volatile("" : "+v"(tid3));
+        if (cpr == 32) {
+#pragma unroll
+            for (int k = 0; k < E8_BM * 32 / 512; ++k) {
+                const int c = tid3 + k * 512, r = c >> 5, col = (c & 31) * 8;
+                if (m0 + r < p.M) *reinterpret_cast<us8*>(outp + (m0 + r) * ldo + col) = *reinterpret_cast<const us8*>(Yt + r * ET_LD + col);
+            }
+        } else {
+            for (int c = tid3; c < E8_BM * cpr; c += 512) {
+                const int r = c / cpr, col = (c - r * cpr) * 8;
+                if (m0 + r < p.M) *reinterpret_cast<us8*>(outp + (m0 + r) * ldo + col) = *reinterpret_cast<const us8*>(Yt + r * ET_LD + col);
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        stamp(13);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores' acknowledgements (not waited for in the product build)
+        stamp(14);
+        if (dbg && lane == 0)
+            for (int i = 0; i < 15; ++i) dbg[((long long)blockIdx.x * 8 + wave) * 16 + i] = ts[i];
+    }
+}
+
+static unsigned long long* g_et_dbg = nullptr;
+extern "C" void nps_enc_tail_debug_buffer(void* buf) { g_et_dbg = (unsigned long long*)buf; }
+
 static int et_launch(const EncTailArgs& a, hipStream_t stream) {
     // the encoder (post-norm, thousands of tokens) on the 64-token kernel; decoder forms and small inputs on the 32-token one
-    if (!a.pre_norm && !a.skip_ffn && a.M >= 2048 && !getenv("NOPESAC_ENC_TAIL_32")) {
+    // (NOPESAC_ENC_TAIL_64=1: the round-3 64-token kernel, NOPESAC_ENC_TAIL_32=1: the 32-token one - A/B runs and the bit-identity test of those two)
+    if (!a.pre_norm && !a.skip_ffn && a.M >= 2048 && !getenv("NOPESAC_ENC_TAIL_32") && !getenv("NOPESAC_ENC_TAIL_64")) {
+        // 96 tokens per workgroup when that fills more CUs than 128 do in one round (the encoder's 19200 tokens: 200 workgroups instead
+        // of 150); NOPESAC_ENC_TAIL_ROWS=3|4 forces one form (A/B runs, tests)
+        int nr = ((a.M + 127) / 128 <= 160 && (a.M + 95) / 96 <= 256) ? 3 : 4;
+        if (const char* e = getenv("NOPESAC_ENC_TAIL_ROWS")) nr = atoi(e) == 3 ? 3 : 4;
+        auto go = [&](auto K, size_t lds, int bm) {
+            NPS_ENSURE_LDS((int)lds, K);
+            hipLaunchKernelGGL(K, dim3((a.M + bm - 1) / bm), dim3(512), lds, stream, a, g_et_dbg);
+        };
+        if (g_et_dbg) {                                       // tuning runs only (scripts/enc_tail_stamps.py)
+            if (nr == 3) go(enc_tail128_kernel<true, 3>, E8<3>::LDS_BYTES, 96); else go(enc_tail128_kernel<true, 4>, E8<4>::LDS_BYTES, 128);
+        } else {
+            if (nr == 3) go(enc_tail128_kernel<false, 3>, E8<3>::LDS_BYTES, 96); else go(enc_tail128_kernel<false, 4>, E8<4>::LDS_BYTES, 128);
+        }
+    } else if (!a.pre_norm && !a.skip_ffn && a.M >= 2048 && !getenv("NOPESAC_ENC_TAIL_32")) {
         NPS_ENSURE_LDS((int)E6_LDS_BYTES, enc_tail64_kernel);
         hipLaunchKernelGGL(enc_tail64_kernel, dim3((a.M + E6_BM - 1) / E6_BM), dim3(512), E6_LDS_BYTES, stream, a);
     } else {

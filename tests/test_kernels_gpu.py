@@ -1477,6 +1477,7 @@ def test_mlp_chain_parallel_stacks_over_the_same_rows(device):
 def test_encoder_tail_64_token_kernel_equals_the_32_token_one(device, M, monkeypatch):
     """enc_tail64_kernel (64 tokens per workgroup, K = 128 weight steps, hidden tile in two halves) computes the same sums in the same
     order as enc_tail_kernel: bit-identical outputs and chained projections (ragged last tile included)."""
+    monkeypatch.setenv("NOPESAC_ENC_TAIL_64", "1")
     from nopesac_amd import ops
     g = torch.Generator().manual_seed(M)
     rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
@@ -1494,6 +1495,60 @@ def test_encoder_tail_64_token_kernel_equals_the_32_token_one(device, M, monkeyp
     torch.cuda.synchronize()
     for k in ("y", "y16", "ypos16", "proj_pos", "proj"):
         assert torch.equal(new[k], old[k]), k
+
+
+@pytest.mark.parametrize("M", [2048, 19200 // 4 + 17, 19200 // 2 + 97, 2048 + 1])
+@pytest.mark.parametrize("outputs", ["all", "y_and_projections", "no_projections"])
+@pytest.mark.parametrize("rows", [3, 4])
+def test_encoder_tail_128_token_kernel(device, M, outputs, rows, monkeypatch):
+    """enc_tail128_kernel (round 6: 96 / 128 tokens per workgroup, every weight fragment feeds three / four MFMAs, linear2 accumulating on
+    top of y1 + b2, hidden tile in four quarters, every output staged through LDS and stored as whole rows) against the 32-token kernel
+    on the same inputs.  Same operands and the same bf16 rounding points; some f32 sums run in a different order ((y1 + b2) + sum_k, fused
+    multiply-adds in the LayerNorms), so the comparison is a tolerance, and the ragged last tile must leave the rows behind M untouched."""
+    from nopesac_amd import ops
+    monkeypatch.setenv("NOPESAC_ENC_TAIL_ROWS", str(rows))
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(device)
+    attn, src, pos = rn(M, 256).bfloat16(), rn(M, 256), rn(300, 256)
+    fm = ops.mfma_fragment_major
+    W = {"wo": fm(rn(256, 256, k=1 / 16).bfloat16()), "w1": fm(rn(1024, 256, k=1 / 16).bfloat16()), "w2": fm(rn(256, 1024, k=1 / 32).bfloat16()),
+         "bo": rn(256, k=0.1), "b1": rn(1024, k=0.1), "b2": rn(256, k=0.1), "ga": 1 + rn(256, k=0.1), "bea": rn(256, k=0.1),
+         "gb": 1 + rn(256, k=0.1), "beb": rn(256, k=0.1)}
+    pp = (fm(rn(512, 256, k=1 / 16).bfloat16()), rn(512, k=0.1), 512)
+    pj = (fm(rn(256, 256, k=1 / 16).bfloat16()), None, 256)
+    kw = {"all": dict(want=("y", "y16", "ypos16"), proj_pos=pp, proj=pj), "y_and_projections": dict(want=("y",), proj_pos=pp, proj=pj),
+          "no_projections": dict(want=("y", "y16", "ypos16"))}[outputs]
+    run = lambda: ops.transformer_tail(attn, src, W, pre_norm=False, pos=pos, **kw)
+    new = run()
+    again = run()
+    monkeypatch.setenv("NOPESAC_ENC_TAIL_32", "1")
+    old = run()
+    torch.cuda.synchronize()
+    assert set(new) == set(old)
+    for k in new:
+        a, b = new[k].float(), old[k].float()
+        assert a.shape == b.shape and torch.equal(new[k], again[k]), k            # (deterministic run to run)
+        # a 1-ulp flip of a bf16 intermediate (LN1 output, hidden tile) moves an output by ~1e-3 of its scale: the bound is statistical
+        # (relative l2 distance, mean absolute difference) plus a cap on the largest single difference
+        d = (a - b).abs()
+        scale = float(b.abs().mean()) + 1e-6
+        assert _rel(a, b) < (5e-3 if new[k].dtype == torch.float32 else 2.0 ** -6), (k, _rel(a, b))          # (bf16: two ulps of the largest value)
+        assert float(d.mean()) < 3e-4 * scale and float(d.max()) < 0.05 * max(1.0, float(b.abs().max())), (k, float(d.mean()) / scale, float(d.max()))
+    monkeypatch.delenv("NOPESAC_ENC_TAIL_32")
+    if M % 128 and outputs == "all":                                               # rows behind M: never written (raw C ABI, padded buffers)
+        from nopesac_amd.ops import _L, _p, _stream
+        pad = {"y": torch.full((M + 128, 256), 7.0, device=device), "y16": torch.full((M + 128, 256), 7.0, device=device).bfloat16(),
+               "ypos16": torch.full((M + 128, 256), 7.0, device=device).bfloat16(), "pp": torch.full((M + 128, 512), 7.0, device=device).bfloat16(),
+               "pj": torch.full((M + 128, 256), 7.0, device=device).bfloat16()}
+        rc = _L().nopesac_transformer_tail_bf16_pf(
+            _p(attn), _p(src), _p(W["wo"]), _p(W["bo"]), _p(W["ga"]), _p(W["bea"]), _p(W["w1"]), _p(W["b1"]), _p(W["w2"]), _p(W["b2"]), _p(W["gb"]),
+            _p(W["beb"]), _p(pos), pos.shape[0], _p(pad["y"]), _p(pad["y16"]), _p(pad["ypos16"]), None, 0, 0, _p(pp[0]), _p(pp[1]), _p(pad["pp"]), 512,
+            _p(pj[0]), None, _p(pad["pj"]), 256, M, None, None, 0, 0, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        for k, t in pad.items():
+            assert bool((t[M:].float() == 7.0).all()), k
+        assert torch.equal(pad["y"][:M], new["y"]) and torch.equal(pad["pp"][:M], new["proj_pos"])
 
 
 def test_host_fetch_gather_kernel(device):
