@@ -364,12 +364,36 @@ def stub_rank_main(args, rank, world, local):
         loop.step(i, slot_step)
     loop.barrier()
     elapsed, host_ms, host = timed_region(loop, lambda i: loop.step(i, slot_step), args.steps, world, device)
+    host = host.clone()                                    # (a view of the loop's row buffer: the leg below steps on)
+    tape = None
+    if not args.no_tape:
+        # the launch-tape leg's PROTOCOL with nothing to capture: capture locally (may fail on one rank: NOPESAC_FAIL_CAPTURE_RANK), agree,
+        # check one replayed step per slot through the loop's own gathers and barriers, agree again, then the timed region once more
+        state = {"replaying": False, "checked_steps": 0}
+
+        def verify_collective():
+            state["replaying"] = True
+            for i in range(loop.n_slots):
+                loop.step(i, slot_step)
+                loop.barrier()
+                rows = loop.last_step_rows()
+                if rows is None or rows.shape[0] != world * B:
+                    return False
+                state["checked_steps"] += 1
+            return True
+
+        def abandon():
+            state["replaying"] = False
+        every = runner.capture_on_all_ranks(lambda: None, verify_collective, abandon, device)
+        el_t = timed_region(loop, lambda i: loop.step(i, slot_step), args.steps, world, device)[0] if every else None
+        tape = {"captured_on_every_rank": bool(every), "replaying": state["replaying"], "checked_steps": state["checked_steps"],
+                "ms_per_step": None if el_t is None else round(1e3 * el_t / max(args.steps, 1), 4)}
     ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     ok = host.shape[0] == world * B and host[:, 12].tolist() == [float(v) for v in range(world * B)]
     if rank == 0:
         print(json.dumps({"INVALID_stub_model": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 4), "rows_gathered": int(host.shape[0]), "rows_in_rank_order": bool(ok),
-                          "steps_per_all_gather": loop.G, "collectives_in_run": getattr(loop, "collectives", None),
+                          "steps_per_all_gather": loop.G, "collectives_in_run": getattr(loop, "collectives", None), "launch_tape": tape,
                           "config": {"rccl_ranks": ranks, "backend": torch.distributed.get_backend() if ranks > 1 else None,
                                      "pairs_per_gpu": B, "global_batch": world * B, "device": str(device) if cuda else "cpu"}}))
     if world > 1:
@@ -524,10 +548,11 @@ def rank_main(args):
                 barrier()
                 out.append(loop.last_step_rows().clone())
             return out
-        try:
-            from nopesac_amd.tape import LaunchTape, TapeUnsupported
-            eager_rows = rows_of_every_slot()                  # eager results of each slot (same static inputs)
-            captured = [None] * n_slots
+        from nopesac_amd.tape import LaunchTape, TapeUnsupported
+        eager_rows = rows_of_every_slot()                      # eager results of each slot (same static inputs); collective, every rank
+        captured = [None] * n_slots
+
+        def capture_local():                                   # this rank's captures: no collective inside (runner.capture_on_all_ranks)
             for slot in range(n_slots):
                 g = torch.cuda.CUDAGraph(keep_graph=not args.whole_graph)
                 with torch.no_grad(), torch.cuda.graph(g, stream=streams[slot]):
@@ -540,9 +565,12 @@ def rank_main(args):
                         print("launch tape unavailable (%s): whole-graph replay" % (e,), file=sys.stderr)
                         g.instantiate()
                 captured[slot] = g
+
+        def verify_collective():                               # one replay per slot outside the timed region (barriers + gathers: every rank)
+            nonlocal graphs
             graphs = captured
             barrier()
-            host_bufs = rows_of_every_slot()                   # one replay per slot outside the timed region
+            host_bufs = rows_of_every_slot()
             if not all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(eager_rows, host_bufs)):
                 diff = [[round(float(x), 6) for x in (a - b).abs().amax(dim=0)[:7]] for a, b in zip(eager_rows, host_bufs)]
                 # (every slot holds the same images: which side is the odd one out?)
@@ -551,10 +579,13 @@ def rank_main(args):
                 raise RuntimeError("graph replay does not reproduce the eager results; max |diff| per slot, columns t, q: %r; eager slots vs the "
                                    "last eager slot: %r; replayed slots vs the last replayed slot: %r" % (diff, e_vs_e0, r_vs_r0))
             return True
-        except Exception as e:                                 # keep the eager path if capture is not possible
-            print("hipGraph capture failed, staying eager: %r" % (e,), file=sys.stderr)
+
+        def abandon():                                         # keep the eager path (on EVERY rank, agreed by all-reduce)
+            nonlocal graphs
             graphs = [None] * n_slots
-            return False
+
+        return runner.capture_on_all_ranks(capture_local, verify_collective, abandon, device,
+                                           log=lambda m: print("hipGraph capture, rank %d: %s" % (rank, m), file=sys.stderr))
 
     def timed(steps):
         return timed_region(loop, step, steps, world, device)
@@ -563,9 +594,11 @@ def rank_main(args):
         use_graph = capture_slots()
     elapsed, host_launch_ms, host = timed(args.steps)
     tape_record = None
-    if not args.graph and not args.ablate and not args.no_tape and args.dtype == "bfloat16" and world == 1:
+    if not args.graph and not args.ablate and not args.no_tape and args.dtype == "bfloat16":
         # the same K steps again, submitted through the launch tape instead of ~270 Python-issued launches per step (outside the
-        # headline's timed region; single-process runs only: a rank whose capture failed would leave the others in a barrier)
+        # headline's timed region).  world > 1 (round 6): the ranks agree by all-reduce that EVERY rank captured and reproduces its eager
+        # rows before anyone replays (runner.capture_on_all_ranks) - a rank that cannot capture sends all of them back to eager launching
+        # instead of leaving the others in the check's barrier
         if capture_slots():
             # a replay submits a batch in < 1 ms: keep two submissions as far apart as eager launching does (0.45 of the eager step
             # time), or the slots re-submit together and run in lockstep (runner.InflightLoop.step)

@@ -317,6 +317,100 @@ __global__ __launch_bounds__(256) void matcher_sinkhorn_w4_kernel(
     sink_finalize<256>(L, b, tid, nq, n1, n2, norm, match_thr, log_scores, assignment);
 }
 
+// Row-group form of the four-wave kernel for nq + 1 > 64 (round 6: BASELINE configs[2] runs nq = 64, configs[4] nq = 128; the 1024-thread
+// kernel they used costs 0.71 / 2.8 ms per launch - 14 us per iteration at nq = 128 against ~1 us of exp arithmetic on one CU - and, as
+// a 16-wave workgroup per pair, holds 32 whole CUs for that long next to the persistent conv kernels).  Same scheme as above with the
+// rows / columns in RG groups of 64: 4 x RG waves, wave (g, c) keeps for row (column) 64 g + lane the KW couplings of columns (rows)
+// c KW .. in registers; u and v live in RG registers (lane = index within a group of 64) in EVERY wave and are read with v_readlane
+// (the group = index >> 6 is wave-uniform); per phase ONE exchange of the (max, sum) partials through LDS and ONE barrier - every wave
+// merges the four partials of ALL row groups itself (RG x 4 exp instead of 4), so that the complete u (or v) is back in its own
+// registers without a second barrier.  Groups behind max(n1, n2) + 1 rows only take part in the barriers.
+template <int RG, int KW>
+__global__ __launch_bounds__(256 * RG) void matcher_sinkhorn_wg_kernel(
+    const float* __restrict__ desc_dot, const float* __restrict__ planes1, const float* __restrict__ planes2,
+    const float* __restrict__ cam7, const int* __restrict__ n1p, const int* __restrict__ n2p,
+    const float* __restrict__ bin_score, float offset_mult, float normal_mult, int iters, float match_thr, int nq,
+    float* __restrict__ log_scores, float* __restrict__ assignment) {
+    constexpr int NT = 256 * RG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), g = w >> 2, c = w & 3;
+    const SinkLds L = sink_lds(smem, nq);
+    const int LD = L.LD;
+    const int n1 = min(max(n1p[b], 0), nq), n2 = min(max(n2p[b], 0), nq);
+    const int R1 = n1 + 1, C1 = n2 + 1;
+    const float norm = sink_setup<NT>(L, b, tid, nq, n1, n2, desc_dot, planes1, planes2, cam7, bin_score, offset_mult, normal_mult);
+    const int ngrp = (max(R1, C1) + 63) >> 6;          // row / column groups in use (workgroup-uniform)
+    const bool active = g < ngrp;
+    const int idx = g * 64 + lane;                     // this lane's row (row phase) / column (column phase)
+    float zr[KW], zc[KW];
+    const bool rok = active && idx < R1, cok = active && idx < C1;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int e = c * KW + k;
+        zr[k] = (rok && e < C1) ? L.Z[idx * LD + e] : -INFINITY;
+        zc[k] = (cok && e < R1) ? L.Z[e * LD + idx] : -INFINITY;
+    }
+    float lmu_l[RG], lnu_l[RG], uu[RG], vv[RG];        // marginals and potentials of rows / columns 64 gg + lane, gg < RG (every wave holds all)
+#pragma unroll
+    for (int gg = 0; gg < RG; ++gg) {
+        const int i = gg * 64 + lane;
+        lmu_l[gg] = i < R1 ? L.lmu[i] : 0.f;
+        lnu_l[gg] = i < C1 ? L.lnu[i] : 0.f;
+        uu[gg] = 0.f; vv[gg] = 0.f;
+    }
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t* xr = reinterpret_cast<f32x2_t*>(L.xch);                 // [RG groups][4 column splits][64 lanes] (m, s)
+    f32x2_t* xc = xr + 64 * 4 * RG;
+    // the other potential as wave-uniform values: with several groups a v_readlane per group and a select per entry cost more than the
+    // exp they feed (three readlanes + two scalar selects per coupling at nq = 128: 6.1 us per iteration).  Every wave parks its own copy
+    // of the vector in a private LDS strip (its own writes, its own reads: no barrier, LDS operations of a wave execute in order) and
+    // reads entry c KW + k back as a broadcast load
+    float* priv = reinterpret_cast<float*>(xc + 64 * 4 * RG) + w * (64 * RG);
+    auto phase = [&](const float (&z)[KW], const float (&other)[RG], const float (&marg)[RG], int n_valid, f32x2_t* xch, float (&res)[RG]) {
+        if (active) {
+#pragma unroll
+            for (int gg = 0; gg < RG; ++gg) priv[gg * 64 + lane] = other[gg];
+            float t[KW];
+            float m = -1e30f;                          // finite floor: a wave whose KW entries are all masked contributes (floor, 0)
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                t[k] = z[k] + priv[c * KW + k];
+                m = fmaxf(m, t[k]);
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) sm += __expf(t[k] - m);
+            xch[w * 64 + lane] = f32x2_t{m, sm};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < RG; ++gg) {
+            if (gg < ngrp) {
+                const f32x2_t q0 = xch[(gg * 4) * 64 + lane], q1 = xch[(gg * 4 + 1) * 64 + lane], q2 = xch[(gg * 4 + 2) * 64 + lane],
+                              q3 = xch[(gg * 4 + 3) * 64 + lane];
+                const float M = fmaxf(fmaxf(q0[0], q1[0]), fmaxf(q2[0], q3[0]));
+                const float S = q0[1] * __expf(q0[0] - M) + q1[1] * __expf(q1[0] - M) + q2[1] * __expf(q2[0] - M) + q3[1] * __expf(q3[0] - M);
+                res[gg] = (gg * 64 + lane < n_valid) ? marg[gg] - (M + __logf(S)) : 0.f;
+            }
+        }
+    };
+    for (int it = 0; it < iters; ++it) {
+        phase(zr, vv, lmu_l, R1, xr, uu);
+        phase(zc, uu, lnu_l, C1, xc, vv);
+    }
+    if (w == 0) {
+#pragma unroll
+        for (int gg = 0; gg < RG; ++gg) {
+            const int i = gg * 64 + lane;
+            if (i < R1) L.u[i] = uu[gg];
+            if (i < C1) L.v[i] = vv[gg];
+        }
+    }
+    __syncthreads();
+    sink_finalize<NT>(L, b, tid, nq, n1, n2, norm, match_thr, log_scores, assignment);
+}
+
 // assignment re-filter under the refined pose (camera_head.py:605-629)
 __global__ __launch_bounds__(256) void refilter_kernel(const float* __restrict__ Ain, const float* __restrict__ planes1,
                                                        const float* __restrict__ planes2, const int* __restrict__ n1p,
@@ -385,6 +479,21 @@ extern "C" int nopesac_matcher_sinkhorn(const float* desc_dot, const float* plan
         else
             hipLaunchKernelGGL((matcher_sinkhorn_w4_kernel<16>), dim3(B), dim3(256), lds4, (hipStream_t)stream, desc_dot, planes1, planes2, cam7,
                                n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);
+    } else if (!getenv("NOPESAC_SINKHORN_NO_WG")) {       // row groups of 64: 8 waves (nq + 1 <= 128) or 12 (nq = 128), one exchange per phase
+        const int R = nq + 1;
+        const int rg = R <= 128 ? 2 : 3;                // exchange buffers of both phases + one private strip of the potentials per wave
+        const size_t ldsg = lds + sizeof(float) * (2 * 64 * 4 * 2 * rg + 4 * rg * 64 * rg);
+#define NPS_SINK_WG(RG_, KW_)                                                                                                              \
+        do {                                                                                                                               \
+            if (ldsg > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, (matcher_sinkhorn_wg_kernel<RG_, KW_>));                                \
+            hipLaunchKernelGGL((matcher_sinkhorn_wg_kernel<RG_, KW_>), dim3(B), dim3(256 * RG_), ldsg, (hipStream_t)stream, desc_dot, planes1, \
+                               planes2, cam7, n1, n2, bin_score, offset_mult, normal_mult, iters, match_thr, nq, log_scores, assignment);  \
+        } while (0)
+        if (R <= 4 * 17) NPS_SINK_WG(2, 17);
+        else if (R <= 4 * 26) NPS_SINK_WG(2, 26);
+        else if (R <= 128) NPS_SINK_WG(2, 32);
+        else NPS_SINK_WG(3, 33);
+#undef NPS_SINK_WG
     } else if (nq + 1 <= 128) {              // 1024 threads: lane groups of 8-64 lanes per row / column, <= 16 entries per lane (no spills)
         if (lds > 64 * 1024) NPS_ENSURE_LDS(160 * 1024 - 256, (matcher_sinkhorn_kernel<1024, 16>));
         hipLaunchKernelGGL((matcher_sinkhorn_kernel<1024, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, desc_dot, planes1, planes2,

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import List, Optional
+from typing import Callable, List, Optional
 
 import numpy as np
 import torch
@@ -165,6 +165,51 @@ def gather_metrics(rows: torch.Tensor) -> torch.Tensor:
     else:
         dist.all_gather_into_tensor(out, rows.contiguous())
     return out
+
+
+def all_ranks_agree(ok: bool, device=None) -> bool:
+    """True only when EVERY rank says ok (an all-reduce MIN of one flag; a single process: `ok`).  Every rank must call it at the same
+    point: it is what lets a step that may fail locally (capturing a forward into a graph / launch tape) sit in front of collectives -
+    the ranks first agree that all of them succeeded, and only then enter the barrier / gather that follows."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def capture_on_all_ranks(capture_local: Callable[[], None], verify_collective: Callable[[], bool], abandon: Callable[[], None], device=None,
+                         log=None) -> bool:
+    """The launch-tape / graph leg under world > 1 (round 6; it used to be single-process only: a rank whose capture failed returned to
+    eager launching while the others walked into the check's barrier and hung there).
+      1. capture_local(): this rank's captures - NO collectives inside; an exception means "this rank cannot";
+      2. all_ranks_agree: if any rank could not, every rank calls abandon() (drop its captures) and stays eager;
+      3. verify_collective(): the replay check - it may use the loop's barriers and gathers, every rank runs it - returns this rank's verdict;
+      4. all_ranks_agree again: one rank whose replay does not reproduce its eager rows sends every rank back to eager launching.
+    Returns True when every rank replays."""
+    err = None
+    try:
+        forced = os.environ.get("NOPESAC_FAIL_CAPTURE_RANK")           # tests / node bring-up: make this rank's capture fail
+        if forced is not None and int(forced) == (dist.get_rank() if dist.is_available() and dist.is_initialized() else 0):
+            raise RuntimeError("capture failure forced by NOPESAC_FAIL_CAPTURE_RANK")
+        capture_local()
+    except Exception as e:  # noqa: BLE001 - whatever the capture raised: the rank stays eager and says so
+        err = e
+    if not all_ranks_agree(err is None, device):
+        if log is not None:
+            log("capture abandoned on every rank (%s)" % ("this rank: %r" % (err,) if err is not None else "another rank could not capture"))
+        abandon()
+        return False
+    try:
+        ok = bool(verify_collective())
+    except Exception as e:  # noqa: BLE001
+        err, ok = e, False
+    if not all_ranks_agree(ok, device):
+        if log is not None:
+            log("replay check failed (%s): every rank stays eager" % ("this rank: %r" % (err,) if err is not None else "on this or another rank"))
+        abandon()
+        return False
+    return True
 
 
 def summarize(rows: torch.Tensor) -> dict:

@@ -1067,6 +1067,36 @@ def test_sinkhorn_four_wave_kernel_matches_the_1024_thread_kernel(device, nq, mo
     assert torch.equal(ls4, ls4b) and torch.equal(A4, A4b)
 
 
+@pytest.mark.parametrize("nq", [64, 67, 68, 100, 104, 127, 128])
+def test_sinkhorn_row_group_kernel_matches_the_1024_thread_kernel(device, nq, monkeypatch):
+    """matcher_sinkhorn_wg_kernel (round 6: rows / columns in groups of 64 lanes, 8 or 12 waves, one exchange + one barrier per phase) for
+    nq + 1 > 64 - BASELINE configs[2] (nq = 64) and configs[4] (nq = 128) - against the 1024-thread kernel it replaces: log scores within
+    2e-5 absolute after 200 iterations, identical assignments, bit-identical run to run; plane counts incl. 0, 1, 63 / 64 / 65 (a row
+    group that is exactly full / one row into the next) and nq; every template instance (KW 17 / 26 / 32, three row groups at nq = 128)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(nq)
+    B = 12
+    dots = (2.0 * torch.randn(B, nq, nq, generator=g)).to(device)
+    p1, p2 = torch.randn(B, nq, 3, generator=g).to(device), torch.randn(B, nq, 3, generator=g).to(device)
+    cam = torch.randn(B, 7, generator=g)
+    cam[:, 3:] = torch.nn.functional.normalize(cam[:, 3:], dim=1)
+    cam = cam.to(device)
+    n1 = torch.tensor([nq, 0, 1, nq, nq // 2, 3, nq - 1, 1, 63, 64, min(65, nq), nq], dtype=torch.int32, device=device)
+    n2 = torch.tensor([nq, 5, 1, 2, nq, nq // 2, nq, 0, 64, 63, 3, min(65, nq)], dtype=torch.int32, device=device)
+    bin_score = torch.tensor([0.7], device=device)
+    args = (dots, p1, p2, cam, n1, n2, bin_score, 4.0, 8.0, 200, 0.2)
+    lsg, Ag = ops.matcher_sinkhorn(*args)
+    monkeypatch.setenv("NOPESAC_SINKHORN_NO_WG", "1")
+    ls, A = ops.matcher_sinkhorn(*args)
+    monkeypatch.delenv("NOPESAC_SINKHORN_NO_WG")
+    valid = ls > -1e29
+    assert torch.equal(valid, lsg > -1e29)
+    assert float((lsg[valid] - ls[valid]).abs().max()) < 2e-5
+    assert torch.equal(Ag, A)
+    lsb, Ab = ops.matcher_sinkhorn(*args)
+    assert torch.equal(lsg, lsb) and torch.equal(Ag, Ab)
+
+
 MLP_CHAIN_CASES = {
     # name: (rows, x_width, bcast_width, rows_per, [(N, act, tapped)])
     "geo_encoder+proj": (100, 8, 0, 1, [(1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (1024, "ACT_RELU", False), (256, "ACT_NONE", True)]),

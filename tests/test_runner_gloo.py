@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -241,11 +242,74 @@ def test_bench_gpus8_global_batch_256_stub():
     """BASELINE configs[3] in shape (8 ranks x 32 pairs = global batch 256, four steps in flight, one all_gather of [32,16] rows per
     step and rank) through bench.py's own launcher on CPU / gloo with the stub model: the 8-rank rendezvous, the rank-major order
     of the 256 gathered rows and the single JSON line are what a node without torchrun would run."""
-    r, j = _run_bench(["--gpus", "8", "--stub-model", "--steps", "6", "--warmup", "2", "--pairs", "32", "--inflight", "4"], timeout=600)
+    r, j = _run_bench(["--gpus", "8", "--stub-model", "--steps", "6", "--warmup", "2", "--pairs", "32", "--inflight", "4", "--no-tape"], timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert j["n_gpus"] == 8 and j["config"]["rccl_ranks"] == 8 and j["config"]["global_batch"] == 256
     assert j["rows_gathered"] == 256 and j["rows_in_rank_order"]
     assert j["steps_per_all_gather"] == 8 and j["collectives_in_run"] == 2          # warm-up flush (2 steps) + the timed region's 6 steps
+
+
+@pytest.mark.parametrize("fail_rank", [None, "0", "1"])
+def test_bench_tape_leg_world2_one_rank_fails_capture(fail_rank):
+    """The launch-tape leg under world > 1 (round 6; single-process only before: a rank whose capture failed went back to eager
+    launching while the others walked into the replay check's barrier).  bench.py's stub model drives the PROTOCOL
+    (runner.capture_on_all_ranks: capture locally, all-reduce an ok flag, collective replay check, all-reduce again) over gloo at world
+    2: with no failure both ranks replay and the timed region runs a second time; with the capture of rank 0 or of rank 1 forced to
+    fail (NOPESAC_FAIL_CAPTURE_RANK) BOTH ranks stay eager, nothing hangs, the run ends with its single JSON line."""
+    env = {} if fail_rank is None else {"NOPESAC_FAIL_CAPTURE_RANK": fail_rank}
+    r, j = _run_bench(["--gpus", "2", "--stub-model", "--steps", "5", "--warmup", "2", "--pairs", "3", "--inflight", "4", "--gather-every", "2"], env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert j["n_gpus"] == 2 and j["rows_gathered"] == 6 and j["rows_in_rank_order"]
+    t = j["launch_tape"]
+    if fail_rank is None:
+        assert t["captured_on_every_rank"] and t["replaying"] and t["checked_steps"] == 4 and t["ms_per_step"] is not None
+    else:
+        assert not t["captured_on_every_rank"] and not t["replaying"] and t["checked_steps"] == 0 and t["ms_per_step"] is None
+
+
+def _capture_protocol_worker(rank, world, port, case, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nopesac_amd import runner
+    r, w, _ = runner.init_distributed("gloo")
+    log = []
+    calls = {"verify": 0, "abandon": 0}
+
+    def capture_local():
+        if case == "capture_raises_on_1" and r == 1:
+            raise RuntimeError("no graph on this rank")
+
+    def verify_collective():
+        calls["verify"] += 1
+        torch.distributed.barrier()                          # the check's own collectives: every rank must get here or nobody
+        if case == "verify_raises_on_0" and r == 0:
+            raise RuntimeError("replay differs")
+        return not (case == "verify_false_on_1" and r == 1)
+
+    def abandon():
+        calls["abandon"] += 1
+    ok = runner.capture_on_all_ranks(capture_local, verify_collective, abandon, None, log=log.append)
+    torch.distributed.barrier()
+    with open(os.path.join(out_dir, "cap_%s_%d.txt" % (case, r)), "w") as f:
+        f.write("%d %d %d %d" % (int(ok), calls["verify"], calls["abandon"], len(log)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all_ok", "capture_raises_on_1", "verify_raises_on_0", "verify_false_on_1"])
+def test_capture_on_all_ranks_world2(tmp_path, case):
+    """runner.capture_on_all_ranks at world 2 over gloo: every rank returns the SAME verdict; a local capture failure keeps every rank
+    out of the collective check (verify not called anywhere); a failed check on one rank abandons on both; nothing deadlocks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_capture_protocol_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = [tuple(int(v) for v in open(tmp_path / ("cap_%s_%d.txt" % (case, r))).read().split()) for r in range(world)]
+    want = {"all_ok": (1, 1, 0, 0), "capture_raises_on_1": (0, 0, 1, 1), "verify_raises_on_0": (0, 1, 1, 1), "verify_false_on_1": (0, 1, 1, 1)}[case]
+    assert got[0] == want and got[1] == want, got
 
 
 def _run_cli(argv, timeout=600):
