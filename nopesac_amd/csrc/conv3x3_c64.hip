@@ -30,10 +30,15 @@ static_assert(256 * C3_PXB <= C3_HALO_BYTES && 3 * C3_HALO_BYTES <= 160 * 1024, 
 constexpr int C3_KS = 9 * C3_C / 16;                              // 36 k-steps of 16
 constexpr int C3_RING = 16;
 
+// STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into dbg[workgroup][4 waves][8] (scripts/c64_stamps.py)
+template <bool STAMP>
 __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
-                                                             bf16_t* __restrict__ y, int H, int W, int act) {
+                                                             bf16_t* __restrict__ y, int H, int W, int act, unsigned long long* dbg) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[C3_HALO_BYTES];
+    unsigned long long ts[8];
+    auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
+    stamp(0);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, y0 = blockIdx.y * C3_T, x0 = blockIdx.x * C3_T;
@@ -66,7 +71,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
             if (i < C3_HT * C3_HT * 8) *reinterpret_cast<us8*>(lds + ((i >> 3) / C3_HT) * C3_ROWB + ((i >> 3) % C3_HT) * C3_PXB + (i & 7) * 16) = hv[it];
         }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     // ---- implicit GEMM out of the halo: lane's pixel in row tile r is (ty, tx) = (2r + (l31 >> 4), l31 & 15)
     f32x16 acc[4];
@@ -92,7 +99,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
         if (ks + C3_RING < C3_KS) ring[ks % C3_RING] = *reinterpret_cast<const bf16x8*>(wp + (ks + C3_RING) * 512);
         if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads of later taps from being hoisted (register pressure)
     }
+    stamp(3);
     __syncthreads();                                              // halo is dead: reuse LDS as the [256][72] output staging tile
+    stamp(4);
 
     // ---- BN + activation -> bf16 staging; lane holds pixel (rt0 + r)*32 + l31, channels nt*32 + 8q + 4*half + e
 #pragma unroll
@@ -111,7 +120,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
             *reinterpret_cast<us4*>(lds + ((rt0 + r) * 32 + l31) * C3_PXB + n * 2) = o;
         }
     }
+    stamp(5);
     __syncthreads();
+    stamp(6);
     // ---- store: pixel p = ty*16 + tx; a tile row is 16 px x 128 B = 2 KB contiguous in the NHWC output
     bf16_t* yb = y + (long long)b * H * W * C3_C;
 #pragma unroll
@@ -120,9 +131,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
         const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
         if (oy < H && ox < W) *reinterpret_cast<us8*>(yb + ((long long)oy * W + ox) * C3_C + ch) = *reinterpret_cast<const us8*>(lds + p * C3_PXB + ch * 2);
     }
+    if constexpr (STAMP) {
+        stamp(7);
+        if (dbg && lane == 0) {
+            const long long wg = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int i = 0; i < 8; ++i) dbg[(wg * 4 + wave) * 8 + i] = ts[i];
+        }
+    }
 }
 
+static unsigned long long* g_c64_dbg = nullptr;
+
 }  // namespace nps
+
+extern "C" void nps_c64_debug_buffer(void* buf) { nps::g_c64_dbg = (unsigned long long*)buf; }
 
 extern "C" int nopesac_conv3x3_c64_bf16(const void* x, const void* w_frag, const float* scale, const float* bias, void* y, int B, int H,
                                         int W, int act, void* stream) {
@@ -132,7 +154,11 @@ extern "C" int nopesac_conv3x3_c64_bf16(const void* x, const void* w_frag, const
     const void* ptrs[] = {x, w_frag, scale, bias, y};
     for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "conv3x3_c64: pointers must be 16-byte aligned");
     dim3 grid((W + C3_T - 1) / C3_T, (H + C3_T - 1) / C3_T, B);
-    hipLaunchKernelGGL(conv3x3_c64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w_frag, scale, bias,
-                       (bf16_t*)y, H, W, act);
+    if (g_c64_dbg)                                                     // tuning runs only
+        hipLaunchKernelGGL(conv3x3_c64_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w_frag, scale, bias,
+                           (bf16_t*)y, H, W, act, g_c64_dbg);
+    else
+        hipLaunchKernelGGL(conv3x3_c64_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w_frag, scale, bias,
+                           (bf16_t*)y, H, W, act, (unsigned long long*)nullptr);
     NPS_LAUNCH_RET();
 }

@@ -40,13 +40,18 @@ constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH
 // the normalised image (the larger half of the stem's bf16 error, profiles/r4_bf16_attribution_stem.json) is gone, and so are the 24
 // f32 divisions per thread.  Positions outside the image hold `mean` = (mean[c] - 128), the value whose folded contribution is zero
 // like the reference's zero padding of the normalised image; `stdv` is not read.
-template <int RAW>
+// STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into dbg[workgroup][4 waves][16] (scripts/stem_stamps.py)
+template <int RAW, bool STAMP = false>
 __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ xraw,
                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
                                                          const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
-                                                         bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW) {
+                                                         bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW,
+                                                         unsigned long long* dbg = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
+    unsigned long long ts[16];
+    auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
+    stamp(0);
     unsigned char* patch = lds;
     bf16_t* wl = reinterpret_cast<bf16_t*>(lds + ST_PATCH_BYTES);
     bf16_t* ctile = reinterpret_cast<bf16_t*>(lds);
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
         }
     }
+    stamp(1);
     {   // weights: all 7 loads of a thread in flight, then the LDS writes
         constexpr int WIT = 64 * (ST_K / 8) / 256;
         static_assert(64 * (ST_K / 8) % 256 == 0, "weight chunking");
@@ -121,7 +127,9 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             *reinterpret_cast<us8*>(wl + (i / (ST_K / 8)) * ST_WLD + (i % (ST_K / 8)) * 8) = wr[it];
         }
     }
+    stamp(2);
     __syncthreads();
+    stamp(3);
     // ---- implicit GEMM: wave owns row tiles t = wave*3 .. +3 (32 conv pixels each), both 32-channel halves
     // Row tile T -> conv pixels: T = 0..8: columns 0..31 of conv row T; T = 9..11: the nine leftover columns - columns 32..39 as
     // 8-lane runs of rows 0..8, then column 40.  A lane's 16-byte A fragment sits at dword 352 cy + 4 cx, i.e. on bank slot
@@ -174,7 +182,9 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[t], acc[t][j], 0, 0, 0);
     }
+    stamp(4);
     __syncthreads();                                            // patch / weights are dead: reuse LDS for the conv tile
+    stamp(5);
     // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 16*half + 4q + {0..3}
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -202,7 +212,9 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                 if (valid) *reinterpret_cast<us8*>(ctile + p * ST_CLD + n) = o;
             }
     }
+    stamp(6);
     __syncthreads();
+    stamp(7);
     // ---- 3x3 / s2 max-pool out of LDS; 8 channels (16 bytes) per work item
     // Item -> (pooled pixel, 16-byte channel piece): ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
     // (+32); a group reads the 2 x 128 bytes of two pooled pixels FOUR apart (8 conv pixels = 288 dwords = 32 banks): conflict-free
@@ -231,7 +243,17 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(m[e]);
         *reinterpret_cast<us8*>(y + (((long long)b * PH + py) * PW + px) * 64 + c8) = o;
     }
+    if constexpr (STAMP) {
+        stamp(8);
+        if (dbg && lane == 0) {
+            const long long wg = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            for (int i = 0; i < 9; ++i) dbg[(wg * 4 + wave) * 16 + i] = ts[i];
+        }
+    }
 }
+
+static unsigned long long* g_stem_dbg = nullptr;
+extern "C" void nps_stem_debug_buffer(void* buf) { nps::g_stem_dbg = (unsigned long long*)buf; }
 
 }  // namespace nps
 
@@ -275,7 +297,11 @@ extern "C" int nopesac_stem_fused_raw_shifted_bf16(const float* x_nchw, const fl
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    hipLaunchKernelGGL(stem_fused_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, pad3, (const float*)nullptr,
-                       (const bf16_t*)w_folded, scale, bias_folded, (bf16_t*)y, H, W, CH, CW, PH, PW);
+    if (g_stem_dbg)                                                    // tuning runs only
+        hipLaunchKernelGGL((stem_fused_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, pad3,
+                           (const float*)nullptr, (const bf16_t*)w_folded, scale, bias_folded, (bf16_t*)y, H, W, CH, CW, PH, PW, g_stem_dbg);
+    else
+        hipLaunchKernelGGL((stem_fused_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, pad3, (const float*)nullptr,
+                           (const bf16_t*)w_folded, scale, bias_folded, (bf16_t*)y, H, W, CH, CW, PH, PW, (unsigned long long*)nullptr);
     NPS_LAUNCH_RET();
 }

@@ -195,6 +195,41 @@ def test_bf16_backbone_pose_error(device):
         assert np.isfinite(y["camera"]["tran"]).all() and np.isfinite(y["camera"]["rot"]).all()
 
 
+def test_bf16_refined_pose_on_natural_matches(device):
+    """The REFINED camera in bf16 on NON-forced inputs with >= 2 matches per pair (round-5 verdict, parity hole (a); round 6).
+    Twin pairs - both views show the same structured image, relaxed thresholds - are the synthetic checkpoint's only source of natural
+    matches (a random-weight matcher finds none between unrelated images).  A pair takes part when both precisions keep the SAME
+    planes and find the SAME >= 2 matches: then the two paths differ by arithmetic only.  Fixed bounds: refined rotation <= 2.5 deg,
+    refined translation <= 5 % of |t| (measured on MI355X: 0.79 / 1.61 deg mean / max, 2.3 / 3.2 %, `scripts/twin_pairs_gate.py`,
+    profiles/r6_d_bf16_refined_pose_non_forced.txt; the same pairs move by 0.22 / 0.50 deg and 1.0 / 2.3 % in PURE f32 under +-0.5 grey
+    levels of input noise).  What the round-5 record's `loose_structured.camera` (T 0.74, R 4.4 deg) showed is something else: pairs
+    with m <= 1 and pairs whose kept-plane sets differ between the precisions, where the random-weight refinement head moves by 5 % / up
+    to 8 deg under that f32 input noise alone (same file) - conditioning of the synthetic checkpoint, not a bf16 defect."""
+    from nopesac_amd import runner
+    from nopesac_amd.synth import synth_pair
+    m32, m16 = make_model(device, LOOSE), make_model(device, LOOSE, dtype="bfloat16")
+    cand = [2, 8, 9, 11, 21, 32, 33, 42, 43, 50, 52, 55, 59, 63, 64, 65, 70, 72, 77, 80, 81, 84, 86, 89, 90, 95]       # fp32: m >= 2 as twins
+    took = []
+    for lo in range(0, len(cand), 13):
+        inp = []
+        for i in cand[lo:lo + 13]:
+            d = synth_pair(i, structured=True)
+            d["1"] = dict(d["0"], image=d["0"]["image"].clone(), image_id=d["1"]["image_id"], file_name=d["1"]["file_name"])
+            inp.append(d)
+        for i, x, y in zip(cand[lo:lo + 13], m32(inp), m16(inp)):
+            if int(x["matched_num"]) < 2 or int(x["matched_num"]) != int(y["matched_num"]):
+                continue
+            if any(x[v]["pred_plane_oriIdxs"] != y[v]["pred_plane_oriIdxs"] for v in "01"):
+                continue
+            if not np.array_equal(np.asarray(x["pred_assignment_beforeRef0"]) > 0, np.asarray(y["pred_assignment_beforeRef0"]) > 0):
+                continue
+            t = float(runner.translation_error(y["camera"]["tran"][None], x["camera"]["tran"][None])[0]) / float(np.linalg.norm(x["camera"]["tran"]))
+            r = float(runner.rotation_error_deg(y["camera"]["rot"][None], x["camera"]["rot"][None])[0])
+            took.append((i, int(x["matched_num"]), round(t, 4), round(r, 3)))
+    assert len(took) >= 3, took                      # (MI355X: six pairs qualify; a flipped plane decision on another box may cost one or two)
+    assert max(t for _, _, t, _ in took) < 0.05 and max(r for _, _, _, r in took) < 2.5, took
+
+
 @pytest.mark.parametrize("replay", ["launches", "graph"])
 def test_hip_graph_mode_reproduces_the_eager_results(device, replay):
     """MODEL.AMD.USE_HIP_GRAPH: the forward of a batch as one hipGraph replay (warm-up call eager, capture on a slot's second
