@@ -52,6 +52,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v > 0.f ? v : neg;
 }
 
+// N values with ONE wave-uniform decision (same values as apply_act per element).  Round 6: conv3x3_c64_kernel called apply_act per element
+// in its unrolled epilogue - 4.7 k lines of ISA (64 inlined sigmoid bodies behind 256 scalar branches, 37 KB of code: more than the
+// instruction cache holds next to the main loop), 11.6 k of the workgroup's 29.8 k cycles (in-kernel stamps, profiles/r6_e_*).
+template <int N>
+__device__ __forceinline__ void apply_act_n(float (&v)[N], int act) {
+    if (act == NPS_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    } else if (act == NPS_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+    } else if (act == NPS_ACT_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+    }
+}
+
 // The epilogue form: 8 values at a time, ONE wave-uniform decision per vector instead of a switch per element (a per-element
 // switch inside unrolled epilogue loops compiled to thousands of scalar branches: the 256x256 conv tile's epilogue was 20 k
 // lines of ISA, larger than the instruction cache, 43 k cycles per tile).  Same operations in the same order as

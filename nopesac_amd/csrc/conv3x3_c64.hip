@@ -26,7 +26,7 @@ constexpr int C3_PXB = (C3_C + 8) * 2;                            // 144 bytes p
 // every group collided (PMC round 2: 47 % of the LDS cycles were bank conflicts).
 constexpr int C3_ROWB = ((C3_HT * C3_PXB + 255) / 256) * 256;     // 2816
 constexpr int C3_HALO_BYTES = C3_HT * C3_ROWB;                    // 50,688 (three workgroups per CU)
-static_assert(256 * C3_PXB <= C3_HALO_BYTES && 3 * C3_HALO_BYTES <= 160 * 1024, "output staging tile / occupancy");
+static_assert(256 * C3_PXB <= C3_HALO_BYTES && 3 * (C3_HALO_BYTES + 512) <= 160 * 1024, "output staging tile / occupancy");
 constexpr int C3_KS = 9 * C3_C / 16;                              // 36 k-steps of 16
 constexpr int C3_RING = 16;
 
@@ -35,7 +35,9 @@ template <bool STAMP>
 __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
                                                              const float* __restrict__ scale, const float* __restrict__ bias,
                                                              bf16_t* __restrict__ y, int H, int W, int act, unsigned long long* dbg) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[C3_HALO_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C3_HALO_BYTES + 512];
+    float* sb_lds = reinterpret_cast<float*>(lds + C3_HALO_BYTES);     // BN scale / shift parked behind the tile (no global loads in the epilogue)
+    const float sb_v = (threadIdx.x & 64 ? bias : scale)[threadIdx.x & 63];      // (unguarded load, written to LDS in front of the first barrier)
     unsigned long long ts[8];
     auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
     stamp(0);
@@ -61,16 +63,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
             const int i = tid + it * 256;
             const int px = i >> 3, ch = (i & 7) * 8;
             const int iy = y0 - 1 + px / C3_HT, ix = x0 - 1 + px % C3_HT;
-            hv[it] = us8{};
-            if (i < C3_HT * C3_HT * 8 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                hv[it] = *reinterpret_cast<const us8*>(xb + ((long long)iy * W + ix) * C3_C + ch);
+            // unconditional load from a clamped pixel, zeroed below where the halo lies outside the image: a GUARDED load compiles to a
+            // branch that waits for its own load inside the block (round 6, stem.hip: the loads ran one memory round trip after the other)
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            hv[it] = *reinterpret_cast<const us8*>(xb + ((long long)iyc * W + ixc) * C3_C + ch);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            if (i < C3_HT * C3_HT * 8) *reinterpret_cast<us8*>(lds + ((i >> 3) / C3_HT) * C3_ROWB + ((i >> 3) % C3_HT) * C3_PXB + (i & 7) * 16) = hv[it];
+            const int px = i >> 3;
+            const int iy = y0 - 1 + px / C3_HT, ix = x0 - 1 + px % C3_HT;
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            if (i < C3_HT * C3_HT * 8) *reinterpret_cast<us8*>(lds + (px / C3_HT) * C3_ROWB + (px % C3_HT) * C3_PXB + (i & 7) * 16) = in ? hv[it] : us8{};
         }
     }
+    if (tid < 128) sb_lds[tid] = sb_v;
     stamp(1);
     __syncthreads();
     stamp(2);
@@ -104,19 +111,30 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(const bf16_t* __res
     stamp(4);
 
     // ---- BN + activation -> bf16 staging; lane holds pixel (rt0 + r)*32 + l31, channels nt*32 + 8q + 4*half + e
+    // (the activation is decided ONCE per 64 values, not per element: apply_act_n, common.h)
+    float ev[64];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = nt * 32 + 8 * q + 4 * half;
-        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + n), bb = *reinterpret_cast<const f32x4*>(bias + n);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sb_lds + n), bb = *reinterpret_cast<const f32x4*>(sb_lds + 64 + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            us4 o;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = acc[r][4 * q + e] * s[e];
                 v += bb[e];
-                o[e] = f32_to_bf16(apply_act(v, act));
+                ev[(q * 4 + r) * 4 + e] = v;
             }
+    }
+    apply_act_n<64>(ev, act);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = nt * 32 + 8 * q + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            us4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(ev[(q * 4 + r) * 4 + e]);
             *reinterpret_cast<us4*>(lds + ((rt0 + r) * 32 + l31) * C3_PXB + n * 2) = o;
         }
     }

@@ -101,13 +101,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs p) 
                 const f32x4 s = *reinterpret_cast<const f32x4*>(p.scale + n), bb = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    us4 o;
+                    float ev[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[r][4 * q + e] * s[e];
                         v += bb[e];
-                        o[e] = f32_to_bf16(apply_act(v, p.act));
+                        ev[e] = v;
                     }
+                    apply_act_n<4>(ev, p.act);                 // (one wave-uniform decision per four values, not a branch per element)
+                    us4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(ev[e]);
                     *reinterpret_cast<us4*>(lds + (r * 32 + l31) * CH_PXB + nl * 2) = o;
                 }
             }

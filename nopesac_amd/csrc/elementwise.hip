@@ -102,7 +102,8 @@ __global__ void upsample_bilinear2x_kernel(const T* __restrict__ x, const T* __r
         load_vec<T, V>(x + (base + (long long)y1 * W + x0) * C + c, v10);
         load_vec<T, V>(x + (base + (long long)y1 * W + x1) * C + c, v11);
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = apply_act(hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]), act);
+        for (int e = 0; e < V; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+        apply_act_n<V>(o, act);
         if (addend) {
             float a[V];
             load_vec<T, V>(addend + opix * C + c, a);
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         float v[8];
         load_vec<T, 8>(xb + p * C + c, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * a8[e] + d8[e], act);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * a8[e] + d8[e];
+        apply_act_n<8>(v, act);
         store_vec<T, 8>(yb + p * C + c, v);
     }
 }

@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW,
                                                          unsigned long long* dbg = nullptr) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS + 512];
+    // BN scale / shift parked in LDS behind the tile (round 6: as global loads inside the epilogue they were exposed L2 round trips -
+    // the epilogue took 6.5 k of the workgroup's 26.9 k cycles for ~800 instructions, in-kernel stamps profiles/r6_e_*)
+    float* sb_lds = reinterpret_cast<float*>(lds + ST_LDS);
+    const float sb_v = (threadIdx.x & 64 ? bias : scale)[threadIdx.x & 63];      // (unguarded load, written to LDS in front of the first barrier)
     unsigned long long ts[16];
     auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
     stamp(0);
@@ -61,7 +65,16 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / col
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- stage the input patch (zero outside the image) and the weights
+    // ---- the weights' loads first (all 7 of a thread in flight; L2 hits), then the patch's: ONE memory round trip for both
+    constexpr int WIT = 64 * (ST_K / 8) / 256;
+    static_assert(64 * (ST_K / 8) % 256 == 0, "weight chunking");
+    us8 wr[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = tid + it * 256;
+        wr[it] = *reinterpret_cast<const us8*>(w + (i / (ST_K / 8)) * ST_K + (i % (ST_K / 8)) * 8);
+    }
+    // ---- stage the input patch (zero outside the image)
     if constexpr (RAW != 0) {
         const float* xr = xraw + (long long)b * 3 * H * W;
         const float m0 = mean[0], m1 = mean[1], m2 = mean[2];
@@ -78,11 +91,13 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             const int i = tid + it * 256;
             const int r = i / ST_IW, c = i % ST_IW;
             const int iy = iy0 + r, ix = ix0 + c;
-            r0[it] = r1[it] = r2[it] = 0.f;
-            if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const long long o = (long long)iy * W + ix;
-                r0[it] = xr[o]; r1[it] = xr[hw + o]; r2[it] = xr[2 * hw + o];
-            }
+            // UNCONDITIONAL loads from a clamped (always valid) pixel; positions outside the image / the patch are replaced when the patch
+            // is written below.  Round 6, read off the ISA: a guarded load (`if (inside) r = x[o]`) compiles to a branch with its
+            // s_waitcnt vmcnt(0) INSIDE the block - the eight iterations ran as eight back-to-back HBM round trips (10.8 k of the
+            // workgroup's 24.8 k cycles, in-kernel stamps) although the source issues all loads first
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const long long o = (long long)iyc * W + ixc;
+            r0[it] = xr[o]; r1[it] = xr[hw + o]; r2[it] = xr[2 * hw + o];
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -94,39 +109,43 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                 const bool in = i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 v.x = f32x2_to_bf16x2(in ? r0[it] - 128.f : m0, in ? r1[it] - 128.f : m1);
                 v.y = f32x2_to_bf16x2(in ? r2[it] - 128.f : m2, 0.f);
-            } else if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                v.x = f32x2_to_bf16x2((r0[it] - m0) / s0, (r1[it] - m1) / s1);
-                v.y = f32x2_to_bf16x2((r2[it] - m2) / s2, 0.f);
+            } else {
+                const bool in = i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                v.x = f32x2_to_bf16x2(in ? (r0[it] - m0) / s0 : 0.f, in ? (r1[it] - m1) / s1 : 0.f);
+                v.y = f32x2_to_bf16x2(in ? (r2[it] - m2) / s2 : 0.f, 0.f);
             }
             if (i < ST_IH * ST_IW + 8) *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
         }
     } else {
         const bf16_t* xb = x + (long long)b * H * W * 4;
-        for (int i = tid; i < ST_IH * ST_IW + 8; i += 256) {
+        constexpr int NIT0 = (ST_IH * ST_IW + 8 + 255) / 256;
+        uint2 pv[NIT0];
+#pragma unroll
+        for (int it = 0; it < NIT0; ++it) {                       // unconditional loads from a clamped pixel (see RAW above)
+            const int i = tid + it * 256;
             const int r = i / ST_IW, c = i % ST_IW;
             const int iy = iy0 + r, ix = ix0 + c;
-            uint2 v = make_uint2(0u, 0u);
-            if (i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = *reinterpret_cast<const uint2*>(xb + ((long long)iy * W + ix) * 4);
-            *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = v;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            pv[it] = *reinterpret_cast<const uint2*>(xb + ((long long)iyc * W + ixc) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT0; ++it) {
+            const int i = tid + it * 256;
+            const int r = i / ST_IW, c = i % ST_IW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool in = i < ST_IH * ST_IW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            if (i < ST_IH * ST_IW + 8) *reinterpret_cast<uint2*>(patch + (size_t)i * 8) = in ? pv[it] : make_uint2(0u, 0u);
         }
     }
     stamp(1);
-    {   // weights: all 7 loads of a thread in flight, then the LDS writes
-        constexpr int WIT = 64 * (ST_K / 8) / 256;
-        static_assert(64 * (ST_K / 8) % 256 == 0, "weight chunking");
-        us8 wr[WIT];
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = tid + it * 256;
-            wr[it] = *reinterpret_cast<const us8*>(w + (i / (ST_K / 8)) * ST_K + (i % (ST_K / 8)) * 8);
-        }
+    {   // weights -> LDS (their loads went out in front of the patch's)
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int i = tid + it * 256;
             *reinterpret_cast<us8*>(wl + (i / (ST_K / 8)) * ST_WLD + (i % (ST_K / 8)) * 8) = wr[it];
         }
     }
+    if (tid < 128) sb_lds[tid] = sb_v;
     stamp(2);
     __syncthreads();
     stamp(3);
@@ -147,6 +166,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         return false;
     };
     static_assert(ST_CW == 41 && ST_CH == 9 && 12 * 32 >= ST_M, "row-tile enumeration");
+    static_assert(3 * (ST_LDS + 512) <= 160 * 1024, "three workgroups per CU");
     int a_base[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                 us8 o;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const float4 s4 = *reinterpret_cast<const float4*>(scale + n + 4 * jj), b4 = *reinterpret_cast<const float4*>(bias + n + 4 * jj);
+                    const float4 s4 = *reinterpret_cast<const float4*>(sb_lds + n + 4 * jj), b4 = *reinterpret_cast<const float4*>(sb_lds + 64 + n + 4 * jj);
                     const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
