@@ -157,15 +157,24 @@ __device__ __forceinline__ void gn_layernorm(f32x16 (&acc)[2], const float* __re
 
 // f32 rows [nq][256] (global) -> bf16 tile [64][GN_LD]; rows >= nq are zero
 __device__ __forceinline__ void gn_load_rows(const float* __restrict__ g, int nq, bf16_t* T, int tid) {
+    // UNCONDITIONAL loads from a clamped row, zeroed afterwards (round 6, read off the ISA: `if (row < nq) load` compiles to a branch with
+    // the s_waitcnt for its own load inside - the four iterations of a tile ran as four back-to-back memory round trips, eight per
+    // launch of a kernel that is a 42 us latency chain)
+    constexpr int NI = 64 * 32 / 512;
+    f32x4 a[NI], b[NI];
+    const int last = nq > 0 ? nq - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 64 * 32 / 512; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = tid + i * 512, row = c >> 5, col = (c & 31) * 8;
-        u32x4 pk = {0u, 0u, 0u, 0u};
-        if (row < nq) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(g + (long long)row * GN_D + col);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(g + (long long)row * GN_D + col + 4);
-            pk = u32x4{gn_pack2(a[0], a[1]), gn_pack2(a[2], a[3]), gn_pack2(b[0], b[1]), gn_pack2(b[2], b[3])};
-        }
+        const int rc = row < nq ? row : last;
+        a[i] = *reinterpret_cast<const f32x4*>(g + (long long)rc * GN_D + col);
+        b[i] = *reinterpret_cast<const f32x4*>(g + (long long)rc * GN_D + col + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = tid + i * 512, row = c >> 5, col = (c & 31) * 8;
+        u32x4 pk = u32x4{gn_pack2(a[i][0], a[i][1]), gn_pack2(a[i][2], a[i][3]), gn_pack2(b[i][0], b[i][1]), gn_pack2(b[i][2], b[i][3])};
+        if (row >= nq) pk = u32x4{0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(T + row * GN_LD + col) = pk;
     }
 }
