@@ -152,7 +152,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("NOPESAC_AB_LIBRARY") or LIB_PATH           # A/B runs only: another BUILD of this library (e.g. last round's)
+    if not os.path.exists(lib_path):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -m nopesac_amd.build` "
             "(needs hipcc for gfx950).  nopesac_amd has no CPU fallback.")
@@ -160,7 +161,7 @@ def load():
     # that this library (linked against the same SONAME) shares torch's runtime, streams and device context - loading the
     # system copy first leaves the kernels of this library without a device ("no ROCm-capable device is detected").
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(lib_path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes

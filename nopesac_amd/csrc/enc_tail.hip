@@ -141,12 +141,24 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     EtRing ring;
 
     et_issue(ring, 0, p.wo, 16, 0, wave, lane);                                   // step 0: out-proj tile `wave`
+    // (round 6: every load of this prologue is UNCONDITIONAL - rows behind M read the last row and are zeroed / never stored.  Guarded
+    // loads compile to one branch + one full memory round trip each: the attention rows, the residual rows and the position rows of
+    // this 24 us latency-chain kernel were seven of them in a row)
+    const long long lastrow = (long long)p.M - 1;
+    us8 av[ET_BM * 32 / 512];
 #pragma unroll
     for (int i = 0; i < ET_BM * 32 / 512; ++i) {                                  // attention rows -> LDS
         const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
-        us8 v = us8{};
-        if (m0 + r < p.M) v = *reinterpret_cast<const us8*>(p.attn + (m0 + r) * ET_D + col);
-        *reinterpret_cast<us8*>(At + r * ET_LD + col) = v;
+        av[i] = *reinterpret_cast<const us8*>(p.attn + (m0 + r < lastrow ? m0 + r : lastrow) * ET_D + col);
+    }
+    f32x4 srcv[4];                                                                // the residual rows: in flight under the out-projection
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        srcv[q] = *reinterpret_cast<const f32x4*>(p.src + (row_ok ? row : lastrow) * ET_D + wave * 32 + 8 * q + 4 * half);
+#pragma unroll
+    for (int i = 0; i < ET_BM * 32 / 512; ++i) {
+        const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
+        *reinterpret_cast<us8*>(At + r * ET_LD + col) = m0 + r < p.M ? av[i] : us8{};
     }
     __syncthreads();
 
@@ -159,8 +171,7 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
     for (int q = 0; q < 4; ++q) {
         const int n = wave * 32 + 8 * q + 4 * half;
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + n);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (row_ok) s = *reinterpret_cast<const f32x4*>(p.src + row * ET_D + n);
+        const f32x4 s = row_ok ? srcv[q] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) y1[4 * q + e] = (y1[4 * q + e] + b[e]) + s[e];
     }
@@ -243,7 +254,10 @@ __global__ __launch_bounds__(512, 2) void enc_tail_kernel(const EncTailArgs p) {
         }
         us4 o, op;
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
-        if (p.pos && row_ok) pv = *reinterpret_cast<const f32x4*>(p.pos + (row % p.pos_rows) * ET_D + n);
+        if (p.pos) {                                          // (wave-uniform condition; rows behind M read a valid row and are never stored)
+            const f32x4 pl = *reinterpret_cast<const f32x4*>(p.pos + ((row_ok ? row : lastrow) % p.pos_rows) * ET_D + n);
+            pv = row_ok ? pl : pv;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o[e] = f32_to_bf16(v[e]); op[e] = f32_to_bf16(v[e] + pv[e]); }
         *reinterpret_cast<us4*>(Yt + l31 * ET_LD + n) = o;

@@ -110,13 +110,14 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
     if (wave == 0) {
         int off = 0;
         for (int base = 0; base < nq; base += 64) {
-            const int q = base + lane;
-            const int v = q < nq ? wk[q] : 0;
+            const int q = base + lane, qc = q < nq ? q : nq - 1;
+            const int vl = wk[qc], sl = wk[nq + qc];              // both loads unconditional and together: ONE round trip in front of the barrier, not two
+            const int v = q < nq ? vl : 0;
             const unsigned long long m = __ballot(v != 0);
             if (v) {
                 const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
                 vq[pos] = q;
-                vs[pos] = __int_as_float(wk[nq + q]);
+                vs[pos] = __int_as_float(sl);
             }
             off += __popcll(m);
         }
@@ -132,20 +133,31 @@ __global__ __launch_bounds__(256) void ps_pixels_kernel(const float* __restrict_
         const unsigned inv = ((1u << 20) + nk4 - 1) / nk4;
         const int items = nrows * ncols * nk4;
         const long long plane = (long long)h * w;
-        for (int it = threadIdx.x; it < items; it += 256) {
-            const int rc = (int)(((unsigned)it * inv) >> 20), k4 = it - rc * nk4;
-            const int r = rc / ncols, c = rc - r * ncols;
-            const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);
-            const long long pix = (long long)(ry0 + r) * w + cx0 + c;
-            float4 v;
-            if (planar) {
-                const float* pb = prob + (long long)b * nq * plane + pix;
-                v = make_float4(pb[q4.x * plane], pb[q4.y * plane], pb[q4.z * plane], pb[q4.w * plane]);
-            } else {
-                const float* pb = prob + ((long long)b * plane + pix) * nq;
-                v = make_float4(pb[q4.x], pb[q4.y], pb[q4.z], pb[q4.w]);
+        // FOUR items per pass with all sixteen loads in flight (round 6: the rolled loop - load, wait, ds_write, next - was one memory
+        // round trip per 256 items: 3 in a row at ~23 valid queries, 14 at K = 128).  The loads are unconditional (a pass's items behind
+        // the last one re-read the last item), only the LDS writes are guarded: a branch around a load makes the compiler wait inside it
+        for (int it0 = threadIdx.x; it0 < items; it0 += 4 * 256) {
+            float4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * 256 < items ? it0 + u * 256 : items - 1;
+                const int rc = (int)(((unsigned)it * inv) >> 20), k4 = it - rc * nk4;
+                const int r = rc / ncols, c = rc - r * ncols;
+                const int4 q4 = *reinterpret_cast<const int4*>(vq + 4 * k4);
+                const long long pix = (long long)(ry0 + r) * w + cx0 + c;
+                if (planar) {
+                    const float* pb = prob + (long long)b * nq * plane + pix;
+                    v[u] = make_float4(pb[q4.x * plane], pb[q4.y * plane], pb[q4.z * plane], pb[q4.w * plane]);
+                } else {
+                    const float* pb = prob + ((long long)b * plane + pix) * nq;
+                    v[u] = make_float4(pb[q4.x], pb[q4.y], pb[q4.z], pb[q4.w]);
+                }
+                dst[u] = (r * src_cols + c) * kp + 4 * k4;
             }
-            *reinterpret_cast<float4*>(tile + ((r * src_cols + c) * kp + 4 * k4)) = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (it0 + u * 256 < items) *reinterpret_cast<float4*>(tile + dst[u]) = v[u];
         }
     }
     __syncthreads();

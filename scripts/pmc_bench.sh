@@ -25,7 +25,7 @@ for f in glob.glob("gpurun_out/pmc_bench/*/*counter_collection.csv"):
     rows=sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     # only the 6 real forward passes at the end (each starts with the preprocess kernel): the load-time autotuner's trial
     # launches before them are not part of a step
-    starts=[int(r["Dispatch_Id"]) for r in rows if (("stem_fused_kernel<1>" in r["Kernel_Name"] or "stem_fused_kernel<2>" in r["Kernel_Name"]) or "preprocess" in r["Kernel_Name"]) and r["Counter_Name"]==rows[0]["Counter_Name"]]
+    starts=[int(r["Dispatch_Id"]) for r in rows if (("stem_fused_kernel<1" in r["Kernel_Name"] or "stem_fused_kernel<2" in r["Kernel_Name"]) or "preprocess" in r["Kernel_Name"]) and r["Counter_Name"]==rows[0]["Counter_Name"]]
     first=sorted(set(starts))[-6]          # warmup 1 + 2 timed + 3 instrumented forward passes
     for r in rows:
         if int(r["Dispatch_Id"]) < first: continue

@@ -10,7 +10,7 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/prof_${TAG}/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if ("stem_fused_kernel<1>" in r["Kernel_Name"] or "stem_fused_kernel<2>" in r["Kernel_Name"])]
+starts = [i for i, r in enumerate(rows) if ("stem_fused_kernel<1" in r["Kernel_Name"] or "stem_fused_kernel<2" in r["Kernel_Name"])]
 n = 40
 sel = rows[starts[-(n + 1)]:starts[-1]]
 tot = collections.defaultdict(lambda: [0, 0.0])

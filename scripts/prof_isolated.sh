@@ -13,7 +13,7 @@ f = glob.glob("gpurun_out/prof_${TAG}/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # step boundaries = the first kernel of a step (raw-input stem, or preprocess); the run ends with 3 instrumented steps
-starts = [i for i, r in enumerate(rows) if (("stem_fused_kernel<1>" in r["Kernel_Name"] or "stem_fused_kernel<2>" in r["Kernel_Name"]) or "preprocess" in r["Kernel_Name"])]
+starts = [i for i, r in enumerate(rows) if (("stem_fused_kernel<1" in r["Kernel_Name"] or "stem_fused_kernel<2" in r["Kernel_Name"]) or "preprocess" in r["Kernel_Name"])]
 n = $STEPS
 sel = rows[starts[-(n + 3)]:starts[-3]]           # n full timed steps (skips the 3 instrumented ones)
 tot = collections.defaultdict(lambda: [0, 0.0])
