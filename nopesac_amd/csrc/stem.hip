@@ -206,6 +206,10 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     __syncthreads();                                            // patch / weights are dead: reuse LDS for the conv tile
     stamp(5);
     // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 16*half + 4q + {0..3}
+    // Round 6 (PMC: 16 VALU instructions per MFMA, the kernel issue-bound once its loads overlapped): BN as ONE fused multiply-add, and
+    // the pool-padding select only in tiles that have a conv pixel outside the image (wave-uniform test; the interior tiles skip it).
+    // Padding value: -0.0 (0x8000) - the pool below compares the bf16 bit patterns as SIGNED 16-bit integers, which orders the
+    // non-negative ReLU outputs like their values and puts -0.0 below all of them (every pool window holds at least one real pixel).
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         int cy, cx;
@@ -213,23 +217,30 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         const int p = cy * ST_CW + cx;
         const int gy = cy0 + cy, gx = cx0 + cx;
         const bool inside = valid && (unsigned)gy < (unsigned)CH && (unsigned)gx < (unsigned)CW;
+        const bool any_outside = __builtin_amdgcn_ballot_w64(valid && !inside) != 0ull;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int n = j * 32 + 16 * half + 8 * qq;
-                us8 o;
+                uint4 o;
+                unsigned ow[4];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const float4 s4 = *reinterpret_cast<const float4*>(sb_lds + n + 4 * jj), b4 = *reinterpret_cast<const float4*>(sb_lds + 64 + n + 4 * jj);
                     const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaxf(acc[t][j][4 * (2 * qq + jj) + e] * sv[e] + bv[e], 0.f);
-                        o[4 * jj + e] = inside ? f32_to_bf16(v) : (bf16_t)0xFF80;   // -inf for the pool's padding positions
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[t][j][4 * (2 * qq + jj) + e], sv[e], bv[e]), 0.f);
+                    ow[2 * jj] = f32x2_to_bf16x2(v[0], v[1]);
+                    ow[2 * jj + 1] = f32x2_to_bf16x2(v[2], v[3]);
                 }
-                if (valid) *reinterpret_cast<us8*>(ctile + p * ST_CLD + n) = o;
+                if (any_outside) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ow[e] = inside ? ow[e] : 0x80008000u;
+                }
+                o = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (valid) *reinterpret_cast<uint4*>(ctile + p * ST_CLD + n) = o;
             }
     }
     stamp(6);
@@ -247,20 +258,28 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         const int ly = pp / ST_PW, lx = pp % ST_PW;
         const int py = py0 + ly, px = px0 + lx;
         if (py >= PH || px >= PW) continue;
-        float m[8];
+        // max of the nine taps on the bf16 BIT PATTERNS as packed signed 16-bit integers (v_pk_max_i16: 4 instructions per tap for the
+        // 8 channels instead of 8 unpacks + 8 f32 max): exact - ReLU outputs are >= +0 (integer order = value order), padding is -0.0
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        s16x2 m[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int e = 0; e < 4; ++e) m[e] = s16x2{(short)0x8000, (short)0x8000};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const us8 v = *reinterpret_cast<const us8*>(ctile + ((2 * ly + dy) * ST_CW + 2 * lx + dx) * ST_CLD + c8);
+                const uint4 v = *reinterpret_cast<const uint4*>(ctile + ((2 * ly + dy) * ST_CW + 2 * lx + dx) * ST_CLD + c8);
+                const unsigned vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf16_to_f32(v[e]));
+                for (int e = 0; e < 4; ++e) m[e] = __builtin_elementwise_max(m[e], __builtin_bit_cast(s16x2, vw[e]));
             }
         us8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(m[e]);
+        for (int e = 0; e < 4; ++e) {
+            const unsigned wv = __builtin_bit_cast(unsigned, m[e]);
+            o[2 * e] = (unsigned short)(wv & 0xFFFFu);
+            o[2 * e + 1] = (unsigned short)(wv >> 16);
+        }
         *reinterpret_cast<us8*>(y + (((long long)b * PH + py) * PW + px) * 64 + c8) = o;
     }
     if constexpr (STAMP) {
