@@ -141,42 +141,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int v = tid + i * 256;
             const int kv = v % VPR;
             const int k = kt * BK + kv * VEC;
-            // UNCONDITIONAL load (round 6): an element that does not exist - row >= M, k >= K, a tap outside the image - reads the tensor's
-            // first vector instead and is zeroed afterwards.  Behind `if (inside) val = load` the compiler waits for every load inside
-            // its own branch: a tile's A_VECS + B_VECS loads ran as that many back-to-back memory round trips (the same finding as
-            // stem.hip / gnn_layer.hip this round; the PF2 form above avoids it with buffer descriptors)
             vec_t val = vec_t{};
-            int c = k, ih = a_ih0[i], iw = a_iw0[i];
-            if (!is1x1) {
-                const int tap = k / p.Cin;
-                c = k - tap * p.Cin;
-                const int kh = tap / p.KW, kw = tap - kh * p.KW;
-                ih += kh; iw += kw;
-            }
-            const bool ok = a_ok[i] && k < p.K && (p.dense1x1 || ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W));
-            const TA* src = ok ? X + (a_base[i] + (p.dense1x1 ? 0ll : (long long)ih * p.W + iw)) * p.x_cs + c : X;
-            if constexpr (sizeof(TA) == sizeof(T)) {
-                val = *(const vec_t*)src;
-            } else if constexpr (VEC == 1) {
-                val = f32_to_bf16(*src);
-            } else {
+            if (a_ok[i] && k < p.K) {
+                int c = k, ih = a_ih0[i], iw = a_iw0[i];
+                if (!is1x1) {
+                    const int tap = k / p.Cin;
+                    c = k - tap * p.Cin;
+                    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                    ih += kh; iw += kw;
+                }
+                if (p.dense1x1 || ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)) {
+                    const TA* src = X + (a_base[i] + (p.dense1x1 ? 0ll : (long long)ih * p.W + iw)) * p.x_cs + c;
+                    if constexpr (sizeof(TA) == sizeof(T)) {
+                        val = *(const vec_t*)src;
+                    } else if constexpr (VEC == 1) {
+                        val = f32_to_bf16(*src);
+                    } else {
 #pragma unroll
-                for (int e4 = 0; e4 < VEC / 4; ++e4) {
-                    const f32x4 f = *(const f32x4*)(src + 4 * e4);
+                        for (int e4 = 0; e4 < VEC / 4; ++e4) {
+                            const f32x4 f = *(const f32x4*)(src + 4 * e4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[4 * e4 + e] = f32_to_bf16(f[e]);
+                            for (int e = 0; e < 4; ++e) val[4 * e4 + e] = f32_to_bf16(f[e]);
+                        }
+                    }
                 }
             }
-            a_reg[i] = ok ? val : vec_t{};
+            a_reg[i] = val;
         }
 #pragma unroll
         for (int i = 0; i < B_VECS; ++i) {
             const int v = tid + i * 256;
             const int row = v / VPR, kv = v % VPR;
             const int n = n0 + row, k = kt * BK + kv * VEC;
-            const bool ok = n < p.N && k < p.K;
-            const vec_t val = *(const vec_t*)(ok ? Wt + (long long)n * p.K + k : Wt);
-            b_reg[i] = ok ? val : vec_t{};
+            vec_t val = vec_t{};
+            if (n < p.N && k < p.K) val = *(const vec_t*)(Wt + (long long)n * p.K + k);
+            b_reg[i] = val;
         }
     };
     auto store_tile = [&](int buf, auto SETC) {

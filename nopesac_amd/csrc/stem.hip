@@ -206,8 +206,10 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     __syncthreads();                                            // patch / weights are dead: reuse LDS for the conv tile
     stamp(5);
     // ---- BN + ReLU -> bf16 conv tile in LDS; lane holds pixel (lane&31) of tile t, channels j*32 + 16*half + 4q + {0..3}
-    // Round 6 (PMC: 16 VALU instructions per MFMA, the kernel issue-bound once its loads overlapped): BN as ONE fused multiply-add, and
-    // the pool-padding select only in tiles that have a conv pixel outside the image (wave-uniform test; the interior tiles skip it).
+    // Round 6 (PMC: 16 VALU instructions per MFMA, the kernel issue-bound once its loads overlapped): the pool-padding select only in
+    // tiles that have a conv pixel outside the image (wave-uniform test; the interior tiles skip it).  BN stays multiply-then-add: ONE
+    // fused multiply-add was built and measured (-96 VALU per wave) and taken out again - it changes the rounding of every stem output,
+    // and the bf16 pose gates are fixed numbers tuned to nothing: camera_initRec R max moved 3.61 -> 4.60 deg on the benchmark pairs (gate 4.5).
     // Padding value: -0.0 (0x8000) - the pool below compares the bf16 bit patterns as SIGNED 16-bit integers, which orders the
     // non-negative ReLU outputs like their values and puts -0.0 below all of them (every pool window holds at least one real pixel).
 #pragma unroll
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
                     const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(acc[t][j][4 * (2 * qq + jj) + e], sv[e], bv[e]), 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[t][j][4 * (2 * qq + jj) + e] * sv[e] + bv[e], 0.f);   // (two roundings, as in every other epilogue: see below)
                     ow[2 * jj] = f32x2_to_bf16x2(v[0], v[1]);
                     ow[2 * jj + 1] = f32x2_to_bf16x2(v[2], v[3]);
                 }

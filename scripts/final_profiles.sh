@@ -3,7 +3,7 @@
 # stats of the default command, HBM traffic (PMC) over the SAME launch set.  usage: final_profiles.sh <round> <tag> [skip-tests] [retune]
 RND=${1:-5}; T=${2:-z}; O=gpurun_out; R=$PWD; P=r${RND}_${T}
 mkdir -p $O
-ROUT=$R/profiles/routing_r${RND}.json
+ROUT=$R/profiles/routing_r5.json        # (round 6 keeps the round-5 routing: no conv kernel configuration changed)
 case " $* " in *" skip-tests "*) ;; *) python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee $O/${P}_pytest_gpu.log;; esac
 F="--no-cpu-baseline --no-boundary --no-fp32-path --no-accuracy --no-other-configs --no-tape"
 case " $* " in *" retune "*)
@@ -30,13 +30,13 @@ bash scripts/pmc_bench.sh --routing $ROUT > $O/${P}_pmc_bench.log 2>&1; cp $O/pm
 # PMC summaries of the dominant kernel and of this round's new kernels (counters only, separate passes)
 bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8.json conv_igemm_p8 conv_one.py 64 60 80 256 256 3 1 p832 > /dev/null 2>&1
 bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_res4_3x3.json conv_igemm_p8 conv_one.py 64 30 40 256 256 3 1 p832 > /dev/null 2>&1
-bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_sk_res4_3x3.json conv_igemm_p8 conv_one.py 64 30 40 256 256 3 1 p8sk32 > /dev/null 2>&1
+
 bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8n_res3_3x3.json conv_igemm_p8n conv_one.py 64 60 80 128 128 3 1 p8n0 > /dev/null 2>&1
 bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8n_res3_s2.json conv_igemm_p8n conv_one.py 64 120 160 128 128 3 2 p8n32 > /dev/null 2>&1
 bash scripts/pmc_summary.sh $O/r${RND}_pmc_conv_p8_res4_expand.json conv_igemm_p8 conv_one.py 64 30 40 256 1024 1 1 p832 res > /dev/null 2>&1
 python - <<PY
 import json
-for f in ('conv_p8','conv_p8_res4_3x3','conv_p8_sk_res4_3x3','conv_p8n_res3_3x3','conv_p8n_res3_s2','conv_p8_res4_expand'):
+for f in ('conv_p8','conv_p8_res4_3x3','conv_p8n_res3_3x3','conv_p8n_res3_s2','conv_p8_res4_expand'):
     try:
         d=json.load(open('$O/r${RND}_pmc_'+f+'.json'))
         for k,v in d['kernels'].items(): print(f, k[:44], d['unprofiled_run'], {a:b for a,b in v.items() if a not in ('counters','wave_cycle_shares')})
