@@ -208,12 +208,6 @@ int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mean, const fl
  * folded contribution is the reference's zero padding of the NORMALISED image; siamese_planeTR.py:534-542 + d2 BasicStem). */
 int nopesac_stem_fused_raw_shifted_bf16(const float* x_nchw, const float* pad3, const void* w_folded, const float* scale,
                                         const float* bias_folded, void* y, int B, int H, int W, void* stream);
-/* The same stem + the 1x1 64 -> 64 conv1 of res2.0 (d2 BottleneckBlock conv1 + FrozenBN + ReLU, folded to scale1 / bias1) evaluated on the
- * pooled tile before it leaves the CU (round 6): y as above, a = relu(bn1(conv1(y))) [B,PH,PW,64] bf16.  w1_frag = conv1's [64][64] bf16
- * matrix in MFMA fragment-major order.  Bit-identical to the stem entry above followed by nopesac_conv2d_nhwc on y. */
-int nopesac_stem_fused_raw_shifted_conv1_bf16(const float* x_nchw, const float* pad3, const void* w_folded, const float* scale,
-                                              const float* bias_folded, void* y, const void* w1_frag, const float* scale1,
-                                              const float* bias1, void* a, int B, int H, int W, void* stream);
 
 /* Fused tail of a bf16 ResNet bottleneck (d2 BottleneckBlock.forward: conv3 + shortcut + ReLU) plus, optionally, the NEXT
  * block's 1x1 reduce conv, in one launch (all tensors bf16 NHWC, pixel-dense; FrozenBN as f32 scale/bias):

@@ -30,7 +30,6 @@ SIGNATURES = {
     "nopesac_stem_fused_bf16": [P, P, P, P, P, I, I, I, P],
     "nopesac_stem_fused_raw_bf16": [P, P, P, P, P, P, P, I, I, I, P],
     "nopesac_stem_fused_raw_shifted_bf16": [P, P, P, P, P, P, I, I, I, P],
-    "nopesac_stem_fused_raw_shifted_conv1_bf16": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "nopesac_bottleneck_tail_bf16": [P] * 9 + [I] * 9 + [P] * 4 + [I, P, P],
     "nopesac_bottleneck_tail_bf16_ex": [P] * 9 + [I] * 9 + [P] * 4 + [I, P, I, P],
     "nopesac_conv2d_nhwc_fp8": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P],

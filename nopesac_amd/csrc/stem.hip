@@ -41,30 +41,18 @@ constexpr int ST_LDS = (ST_PATCH_BYTES + ST_W_BYTES) > ST_CONV_BYTES ? (ST_PATCH
 // f32 divisions per thread.  Positions outside the image hold `mean` = (mean[c] - 128), the value whose folded contribution is zero
 // like the reference's zero padding of the normalised image; `stdv` is not read.
 // STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into dbg[workgroup][4 waves][16] (scripts/stem_stamps.py)
-// FUSE1 (round 6): the 1x1 64 -> 64 conv1 of res2.0 (+ its BN + ReLU) on the pooled tile before it leaves the CU - a second output
-// `a` [B,PH,PW,64] next to y.  As its own launch that conv read the 157 MB stem output back from HBM (87 us, HBM-bound); here the pooled
-// tile is the A operand out of LDS, the 8 KB of weights are eight fragments per wave from L2: 24 MFMAs per workgroup.
-struct StemConv1 {
-    const bf16_t* w1;              // fragment-major [2 column tiles][4 k-steps][64 lanes][8]
-    const float* s1; const float* b1;
-    bf16_t* a;
-};
-constexpr int ST_PLD = 72;                            // pooled tile row: 64 + 8 pad elements
-template <int RAW, bool STAMP = false, bool FUSE1 = false>
+template <int RAW, bool STAMP = false>
 __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __restrict__ x, const float* __restrict__ xraw,
                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
                                                          const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y, int H, int W, int CH, int CW, int PH, int PW,
-                                                         unsigned long long* dbg = nullptr, const StemConv1 f1 = StemConv1{}) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS + 512 + (FUSE1 ? 512 : 0)];
+                                                         unsigned long long* dbg = nullptr) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ST_LDS + 512];
     // BN scale / shift parked in LDS behind the tile (round 6: as global loads inside the epilogue they were exposed L2 round trips -
     // the epilogue took 6.5 k of the workgroup's 26.9 k cycles for ~800 instructions, in-kernel stamps profiles/r6_e_*)
     float* sb_lds = reinterpret_cast<float*>(lds + ST_LDS);
     const float sb_v = (threadIdx.x & 64 ? bias : scale)[threadIdx.x & 63];      // (unguarded load, written to LDS in front of the first barrier)
-    float* sb1_lds = sb_lds + 128;                                               // FUSE1: conv1's BN scale / shift
-    float sb1_v = 0.f;
-    if constexpr (FUSE1) sb1_v = (threadIdx.x & 64 ? f1.b1 : f1.s1)[threadIdx.x & 63];
     unsigned long long ts[16];
     auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
     stamp(0);
@@ -157,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             *reinterpret_cast<us8*>(wl + (i / (ST_K / 8)) * ST_WLD + (i % (ST_K / 8)) * 8) = wr[it];
         }
     }
-    if (tid < 128) { sb_lds[tid] = sb_v; if constexpr (FUSE1) sb1_lds[tid] = sb1_v; }
+    if (tid < 128) sb_lds[tid] = sb_v;
     stamp(2);
     __syncthreads();
     stamp(3);
@@ -178,8 +166,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
         return false;
     };
     static_assert(ST_CW == 41 && ST_CH == 9 && 12 * 32 >= ST_M, "row-tile enumeration");
-    static_assert(3 * (ST_LDS + 1024) <= 160 * 1024, "three workgroups per CU");
-    static_assert(96 * ST_PLD * 2 <= ST_CONV_BYTES, "pooled tile fits the conv tile region");
+    static_assert(3 * (ST_LDS + 512) <= 160 * 1024, "three workgroups per CU");
     int a_base[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -267,18 +254,7 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
     // (consecutive pooled pixels per 8 lanes put three of a group's four pixels on overlapping banks).  A block of 8 pooled pixels per
     // wave and pass; any bijection is correct, the pairing only matters for the banks.
     static_assert(ST_PH * ST_PW % 8 == 0, "pool blocks");
-    constexpr int NBLK = ST_PH * ST_PW / 8, BPW = (NBLK + 3) / 4;          // blocks of 8 pooled pixels; at most BPW per wave
-    us8 pooled[FUSE1 ? BPW : 1];
-    bf16x8 w1f[FUSE1 ? 8 : 1];
-    if constexpr (FUSE1) {                                                 // conv1's eight weight fragments: in flight under the pool
-#pragma unroll
-        for (int f = 0; f < 8; ++f) w1f[f] = *reinterpret_cast<const bf16x8*>(f1.w1 + ((long long)f * 64 + lane) * 8);
-    }
-#pragma unroll
-    for (int bi = 0; bi < BPW; ++bi) {
-        const int blk = wave + 4 * bi;
-        if constexpr (FUSE1) pooled[bi] = us8{};
-        if (blk >= NBLK) continue;
+    for (int blk = wave; blk < ST_PH * ST_PW / 8; blk += 4) {
         const int c8 = (lane & 7) * 8;
         const int pp = blk * 8 + 4 * ((lane >> 4) & 1) + 2 * (lane >> 5) + (((lane >> 2) ^ (lane >> 3) ^ (lane >> 4)) & 1);
         const int ly = pp / ST_PW, lx = pp % ST_PW;
@@ -307,52 +283,6 @@ __global__ __launch_bounds__(256, 3) void stem_fused_kernel(const bf16_t* __rest
             o[2 * e + 1] = (unsigned short)(wv >> 16);
         }
         *reinterpret_cast<us8*>(y + (((long long)b * PH + py) * PW + px) * 64 + c8) = o;
-        if constexpr (FUSE1) pooled[bi] = o;
-    }
-    if constexpr (FUSE1) {
-        // ---- a = relu(bn1(W1 x)): the pooled tile [80 px][64] goes to LDS (the conv tile is dead once every wave has pooled), row tile
-        //      w of waves 0..2 x both 32-channel column tiles, K = 64 in four MFMA steps; same accumulation order as the per-layer kernel
-        __syncthreads();
-        bf16_t* ptile = ctile;
-#pragma unroll
-        for (int bi = 0; bi < BPW; ++bi) {
-            const int blk = wave + 4 * bi;
-            if (blk >= NBLK) continue;
-            const int pp = blk * 8 + 4 * ((lane >> 4) & 1) + 2 * (lane >> 5) + (((lane >> 2) ^ (lane >> 3) ^ (lane >> 4)) & 1);
-            *reinterpret_cast<us8*>(ptile + pp * ST_PLD + (lane & 7) * 8) = pooled[bi];
-        }
-        __syncthreads();
-        if (wave < 3) {                                                    // 96 rows = 3 row tiles (rows 80..95: stale LDS, never stored)
-            f32x16 a1[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a1[j][e] = 0.f;
-            const int l31b = lane & 31, halfb = lane >> 5;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ptile + (wave * 32 + l31b) * ST_PLD + kk * 16 + halfb * 8);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) a1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[j * 4 + kk], af, a1[j], 0, 0, 0);
-            }
-            const int pp = wave * 32 + l31b, ly = pp / ST_PW, lx = pp % ST_PW;
-            const int py = py0 + ly, px = px0 + lx;
-            if (pp < ST_PH * ST_PW && py < PH && px < PW) {
-                bf16_t* ap = f1.a + (((long long)b * PH + py) * PW + px) * 64;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = j * 32 + 8 * q + 4 * halfb;
-                        const float4 s4 = *reinterpret_cast<const float4*>(sb1_lds + n), b4 = *reinterpret_cast<const float4*>(sb1_lds + 64 + n);
-                        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(a1[j][4 * q + e] * sv[e] + bv[e], 0.f);
-                        *reinterpret_cast<uint2*>(ap + n) = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
-                    }
-            }
-        }
     }
     if constexpr (STAMP) {
         stamp(8);
@@ -393,26 +323,6 @@ extern "C" int nopesac_stem_fused_raw_bf16(const float* x_nchw, const float* mea
     dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
     hipLaunchKernelGGL(stem_fused_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, mean, stdv,
                        (const bf16_t*)w, scale, bias, (bf16_t*)y, H, W, CH, CW, PH, PW);
-    NPS_LAUNCH_RET();
-}
-
-// The raw-image stem below + res2.0's conv1 (1x1, 64 -> 64, BN + ReLU folded to scale1 / bias1) on the pooled tile: y as below and
-// a = relu(bn1(conv1(y))) [B,PH,PW,64]; w1_frag = conv1's [64][64] bf16 matrix in MFMA fragment-major order (ops.mfma_fragment_major).
-extern "C" int nopesac_stem_fused_raw_shifted_conv1_bf16(const float* x_nchw, const float* pad3, const void* w_folded, const float* scale,
-                                                         const float* bias_folded, void* y, const void* w1_frag, const float* scale1,
-                                                         const float* bias1, void* a, int B, int H, int W, void* stream) {
-    using namespace nps;
-    NPS_CHECK_ARG(x_nchw && pad3 && w_folded && scale && bias_folded && y && w1_frag && scale1 && bias1 && a && B > 0 && H >= 7 && W >= 7,
-                  "stem_fused_raw_shifted_conv1: bad args");
-    const void* ptrs[] = {w_folded, y, scale, bias_folded, w1_frag, scale1, bias1, a};
-    for (const void* q : ptrs) NPS_CHECK_ARG(((uintptr_t)q & 15) == 0, "stem_fused_raw_shifted_conv1: pointers must be 16-byte aligned");
-    const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;      // conv 7x7 / s2 / p3
-    const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;    // pool 3x3 / s2 / p1
-    dim3 grid((PW + ST_PW - 1) / ST_PW, (PH + ST_PH - 1) / ST_PH, B);
-    const StemConv1 f1{(const bf16_t*)w1_frag, scale1, bias1, (bf16_t*)a};
-    hipLaunchKernelGGL((stem_fused_kernel<2, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, x_nchw, pad3,
-                       (const float*)nullptr, (const bf16_t*)w_folded, scale, bias_folded, (bf16_t*)y, H, W, CH, CW, PH, PW,
-                       (unsigned long long*)nullptr, f1);
     NPS_LAUNCH_RET();
 }
 

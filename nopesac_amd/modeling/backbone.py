@@ -42,8 +42,6 @@ class HipResNet50(ParamModule):
         self.stem_folded_norm = os.environ.get("NOPESAC_STEM_FOLDED", "1") != "0"
         self.fused_tail = True
         self.halo_conv2 = not os.environ.get("NOPESAC_NO_HALO_CONV2")
-        # round 6: res2.0's conv1 (1x1, 64 -> 64) evaluated by the stem launch on its pooled tile (csrc/stem.hip, FUSE1); NOPESAC_NO_STEM_CONV1=1: as its own launch
-        self.stem_conv1 = not os.environ.get("NOPESAC_NO_STEM_CONV1")
         # fp8 mode (MODEL.AMD.BACKBONE_FP8): the 3x3 conv of every res3 / res4 / res5 bottleneck runs on the fp8 MFMA; its input (the block's conv1 output)
         # is written as e4m3fn by the producing kernel.  act_scale[block] = static scale of that input (x ~= x8 * scale).
         self.fp8_conv2 = bool(amd_options(cfg).BACKBONE_FP8) if cfg is not None else False
@@ -129,7 +127,6 @@ class HipResNet50(ParamModule):
 
         stages = ["stem"] + [name for name, _, _, _ in RES_STAGES]
         skip_until = None
-        stem_a = None                                 # res2.0's conv1 output when the stem launch produced it
         if resume is not None:
             skip_until, x = resume
             dt = x.dtype
@@ -141,11 +138,7 @@ class HipResNet50(ParamModule):
                     P[key] = ops.fold_stem_normalisation(self.raw("stem.conv1.weight").float().permute(0, 2, 3, 1), P["stem"].scale,
                                                          P["stem"].bias, raw[1], raw[2])
                 pad3, wsh, bsh = P[key]
-                c1 = P["res2.0.conv1"]
-                if self.stem_conv1 and stop_after != "stem" and self.fused_tail and not self.fp8_conv2 and self._calib is None and c1.w(dt).shape == (64, 1, 1, 64):
-                    x, stem_a = ops.stem_fused_raw_shifted_conv1(raw[0], pad3, wsh, P["stem"].scale, bsh, c1.wfrag(dt), c1.scale, c1.bias)
-                else:
-                    x = ops.stem_fused_raw_shifted(raw[0], pad3, wsh, P["stem"].scale, bsh)
+                x = ops.stem_fused_raw_shifted(raw[0], pad3, wsh, P["stem"].scale, bsh)
             else:
                 x = ops.stem_fused_raw(raw[0], raw[1], raw[2], P["stem_fused_w"], P["stem"].scale, P["stem"].bias)
         elif dt == torch.bfloat16 and self.fused_stem:
@@ -159,7 +152,7 @@ class HipResNet50(ParamModule):
         cin = 64
         fuse = dt == torch.bfloat16 and self.fused_tail
         blocks = [(name, i, n, cmid, cout) for name, n, cmid, cout in RES_STAGES for i in range(n)]
-        a_pre = stem_a                                # conv1 output of the current block, when the previous launch (tail / stem) produced it
+        a_pre = None                                  # conv1 output of the current block, when the previous tail produced it
         for bi, (name, i, n, cmid, cout) in enumerate(blocks):
             if skip_until is not None and stages.index(name) <= stages.index(skip_until):
                 cin = cout

@@ -383,24 +383,6 @@ def stem_fused_raw_shifted(images: torch.Tensor, pad3: torch.Tensor, w224_folded
     return y
 
 
-def stem_fused_raw_shifted_conv1(images: torch.Tensor, pad3: torch.Tensor, w224_folded: torch.Tensor, scale: torch.Tensor, bias_folded: torch.Tensor,
-                                 w1_frag: torch.Tensor, scale1: torch.Tensor, bias1: torch.Tensor):
-    """`stem_fused_raw_shifted` + the 1x1 64 -> 64 conv1 (+ BN + ReLU) of res2.0 on the pooled tile: returns (y, a), both [B,PH,PW,64] bf16.
-    w1_frag = mfma_fragment_major(conv1 weight [64, 64] bf16)."""
-    _chk(images, torch.float32); _chk(pad3, torch.float32); _chk(w224_folded, torch.bfloat16); _chk(scale, torch.float32); _chk(bias_folded, torch.float32)
-    _chk(w1_frag, torch.bfloat16); _chk(scale1, torch.float32); _chk(bias1, torch.float32)
-    B, C, H, W = images.shape
-    _require(C == 3 and pad3.numel() == 3 and w224_folded.shape == (64, 224) and w1_frag.shape == (64, 64) and scale1.numel() == 64 and bias1.numel() == 64,
-             'stem_fused_raw_shifted_conv1: shapes')
-    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
-    y = torch.empty((B, PH, PW, 64), device=images.device, dtype=torch.bfloat16)
-    a = torch.empty((B, PH, PW, 64), device=images.device, dtype=torch.bfloat16)
-    _lib.check(_L().nopesac_stem_fused_raw_shifted_conv1_bf16(_p(images), _p(pad3), _p(w224_folded), _p(scale), _p(bias_folded), _p(y), _p(w1_frag),
-                                                             _p(scale1), _p(bias1), _p(a), B, H, W, _stream()), "nopesac_stem_fused_raw_shifted_conv1_bf16")
-    return y, a
-
-
 def fold_stem_normalisation(w_o773: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, mean: torch.Tensor, std: torch.Tensor):
     """Operands of `stem_fused_raw_shifted` from the stem's f32 weights [64,7,7,3] (o, kh, kw, c), its folded-BN scale / shift and the
     per-channel pixel mean / std:  sum_k w (v - mean) / std = sum_k (w / std) (v - 128) + sum_k (w / std) (128 - mean).

@@ -723,27 +723,6 @@ def test_stem_fused_raw_equals_preprocess_plus_stem(device, H, W):
     assert a.shape == b.shape and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("H,W", [(100, 172), (480, 640), (61, 93)])
-def test_stem_fused_with_res2_conv1(device, H, W):
-    """Round 6: the stem launch also evaluates res2.0's conv1 (1x1 64 -> 64 + BN + ReLU) on its pooled tile (csrc/stem.hip, FUSE1).
-    y must be the plain stem's output bit for bit, a the per-layer conv kernel's result on y bit for bit (same operands, same K order in
-    the MFMA accumulators, the same multiply-then-add BN), ragged tiles at the right / bottom border included."""
-    from nopesac_amd import ops
-    g = torch.Generator().manual_seed(H + W)
-    img = torch.randint(0, 256, (3, 3, H, W), generator=g).float().to(device)
-    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
-    w = torch.randn(64, 7, 7, 3, generator=g) / 12
-    sc, bi = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
-    pad3, w224, bsh = [t.to(device) for t in ops.fold_stem_normalisation(w, sc, bi, mean, std)]
-    w1 = (torch.randn(64, 1, 1, 64, generator=g) / 8).bfloat16().to(device)
-    s1, b1 = (1 + 0.1 * torch.randn(64, generator=g)).to(device), (0.1 * torch.randn(64, generator=g)).to(device)
-    y0 = ops.stem_fused_raw_shifted(img, pad3, w224, sc.to(device), bsh)
-    y, a = ops.stem_fused_raw_shifted_conv1(img, pad3, w224, sc.to(device), bsh, ops.mfma_fragment_major(w1.view(64, 64)), s1, b1)
-    ref = ops.conv2d(y0, w1, s1, b1, act=ops.ACT_RELU)
-    assert torch.equal(y, y0)
-    assert a.shape == ref.shape and torch.equal(a, ref), float((a.float() - ref.float()).abs().max())
-
-
 @pytest.mark.parametrize("H,W", [(100, 172), (480, 640)])
 def test_stem_fused_raw_shifted_has_no_input_rounding(device, H, W):
     """Round 4: the raw-image stem with the normalisation folded into its weights / BN shift (the patch holds v - 128, exact in bf16
