@@ -612,7 +612,11 @@ __global__ __launch_bounds__(512, 1) void enc_tail64_kernel(const EncTailArgs p)
 // encoder tokens - more CUs busy, three MFMAs per fragment)
 template <int NR> struct E8 {
     static constexpr int BM = 32 * NR, A = BM * ET_LD, HALF = 16 * NR;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)(2 * A) + 2 * 8 * BM * sizeof(float);
+    // NR = 3: a THIRD tile region - the hidden quarters alternate between it and the attention-row region, so the barrier "every wave is
+    // done reading the previous quarter" disappears (158 KB; at NR = 4 three regions would be 203 KB)
+    static constexpr bool HDB = NR == 3;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)((HDB ? 3 : 2) * A) + 2 * 8 * BM * sizeof(float);
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((size_t)HALF * ET_FLD * 4 <= 2 * (size_t)A, "half of the f32 rows must fit one bf16 tile region");
 };
 
@@ -685,7 +689,8 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
     extern __shared__ __attribute__((aligned(16))) unsigned char et_smem[];
     bf16_t* At = reinterpret_cast<bf16_t*>(et_smem);         // attention rows [128][264]; then the hidden quarter; later bf16(y + pos)
     bf16_t* Yt = At + E8_A;                                  // bf16(y1) [128][264]; later bf16(y); last the projections' output staging
-    float* red = reinterpret_cast<float*>(Yt + E8_A);
+    bf16_t* Hb = E8<NR>::HDB ? Yt + E8_A : At;               // hidden quarters 1 and 3 (NR = 3: their own region)
+    float* red = reinterpret_cast<float*>(Yt + (E8<NR>::HDB ? 2 : 1) * E8_A);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * E8_BM;
@@ -784,7 +789,10 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
         e8_gemm<0, NR>(ring, Yt, 0, hd, lane);
         e6_issue<0>(ring, p.w2, 64, 16 * q, wave, lane);                          // linear2, K 256q .. +127
         e8_gemm<1, NR>(ring, Yt, 8, hd, lane);
-        if constexpr (q > 0) __syncthreads();                 // every wave is done reading hidden quarter q - 1
+        bf16_t* Hq = (q & 1) ? Hb : At;                       // this quarter's hidden tile
+        if constexpr (q > 0 && !E8<NR>::HDB) __syncthreads(); // every wave is done reading hidden quarter q - 1 (two regions: not needed -
+                                                              // whoever writes quarter q has passed the barrier behind quarter q - 1's
+                                                              // writes, which every wave reaches only after its reads of quarter q - 2)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int nl = wave * 32 + 8 * qq + 4 * half;
@@ -797,14 +805,14 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
                     const float v = hd[r][4 * qq + e] + b[e];
                     o[e] = f32_to_bf16(v > 0.f ? v : 0.f);
                 }
-                *reinterpret_cast<us4*>(At + (r * 32 + l31) * ET_LD + nl) = o;
+                *reinterpret_cast<us4*>(Hq + (r * 32 + l31) * ET_LD + nl) = o;
             }
         }
         __syncthreads();
         e6_issue<1>(ring, p.w2, 64, 16 * q + 8, wave, lane);
-        e8_gemm<0, NR>(ring, At, 0, y, lane);
+        e8_gemm<0, NR>(ring, Hq, 0, y, lane);
         if constexpr (q < 3) e6_issue<0>(ring, p.w1, 16, 0, 8 * (q + 1) + wave, lane);
-        e8_gemm<1, NR>(ring, At, 8, y, lane);
+        e8_gemm<1, NR>(ring, Hq, 8, y, lane);
     };
     quarter(std::integral_constant<int, 0>{});
     stamp(6);
