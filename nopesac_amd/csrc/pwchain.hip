@@ -771,6 +771,19 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
     };
     // ---- prologue: every global read goes out first (b tile, residual chunk 0, the first weight fragments)
     {
+        // (the bn scale / shift loads FIRST: loads return in issue order, so nothing parked behind them waits for the big operand loads)
+        constexpr int NSB = (C4 / 4 + 256 - 1) / 256;
+        f32x4 sbv[NSB][C2 > 0 ? 4 : 2];
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int i = tid + it * 256 < C4 / 4 ? tid + it * 256 : C4 / 4 - 1;
+            sbv[it][0] = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
+            sbv[it][1] = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+            if constexpr (C2 > 0) {
+                sbv[it][2] = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
+                sbv[it][3] = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+            }
+        }
         constexpr int CPR = C / 8, NB = BM * CPR / 256;
         us8 rb[NB];
 #pragma unroll
@@ -790,12 +803,22 @@ __global__ __launch_bounds__(256, 2) void pw_chain_rt4_kernel(const PwArgs p) {
             fetch_res(0, 0, RCH);
         }
         load_wa(0);
-        for (int i = tid; i < C4 / 4; i += 256) {
-            *reinterpret_cast<f32x4*>(S3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
-            *reinterpret_cast<f32x4*>(B3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
-            if constexpr (C2 > 0) {
-                *reinterpret_cast<f32x4*>(SSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
-                *reinterpret_cast<f32x4*>(BSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+        // bn scale / shift -> LDS.  Round 6 (in-kernel stamps + ISA): as a guarded loop (`for i = tid; i < C4 / 4`) this compiled to a branch
+        // with an s_waitcnt vmcnt(0) behind EACH of its loads - every operand and weight load issued above had to land first, then two to
+        // four more round trips followed one after the other: a third of the projection tail's workgroup time.  Now: unconditional loads
+        // (index clamped), only the LDS writes are guarded.
+        {
+#pragma unroll
+            for (int it = 0; it < NSB; ++it) {
+                const int i = tid + it * 256;
+                if (i < C4 / 4) {
+                    *reinterpret_cast<f32x4*>(S3 + 4 * i) = sbv[it][0];
+                    *reinterpret_cast<f32x4*>(B3 + 4 * i) = sbv[it][1];
+                    if constexpr (C2 > 0) {
+                        *reinterpret_cast<f32x4*>(SSC + 4 * i) = sbv[it][2];
+                        *reinterpret_cast<f32x4*>(BSC + 4 * i) = sbv[it][3];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1008,8 +1031,12 @@ struct PwRt8 {
 };
 
 // (C = 256 - the res4 form, round 5 experiment - holds 16 + 8 weight fragments per lane: one workgroup per CU, 256 registers)
-template <int C, int C4, int CN, int C2>
-__global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(const PwArgs p) {
+// STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into dbg[workgroup][8 waves][24] (scripts/rt8_stamps.py)
+template <int C, int C4, int CN, int C2, bool STAMP = false>
+__global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(const PwArgs p, unsigned long long* dbg = nullptr) {
+    unsigned long long ts[24];
+    auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
+    stamp(0);
     typedef PwRt8<C, C4, CN, C2> S;
     constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, A_LD = S::A_LD, A2_LD = S::A2_LD, Y_LD = S::Y_LD, O_LD = S::O_LD;
     constexpr int KF1 = S::KF1, KF1S = S::KF1S, KF2 = S::KF2, NR2 = S::NR2;
@@ -1065,6 +1092,19 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
     };
     // ---- prologue
     {
+        // (the bn scale / shift loads FIRST: loads return in issue order, so nothing parked behind them waits for the big operand loads)
+        constexpr int NSB = (C4 / 4 + 512 - 1) / 512;
+        f32x4 sbv[NSB][C2 > 0 ? 4 : 2];
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int i = tid + it * 512 < C4 / 4 ? tid + it * 512 : C4 / 4 - 1;
+            sbv[it][0] = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
+            sbv[it][1] = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+            if constexpr (C2 > 0) {
+                sbv[it][2] = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
+                sbv[it][3] = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+            }
+        }
         constexpr int CPR = C / 8, NB = BM * CPR / 512;
         us8 rb[NB];
 #pragma unroll
@@ -1075,26 +1115,45 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
         constexpr int CPR2 = C2 ? C2 / 8 : 1, NB2 = C2 ? BM * CPR2 / 512 : 1;
         us8 rb2[NB2];
         if constexpr (C2 > 0) {
-            // projection source: pixel m = (b, oy, ox) reads x2[b][oy * s][ox * s] (a 2 C2-byte row each)
+            // projection source: pixel m = (b, oy, ox) reads x2[b][oy * s][ox * s] (a 2 C2-byte row each).  Round 6: the thread's rows are
+            // (tid / CPR2) + RSTEP i - ONE (image, row, column) decomposition per thread, then a step of RSTEP pixels with carries (the
+            // per-load 64-bit m / per, m % per, rem / OW were three software divisions per load: ~1000 VALU instructions per thread in
+            // front of the first load of a one-workgroup-per-CU kernel)
+            static_assert(512 % CPR2 == 0, "a thread's rows are RSTEP apart");
+            constexpr int RSTEP = 512 / CPR2;
             const int per = p.OH * p.OW;
+            const int col = (tid % CPR2) * 8;
+            const long long mq = m0 + tid / CPR2;
+            int bb = (int)(mq / per), rem = (int)(mq - (long long)bb * per), oy = rem / p.OW, ox = rem - oy * p.OW;
 #pragma unroll
             for (int i = 0; i < NB2; ++i) {
-                const int ch = tid + i * 512, row = ch / CPR2, col = (ch % CPR2) * 8;
-                const long long m = m0 + row;
-                const int b = (int)(m / per), rem = (int)(m % per), oy = rem / p.OW, ox = rem % p.OW;
-                const long long pix = ((long long)b * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
+                const long long pix = ((long long)bb * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
                 rb2[i] = *reinterpret_cast<const us8*>(p.a2 + pix * C2 + col);
+                ox += RSTEP;
+                while (ox >= p.OW) { ox -= p.OW; ++oy; }
+                if (oy >= p.OH) { oy -= p.OH; ++bb; }
             }
         } else {
             fetch_res(0);
         }
         load_wa(0);
-        for (int i = tid; i < C4 / 4; i += 512) {
-            *reinterpret_cast<f32x4*>(S3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
-            *reinterpret_cast<f32x4*>(B3 + 4 * i) = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
-            if constexpr (C2 > 0) {
-                *reinterpret_cast<f32x4*>(SSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
-                *reinterpret_cast<f32x4*>(BSC + 4 * i) = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+        stamp(1);
+        // bn scale / shift -> LDS.  Round 6 (in-kernel stamps + ISA): as a guarded loop (`for i = tid; i < C4 / 4`) this compiled to a branch
+        // with an s_waitcnt vmcnt(0) behind EACH of its loads - every operand and weight load issued above had to land first, then two to
+        // four more round trips followed one after the other: a third of the projection tail's workgroup time.  Now: unconditional loads
+        // (index clamped), only the LDS writes are guarded.
+        {
+#pragma unroll
+            for (int it = 0; it < NSB; ++it) {
+                const int i = tid + it * 512;
+                if (i < C4 / 4) {
+                    *reinterpret_cast<f32x4*>(S3 + 4 * i) = sbv[it][0];
+                    *reinterpret_cast<f32x4*>(B3 + 4 * i) = sbv[it][1];
+                    if constexpr (C2 > 0) {
+                        *reinterpret_cast<f32x4*>(SSC + 4 * i) = sbv[it][2];
+                        *reinterpret_cast<f32x4*>(BSC + 4 * i) = sbv[it][3];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1112,7 +1171,9 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
             park_res();
         }
     }
+    stamp(2);
     __syncthreads();
+    stamp(3);
 
     f32x16 acc2[NR2];
 #pragma unroll
@@ -1142,6 +1203,13 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
                     accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[kk], af, accs, 0, 0, 0);
                     if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            // round 6: the NEXT chunk's expand / shortcut fragments go out here, behind this chunk's last GEMM-1 MFMA (their registers are
+            // dead from here on) - they used to be requested behind the y store, with only GEMM 2's 16 MFMAs of cover for an L2 round trip
+            if (r == 1 && c + 1 < NCH) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_wa(c + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
@@ -1174,17 +1242,16 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(4 + 4 * c);
         __syncthreads();                                     // y chunk complete
+        stamp(5 + 4 * c);
 #pragma unroll
         for (int i = 0; i < RCH; ++i) {
             const us8 v = *reinterpret_cast<const us8*>(Y + (srow + 32 * i) * Y_LD + (tid & 15) * 8);
             *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (soff + (unsigned)(i * 32 * C4 * 2))) = v;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NCH) {
-            load_wa(c + 1);
-            if (C2 == 0) fetch_res(c + 1);
-        }
+        if (C2 == 0 && c + 1 < NCH) fetch_res(c + 1);
         // ---- GEMM 2: a' += y_c W1'[:, chunk c]^T
 #pragma unroll
         for (int kk = 0; kk < KF2; ++kk)
@@ -1194,11 +1261,13 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
                 acc2[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk], af, acc2[r], 0, 0, 0);
                 if (r == NR2 - 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
             }
+        stamp(6 + 4 * c);
         __syncthreads();                                     // every wave is done with chunk c
         if (C2 == 0 && c + 1 < NCH) {
             park_res();
             __syncthreads();
         }
+        stamp(7 + 4 * c);
     }
     // ---- a' = relu(bn1(acc2)) -> LDS -> whole rows
 #pragma unroll
@@ -1239,13 +1308,315 @@ __global__ __launch_bounds__(512, (C >= 256 ? 1 : 2)) void pw_chain_rt8_kernel(c
             *reinterpret_cast<us8*>(o_b + (unsigned)(row * CN + ocol * 8) * 2u) = v;
         }
     }
+    if constexpr (STAMP) {
+        stamp(4 + 4 * NCH);
+        if (dbg && lane == 0)
+            for (int i = 0; i < 5 + 4 * NCH; ++i) dbg[((long long)blockIdx.x * 8 + wave) * 24 + i] = ts[i];
+    }
+}
+
+static unsigned long long* g_rt8_dbg = nullptr;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 6: the edge tails of res3 as FOUR-wave workgroups of 64 pixels, two per CU (pw_chain_rt4h_kernel).  In-kernel stamps of the
+// eight-wave kernel above (scripts/rt8_stamps.py, profiles/r6_g_*): 56 k cycles per 128-pixel workgroup of the projection block for
+// 16 k cycles of MFMA work; a third of it is the prologue - 96 KB of operands per workgroup, requested by all 256 single-resident
+// workgroups AT ONCE (2 TB/s over the launch; the two-per-CU identity tails stream at 4.2-5.1) - and nothing runs on the CU meanwhile.
+// (Not the L2 -> CU weight stream: a 96-pixel / 256-channel-chunk form that loads every fragment once instead of twice measured the
+// same 310 us and was dropped.)  The remedy is the identity tails': TWO workgroups per CU, so that one's loads and stores run under the
+// other's MFMAs - which takes <= 80 KB of LDS and <= 256 registers at 8 waves per CU: 64 pixels, four waves, 128-channel chunks = one
+// column tile per wave (b tile 17 KB + projection source 34 KB + y chunk 17 KB + bn vectors 8 KB = 77 KB in the projection form).
+// GEMM 2: CN = 128: column tile `wave`; CN = 256: column tiles wave and wave + 4.  Same operands, same K order in every accumulator,
+// same multiply-then-add epilogues as the kernels above: bit-identical results.
+template <int C, int C4, int CN, int C2>
+struct PwRt4h {
+    static constexpr int BM = 64, CH = 128, NCH = C4 / CH, NRT = BM / 32, NW = 4, CPT = CN / 32 / NW;
+    static constexpr int A_LD = C + 8, A2_LD = C2 + 8, Y_LD = CH + 8, O_LD = CN + 8;
+    static constexpr int KF1 = C / 16, KF1S = C2 / 16, KF2 = CH / 16;
+    static constexpr int OPER = BM * A_LD + (C2 ? BM * A2_LD : 0) + BM * Y_LD;
+    static constexpr size_t BYTES = 2 * (size_t)OPER + (C2 ? 4 : 2) * C4 * sizeof(float);
+    static_assert(C % 16 == 0 && C4 % CH == 0 && (CN == 128 || CN == 256) && C2 % 16 == 0, "rt4h tail: shapes");
+    static_assert(O_LD <= Y_LD || (C2 == 0 && BM * O_LD <= BM * A_LD + BM * Y_LD), "the a' staging tile aliases dead operand tiles");
+    static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int C, int C4, int CN, int C2>
+__global__ __launch_bounds__(256, 2) void pw_chain_rt4h_kernel(const PwArgs p) {
+    typedef PwRt4h<C, C4, CN, C2> S;
+    constexpr int BM = S::BM, CH = S::CH, NCH = S::NCH, NRT = S::NRT, NW = S::NW, CPT = S::CPT;
+    constexpr int A_LD = S::A_LD, A2_LD = S::A2_LD, Y_LD = S::Y_LD, O_LD = S::O_LD, KF1 = S::KF1, KF1S = S::KF1S, KF2 = S::KF2;
+    constexpr int RCH = BM * (CH / 8) / 256;                 // 16-byte chunks per thread of one [BM][CH] tile (4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pw_smem[];
+    bf16_t* A1 = reinterpret_cast<bf16_t*>(pw_smem);
+    bf16_t* A2 = A1 + BM * A_LD;
+    bf16_t* Y = A2 + (C2 ? BM * A2_LD : 0);
+    bf16_t* O = O_LD <= Y_LD ? Y : A1;                       // a' staging: over the y chunk, or (CN = 256, identity form) over b tile + y chunk
+    float* S3 = reinterpret_cast<float*>(A1 + S::OPER);
+    float* B3 = S3 + C4;
+    float* SSC = B3 + C4;
+    float* BSC = SSC + C4;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * BM;
+    // (the rt4 / rt8 channel order: MFMA row 8q + 4h + e carries channel 16h + 4q + e of the column tile - 16-byte epilogues)
+    const int wl = half * 32 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+
+    bf16x8 wa[KF1], wb[CPT][KF2], ws[C2 ? KF1S : 1];
+    auto load_wa = [&](int c) {                              // expand (+ shortcut) fragments of y channels c*128 + wave*32 .. +32
+        const bf16_t* w = p.w3 + ((long long)((c * (CH / 32) + wave) * KF1) * 64 + wl) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KF1; ++kk) wa[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+        if constexpr (C2 > 0) {
+            const bf16_t* v = p.wsc + ((long long)((c * (CH / 32) + wave) * KF1S) * 64 + wl) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KF1S; ++kk) ws[kk] = *reinterpret_cast<const bf16x8*>(v + kk * 512);
+        }
+    };
+    auto load_wb = [&](int c) {                              // conv1 fragments of column tiles wave + 4 t, K-slice c
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+            const bf16_t* w = p.w1 + ((long long)((wave + NW * t) * (C4 / 16) + c * KF2) * 64 + wl) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KF2; ++kk) wb[t][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 512);
+        }
+    };
+    // [BM][CH] tile <-> threads: 16 rows per pass (16 16-byte chunks per row), RCH passes
+    const int trow = tid >> 4, tcol = (tid & 15) * 8;
+    const unsigned toff = (unsigned)(trow * C4 + tcol) * 2u;
+    const char* res_b = reinterpret_cast<const char*>(C2 ? p.y : p.res) + m0 * C4 * 2;       // (never read in the projection form)
+    char* y_b = reinterpret_cast<char*>(p.y + m0 * C4);
+    us8 rres[RCH];
+    auto fetch_res = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) rres[i] = *reinterpret_cast<const us8*>(res_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2)));
+    };
+    auto park_res = [&]() {
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) *reinterpret_cast<us8*>(Y + (trow + 16 * i) * Y_LD + tcol) = rres[i];
+    };
+    // ---- prologue: bn vectors first (loads return in issue order), then the operand tiles, then the first weight fragments
+    {
+        constexpr int NSB = (C4 / 4 + 255) / 256;
+        f32x4 sbv[NSB][C2 > 0 ? 4 : 2];
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int i = tid + it * 256 < C4 / 4 ? tid + it * 256 : C4 / 4 - 1;
+            sbv[it][0] = *reinterpret_cast<const f32x4*>(p.s3 + 4 * i);
+            sbv[it][1] = *reinterpret_cast<const f32x4*>(p.b3 + 4 * i);
+            if constexpr (C2 > 0) {
+                sbv[it][2] = *reinterpret_cast<const f32x4*>(p.ssc + 4 * i);
+                sbv[it][3] = *reinterpret_cast<const f32x4*>(p.bsc + 4 * i);
+            }
+        }
+        constexpr int CPR = C / 8, NB = BM * CPR / 256;
+        static_assert(BM * CPR % 256 == 0, "b tile chunking");
+        us8 rb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
+            rb[i] = *reinterpret_cast<const us8*>(p.a1 + (m0 + row) * C + col);
+        }
+        constexpr int CPR2 = C2 ? C2 / 8 : 1, NB2 = C2 ? BM * CPR2 / 256 : 1;
+        us8 rb2[NB2];
+        if constexpr (C2 > 0) {
+            static_assert(256 % CPR2 == 0 && BM * CPR2 % 256 == 0, "projection tile chunking");
+            constexpr int RSTEP = 256 / CPR2;
+            const int per = p.OH * p.OW;
+            const int col = (tid % CPR2) * 8;
+            const long long mq = m0 + tid / CPR2;
+            int bb = (int)(mq / per), rem = (int)(mq - (long long)bb * per), oy = rem / p.OW, ox = rem - oy * p.OW;
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const long long pix = ((long long)bb * p.a2_H + oy * p.a2_stride) * p.a2_W + ox * p.a2_stride;
+                rb2[i] = *reinterpret_cast<const us8*>(p.a2 + pix * C2 + col);
+                ox += RSTEP;
+                while (ox >= p.OW) { ox -= p.OW; ++oy; }
+                if (oy >= p.OH) { oy -= p.OH; ++bb; }
+            }
+        } else {
+            fetch_res(0);
+        }
+        load_wa(0);
+#pragma unroll
+        for (int it = 0; it < NSB; ++it) {
+            const int i = tid + it * 256;
+            if (i < C4 / 4) {
+                *reinterpret_cast<f32x4*>(S3 + 4 * i) = sbv[it][0];
+                *reinterpret_cast<f32x4*>(B3 + 4 * i) = sbv[it][1];
+                if constexpr (C2 > 0) {
+                    *reinterpret_cast<f32x4*>(SSC + 4 * i) = sbv[it][2];
+                    *reinterpret_cast<f32x4*>(BSC + 4 * i) = sbv[it][3];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int ch = tid + i * 256, row = ch / CPR, col = (ch % CPR) * 8;
+            *reinterpret_cast<us8*>(A1 + row * A_LD + col) = rb[i];
+        }
+        if constexpr (C2 > 0) {
+#pragma unroll
+            for (int i = 0; i < NB2; ++i) {
+                const int ch = tid + i * 256, row = ch / CPR2, col = (ch % CPR2) * 8;
+                *reinterpret_cast<us8*>(A2 + row * A2_LD + col) = rb2[i];
+            }
+        } else {
+            park_res();
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc2[CPT][NRT];
+#pragma unroll
+    for (int t = 0; t < CPT; ++t)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[t][r][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // ---- GEMM 1: this wave's 32 channels of y chunk c, one 32-pixel row tile at a time (the fragments stay in registers for both)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            f32x16 acc, accs;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KF1; ++kk) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(A1 + (r * 32 + l31) * A_LD + kk * 16 + half * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk], af, acc, 0, 0, 0);
+                if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (C2 > 0) {
+#pragma unroll
+                for (int kk = 0; kk < KF1S; ++kk) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(A2 + (r * 32 + l31) * A2_LD + kk * 16 + half * 8);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws[kk], af, accs, 0, 0, 0);
+                    if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (r == NRT - 1) {                              // the fragments are dead: GEMM 2's and the next chunk's go out behind the last MFMA
+                __builtin_amdgcn_sched_barrier(0);
+                load_wb(c);
+                if (c + 1 < NCH) load_wa(c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int nl = wave * 32 + 16 * half + 8 * qq, n = c * CH + nl;
+                bf16_t* yp = Y + (r * 32 + l31) * Y_LD + nl;
+                us8 r8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (C2 == 0) r8 = *reinterpret_cast<const us8*>(yp);
+                us8 o8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(S3 + n + 4 * j), b3 = *reinterpret_cast<const f32x4*>(B3 + n + 4 * j);
+                    f32x4 ss = {0.f, 0.f, 0.f, 0.f}, bs = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (C2 > 0) { ss = *reinterpret_cast<const f32x4*>(SSC + n + 4 * j); bs = *reinterpret_cast<const f32x4*>(BSC + n + 4 * j); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[4 * (2 * qq + j) + e] * s3[e];
+                        v += b3[e];
+                        if constexpr (C2 > 0) {
+                            float sc = accs[4 * (2 * qq + j) + e] * ss[e];
+                            sc += bs[e];
+                            v += sc;
+                        } else {
+                            v += bf16_to_f32(r8[4 * j + e]);
+                        }
+                        o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                    if (C2 > 0) __builtin_amdgcn_sched_barrier(0);
+                }
+                *reinterpret_cast<us8*>(yp) = o8;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                     // y chunk complete
+#pragma unroll
+        for (int i = 0; i < RCH; ++i) {                      // y chunk -> HBM as 256-byte row segments
+            const us8 v = *reinterpret_cast<const us8*>(Y + (trow + 16 * i) * Y_LD + tcol);
+            *reinterpret_cast<us8*>(y_b + c * (CH * 2) + (toff + (unsigned)(i * 16 * C4 * 2))) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (C2 == 0 && c + 1 < NCH) fetch_res(c + 1);
+        // ---- GEMM 2: a' += y_c W1'[:, chunk c]^T
+#pragma unroll
+        for (int kk = 0; kk < KF2; ++kk)
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(Y + (r * 32 + l31) * Y_LD + kk * 16 + half * 8);
+#pragma unroll
+                for (int t = 0; t < CPT; ++t) acc2[t][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[t][kk], af, acc2[t][r], 0, 0, 0);
+                if (r == NRT - 1 && (kk & 1)) __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();                                     // every wave is done with chunk c
+        if (C2 == 0 && c + 1 < NCH) {
+            park_res();
+            __syncthreads();
+        }
+    }
+    // ---- a' = relu(bn1(acc2)) -> LDS -> whole rows
+#pragma unroll
+    for (int t = 0; t < CPT; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int n = (wave + NW * t) * 32 + 16 * half + 8 * qq;
+            f32x4 s1[2], b1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s1[j] = *reinterpret_cast<const f32x4*>(p.s1 + n + 4 * j); b1[j] = *reinterpret_cast<const f32x4*>(p.b1 + n + 4 * j); }
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                us8 o8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc2[t][r][4 * (2 * qq + j) + e] * s1[j][e];
+                        v += b1[j][e];
+                        o8[4 * j + e] = f32_to_bf16(v > 0.f ? v : 0.f);
+                    }
+                *reinterpret_cast<us8*>(O + (r * 32 + l31) * O_LD + n) = o8;
+            }
+        }
+    __syncthreads();
+    constexpr int CPRO = CN / 8, RPI = 256 / CPRO;
+    static_assert(BM * CPRO % 256 == 0, "a' tile chunking");
+    const int orow = tid / CPRO, ocol = tid % CPRO;
+    unsigned char* o_b = reinterpret_cast<unsigned char*>(p.o) + m0 * CN * (p.o_fp8 ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < BM * CPRO / 256; ++i) {
+        const int row = orow + i * RPI;
+        const us8 v = *reinterpret_cast<const us8*>(O + row * O_LD + ocol * 8);
+        if (p.o_fp8) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+            *reinterpret_cast<uint2*>(o_b + (unsigned)(row * CN + ocol * 8)) = f32x8_to_fp8(f);
+        } else {
+            *reinterpret_cast<us8*>(o_b + (unsigned)(row * CN + ocol * 8) * 2u) = v;
+        }
+    }
+}
+
+template <int C, int C4, int CN, int C2>
+static int pw_launch_rt4h(const PwArgs& a, hipStream_t stream) {
+    constexpr size_t lds = PwRt4h<C, C4, CN, C2>::BYTES;
+    NPS_ENSURE_LDS((int)lds, pw_chain_rt4h_kernel<C, C4, CN, C2>);
+    hipLaunchKernelGGL((pw_chain_rt4h_kernel<C, C4, CN, C2>), dim3((unsigned)(a.M / 64)), dim3(256), lds, stream, a);
+    return 0;
 }
 
 template <int C, int C4, int CN, int C2>
 static int pw_launch_rt8(const PwArgs& a, hipStream_t stream) {
     constexpr size_t lds = PwRt8<C, C4, CN, C2>::BYTES;
+    if (g_rt8_dbg && C == 128) {                              // tuning runs only
+        NPS_ENSURE_LDS((int)lds, pw_chain_rt8_kernel<C, C4, CN, C2, true>);
+        hipLaunchKernelGGL((pw_chain_rt8_kernel<C, C4, CN, C2, true>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, stream, a, g_rt8_dbg);
+        return 0;
+    }
     NPS_ENSURE_LDS((int)lds, pw_chain_rt8_kernel<C, C4, CN, C2>);
-    hipLaunchKernelGGL((pw_chain_rt8_kernel<C, C4, CN, C2>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((pw_chain_rt8_kernel<C, C4, CN, C2>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, stream, a, (unsigned long long*)nullptr);
     return 0;
 }
 
@@ -1259,6 +1630,8 @@ static int pw_launch(const PwArgs& a, hipStream_t stream) {
 }
 
 }  // namespace nps
+
+extern "C" void nps_rt8_debug_buffer(void* buf) { nps::g_rt8_dbg = (unsigned long long*)buf; }
 
 extern "C" int nopesac_bottleneck_tail_bf16(const void* b, const void* w3, const float* scale3, const float* bias3, const void* residual,
                                             const void* x2, const void* wsc, const float* scale_sc, const float* bias_sc, int B, int OH,
@@ -1301,6 +1674,11 @@ extern "C" int nopesac_bottleneck_tail_bf16_ex(const void* b, const void* w3, co
     }
     // res3's edge blocks (CN = 256 into res4; the stride-2 projection of res3.0): the eight-wave form
     static const bool no_rt8 = getenv("NOPESAC_TAIL_NO_RT8") != nullptr;
+    // round 6: four-wave workgroups of 64 pixels, two per CU (NOPESAC_TAIL_NO_RT4H=1: the eight-wave 128-pixel form below)
+    if (!no_rt4 && !no_rt8 && a.M % 64 == 0 && C == 128 && C4 == 512 && !getenv("NOPESAC_TAIL_NO_RT4H")) {
+        if (!x2 && CN == 256) { pw_launch_rt4h<128, 512, 256, 0>(a, st); NPS_LAUNCH_RET(); }
+        if (x2 && CN == 128 && c2 == 256) { pw_launch_rt4h<128, 512, 128, 256>(a, st); NPS_LAUNCH_RET(); }
+    }
     if (!no_rt4 && !no_rt8 && a.M % 128 == 0 && C == 128 && C4 == 512) {
         if (!x2 && CN == 256) { pw_launch_rt8<128, 512, 256, 0>(a, st); NPS_LAUNCH_RET(); }
         if (x2 && CN == 128 && c2 == 256) { pw_launch_rt8<128, 512, 128, 256>(a, st); NPS_LAUNCH_RET(); }
