@@ -29,6 +29,10 @@ constexpr size_t MH_LDS_BYTES = (size_t)(2 * MH_BM * MH_LD);      // ONE 128 x 2
 constexpr int MH_RING = 8;                                          // weight fragments in flight per wave (rolling ring)
 static_assert((size_t)MH_BM * MH_NQP_MAX * 4 <= 2 * (size_t)MH_BM * MH_LD, "output staging must fit the A tile");
 
+// sigmoid on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each): 5 instructions instead of the ~25 of expf + an IEEE
+// division - the bias + sigmoid + staging phase was 5.3 k of the workgroup's 40 k cycles (in-kernel stamps, profiles/r6_h_*)
+__device__ __forceinline__ float mh_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
 struct MaskHeadArgs {
     const bf16_t* c1; const bf16_t* t1;          // [B][H][W][256], [B][H/2][W/2][256]
     const bf16_t* wc; const float* sc; const float* bc;   // lateral conv (fragment-major) + folded BN
@@ -43,11 +47,18 @@ struct MaskHeadArgs {
 // place: c1 rows (A of the lateral GEMM) -> p1 (A of the mask GEMM) -> f32 probabilities.
 // NQP: planes padded to 64 (2 column tiles x 4 row tiles = one (tile, rows) pair per wave) or 128 (two pairs per wave: column tiles
 // wave & 1 and (wave & 1) + 2 of the same 32 rows).
-template <int NQP>
-__global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p) {
+// STAMP: tuning build - cycle stamps of every (workgroup, wave) at the phase boundaries into dbg[workgroup][8 waves][16] (scripts/mask_head_stamps.py)
+template <int NQP, bool STAMP = false>
+__global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p, unsigned long long* dbg = nullptr) {
     constexpr int NPASS = NQP / 64, NTILES = NQP / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char mh_smem[];
     bf16_t* At = reinterpret_cast<bf16_t*>(mh_smem);
+    // round 6: the lateral conv's BN scale / shift (256 + 256 floats) and the image's mask biases (NQP floats) parked behind the tile:
+    // as global loads inside the two epilogues they were exposed L2 round trips behind every older load of the wave
+    float* SB = reinterpret_cast<float*>(mh_smem + MH_LDS_BYTES);
+    unsigned long long ts[16];
+    auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
+    stamp(0);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = p.H * p.W;
@@ -65,6 +76,8 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
     bf16x8 ring[MH_RING];
     const bf16_t* wlp = p.wc + ((long long)wave * 16 * 64 + lane) * 8;                              // lateral column tile `wave`
     const bf16_t* wmp = p.mw + (((long long)b * NTILES + (wave & 1)) * 16) * 512 + lane * 8;       // mask column tile wave & 1 of image b
+    // (unconditional, first in issue order: thread t < 256 the lateral vectors' entry t, every thread a mask bias of its image)
+    const float sb_s = p.sc[tid & 255], sb_b = p.bc[tid & 255], sb_m = p.mb[(long long)b * NQP + (tid & (NQP - 1))];
 #pragma unroll
     for (int s = 0; s < MH_RING; ++s) ring[s] = *reinterpret_cast<const bf16x8*>(wlp + s * 512);
     // c1 rows -> LDS
@@ -75,7 +88,11 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
         *reinterpret_cast<us8*>(At + r * MH_LD + col) = *reinterpret_cast<const us8*>(p.c1 + (m0 + r) * MH_C + col);
 #endif
     }
+    if (tid < 256) { SB[tid] = sb_s; SB[256 + tid] = sb_b; }
+    if (tid < NQP) SB[512 + tid] = sb_m;
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     // ---- lateral = relu(bn(W_c1 c1)): wave owns channels wave*32 .. +32 of all four 32-pixel row tiles
     {
@@ -97,11 +114,13 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             else ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + (kk + MH_RING - 16) * 512);     // mask GEMM k-steps 0..7
             if ((kk & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(3);
         __syncthreads();                                      // every wave is done reading the c1 rows
+        stamp(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = wave * 32 + 8 * q + 4 * half;
-            const f32x4 s = *reinterpret_cast<const f32x4*>(p.sc + n), bb = *reinterpret_cast<const f32x4*>(p.bc + n);
+            const f32x4 s = *reinterpret_cast<const f32x4*>(SB + n), bb = *reinterpret_cast<const f32x4*>(SB + 256 + n);
 #pragma unroll
             for (int r = 0; r < MH_RT; ++r) {
                 us4 o;
@@ -115,7 +134,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             }
         }
     }
+    stamp(5);
     __syncthreads();
+    stamp(6);
 
     // ---- p1 = lateral + relu(bilinear_2x(t1)); F.interpolate align_corners=False.
     // Round 5: thread = (FOUR consecutive output pixels, 8-channel chunk).  Under exact 2x up-sampling the pixels 4j .. 4j+3 of an output
@@ -194,7 +215,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             }
         }
     }
+    stamp(7);
     __syncthreads();
+    stamp(8);
 
     // ---- mask logits: NQP (padded) planes = NQP/32 column tiles x 4 row tiles = 8 * NPASS (tile, rows) pairs, NPASS per wave
     {
@@ -214,7 +237,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
                 else if (ps + 1 < NPASS) ring[kk % MH_RING] = *reinterpret_cast<const bf16x8*>(wmp + ((long long)(ps + 1) * 32 + kk + MH_RING - 16) * 512);
             }
         }
+        stamp(9);
         __syncthreads();                                      // p1 is dead: the tile becomes the [128][nq] f32 staging buffer
+        stamp(10);
         float* St = reinterpret_cast<float*>(At);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -222,13 +247,13 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = nt * 32 + 8 * q + 4 * half;
-                const f32x4 mbv = *reinterpret_cast<const f32x4*>(p.mb + (long long)b * NQP + n);
+                const f32x4 mbv = *reinterpret_cast<const f32x4*>(SB + 512 + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (n + e < p.nq) {
                         float v = acc[ps][4 * q + e] + mbv[e];
 #if MH_ABLATE != 5
-                        if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+                        if (p.apply_sigmoid) v = mh_sigmoid(v);
 #endif
                         if (p.planar) St[(n + e) * MH_BM + r * 32 + l31] = v;
                         else St[(r * 32 + l31) * p.nq + n + e] = v;
@@ -237,7 +262,9 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
             }
         }
     }
+    stamp(11);
     __syncthreads();
+    stamp(12);
     {
         const float* St = reinterpret_cast<const float*>(At);
         float* og = p.prob + m0 * p.nq;                       // 128 * nq floats, contiguous; 16-byte aligned when nq % 2 == 0 (m0 % 128 == 0)
@@ -254,7 +281,16 @@ __global__ __launch_bounds__(512, 4) void mask_head_kernel(const MaskHeadArgs p)
 #endif
         }
     }
+    if constexpr (STAMP) {
+        stamp(13);
+        if (dbg && lane == 0)
+            for (int i = 0; i < 14; ++i) dbg[((long long)blockIdx.x * 8 + wave) * 16 + i] = ts[i];
+    }
 }
+
+static unsigned long long* g_mh_dbg = nullptr;
+constexpr size_t MH_LDS_TOTAL = MH_LDS_BYTES + (512 + MH_NQP_MAX) * sizeof(float);
+static_assert(2 * MH_LDS_TOTAL <= 160 * 1024, "two workgroups per CU");
 
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -489,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void mask_head_pipe_kernel(const MaskHeadAr
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < p.nq) {
                             float v = acc[ps][4 * q + e] + mb4[e];
-                            if (p.apply_sigmoid) v = 1.f / (1.f + expf(-v));
+                            if (p.apply_sigmoid) v = mh_sigmoid(v);
                             St[(r * 32 + l31) * p.nq + n + e] = v;
                         }
                     }
@@ -554,6 +590,8 @@ extern "C" int nopesac_mask_operands(const float* fold, int ld, void* mw, float*
     NPS_LAUNCH_RET();
 }
 
+extern "C" void nps_mask_head_debug_buffer(void* buf) { nps::g_mh_dbg = (unsigned long long*)buf; }
+
 extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void* w_lateral, const float* scale, const float* bias,
                                       const void* mask_w, const float* mask_b, float* prob, void* p1_out, int B, int H, int W, int nq,
                                       int apply_sigmoid, void* stream) {
@@ -591,11 +629,16 @@ extern "C" int nopesac_mask_head_bf16(const void* c1, const void* t1, const void
         NPS_LAUNCH_RET();
     }
     if (nq <= 64) {
-        NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<64>);
-        hipLaunchKernelGGL(mask_head_kernel<64>, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+        if (g_mh_dbg) {                                       // tuning runs only (scripts/mask_head_stamps.py)
+            NPS_ENSURE_LDS((int)MH_LDS_TOTAL, mask_head_kernel<64, true>);
+            hipLaunchKernelGGL((mask_head_kernel<64, true>), dim3((unsigned)blocks), dim3(512), MH_LDS_TOTAL, (hipStream_t)stream, a, g_mh_dbg);
+            NPS_LAUNCH_RET();
+        }
+        NPS_ENSURE_LDS((int)MH_LDS_TOTAL, mask_head_kernel<64>);
+        hipLaunchKernelGGL((mask_head_kernel<64>), dim3((unsigned)blocks), dim3(512), MH_LDS_TOTAL, (hipStream_t)stream, a, (unsigned long long*)nullptr);
     } else {
-        NPS_ENSURE_LDS((int)MH_LDS_BYTES, mask_head_kernel<128>);
-        hipLaunchKernelGGL(mask_head_kernel<128>, dim3((unsigned)blocks), dim3(512), MH_LDS_BYTES, (hipStream_t)stream, a);
+        NPS_ENSURE_LDS((int)MH_LDS_TOTAL, mask_head_kernel<128>);
+        hipLaunchKernelGGL((mask_head_kernel<128>), dim3((unsigned)blocks), dim3(512), MH_LDS_TOTAL, (hipStream_t)stream, a, (unsigned long long*)nullptr);
     }
     NPS_LAUNCH_RET();
 }
