@@ -615,7 +615,10 @@ template <int NR> struct E8 {
     // NR = 3: a THIRD tile region - the hidden quarters alternate between it and the attention-row region, so the barrier "every wave is
     // done reading the previous quarter" disappears (158 KB; at NR = 4 three regions would be 203 KB)
     static constexpr bool HDB = NR == 3;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)((HDB ? 3 : 2) * A) + 2 * 8 * BM * sizeof(float);
+    // + b1 (1024 floats) and b_o (256) parked behind the reduction scratch: as global loads inside the epilogues each was an exposed L2
+    // round trip (and, vmcnt retiring in order, a wait for every weight fragment requested before it)
+    static constexpr int VEC_FLOATS = 1024 + 256;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)((HDB ? 3 : 2) * A) + 2 * 8 * BM * sizeof(float) + VEC_FLOATS * sizeof(float);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((size_t)HALF * ET_FLD * 4 <= 2 * (size_t)A, "half of the f32 rows must fit one bf16 tile region");
 };
@@ -642,6 +645,16 @@ __device__ __forceinline__ void e8_layernorm(f32x16 (&acc)[NR], const float* __r
     const int l31 = lane & 31, half = lane >> 5;
     constexpr int BM = 32 * NR;
     float mean[NR], rstd[NR];
+    // gamma / beta requested in FRONT of the two reduction passes (they arrive under them; behind the passes each LayerNorm ended with
+    // an exposed L2 round trip)
+    f32x4 gq[4], bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = wave * 32 + 8 * q + 4 * half;
+        gq[q] = *reinterpret_cast<const f32x4*>(gamma + n);
+        bq[q] = *reinterpret_cast<const f32x4*>(beta + n);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float* rp = red + pass * 8 * BM;
@@ -673,8 +686,7 @@ __device__ __forceinline__ void e8_layernorm(f32x16 (&acc)[NR], const float* __r
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int n = wave * 32 + 8 * q + 4 * half;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n), b = *reinterpret_cast<const f32x4*>(beta + n);
+        const f32x4 g = gq[q], b = bq[q];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -698,7 +710,10 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
     unsigned long long ts[16];
     auto stamp = [&](int i) { if constexpr (STAMP) ts[i] = __builtin_readcyclecounter(); };
     stamp(0);
-
+    // b1 / b_o -> LDS: the first loads of the kernel (unconditional: threads behind the 320th re-read the last piece), written with the attention rows
+    float* VEC = red + 2 * 8 * E8_BM;
+    const int vi = tid < 320 ? tid : 319;
+    const f32x4 vec_in = *reinterpret_cast<const f32x4*>(vi < 256 ? p.b1 + 4 * vi : p.bo + 4 * (vi - 256));
     e6_issue<0>(ring, p.wo, 16, 0, wave, lane);                                   // out-proj tile `wave`, K 0..127
     // ---- the attention rows first (GEMM 1 waits for them), the residual rows behind them (they land under GEMM 1)
     // (rows behind M: the LAST row's data instead of a guarded load - a branch around a load is something the compiler's s_waitcnt
@@ -724,6 +739,7 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
         const int c = tid + i * 512, r = c >> 5, col = (c & 31) * 8;
         *reinterpret_cast<us8*>(At + r * ET_LD + col) = av[i];
     }
+    if (tid < 320) *reinterpret_cast<f32x4*>(VEC + 4 * tid) = vec_in;
     stamp(1);
     __syncthreads();
     stamp(2);
@@ -737,19 +753,23 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
     e8_gemm<1, NR>(ring, At, 8, y, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + wave * 32 + 8 * q + 4 * half);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(VEC + 1024 + wave * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[r][4 * q + e] = (y[r][4 * q + e] + b[e]) + sv[r][q][e];
     }
     stamp(3);
+    f32x4 b2v[4];                                             // requested in front of LayerNorm 1, consumed behind it
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b2v[q] = *reinterpret_cast<const f32x4*>(p.b2 + wave * 32 + 8 * q + 4 * half);
+    __builtin_amdgcn_sched_barrier(0);
     e8_layernorm<NR>(y, p.g1, p.be1, red, wave, lane);
     stamp(4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = wave * 32 + 8 * q + 4 * half;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
+        const f32x4 b = b2v[q];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             us4 o;
@@ -796,7 +816,7 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int nl = wave * 32 + 8 * qq + 4 * half;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + 256 * q + nl);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(VEC + 256 * q + nl);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 us4 o;
@@ -893,6 +913,18 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
         f32x16 acc[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) et_zero(acc[r]);
+        // this round's bias in front of the GEMM: the load is unconditional (a wave without a tile / a projection without a bias reads b2
+        // and selects zero) and old by the time the epilogue wants it - behind the GEMM it was an exposed L2 round trip per round
+        const float* bias_v = nt >= 0 ? (is_a ? p.bpa : p.bpb) : nullptr;
+        const bool has_bias = bias_v != nullptr;              // (wave-uniform)
+        const float* bias_p = has_bias ? bias_v + ct * 32 : p.b2;
+        f32x4 pbv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bias_p + 8 * q + 4 * half2);
+            pbv[q] = has_bias ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (nt >= 0) {
             e8_gemm<0, NR>(ring, is_a ? At : Yt, 0, acc, lane2);
             if (nn >= 0) e6_issue<0>(ring, tile_w(nn), 16, 0, nn < ta ? nn : nn - ta, lane2);   // the next tile's fragments replace this one's
@@ -902,14 +934,12 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
             e6_issue<0>(ring, tile_w(nn), 16, 0, nn < ta ? nn : nn - ta, lane2);
             e6_issue<1>(ring, tile_w(nn), 16, 8, nn < ta ? nn : nn - ta, lane2);
         }
-        const float* bias = nt >= 0 ? (is_a ? p.bpa : p.bpb) : nullptr;
         if (!staged) {
             if (nt >= 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = 8 * q + 4 * half2;
-                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                    if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+                    const f32x4 b = pbv[q];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const long long row = m0 + r * 32 + l31b;
@@ -931,8 +961,7 @@ __global__ __launch_bounds__(512, 1) void enc_tail128_kernel(const EncTailArgs p
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = 8 * q + 4 * half2;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (bias) b = *reinterpret_cast<const f32x4*>(bias + ct * 32 + n);
+                const f32x4 b = pbv[q];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     us4 o;
