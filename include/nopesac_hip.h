@@ -130,6 +130,15 @@ int nopesac_conv2d_nhwc_p8_sk(const void* x, const void* w, const float* scale, 
 int nopesac_conv2d_nhwc_p8n(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
                             int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
                             int variant, void* stream);
+/* The same kernel with SPLIT-K work units (round 6) for layers with few tiles and a long K loop - the pose net's first conv (3x3, 2048 -> 128
+ * at 15 x 20: 75 tiles x 288 K-tiles; reference camera_head.py:97-112 convs_trans / convs_rots are fed by it through the correlation, the
+ * layer itself is the pixel decoder's `layer_3` output conv, camera_modules.py:271-321).  A unit = (tile, slice of the 64-channel groups);
+ * partial tiles leave as f32 into workspace[splits][M][Cout] (M = B * OH * OW; >= splits * M * Cout * 4 bytes, 16-byte aligned, < 2 GB) and a
+ * second launch on the same stream sums the slices in fixed order (deterministic) and applies the epilogue.  variant must carry + 32
+ * (channel-major K order); 2 <= splits <= min(Cin / 64, 16).  Everything else as nopesac_conv2d_nhwc_p8n. */
+int nopesac_conv2d_nhwc_p8n_splitk(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
+                                   int variant, int splits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- a stack of Linear(+bias)(+activation) layers in ONE launch (csrc/mlp_chain.hip) --------------------------------------------
  * Replaces one nopesac_conv2d_nhwc launch per layer for the row-wise MLP stacks of the heads in bf16 mode (reference:

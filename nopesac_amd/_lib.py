@@ -26,6 +26,7 @@ SIGNATURES = {
     "nopesac_conv2d_nhwc_p8_sk": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, I, I, I, P, L, P],
     "nopesac_conv2d_p8_sk_workspace_bytes": [],
     "nopesac_conv2d_nhwc_p8n": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, I, I, P],
+    "nopesac_conv2d_nhwc_p8n_splitk": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, I, I, I, P, L, P],
     "nopesac_conv2d_nhwc_ex": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, L, L, I, I, I, I, P],
     "nopesac_stem_fused_bf16": [P, P, P, P, P, I, I, I, P],
     "nopesac_stem_fused_raw_bf16": [P, P, P, P, P, P, P, I, I, I, P],

@@ -27,6 +27,7 @@ struct ConvParams {
     unsigned long long* dbg;   // tuning builds only: per-workgroup cycle stamps (nullptr in product launches)
     void* sk_ws;               // conv_igemm_p8_kernel<.., SK>: stream-K workspace (arrival counters + partial-tile slabs)
     int sk_ws_bytes;
+    int ksplit;                // conv_igemm_p8n_kernel<.., SPLIT>: K slices per output tile (f32 partial tiles in sk_ws, summed by p8n_split_reduce_kernel)
 };
 
 template <typename T> struct Cfg;

@@ -20,6 +20,11 @@
 //     epilogue, which stages through slot 2 (bf16, arithmetic in the accumulator layout, 16-byte stores through a bounds-checked buffer
 //     descriptor, LDS-only barriers: stores are never waited for; the DMAs are the oldest operations in flight and are retired by one
 //     counted wait in the last pass).
+// SPLIT (round 6): split-K for the layers with FEW tiles and a LONG K loop (the pose net's first conv: 3x3, 2048 -> 128 at 15 x 20 x 64 images =
+// 75 tiles x 288 K-tiles - 75 busy CUs for 230 us, or 221 us on 300 workgroups of the round-1 LDS-DMA kernel at 0.16 of the MFMA peak).  A
+// work unit = (tile, slice s of the 64-channel groups): the K walk is channel-major, so a slice is a contiguous run of groups with all their
+// taps; the unit's accumulators leave as raw f32 into workspace[s][M][N] (16-byte stores straight from the accumulator layout: a row's 32
+// channels of one wave = one 128-byte line), and p8n_split_reduce_kernel sums the slices in fixed order and applies the epilogue.
 // Epilogue forms: no residual, bf16 output, ReLU / none / LeakyReLU (every Cout = 128 layer on the path is one of these); anything else is
 // rejected by the entry point and stays on the other conv kernels.
 #include "conv_common.h"
@@ -60,7 +65,7 @@ struct N8EpiRegs {
 };
 
 // ACT: NPS_ACT_RELU / NONE / LEAKY fixed at compile time
-template <int ACT>
+template <int ACT, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[N8_LDS];
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
     const int wr = wave >> 2, wc = wave & 3;                 // pixel half / 32-channel quarter of the workgroup tile; stagger group = wr
 
     // ---- tiles of this workgroup: XCD x (= blockIdx % 8) owns a contiguous run, its workgroups walk it with stride = workgroups on that XCD
-    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ntiles = p.tiles_m * p.tiles_n * (SPLIT ? p.ksplit : 1);       // SPLIT: work units (tile, K slice), slice fastest
     const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
     const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int tq = ntiles / nx, tr = ntiles % nx;
@@ -93,7 +98,6 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
     int m0 = 0, n0 = 0;
     int cur_tap = 0, cur_kw = 0, cur_c0 = 0;                 // wave-uniform K-tile cursor of the NEXT K-tile to stage
     unsigned cur_tapoff = 0u, cur_k0b = 0u;
-    const int ntaps = p.KH * p.KW;
     const float rcp_rpb = 1.0f / (float)p.rows_per_b, rcp_ow = 1.0f / (float)p.OW;
     auto divmod = [](int a, int d, float rcp, int& q, int& r) {
         q = (int)((float)a * rcp);
@@ -116,7 +120,19 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
         const int br = (wave * 2 + j) * 8 + rsub;
         b_base[j] = (__umul24((unsigned)br, (unsigned)p.K) + (unsigned)(slot8 ^ ((br >> 1) & 7)) * 8u) * 2u;
     }
+    const int ntaps = p.KH * p.KW;
+    int nk = p.K / N8_BK;                                     // K-tiles of the current work unit (SPLIT: of its slice)
+    int ks = 0;                                               // SPLIT: the unit's slice
     auto set_tile = [&](int t) {                                       // workgroup-collective (contains a barrier)
+        int c_begin = 0;
+        if constexpr (SPLIT) {
+            const int tt = t / p.ksplit, ngroups = p.Cin / N8_BK;
+            ks = t - tt * p.ksplit;
+            c_begin = (ks * ngroups) / p.ksplit;              // 64-channel groups [c_begin, c_end) with all their taps (channel-major K order)
+            nk = (((ks + 1) * ngroups) / p.ksplit - c_begin) * ntaps;
+            c_begin *= N8_BK;
+            t = tt;
+        }
         m0 = (t / p.tiles_n) * N8_BM;
         n0 = (t % p.tiles_n) * N8_BN;
         if (tid < N8_BM) {
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
             }
 #pragma unroll
         for (int j = 0; j < 2; ++j) b_voff[j] = b_base[j] + nb;          // Cout % 128 == 0: every weight row of the tile exists
-        cur_tap = 0; cur_kw = 0; cur_c0 = 0; cur_tapoff = 0u; cur_k0b = 0u;
+        cur_tap = 0; cur_kw = 0; cur_c0 = c_begin; cur_tapoff = 0u; cur_k0b = (unsigned)c_begin * 2u;
     };
     // K order: p.force == 0 tap-major, 1 channel-major (the KH*KW taps of a 64-channel slice back to back: the slice stays in L2)
     auto advance = [&]() {
@@ -186,7 +202,6 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)(buf + N8_A_BYTES + ((wave * 2 + j) * 8) * N8_ROWB), 16, b_voff[j], cur_k0b, 0, 0);
     };
-    const int nk = p.K / N8_BK;
     auto stage_first = [&]() {                               // G0 H0 [G1 H1] -> slots 0 [, 1]; leaves the cursor at K-tile min(2, nk)
         stage_a(lds, 0); stage_b(lds); stage_a(lds, 1);
         advance();
@@ -288,9 +303,31 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
         N8_LDS_SYNC();                                           // every fragment read of the tile is done: the ring is free
 
         // ---- next tile's addresses and its first two K-tiles (slots 0, 1) BEFORE this tile's epilogue (staging in slot 2)
-        const int cur_m0 = m0, cur_n0 = n0;
+        const int cur_m0 = m0, cur_n0 = n0, cur_ks = ks;
         const int next = tile + stride;
         const bool more = next < run_end;
+        if constexpr (SPLIT) {
+            // raw f32 partial tile -> workspace[slice][M][N]: lane (pixel l31, half) holds channels wc * 32 + 8 q + 4 half + e of its pixel -
+            // 16 stores of 16 bytes per lane, unconditional (rows >= M go to an out-of-range offset the descriptor drops)
+            if (more) { set_tile(next); stage_first(); }
+            const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws, 0, p.sk_ws_bytes, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned m = (unsigned)(cur_m0 + wr * 128 + a * 32 + (lane & 31));
+                const unsigned row = ((unsigned)cur_ks * (unsigned)p.M + m) * (unsigned)p.N + (unsigned)(cur_n0 + wc * 32 + 4 * (lane >> 5));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[a][4 * q], acc[a][4 * q + 1], acc[a][4 * q + 2], acc[a][4 * q + 3]};
+                    const unsigned off = m < (unsigned)p.M ? (row + 8u * q) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(n8_u32x4, v), rws, (int)off, 0, 0);
+                }
+            }
+            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the next unit's 12 DMAs are older than these 16 stores
+            if (!more) break;
+            tile = next;
+            first = false;
+            continue;
+        }
         N8EpiRegs R;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -359,6 +396,44 @@ __global__ __launch_bounds__(512) void conv_igemm_p8n_kernel(const ConvParams p)
 #endif
 }
 
+// Sum of the K slices' partial tiles (fixed order s = 0, 1, ..: deterministic) + the bf16 epilogue of conv_igemm_p8n_kernel
+// (v * scale + bias, + 0, activation), 8 channels per thread.
+__global__ __launch_bounds__(256) void p8n_split_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, const float* __restrict__ scale,
+                                                               const float* __restrict__ bias, bf16_t* __restrict__ y, long long y_cs, int act) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, per_row = N / 8;
+    if (i >= (long long)M * per_row) return;
+    const long long m = i / per_row;
+    const int n = (int)(i - m * per_row) * 8;
+    const float* src = ws + m * N + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    for (int s = 1; s < splits; ++s) {
+        const float* q = src + (long long)s * M * N;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(q), d = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] += c[e]; b[e] += d[e]; }
+    }
+    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (scale) { s0 = *reinterpret_cast<const f32x4*>(scale + n); s1 = *reinterpret_cast<const f32x4*>(scale + n + 4); }
+    if (bias) { b0 = *reinterpret_cast<const f32x4*>(bias + n); b1 = *reinterpret_cast<const f32x4*>(bias + n + 4); }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = a[e] * s0[e];
+        v[e] += b0[e];
+        v[4 + e] = b[e] * s1[e];
+        v[4 + e] += b1[e];
+    }
+    us8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = v[e] + 0.f;
+        if (act == NPS_ACT_RELU) t = t > 0.f ? t : 0.f;
+        else if (act == NPS_ACT_LEAKY) t = t > 0.f ? t : 0.01f * t;
+        o[e] = f32_to_bf16(t);
+    }
+    *reinterpret_cast<us8*>(y + m * y_cs + n) = o;
+}
+
 }  // namespace nps
 
 extern int nps_p8_num_cus();
@@ -366,9 +441,9 @@ extern int nps_p8_num_cus();
 // x [B,H,W,Cin] bf16 (pixel stride x_cstride), w [Cout][KH][KW][Cin] bf16 (plain K-contiguous rows), Cin % 64 == 0, Cout % 128 == 0;
 // y bf16 = act(conv * scale + bias), act in {none, ReLU, LeakyReLU}; variant: 0, + 32 = channel-major K order, + (n << 8) = at most n
 // persistent workgroups (tuning aid).
-extern "C" int nopesac_conv2d_nhwc_p8n(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
-                                       int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
-                                       int variant, void* stream) {
+static int p8n_launch(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
+                      int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
+                      int variant, int splits, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace nps;
     NPS_CHECK_ARG(x && w && y, "conv2d_p8n: null pointer");
     NPS_CHECK_ARG(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && KH * KW <= 32, "conv2d_p8n: bad dims");
@@ -398,14 +473,46 @@ extern "C" int nopesac_conv2d_nhwc_p8n(const void* x, const void* w, const float
                   "conv2d_p8n: pixel count / strides beyond the 24-bit index math of this kernel");
     p.tiles_m = (p.M + N8_BM - 1) / N8_BM;
     p.tiles_n = p.N / N8_BN;
+    const hipStream_t st = (hipStream_t)stream;
+    if (splits > 1) {
+        const long long need = (long long)splits * p.M * p.N * 4;
+        NPS_CHECK_ARG(kmajor && splits <= Cin / 64 && splits <= 16, "conv2d_p8n_splitk: channel-major K order, 2 <= splits <= min(Cin / 64, 16)");
+        NPS_CHECK_ARG(workspace && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= need && need < (1ll << 31),
+                      "conv2d_p8n_splitk: workspace of splits * M * N * 4 bytes (< 2 GB), 16-byte aligned");
+        p.ksplit = splits; p.sk_ws = workspace; p.sk_ws_bytes = (int)need;
+        const int units = p.tiles_m * p.tiles_n * splits;
+        int nwg = nps_p8_num_cus();
+        if (grid_cap > 0 && grid_cap < nwg) nwg = grid_cap;
+        if (units < nwg) nwg = units;
+        hipLaunchKernelGGL((conv_igemm_p8n_kernel<NPS_ACT_NONE, true>), dim3(nwg), dim3(512), 0, st, p);
+        const long long items = (long long)p.M * (p.N / 8);
+        hipLaunchKernelGGL(p8n_split_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const float*)workspace, splits, p.M, p.N,
+                           scale, bias, (bf16_t*)y, (long long)y_cstride, act);
+        NPS_LAUNCH_RET();
+    }
     const int ntiles = p.tiles_m * p.tiles_n;
     int nwg = nps_p8_num_cus();
     if (grid_cap > 0 && grid_cap < nwg) nwg = grid_cap;
     if (ntiles < nwg) nwg = ntiles;
     const dim3 grid(nwg);
-    const hipStream_t st = (hipStream_t)stream;
     if (act == NPS_ACT_RELU) hipLaunchKernelGGL((conv_igemm_p8n_kernel<NPS_ACT_RELU>), grid, dim3(512), 0, st, p);
     else if (act == NPS_ACT_LEAKY) hipLaunchKernelGGL((conv_igemm_p8n_kernel<NPS_ACT_LEAKY>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_igemm_p8n_kernel<NPS_ACT_NONE>), grid, dim3(512), 0, st, p);
     NPS_LAUNCH_RET();
+}
+
+extern "C" int nopesac_conv2d_nhwc_p8n(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
+                                       int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride, int act,
+                                       int variant, void* stream) {
+    return p8n_launch(x, w, scale, bias, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, act, variant, 1, nullptr, 0, stream);
+}
+
+// Split-K form (round 6): `splits` K slices per 256 x 128 output tile (channel-major K order: variant must carry + 32), f32 partial tiles in
+// `workspace` (>= splits * M * Cout * 4 bytes, M = B * OH * OW), summed in fixed order by a second launch that applies the epilogue.
+extern "C" int nopesac_conv2d_nhwc_p8n_splitk(const void* x, const void* w, const float* scale, const float* bias, void* y, int B, int H, int W,
+                                              int Cin, int Cout, int KH, int KW, int stride, int pad, int64_t x_cstride, int64_t y_cstride,
+                                              int act, int variant, int splits, void* workspace, int64_t workspace_bytes, void* stream) {
+    NPS_CHECK_ARG(splits >= 2, "conv2d_p8n_splitk: splits >= 2");
+    return p8n_launch(x, w, scale, bias, y, B, H, W, Cin, Cout, KH, KW, stride, pad, x_cstride, y_cstride, act, variant, splits, workspace,
+                      workspace_bytes, stream);
 }

@@ -145,6 +145,7 @@ CFG_BFRAG3, CFG_BFRAG32 = 7, 8         # tuner-only configurations: nopesac_conv
 CFG_HALO16, CFG_HALO8 = 9, 10          # tuner-only: nopesac_conv3x3_halo_bf16, 16x16 / 16x8 pixel tiles
 CFG_P8 = 11                            # tuner-only: nopesac_conv2d_nhwc_p8 (256x256x64 tiles, phase-interleaved 8-wave schedule)
 CFG_P8N, CFG_P8N_TAP = 13, 14          # tuner-only: nopesac_conv2d_nhwc_p8n (256x128 tiles: the Cout % 128 == 0 layers, round 5), channel- / tap-major K order
+CFG_P8N_SPLIT = 15                     # tuner-only: nopesac_conv2d_nhwc_p8n_splitk (few tiles x long K: the pose net's first conv; round 6)
 CFG_P8_SK = 12                         # tuner-only: nopesac_conv2d_nhwc_p8_sk (the same kernel with stream-K work distribution, round 5)
 # NOPESAC_P8_CAP_1X1=n (experiment, round 5): persistent workgroups of the p8 kernel on 1x1 layers (the HBM-bound ones) capped at n
 P8_CAP_1X1 = [int(os.environ.get("NOPESAC_P8_CAP_1X1", "0"))]
@@ -156,7 +157,7 @@ LAST_CONV_CFG = [0]                    # kernel configuration of the most recent
 CONV_CFG_KERNEL = {1: "conv_igemm_kernel<128x128>", 2: "conv_igemm_kernel<64x64>", 3: "conv_igemm_glds_kernel<BK=64>", 4: "conv_igemm_glds_kernel<BK=32>",
                    7: "conv_igemm_bfrag_kernel<3, 64, false>", 8: "conv_igemm_bfrag_kernel<4, 32, false>", 9: "conv3x3_halo_kernel<16, 16>",
                    10: "conv3x3_halo_kernel<16, 8>", 11: "conv_igemm_p8_kernel", 12: "conv_igemm_p8_kernel<stream-K>",
-                   13: "conv_igemm_p8n_kernel", 14: "conv_igemm_p8n_kernel<tap-major>"}
+                   13: "conv_igemm_p8n_kernel", 14: "conv_igemm_p8n_kernel<tap-major>", 15: "conv_igemm_p8n_kernel<split-K>"}
 P8N_TUNABLE = [os.environ.get("NOPESAC_P8N", "1") != "0"]           # NOPESAC_P8N=0: the tuner never offers the 256x128-tile kernel (A/B runs)
 P8_SK_TUNABLE = [os.environ.get("NOPESAC_P8_SK", "0") == "1"]      # NOPESAC_P8_SK=1: the tuner may pick the stream-K form (wins isolated launches, loses 1.2 % in the four-in-flight loop: profiles/r5_b_*)
 _P8_SK_WS = {}                         # (device index, stream handle) -> workspace tensor of the stream-K conv
@@ -255,7 +256,18 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
               and Cout * KH * KW * Cin * 2 < 2 ** 31 and (B * OH * OW + 256) * y_cs * 2 < 2 ** 31
               and all(t is None or t.data_ptr() % 16 == 0 for t in (x, w, out, scale, bias)))
 
+    # split-K on the p8n structure: fewer tiles than half the CUs and a K loop of >= 64 K-tiles; slices = CUs // tiles (at most 8)
+    p8n_tiles = (-(-(B * OH * OW) // 256)) * (Cout // 128) if Cout % 128 == 0 else 0
+    p8n_splits = min(8, Cin // 64, 256 // p8n_tiles) if p8n_tiles else 0
+    p8n_split_ok = p8n_ok and KH * KW * Cin >= 4096 and p8n_splits >= 2 and p8n_splits * B * OH * OW * Cout * 4 < 2 ** 31
+
     def launch(cfg):
+        if cfg == CFG_P8N_SPLIT:
+            ws = torch.empty(p8n_splits * B * OH * OW * Cout, device=x.device, dtype=torch.float32)    # (caching allocator: capture-safe)
+            rc = _L().nopesac_conv2d_nhwc_p8n_splitk(_p(x), _p(w), _p(scale), _p(bias), _p(out), B, H, W, Cin, Cout, KH, KW, stride, pad, x_cs,
+                                                     y_cs, act, 32, p8n_splits, _p(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "nopesac_conv2d_nhwc_p8n_splitk")
+            return
         if cfg in (CFG_P8N, CFG_P8N_TAP):
             rc = _L().nopesac_conv2d_nhwc_p8n(_p(x), _p(w), _p(scale), _p(bias), _p(out), B, H, W, Cin, Cout, KH, KW, stride, pad, x_cs, y_cs,
                                               act, 32 if cfg == CFG_P8N else 0, _stream())
@@ -296,7 +308,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale=None, bias=None, residual=Non
                scale is not None, bias is not None, act, bfrag_ok, halo_ok, p8_ok)
         cfg = TUNER.choose(key, launch, ((CFG_BFRAG3, CFG_BFRAG32) if bfrag_ok else ()) + ((CFG_HALO16, CFG_HALO8) if halo_ok else ())
                            + ((CFG_P8,) if p8_ok else ()) + ((CFG_P8_SK,) if (p8_sk_ok and P8_SK_TUNABLE[0]) else ())
-                           + (((CFG_P8N,) + ((CFG_P8N_TAP,) if KH * KW > 1 else ())) if (p8n_ok and P8N_TUNABLE[0]) else ()))
+                           + (((CFG_P8N,) + ((CFG_P8N_TAP,) if KH * KW > 1 else ())) if (p8n_ok and P8N_TUNABLE[0]) else ())
+                           + ((CFG_P8N_SPLIT,) if (p8n_split_ok and P8N_TUNABLE[0]) else ()))
     try:
         launch(cfg)
     except _lib.HipKernelError:

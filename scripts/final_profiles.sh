@@ -3,7 +3,7 @@
 # stats of the default command, HBM traffic (PMC) over the SAME launch set.  usage: final_profiles.sh <round> <tag> [skip-tests] [retune]
 RND=${1:-5}; T=${2:-z}; O=gpurun_out; R=$PWD; P=r${RND}_${T}
 mkdir -p $O
-ROUT=$R/profiles/routing_r5.json        # (round 6 keeps the round-5 routing: no conv kernel configuration changed)
+ROUT=$R/profiles/routing_r5.json        # (round 6 keeps the round-5 tuning pass; one entry moved by hand: the pose net's first conv on the split-K form, configuration 15)
 case " $* " in *" skip-tests "*) ;; *) python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee $O/${P}_pytest_gpu.log;; esac
 F="--no-cpu-baseline --no-boundary --no-fp32-path --no-accuracy --no-other-configs --no-tape"
 case " $* " in *" retune "*)

@@ -925,6 +925,71 @@ def test_conv2d_p8n(device, case, variant, act):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("case", [(2, 15, 20, 2048, 128, 3, 1, 1, 3, 0),     # layer_3's shape at two images: 3 tiles x 3 slices of 11 / 10 / 11 channel groups
+                                  (4, 15, 20, 2048, 128, 3, 1, 1, 8, 0),     # 5 tiles (M tail: 1200 rows) x 8 slices of 4 groups
+                                  (1, 15, 20, 512, 128, 3, 1, 1, 5, 0),      # 8 groups in 5 slices: 1 / 2 / 1 / 2 / 2 groups (9 and 18 K-tiles per unit)
+                                  (1, 9, 7, 128, 128, 1, 1, 0, 2, 0),        # 1x1: ONE K-tile per unit, 63 rows
+                                  (3, 16, 16, 256, 256, 3, 2, 1, 4, 0),      # stride 2, two channel tiles
+                                  (6, 15, 20, 1024, 128, 3, 1, 1, 4, 3),     # 8 tiles x 4 slices on THREE persistent workgroups: units walked with a stride, next unit's DMAs behind the partial stores
+                                  (2, 12, 20, 320, 384, 1, 1, 0, 5, 0)])     # five groups, five slices, three channel tiles
+@pytest.mark.parametrize("act", ["ACT_RELU", "ACT_NONE", "ACT_LEAKY"])
+def test_conv2d_p8n_split_k(device, case, act):
+    """Round 6: split-K work units of the 256x128-tile kernel (K slices = runs of 64-channel groups, f32 partial tiles in a workspace, a
+    second launch sums them in fixed order and applies the epilogue) vs F.conv2d in float64 on the bf16-rounded operands: within one bf16
+    rounding; run-to-run identical (fixed summation order; a race between a unit's partial stores and the next unit's DMAs would show);
+    the output may be a channel slice of a wider buffer; a workspace that is too small is an argument error."""
+    from nopesac_amd import _lib, ops
+    B, H, W, Cin, Cout, k, s, p, splits, cap = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+    scale, bias = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, s, p) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)
+    ref = {"ACT_RELU": F.relu, "ACT_NONE": lambda t: t, "ACT_LEAKY": lambda t: F.leaky_relu(t, 0.01)}[act](ref)
+    xd = _nhwc(x).to(device, torch.bfloat16)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device, torch.bfloat16)
+    sd, bd = scale.to(device), bias.to(device)
+    OH, OW = ref.shape[2], ref.shape[3]
+    ws = torch.full((splits * B * OH * OW * Cout,), float("nan"), device=device)
+    L, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    outs = []
+    for rep in range(3):
+        wide = torch.full((B, OH, OW, Cout + 16), float("nan"), device=device, dtype=torch.bfloat16)
+        y = wide[..., 8:8 + Cout]
+        rc = L.nopesac_conv2d_nhwc_p8n_splitk(xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, k, k, s, p,
+                                              Cin, Cout + 16, getattr(ops, act), 32 | (cap << 8), splits, ws.data_ptr(), ws.numel() * 4, st)
+        assert rc == 0
+        outs.append(wide)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(outs[0][..., :8].float()).all()) and bool(torch.isnan(outs[0][..., 8 + Cout:].float()).all())      # nothing written next to the slice
+    got = outs[0][..., 8:8 + Cout].float().permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-4 * (1 + math.sqrt(Cin * k * k) * 0.01)).all()), float(err.max())
+    assert torch.equal(outs[0][..., 8:8 + Cout], outs[1][..., 8:8 + Cout]) and torch.equal(outs[0][..., 8:8 + Cout], outs[2][..., 8:8 + Cout])
+    y = torch.empty(B, OH, OW, Cout, device=device, dtype=torch.bfloat16)
+    args = (xd.data_ptr(), wd.data_ptr(), sd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, k, k, s, p, Cin, Cout, getattr(ops, act))
+    assert L.nopesac_conv2d_nhwc_p8n_splitk(*args, 32, splits, ws.data_ptr(), ws.numel() * 4 - 4, st) != 0        # workspace too small
+    assert L.nopesac_conv2d_nhwc_p8n_splitk(*args, 0, splits, ws.data_ptr(), ws.numel() * 4, st) != 0             # tap-major K order
+    assert L.nopesac_conv2d_nhwc_p8n_splitk(*args, 32, 1, ws.data_ptr(), ws.numel() * 4, st) != 0                  # one slice is not a split
+    assert L.nopesac_conv2d_nhwc_p8n_splitk(*args, 32, Cin // 64 + 1, ws.data_ptr(), ws.numel() * 4, st) != 0     # more slices than channel groups
+
+
+def test_conv2d_p8n_split_k_through_the_tuner_route(device, monkeypatch):
+    """ops.conv2d routed to the split-K configuration (the pose net's first conv at four images: no scale / bias / activation)."""
+    from nopesac_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, H, W, Cin, Cout = 4, 15, 20, 2048, 128
+    x = torch.randn(B, H, W, Cin, generator=g).to(device, torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).to(device, torch.bfloat16)
+    ref = ops.conv2d(x, w, None, None, pad=1)
+    monkeypatch.setattr(ops.TUNER, "measuring", True)
+    monkeypatch.setattr(ops.TUNER, "choose", lambda key, launch, extra=(): ops.CFG_P8N_SPLIT if ops.CFG_P8N_SPLIT in extra else 0)
+    y = ops.conv2d(x, w, None, None, pad=1)
+    assert ops.LAST_CONV_CFG[0] == ops.CFG_P8N_SPLIT
+    assert _rel(y.float(), ref.float()) < 1e-2
+
+
 def test_conv2d_p8n_through_the_tuner_route(device, monkeypatch):
     """ops.conv2d routed to the 256x128-tile configuration: strided output view (a channel slice of a wider buffer), no scale."""
     from nopesac_amd import ops
